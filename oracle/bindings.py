@@ -1,0 +1,373 @@
+"""ctypes bindings for the parity oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under peapods_amd/ imports this module.
+
+`OracleSimulation` mirrors the reference's PyO3 class `IsingSimulation`
+(src/lib.rs:104-634): same constructor arguments, `sample()` returning the same
+dictionary keys/shapes/dtypes for the options on the hot path, `get_spins()`
+and `reset()`.  The disorder aggregation restates
+spin-sim/src/statistics/results.rs:165-282 and overlap.rs:106-152 (sequential
+f64 sums in realisation order, then one division).
+"""
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+SWEEP_MODES = {"metropolis": 0, "gibbs": 1}
+PT_SCHEDULES = {"single_random_edge": 0, "full_ladder": 1}
+OC_MODES = {"houdayer": 1, "houd2": 1, "jorg": 2}
+CLUSTER_MODES = {"wolff": 0, "sw": 1}
+
+
+class OrcConfig(C.Structure):
+    _fields_ = [
+        ("n_sweeps", C.c_uint64),
+        ("warmup_sweeps", C.c_uint64),
+        ("sweep_mode", C.c_int32),
+        ("pt_interval", C.c_uint64),
+        ("pt_schedule", C.c_int32),
+        ("overlap_cluster_interval", C.c_uint64),
+        ("overlap_cluster_modes", C.c_int32 * 4),
+        ("n_overlap_cluster_modes", C.c_int32),
+        ("overlap_cluster_mode", C.c_int32),
+        ("n_threads", C.c_int32),
+    ]
+
+
+class OrcAttempt(C.Structure):
+    _fields_ = [
+        ("edge", C.c_uint64),
+        ("accepted", C.c_int),
+        ("left_system", C.c_uint64),
+        ("right_system", C.c_uint64),
+    ]
+
+
+class OrcRng(C.Structure):
+    _fields_ = [("s", C.c_uint64 * 4)]
+
+
+def build(native=False):
+    """Compile the oracle with the committed Makefile.  Returns the .so path."""
+    out = os.path.join(_HERE, "liboracle_native.so" if native else "liboracle.so")
+    args = ["make", "-s", "-C", _HERE, f"OUT={out}"]
+    if native:
+        args.append("ARCHFLAGS=-march=native")
+    subprocess.run(args, check=True)
+    return out
+
+
+def load(path=None):
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    if path is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+    lib = C.CDLL(path)
+    u64, i64, u32, i32, f32, vp = C.c_uint64, C.c_int64, C.c_uint32, C.c_int32, C.c_float, C.c_void_p
+    P = C.POINTER
+    sig = {
+        "orc_splitmix64": (u64, [u64]),
+        "orc_child_seed": (u64, [u64, u64, u64]),
+        "orc_realization_seed": (u64, [u64, u64]),
+        "orc_rng_seed_from_u64": (None, [P(OrcRng), u64]),
+        "orc_rng_next_u64": (u64, [P(OrcRng)]),
+        "orc_rng_next_u32": (u32, [P(OrcRng)]),
+        "orc_rng_gen_f32": (f32, [P(OrcRng)]),
+        "orc_rng_gen_range_usize": (u64, [P(OrcRng), u64, u64]),
+        "orc_rng_shuffle_usize": (None, [P(OrcRng), vp, C.c_size_t]),
+        "orc_lattice_new": (vp, [vp, C.c_int]),
+        "orc_lattice_with_offsets": (vp, [vp, C.c_int, vp, C.c_size_t]),
+        "orc_lattice_free": (None, [vp]),
+        "orc_lattice_n_spins": (u64, [vp]),
+        "orc_lattice_n_neighbors": (u64, [vp]),
+        "orc_lattice_stride": (u64, [vp, C.c_int]),
+        "orc_lattice_neighbor_fwd": (u64, [vp, u64, u64]),
+        "orc_lattice_neighbor_bwd": (u64, [vp, u64, u64]),
+        "orc_lookup_new": (vp, [vp, C.c_size_t, vp, C.c_size_t, C.c_size_t]),
+        "orc_lookup_free": (None, [vp]),
+        "orc_lookup_accepted_count": (u32, [f32, i32]),
+        "orc_lookup_legacy_accepts": (C.c_int, [f32, i32, u32]),
+        "orc_lookup_get": (u32, [vp, C.c_size_t, i32]),
+        "orc_metropolis_sweep": (None, [vp, vp, vp, vp, vp, C.c_size_t, vp, vp]),
+        "orc_gibbs_sweep": (None, [vp, vp, vp, vp, vp, C.c_size_t, vp]),
+        "orc_compute_energies": (None, [vp, vp, vp, C.c_size_t, vp, vp, vp]),
+        "orc_parallel_tempering": (C.c_size_t, [vp, vp, vp, C.c_size_t, C.c_size_t, P(OrcRng), vp]),
+        "orc_parallel_tempering_full_ladder": (
+            C.c_size_t,
+            [vp, vp, vp, C.c_size_t, C.c_size_t, P(OrcRng), C.c_size_t, vp],
+        ),
+        "orc_pt_replay": (None, [C.c_size_t, C.c_size_t, vp, vp, C.c_size_t, vp, vp, vp]),
+        "orc_uf_from_bonds": (None, [vp, vp, vp, C.c_size_t, vp, vp]),
+        "orc_uf_histogram": (None, [vp, C.c_size_t, vp]),
+        "orc_top4_sizes": (None, [vp, C.c_size_t, vp]),
+        "orc_sim_create": (
+            vp,
+            [vp, C.c_int, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, u64],
+        ),
+        "orc_sim_destroy": (None, [vp]),
+        "orc_sim_reset": (None, [vp, u64]),
+        "orc_sim_sample": (C.c_int, [vp, P(OrcConfig)]),
+        "orc_sim_last_error": (C.c_char_p, [vp]),
+        "orc_sim_n_spins": (u64, [vp]),
+        "orc_sim_n_neighbors": (u64, [vp]),
+        "orc_sim_get_spins": (None, [vp, C.c_size_t, vp]),
+        "orc_sim_get_system_ids": (None, [vp, C.c_size_t, vp]),
+        "orc_sim_get_energies": (None, [vp, C.c_size_t, vp]),
+        "orc_sim_get_rng_state": (None, [vp, C.c_size_t, C.c_size_t, vp]),
+        "orc_sim_get_pt_counters": (None, [vp, C.c_size_t, vp, vp, vp]),
+        "orc_sim_get_result_moments": (None, [vp, C.c_size_t, vp]),
+        "orc_sim_has_overlap": (C.c_int, [vp]),
+        "orc_sim_get_result_overlap": (None, [vp, C.c_size_t, vp]),
+        "orc_sim_get_result_histograms": (None, [vp, C.c_size_t, vp, vp, vp]),
+    }
+    for name, (restype, argtypes) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if path.endswith("liboracle.so"):
+        _LIB = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Lattice:
+    """Handle on the oracle's neighbour tables (ss/geometry/lattice.rs)."""
+
+    def __init__(self, shape, offsets=None, lib=None):
+        self.lib = lib or load()
+        shape_arr = np.asarray(shape, dtype=np.uint64)
+        self.shape = tuple(int(x) for x in shape)
+        if offsets is None:
+            self.handle = self.lib.orc_lattice_new(_ptr(shape_arr), len(shape))
+        else:
+            off = np.ascontiguousarray(offsets, dtype=np.int64)
+            self.handle = self.lib.orc_lattice_with_offsets(
+                _ptr(shape_arr), len(shape), _ptr(off), off.shape[0]
+            )
+        self.n_spins = int(self.lib.orc_lattice_n_spins(self.handle))
+        self.n_neighbors = int(self.lib.orc_lattice_n_neighbors(self.handle))
+
+    def strides(self):
+        return [int(self.lib.orc_lattice_stride(self.handle, d)) for d in range(len(self.shape))]
+
+    def neighbor_fwd(self, i, d):
+        return int(self.lib.orc_lattice_neighbor_fwd(self.handle, i, d))
+
+    def neighbor_bwd(self, i, d):
+        return int(self.lib.orc_lattice_neighbor_bwd(self.handle, i, d))
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self.lib.orc_lattice_free(self.handle)
+            self.handle = None
+
+
+def make_rngs(seeds, lib=None):
+    lib = lib or load()
+    arr = (OrcRng * len(seeds))()
+    for i, s in enumerate(seeds):
+        lib.orc_rng_seed_from_u64(C.byref(arr[i]), int(s))
+    return arr
+
+
+def aggregate_results(per_real, n_temps, has_overlap, with_samples):
+    """SweepResult::aggregate_impl (statistics/results.rs:84-285) + OverlapStats::aggregate_impl
+    (statistics/overlap.rs:67-155): sequential sums in realisation order, then /= n."""
+    n = float(len(per_real))
+    out = {}
+    moment_keys = ["mags", "mags2", "mags4", "energies", "energies2"]
+    for k, key in enumerate(moment_keys):
+        acc = np.zeros(n_temps, dtype=np.float64)
+        for res in per_real:
+            acc = acc + res["moments"][k]
+        out[key] = acc / n if len(per_real) > 1 else acc
+    if has_overlap:
+        ov_keys = ["overlap", "overlap2", "overlap4", "link_overlap", "link_overlap2", "link_overlap4"]
+        for k, key in enumerate(ov_keys):
+            acc = np.zeros(n_temps, dtype=np.float64)
+            for res in per_real:
+                acc = acc + res["overlap"][k]
+            out[key] = acc / n if len(per_real) > 1 else acc
+        hist = np.zeros_like(per_real[0]["histogram"])
+        ql = np.zeros_like(per_real[0]["ql_at_q_sum"])
+        ql2 = np.zeros_like(per_real[0]["ql2_at_q_sum"])
+        for res in per_real:
+            hist = hist + res["histogram"]
+            ql = ql + res["ql_at_q_sum"]
+            ql2 = ql2 + res["ql2_at_q_sum"]
+        out["overlap_histogram"] = [hist[t].copy() for t in range(n_temps)]
+        out["ql_at_q_sum"] = ql
+        out["ql2_at_q_sum"] = ql2
+        if with_samples:
+            out["per_sample_overlap_histogram"] = np.stack([r["histogram"] for r in per_real])
+            out["per_sample_ql_at_q_sum"] = np.stack([r["ql_at_q_sum"] for r in per_real])
+            out["per_sample_ql2_at_q_sum"] = np.stack([r["ql2_at_q_sum"] for r in per_real])
+    return out
+
+
+class OracleSimulation:
+    """Mirror of the reference's `IsingSimulation` pyclass (src/lib.rs:104-634)."""
+
+    def __init__(self, lattice_shape, couplings, temperatures, n_replicas=None,
+                 neighbor_offsets=None, seed=None, lib=None):
+        self.lib = lib or load()
+        self.shape = [int(x) for x in lattice_shape]
+        n_dims = len(self.shape)
+        n_neighbors = len(neighbor_offsets) if neighbor_offsets is not None else n_dims
+        couplings = np.ascontiguousarray(couplings, dtype=np.float32)
+        temps = np.ascontiguousarray(temperatures, dtype=np.float32)
+        expected_single = tuple(self.shape) + (n_neighbors,)
+        if couplings.shape == expected_single:
+            n_real = 1
+        elif couplings.ndim == len(expected_single) + 1 and couplings.shape[1:] == expected_single:
+            n_real = couplings.shape[0]
+        else:  # src/lib.rs:146-149
+            raise ValueError(
+                f"couplings shape {list(couplings.shape)} does not match lattice {list(expected_single)}"
+            )
+        self.n_replicas = 1 if n_replicas is None else int(n_replicas)
+        self.n_temps = len(temps)
+        self.n_realizations = n_real
+        self.constructor_seed = 42 if seed is None else int(seed)
+        shape_arr = np.asarray(self.shape, dtype=np.uint64)
+        if neighbor_offsets is not None:
+            off = np.ascontiguousarray(neighbor_offsets, dtype=np.int64)
+            off_ptr, n_off = _ptr(off), off.shape[0]
+        else:
+            off_ptr, n_off = None, 0
+        self.handle = self.lib.orc_sim_create(
+            _ptr(shape_arr), n_dims, off_ptr, n_off, _ptr(couplings), n_real, _ptr(temps),
+            self.n_temps, self.n_replicas, self.constructor_seed,
+        )
+        self.n_spins = int(self.lib.orc_sim_n_spins(self.handle))
+        self.n_systems = self.n_replicas * self.n_temps
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self.lib.orc_sim_destroy(self.handle)
+            self.handle = None
+
+    # -- state ------------------------------------------------------------
+    def get_spins(self, realization=0):
+        out = np.empty(self.n_systems * self.n_spins, dtype=np.int8)
+        self.lib.orc_sim_get_spins(self.handle, realization, _ptr(out))
+        return out
+
+    def get_system_ids(self, realization=0):
+        out = np.empty(self.n_systems, dtype=np.uint64)
+        self.lib.orc_sim_get_system_ids(self.handle, realization, _ptr(out))
+        return out
+
+    def get_energies(self, realization=0):
+        out = np.empty(self.n_systems, dtype=np.float32)
+        self.lib.orc_sim_get_energies(self.handle, realization, _ptr(out))
+        return out
+
+    def get_rng_state(self, realization, system):
+        out = np.empty(4, dtype=np.uint64)
+        self.lib.orc_sim_get_rng_state(self.handle, realization, system, _ptr(out))
+        return out
+
+    def get_pt_counters(self, realization=0):
+        n_edges = max(self.n_temps - 1, 0)
+        att = np.zeros(n_edges, dtype=np.uint64)
+        acc = np.zeros(n_edges, dtype=np.uint64)
+        trips = np.zeros(self.n_systems, dtype=np.uint64)
+        self.lib.orc_sim_get_pt_counters(self.handle, realization, _ptr(att), _ptr(acc), _ptr(trips))
+        return att, acc, trips.reshape(self.n_replicas, self.n_temps)
+
+    def reset(self, seed=None):
+        self.lib.orc_sim_reset(self.handle, self.constructor_seed if seed is None else int(seed))
+
+    # -- sampling ---------------------------------------------------------
+    def make_config(self, n_sweeps, sweep_mode, pt_interval=None, pt_schedule=None,
+                    overlap_cluster_update_interval=None, overlap_cluster_build_mode=None,
+                    overlap_cluster_mode=None, warmup_ratio=None, n_threads=1):
+        warmup = 0.25 if warmup_ratio is None else warmup_ratio
+        cfg = OrcConfig()
+        cfg.n_sweeps = int(n_sweeps)
+        # Rust f64::round = half away from zero (src/lib.rs:220)
+        cfg.warmup_sweeps = int(np.floor(n_sweeps * warmup + 0.5))
+        if sweep_mode not in SWEEP_MODES:
+            raise ValueError(f"unknown sweep_mode '{sweep_mode}', expected 'metropolis' or 'gibbs'")
+        cfg.sweep_mode = SWEEP_MODES[sweep_mode]
+        if pt_interval == 0:
+            raise ValueError("pt_interval must be >= 1")
+        cfg.pt_interval = 0 if pt_interval is None else int(pt_interval)
+        sched = pt_schedule or "single_random_edge"
+        if sched not in PT_SCHEDULES:
+            raise ValueError(
+                f"unknown pt_schedule '{sched}', expected 'single_random_edge' or 'full_ladder'"
+            )
+        cfg.pt_schedule = PT_SCHEDULES[sched]
+        if overlap_cluster_update_interval is not None:
+            if overlap_cluster_update_interval < 1:
+                raise ValueError("overlap_cluster interval must be >= 1")
+            cfg.overlap_cluster_interval = int(overlap_cluster_update_interval)
+            modes = [m.strip() for m in (overlap_cluster_build_mode or "houdayer").split("+")]
+            for k, m in enumerate(modes):
+                if m not in OC_MODES:
+                    raise ValueError(f"oracle does not restate overlap mode '{m}'")
+                cfg.overlap_cluster_modes[k] = OC_MODES[m]
+            cfg.n_overlap_cluster_modes = len(modes)
+            cfg.overlap_cluster_mode = CLUSTER_MODES[overlap_cluster_mode or "wolff"]
+        cfg.n_threads = int(n_threads)
+        return cfg
+
+    def run(self, cfg):
+        rc = self.lib.orc_sim_sample(self.handle, C.byref(cfg))
+        if rc != 0:
+            raise ValueError(self.lib.orc_sim_last_error(self.handle).decode())
+
+    def per_realization_results(self):
+        n_t, n_bins = self.n_temps, self.n_spins + 1
+        has_ov = bool(self.lib.orc_sim_has_overlap(self.handle))
+        per_real = []
+        for r in range(self.n_realizations):
+            res = {"moments": np.empty((5, n_t), dtype=np.float64)}
+            self.lib.orc_sim_get_result_moments(self.handle, r, _ptr(res["moments"]))
+            if has_ov:
+                res["overlap"] = np.empty((6, n_t), dtype=np.float64)
+                self.lib.orc_sim_get_result_overlap(self.handle, r, _ptr(res["overlap"]))
+                res["histogram"] = np.empty((n_t, n_bins), dtype=np.uint64)
+                res["ql_at_q_sum"] = np.empty((n_t, n_bins), dtype=np.float64)
+                res["ql2_at_q_sum"] = np.empty((n_t, n_bins), dtype=np.float64)
+                self.lib.orc_sim_get_result_histograms(
+                    self.handle, r, _ptr(res["histogram"]), _ptr(res["ql_at_q_sum"]),
+                    _ptr(res["ql2_at_q_sum"]),
+                )
+            per_real.append(res)
+        return per_real, has_ov
+
+    def sample(self, n_sweeps, sweep_mode, pt_interval=None, pt_schedule=None,
+               overlap_cluster_update_interval=None, overlap_cluster_build_mode=None,
+               overlap_cluster_mode=None, warmup_ratio=None, n_threads=1, **ignored):
+        cfg = self.make_config(n_sweeps, sweep_mode, pt_interval, pt_schedule,
+                               overlap_cluster_update_interval, overlap_cluster_build_mode,
+                               overlap_cluster_mode, warmup_ratio, n_threads)
+        self.run(cfg)
+        per_real, has_ov = self.per_realization_results()
+        out = aggregate_results(per_real, self.n_temps, has_ov, self.n_realizations > 1)
+        if pt_interval is not None:  # src/lib.rs:458-487
+            att, acc, trips = zip(*(self.get_pt_counters(r) for r in range(self.n_realizations)))
+            out["per_disorder"] = {
+                "parallel_tempering": {
+                    "edge_attempts": np.stack(att),
+                    "edge_acceptances": np.stack(acc),
+                    "round_trips": np.stack(trips),
+                }
+            }
+        return out

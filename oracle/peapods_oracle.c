@@ -1,0 +1,1159 @@
+/*
+ * peapods_oracle.c -- CPU restatement of the PeaBrane/peapods spin-sim hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see peapods_oracle.h).  PARITY UNPINNED against
+ * upstream binaries; pinned by the reference's own known-answer tests and the
+ * published xoshiro256** / SplitMix64 vectors (tests/test_oracle_*.py).
+ *
+ * Reference paths are relative to the reference root; "ss/" = spin-sim/src/.
+ * Floating-point note: the reference is Rust; f32::ln / f32::exp lower to the
+ * platform libm (logf/expf of glibc on Linux), which is what this file calls.
+ * Build with -ffp-contract=off so no multiply-add is fused (rustc never fuses).
+ */
+#include "peapods_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ========================================================================== */
+/* Seeds and RNG                                                              */
+/* ========================================================================== */
+
+/* ss/simulation/realization.rs:9-15 and src/lib.rs:22-28 (identical bodies). */
+uint64_t orc_splitmix64(uint64_t value) {
+    value += 0x9E3779B97F4A7C15ULL;
+    uint64_t mixed = value;
+    mixed = (mixed ^ (mixed >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    mixed = (mixed ^ (mixed >> 27)) * 0x94D049BB133111EBULL;
+    return mixed ^ (mixed >> 31);
+}
+
+/* ss/simulation/realization.rs:17-19 */
+uint64_t orc_child_seed(uint64_t root, uint64_t domain, uint64_t index) {
+    return orc_splitmix64(root ^ domain ^ orc_splitmix64(index));
+}
+
+/* src/lib.rs:30-32 */
+uint64_t orc_realization_seed(uint64_t root, uint64_t realization) {
+    return orc_splitmix64(root ^ orc_splitmix64(realization));
+}
+
+/* rand_xoshiro 0.6.0 Xoshiro256StarStar::seed_from_u64: the 32 seed bytes are
+ * four successive SplitMix64 outputs (little endian) starting from state
+ * `seed`; an all-zero seed would be replaced by seed_from_u64(0), which cannot
+ * happen for SplitMix64 output.  Call sites: realization.rs:170,189,219,234. */
+void orc_rng_seed_from_u64(orc_rng *rng, uint64_t seed) {
+    uint64_t x = seed;
+    for (int i = 0; i < 4; ++i) {
+        x += 0x9E3779B97F4A7C15ULL;
+        uint64_t z = x;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        rng->s[i] = z ^ (z >> 31);
+    }
+}
+
+static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+/* xoshiro256** (Blackman & Vigna), as rand_xoshiro 0.6.0 next_u64. */
+uint64_t orc_rng_next_u64(orc_rng *rng) {
+    uint64_t *s = rng->s;
+    uint64_t result = rotl64(s[1] * 5, 7) * 9;
+    uint64_t t = s[1] << 17;
+    s[2] ^= s[0];
+    s[3] ^= s[1];
+    s[1] ^= s[2];
+    s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl64(s[3], 45);
+    return result;
+}
+
+/* rand_xoshiro 0.6.0: next_u32 = upper half of next_u64. */
+uint32_t orc_rng_next_u32(orc_rng *rng) { return (uint32_t)(orc_rng_next_u64(rng) >> 32); }
+
+/* rand 0.8.5 Standard f32: 24 high bits of one u32, scaled by 2^-24
+ * (confirmed by the in-tree comment ss/mcmc/sweep.rs:179-181). */
+float orc_rng_gen_f32(orc_rng *rng) {
+    uint32_t value = orc_rng_next_u32(rng);
+    return (float)(value >> 8) * (1.0f / 16777216.0f);
+}
+
+/* rand 0.8.5 UniformInt<usize>::sample_single (64-bit): widening multiply with
+ * the "conservative zone" rejection.  Call sites: tempering.rs:33, utils.rs:113. */
+uint64_t orc_rng_gen_range_usize(orc_rng *rng, uint64_t low, uint64_t high) {
+    uint64_t range = high - low;
+    int lz = __builtin_clzll(range);
+    uint64_t zone = (range << lz) - 1;
+    for (;;) {
+        uint64_t v = orc_rng_next_u64(rng);
+        __uint128_t m = (__uint128_t)v * (__uint128_t)range;
+        uint64_t hi = (uint64_t)(m >> 64), lo = (uint64_t)m;
+        if (lo <= zone) return low + hi;
+    }
+}
+
+/* rand 0.8.5 UniformInt<u32>::sample_single, used by gen_index for bounds that
+ * fit a u32 (seq/mod.rs gen_index). */
+static uint32_t gen_range_u32(orc_rng *rng, uint32_t low, uint32_t high) {
+    uint32_t range = high - low;
+    int lz = __builtin_clz(range);
+    uint32_t zone = (range << lz) - 1;
+    for (;;) {
+        uint32_t v = orc_rng_next_u32(rng);
+        uint64_t m = (uint64_t)v * (uint64_t)range;
+        uint32_t hi = (uint32_t)(m >> 32), lo = (uint32_t)m;
+        if (lo <= zone) return low + hi;
+    }
+}
+
+/* rand 0.8.5 SliceRandom::shuffle: for i in (1..len).rev() swap(i, gen_index(i+1)).
+ * Call site: ss/clusters/overlap.rs:48. */
+void orc_rng_shuffle_usize(orc_rng *rng, uint64_t *values, size_t len) {
+    for (size_t i = len; i-- > 1;) {
+        size_t j = (size_t)gen_range_u32(rng, 0, (uint32_t)(i + 1));
+        uint64_t tmp = values[i];
+        values[i] = values[j];
+        values[j] = tmp;
+    }
+}
+
+/* ========================================================================== */
+/* Lattice                                                                    */
+/* ========================================================================== */
+
+/* ss/geometry/lattice.rs:44-99 */
+orc_lattice *orc_lattice_with_offsets(const uint64_t *shape, int n_dims, const int64_t *offsets,
+                                      size_t n_offsets) {
+    if (n_dims < 1 || n_dims > ORC_MAX_DIMS) return NULL;
+    orc_lattice *lat = (orc_lattice *)calloc(1, sizeof(*lat));
+    lat->n_dims = n_dims;
+    lat->n_neighbors = n_offsets;
+    lat->n_spins = 1;
+    for (int d = 0; d < n_dims; ++d) {
+        lat->shape[d] = (size_t)shape[d];
+        lat->n_spins *= (size_t)shape[d];
+    }
+    for (int d = 0; d < n_dims; ++d) lat->strides[d] = 1;
+    for (int d = n_dims - 2; d >= 0; --d) lat->strides[d] = lat->strides[d + 1] * lat->shape[d + 1];
+
+    lat->fwd = (uint32_t *)calloc(lat->n_spins * n_offsets + 1, sizeof(uint32_t));
+    lat->bwd = (uint32_t *)calloc(lat->n_spins * n_offsets + 1, sizeof(uint32_t));
+    for (size_t i = 0; i < lat->n_spins; ++i) {
+        int64_t coords[ORC_MAX_DIMS];
+        for (int d = 0; d < n_dims; ++d) coords[d] = (int64_t)((i / lat->strides[d]) % lat->shape[d]);
+        for (size_t k = 0; k < n_offsets; ++k) {
+            for (int pass = 0; pass < 2; ++pass) {
+                int64_t sign = pass == 0 ? 1 : -1;
+                size_t flat = 0;
+                for (int dim = 0; dim < n_dims; ++dim) {
+                    int64_t extent = (int64_t)lat->shape[dim];
+                    int64_t c = (coords[dim] + sign * offsets[k * n_dims + dim]) % extent;
+                    if (c < 0) c += extent; /* rem_euclid */
+                    flat += (size_t)c * lat->strides[dim];
+                }
+                (pass == 0 ? lat->fwd : lat->bwd)[i * n_offsets + k] = (uint32_t)flat;
+            }
+        }
+    }
+    lat->has_square_shape = 0;
+    return lat;
+}
+
+/* ss/geometry/lattice.rs:31-38 with offsets.rs:4-13 (hypercubic unit vectors). */
+orc_lattice *orc_lattice_new(const uint64_t *shape, int n_dims) {
+    int64_t offsets[ORC_MAX_DIMS * ORC_MAX_DIMS] = {0};
+    for (int d = 0; d < n_dims; ++d) offsets[d * n_dims + d] = 1;
+    orc_lattice *lat = orc_lattice_with_offsets(shape, n_dims, offsets, (size_t)n_dims);
+    if (lat) lat->has_square_shape = (n_dims == 2);
+    return lat;
+}
+
+void orc_lattice_free(orc_lattice *lat) {
+    if (!lat) return;
+    free(lat->fwd);
+    free(lat->bwd);
+    free(lat);
+}
+
+uint64_t orc_lattice_n_spins(const orc_lattice *lat) { return lat->n_spins; }
+uint64_t orc_lattice_n_neighbors(const orc_lattice *lat) { return lat->n_neighbors; }
+uint64_t orc_lattice_stride(const orc_lattice *lat, int d) { return lat->strides[d]; }
+uint64_t orc_lattice_neighbor_fwd(const orc_lattice *lat, uint64_t i, uint64_t d) {
+    return lat->fwd[i * lat->n_neighbors + d];
+}
+uint64_t orc_lattice_neighbor_bwd(const orc_lattice *lat, uint64_t i, uint64_t d) {
+    return lat->bwd[i * lat->n_neighbors + d];
+}
+
+/* ========================================================================== */
+/* Metropolis acceptance table                                                */
+/* ========================================================================== */
+
+#define F32_UNIFORM_BITS 24
+#define F32_UNIFORM_VALUES (1u << F32_UNIFORM_BITS)
+
+/* ss/mcmc/sweep.rs:155-159 */
+int orc_lookup_legacy_accepts(float temperature, int32_t energy_change, uint32_t draw) {
+    float uniform = (float)draw / (float)F32_UNIFORM_VALUES;
+    return (float)energy_change >= (temperature / 2.0f) * logf(uniform);
+}
+
+/* ss/mcmc/sweep.rs:141-153 */
+uint32_t orc_lookup_accepted_count(float temperature, int32_t energy_change) {
+    uint32_t low = 0, high = F32_UNIFORM_VALUES;
+    while (low < high) {
+        uint32_t midpoint = low + (high - low) / 2;
+        if (orc_lookup_legacy_accepts(temperature, energy_change, midpoint))
+            low = midpoint + 1;
+        else
+            high = midpoint;
+    }
+    return low;
+}
+
+/* ss/mcmc/sweep.rs:109-139: fail closed unless every coupling is -1/0/+1 and
+ * every temperature is finite with T/2 > 0. */
+orc_lookup *orc_lookup_new(const float *couplings, size_t n_couplings, const float *temperatures,
+                           size_t n_temperatures, size_t n_neighbors) {
+    for (size_t i = 0; i < n_couplings; ++i) {
+        float c = couplings[i];
+        if (!(c == -1.0f || c == 0.0f || c == 1.0f)) return NULL;
+    }
+    for (size_t i = 0; i < n_temperatures; ++i) {
+        float t = temperatures[i];
+        if (!(isfinite(t) && t / 2.0f > 0.0f)) return NULL;
+    }
+    size_t offset = n_neighbors * 2;
+    if (offset > F32_UNIFORM_VALUES) return NULL;
+    orc_lookup *lookup = (orc_lookup *)calloc(1, sizeof(*lookup));
+    lookup->offset = (int32_t)offset;
+    lookup->table_width = offset * 2 + 1;
+    lookup->n_rows = n_temperatures;
+    lookup->accepted_counts =
+        (uint32_t *)malloc(sizeof(uint32_t) * (n_temperatures * lookup->table_width + 1));
+    size_t k = 0;
+    for (size_t t = 0; t < n_temperatures; ++t)
+        for (int32_t e = -lookup->offset; e <= lookup->offset; ++e)
+            lookup->accepted_counts[k++] = orc_lookup_accepted_count(temperatures[t], e);
+    return lookup;
+}
+
+void orc_lookup_free(orc_lookup *lookup) {
+    if (!lookup) return;
+    free(lookup->accepted_counts);
+    free(lookup);
+}
+
+/* ss/mcmc/sweep.rs:161-166 */
+uint32_t orc_lookup_get(const orc_lookup *lookup, size_t temperature_id, int32_t energy_change) {
+    int32_t idx = energy_change + lookup->offset;
+    if (idx < 0 || (size_t)idx >= lookup->table_width) {
+        fprintf(stderr, "oracle: unit coupling energy change is out of range\n");
+        abort();
+    }
+    return lookup->accepted_counts[temperature_id * lookup->table_width + (size_t)idx];
+}
+
+/* ========================================================================== */
+/* Single-spin sweeps                                                         */
+/* ========================================================================== */
+
+/* ss/mcmc/sweep.rs:8-19.  The canonical-2D interior specialisation (:22-32)
+ * adds the same four terms in the same order, so it is arithmetic-identical
+ * (the reference's own test :293-343 asserts that); one path restates both. */
+static inline float local_field(const orc_lattice *lat, const int8_t *spin_slice,
+                                const float *couplings, size_t i) {
+    size_t nn = lat->n_neighbors;
+    float h = 0.0f;
+    for (size_t d = 0; d < nn; ++d) {
+        size_t j_fwd = lat->fwd[i * nn + d];
+        h += (float)spin_slice[j_fwd] * couplings[i * nn + d];
+        size_t j_bwd = lat->bwd[i * nn + d];
+        h += (float)spin_slice[j_bwd] * couplings[j_bwd * nn + d];
+    }
+    return h;
+}
+
+/* ss/mcmc/sweep.rs:220-258 via ss/parallel.rs:15-41 (slot -> system spin slice,
+ * system RNG, slot temperature / table row) and sweep_sites :51-97 (sites
+ * 0..N-1 in order, one draw per site). */
+void orc_metropolis_sweep(const orc_lattice *lat, int8_t *spins, const float *couplings,
+                          const float *temperatures, const uint64_t *system_ids, size_t n_slots,
+                          orc_rng *rngs, const orc_lookup *lookup) {
+    size_t n = lat->n_spins;
+    for (size_t slot = 0; slot < n_slots; ++slot) {
+        size_t system_id = (size_t)system_ids[slot];
+        int8_t *spin_slice = spins + system_id * n;
+        orc_rng *rng = &rngs[system_id];
+        float temp = temperatures[slot];
+        if (lookup) {
+            /* attempt_flip_lookup, sweep.rs:170-185 */
+            for (size_t i = 0; i < n; ++i) {
+                float h = local_field(lat, spin_slice, couplings, i);
+                int32_t energy_change = (int32_t)((float)(-spin_slice[i]) * h);
+                uint32_t draw = orc_rng_next_u32(rng) >> (32 - F32_UNIFORM_BITS);
+                if (draw < orc_lookup_get(lookup, slot, energy_change)) spin_slice[i] = -spin_slice[i];
+            }
+        } else {
+            /* attempt_flip with the log threshold, sweep.rs:35-48,256 */
+            for (size_t i = 0; i < n; ++i) {
+                float h = local_field(lat, spin_slice, couplings, i);
+                float si = (float)spin_slice[i];
+                float eng_change = -si * h;
+                float threshold = (temp / 2.0f) * logf(orc_rng_gen_f32(rng));
+                if (eng_change >= threshold) spin_slice[i] = -spin_slice[i];
+            }
+        }
+    }
+}
+
+/* ss/mcmc/sweep.rs:262-284 */
+void orc_gibbs_sweep(const orc_lattice *lat, int8_t *spins, const float *couplings,
+                     const float *temperatures, const uint64_t *system_ids, size_t n_slots,
+                     orc_rng *rngs) {
+    size_t n = lat->n_spins;
+    for (size_t slot = 0; slot < n_slots; ++slot) {
+        size_t system_id = (size_t)system_ids[slot];
+        int8_t *spin_slice = spins + system_id * n;
+        orc_rng *rng = &rngs[system_id];
+        float temp = temperatures[slot];
+        for (size_t i = 0; i < n; ++i) {
+            float h = local_field(lat, spin_slice, couplings, i);
+            float si = (float)spin_slice[i];
+            float eng_change = -si * h;
+            float u = orc_rng_gen_f32(rng);
+            float threshold = (temp / 2.0f) * logf(u / (1.0f - u));
+            if (eng_change >= threshold) spin_slice[i] = -spin_slice[i];
+        }
+    }
+}
+
+/* ========================================================================== */
+/* Energies                                                                   */
+/* ========================================================================== */
+
+/* ss/spins/energy.rs:78-110: sequential f32 accumulation over (i, d); E/N;
+ * magnetisation sums as i64; optional per-bond interactions (:14-40). */
+void orc_compute_energies(const orc_lattice *lat, const int8_t *spins, const float *couplings,
+                          size_t n_systems, float *energies, int64_t *magnetization_sums,
+                          float *interactions) {
+    size_t n = lat->n_spins, nn = lat->n_neighbors;
+    for (size_t r = 0; r < n_systems; ++r) {
+        size_t base = r * n;
+        float total = 0.0f;
+        int64_t mag = 0;
+        for (size_t i = 0; i < n; ++i) {
+            int8_t spin = spins[base + i];
+            mag += spin;
+            float si = (float)spin;
+            for (size_t d = 0; d < nn; ++d) {
+                size_t j = lat->fwd[i * nn + d];
+                float sj = (float)spins[base + j];
+                float c = couplings[i * nn + d];
+                float interaction = si * sj * c;
+                if (interactions) interactions[(r * n + i) * nn + d] = interaction;
+                total += interaction;
+            }
+        }
+        energies[r] = total / (float)n;
+        if (magnetization_sums) magnetization_sums[r] = mag;
+    }
+}
+
+/* ========================================================================== */
+/* Parallel tempering                                                         */
+/* ========================================================================== */
+
+/* ss/mcmc/tempering.rs:73-102 */
+static orc_tempering_attempt attempt_edge(const float *energies, const float *temperatures,
+                                          uint64_t *system_ids, size_t n_spins, orc_rng *rng,
+                                          size_t temp_id) {
+    float temp_1 = temperatures[temp_id];
+    float temp_2 = temperatures[temp_id + 1];
+    float energy_1 = energies[system_ids[temp_id]];
+    float energy_2 = energies[system_ids[temp_id + 1]];
+    orc_tempering_attempt attempt;
+    attempt.edge = temp_id;
+    attempt.left_system = system_ids[temp_id];
+    attempt.right_system = system_ids[temp_id + 1];
+
+    float delta = (float)n_spins * (energy_2 - energy_1) * (1.0f / temp_1 - 1.0f / temp_2);
+    float log_rand = logf(orc_rng_gen_f32(rng));
+    attempt.accepted = delta >= log_rand;
+    if (attempt.accepted) {
+        uint64_t tmp = system_ids[temp_id];
+        system_ids[temp_id] = system_ids[temp_id + 1];
+        system_ids[temp_id + 1] = tmp;
+    }
+    return attempt;
+}
+
+/* ss/mcmc/tempering.rs:20-42 */
+size_t orc_parallel_tempering(const float *energies, const float *temperatures,
+                              uint64_t *system_ids, size_t n_temps, size_t n_spins, orc_rng *rng,
+                              orc_tempering_attempt *attempts) {
+    if (n_temps < 2) return 0;
+    size_t temp_id = (size_t)orc_rng_gen_range_usize(rng, 0, n_temps - 1);
+    attempts[0] = attempt_edge(energies, temperatures, system_ids, n_spins, rng, temp_id);
+    return 1;
+}
+
+/* ss/mcmc/tempering.rs:45-71 */
+size_t orc_parallel_tempering_full_ladder(const float *energies, const float *temperatures,
+                                          uint64_t *system_ids, size_t n_temps, size_t n_spins,
+                                          orc_rng *rng, size_t first_parity,
+                                          orc_tempering_attempt *attempts) {
+    if (n_temps < 2) return 0;
+    size_t count = 0;
+    size_t parities[2] = {first_parity, 1 - first_parity};
+    for (int p = 0; p < 2; ++p)
+        for (size_t edge = parities[p]; edge < n_temps - 1; edge += 2)
+            attempts[count++] = attempt_edge(energies, temperatures, system_ids, n_spins, rng, edge);
+    return count;
+}
+
+/* ========================================================================== */
+/* Union-find / DFS helpers                                                   */
+/* ========================================================================== */
+
+/* ss/clusters/utils.rs:68-74 (path halving) */
+uint32_t orc_uf_find(uint32_t *parent, uint32_t x) {
+    while (parent[x] != x) {
+        parent[x] = parent[parent[x]];
+        x = parent[x];
+    }
+    return x;
+}
+
+/* ss/clusters/utils.rs:77-91 (union by rank) */
+void orc_uf_union(uint32_t *parent, uint8_t *rank, uint32_t x, uint32_t y) {
+    uint32_t rx = orc_uf_find(parent, x), ry = orc_uf_find(parent, y);
+    if (rx == ry) return;
+    if (rank[rx] < rank[ry]) {
+        parent[rx] = ry;
+    } else {
+        parent[ry] = rx;
+        if (rank[rx] == rank[ry]) rank[rx] += 1;
+    }
+}
+
+/* ss/clusters/utils.rs:283-293 + :260-281 (flatten, count per root) */
+static void uf_flatten_counts(uint32_t *parent, size_t n, uint32_t *counts) {
+    for (size_t i = 0; i < n; ++i) parent[i] = orc_uf_find(parent, (uint32_t)i);
+    memset(counts, 0, sizeof(uint32_t) * n);
+    for (size_t i = 0; i < n; ++i) counts[parent[i]] += 1;
+}
+
+void orc_uf_from_bonds(const orc_lattice *lat, const uint64_t *bond_sites, const uint64_t *bond_dims,
+                       size_t n_bonds, uint32_t *parent, uint32_t *counts) {
+    size_t n = lat->n_spins;
+    uint8_t *rank = (uint8_t *)calloc(n, 1);
+    for (size_t i = 0; i < n; ++i) parent[i] = (uint32_t)i;
+    /* activate_bonds visits (site, dim) in ascending order, utils.rs:219-236 */
+    for (size_t i = 0; i < n; ++i)
+        for (size_t d = 0; d < lat->n_neighbors; ++d)
+            for (size_t b = 0; b < n_bonds; ++b)
+                if (bond_sites[b] == i && bond_dims[b] == d)
+                    orc_uf_union(parent, rank, (uint32_t)i, lat->fwd[i * lat->n_neighbors + d]);
+    uf_flatten_counts(parent, n, counts);
+    free(rank);
+}
+
+/* ss/clusters/utils.rs:297-303 */
+void orc_uf_histogram(const uint32_t *counts, size_t n, uint64_t *hist) {
+    for (size_t i = 0; i < n; ++i)
+        if (counts[i] > 0) hist[counts[i]] += 1;
+}
+
+/* ss/clusters/utils.rs:305-316 */
+void orc_top4_sizes(const uint32_t *counts, size_t n, uint32_t out[4]) {
+    uint32_t top[4] = {0, 0, 0, 0}; /* ascending */
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t c = counts[i];
+        if (c > top[0]) {
+            top[0] = c;
+            for (int a = 1; a < 4; ++a) /* insertion sort of 4 == sort_unstable result */
+                for (int b = a; b > 0 && top[b - 1] > top[b]; --b) {
+                    uint32_t t = top[b];
+                    top[b] = top[b - 1];
+                    top[b - 1] = t;
+                }
+        }
+    }
+    out[0] = top[3];
+    out[1] = top[2];
+    out[2] = top[1];
+    out[3] = top[0];
+}
+
+/* ========================================================================== */
+/* Realisation state                                                          */
+/* ========================================================================== */
+
+/* ss/simulation/realization.rs:21-29 */
+typedef struct {
+    uint64_t *edge_attempts;
+    uint64_t *edge_acceptances;
+    uint64_t *round_trips;
+    uint8_t *trip_state;
+    size_t next_parity;
+    size_t cold_slot;
+    size_t hot_slot;
+} pt_state;
+
+/* ss/simulation/realization.rs:132-149 */
+typedef struct {
+    float *couplings;
+    int8_t *spins;
+    float *temperatures;
+    uint64_t *system_ids;
+    orc_rng *rngs;
+    orc_rng *pair_rngs;
+    pt_state pt;
+    float *energies;
+} realization;
+
+/* statistics/stats.rs:2-35 */
+typedef struct {
+    size_t count;
+    double *aggregate;
+    uint32_t power;
+} statistics;
+
+/* SweepResult fields on the path (statistics/results.rs:56-77, overlap.rs:8-39) */
+typedef struct {
+    double *moments;      /* [5][n_temps] mags, mags2, mags4, energies, energies2 */
+    double *overlap;      /* [6][n_temps] q, q2, q4, ql, ql2, ql4 (NULL if n_pairs == 0) */
+    uint64_t *histogram;  /* [n_temps][N+1] */
+    double *ql_at_q_sum;  /* [n_temps][N+1] */
+    double *ql2_at_q_sum; /* [n_temps][N+1] */
+} sweep_result;
+
+struct orc_sim {
+    orc_lattice *lattice;
+    size_t n_replicas, n_temps, n_realizations;
+    uint64_t constructor_seed;
+    realization *realizations;
+    sweep_result *results;
+    char error[256];
+};
+
+/* ss/simulation/realization.rs:92-107 */
+static void extreme_temperature_slots(const float *temperatures, size_t n_temps, size_t *cold,
+                                      size_t *hot) {
+    *cold = 0;
+    *hot = 0;
+    for (size_t slot = 1; slot < n_temps; ++slot) {
+        if (temperatures[slot] < temperatures[*cold]) *cold = slot;
+        if (temperatures[slot] > temperatures[*hot]) *hot = slot;
+    }
+}
+
+/* ss/simulation/realization.rs:46-71 */
+static void pt_reset(pt_state *pt, size_t n_replicas, size_t n_temps, const uint64_t *system_ids,
+                     const float *temperatures) {
+    size_t n_edges = n_temps > 0 ? n_temps - 1 : 0;
+    memset(pt->edge_attempts, 0, sizeof(uint64_t) * (n_edges + 1));
+    memset(pt->edge_acceptances, 0, sizeof(uint64_t) * (n_edges + 1));
+    memset(pt->round_trips, 0, sizeof(uint64_t) * n_replicas * n_temps);
+    memset(pt->trip_state, 0, n_replicas * n_temps);
+    pt->next_parity = 0;
+    extreme_temperature_slots(temperatures, n_temps, &pt->cold_slot, &pt->hot_slot);
+    if (n_temps == 0) return;
+    for (size_t replica = 0; replica < n_replicas; ++replica)
+        pt->trip_state[system_ids[replica * n_temps + pt->hot_slot]] = 1;
+}
+
+/* ss/simulation/realization.rs:109-120 */
+static void pt_record_arrival(pt_state *pt, size_t system, size_t slot) {
+    if (slot == pt->hot_slot) {
+        if (pt->trip_state[system] == 2) pt->round_trips[system] += 1;
+        pt->trip_state[system] = 1;
+        return;
+    }
+    if (slot == pt->cold_slot && pt->trip_state[system] == 1) pt->trip_state[system] = 2;
+}
+
+/* ss/simulation/realization.rs:73-82 */
+static void pt_record_attempt(pt_state *pt, orc_tempering_attempt attempt) {
+    pt->edge_attempts[attempt.edge] += 1;
+    if (!attempt.accepted) return;
+    pt->edge_acceptances[attempt.edge] += 1;
+    pt_record_arrival(pt, (size_t)attempt.left_system, (size_t)attempt.edge + 1);
+    pt_record_arrival(pt, (size_t)attempt.right_system, (size_t)attempt.edge);
+}
+
+/* Replays a list of attempts through PtState (realization.rs:46-120) starting
+ * from the identity permutation; used to pin the round-trip bookkeeping on the
+ * reference's own test (realization.rs:285-302). */
+void orc_pt_replay(size_t n_replicas, size_t n_temps, const float *temps,
+                   const orc_tempering_attempt *attempts, size_t n_attempts,
+                   uint64_t *edge_attempts, uint64_t *edge_acceptances, uint64_t *round_trips) {
+    size_t n_systems = n_replicas * n_temps;
+    pt_state pt;
+    pt.edge_attempts = (uint64_t *)calloc(n_temps + 1, sizeof(uint64_t));
+    pt.edge_acceptances = (uint64_t *)calloc(n_temps + 1, sizeof(uint64_t));
+    pt.round_trips = (uint64_t *)calloc(n_systems + 1, sizeof(uint64_t));
+    pt.trip_state = (uint8_t *)calloc(n_systems + 1, 1);
+    uint64_t *system_ids = (uint64_t *)malloc(sizeof(uint64_t) * (n_systems + 1));
+    float *temperatures = (float *)malloc(sizeof(float) * (n_systems + 1));
+    for (size_t i = 0; i < n_systems; ++i) {
+        system_ids[i] = i;
+        temperatures[i] = temps[i % n_temps];
+    }
+    pt_reset(&pt, n_replicas, n_temps, system_ids, temperatures);
+    for (size_t a = 0; a < n_attempts; ++a) pt_record_attempt(&pt, attempts[a]);
+    size_t n_edges = n_temps > 0 ? n_temps - 1 : 0;
+    memcpy(edge_attempts, pt.edge_attempts, sizeof(uint64_t) * n_edges);
+    memcpy(edge_acceptances, pt.edge_acceptances, sizeof(uint64_t) * n_edges);
+    memcpy(round_trips, pt.round_trips, sizeof(uint64_t) * n_systems);
+    free(pt.edge_attempts);
+    free(pt.edge_acceptances);
+    free(pt.round_trips);
+    free(pt.trip_state);
+    free(system_ids);
+    free(temperatures);
+}
+
+/* ss/simulation/realization.rs:213-246 (reset); new() :155-211 does the same
+ * after allocating, so both go through here. */
+static void realization_reset(const orc_lattice *lat, realization *real, size_t n_replicas,
+                              size_t n_temps, uint64_t base_seed) {
+    size_t n = lat->n_spins, n_systems = n_replicas * n_temps;
+    for (size_t i = 0; i < n_systems; ++i) {
+        orc_rng_seed_from_u64(&real->rngs[i], orc_child_seed(base_seed, ORC_SYSTEM_SEED_DOMAIN, i));
+        for (size_t j = 0; j < n; ++j)
+            real->spins[i * n + j] = orc_rng_gen_f32(&real->rngs[i]) < 0.5f ? -1 : 1;
+    }
+    for (size_t i = 0; i < n_systems; ++i) real->system_ids[i] = i;
+    size_t n_pairs = n_replicas / 2;
+    for (size_t i = 0; i < n_temps * n_pairs; ++i)
+        orc_rng_seed_from_u64(&real->pair_rngs[i], orc_child_seed(base_seed, ORC_PAIR_SEED_DOMAIN, i));
+    orc_compute_energies(lat, real->spins, real->couplings, n_systems, real->energies, NULL, NULL);
+    pt_reset(&real->pt, n_replicas, n_temps, real->system_ids, real->temperatures);
+}
+
+static void realization_alloc(const orc_lattice *lat, realization *real, const float *couplings,
+                              const float *temps, size_t n_replicas, size_t n_temps) {
+    size_t n = lat->n_spins, nn = lat->n_neighbors, n_systems = n_replicas * n_temps;
+    real->couplings = (float *)malloc(sizeof(float) * (n * nn + 1));
+    memcpy(real->couplings, couplings, sizeof(float) * n * nn);
+    real->spins = (int8_t *)malloc(n_systems * n + 1);
+    real->temperatures = (float *)malloc(sizeof(float) * (n_systems + 1));
+    for (size_t r = 0; r < n_replicas; ++r) /* temps.repeat(n_replicas), realization.rs:166 */
+        memcpy(real->temperatures + r * n_temps, temps, sizeof(float) * n_temps);
+    real->system_ids = (uint64_t *)malloc(sizeof(uint64_t) * (n_systems + 1));
+    real->rngs = (orc_rng *)malloc(sizeof(orc_rng) * (n_systems + 1));
+    real->pair_rngs = (orc_rng *)malloc(sizeof(orc_rng) * (n_temps * (n_replicas / 2) + 1));
+    real->energies = (float *)malloc(sizeof(float) * (n_systems + 1));
+    real->pt.edge_attempts = (uint64_t *)calloc(n_temps + 1, sizeof(uint64_t));
+    real->pt.edge_acceptances = (uint64_t *)calloc(n_temps + 1, sizeof(uint64_t));
+    real->pt.round_trips = (uint64_t *)calloc(n_systems + 1, sizeof(uint64_t));
+    real->pt.trip_state = (uint8_t *)calloc(n_systems + 1, 1);
+}
+
+static void realization_free(realization *real) {
+    free(real->couplings);
+    free(real->spins);
+    free(real->temperatures);
+    free(real->system_ids);
+    free(real->rngs);
+    free(real->pair_rngs);
+    free(real->energies);
+    free(real->pt.edge_attempts);
+    free(real->pt.edge_acceptances);
+    free(real->pt.round_trips);
+    free(real->pt.trip_state);
+}
+
+/* ========================================================================== */
+/* Statistics                                                                 */
+/* ========================================================================== */
+
+static void stat_init(statistics *st, size_t n_temps, uint32_t power) {
+    st->count = 0;
+    st->aggregate = (double *)calloc(n_temps + 1, sizeof(double));
+    st->power = power;
+}
+
+/* statistics/stats.rs:17-27; powi(2) of an f64 is the exact product v*v. */
+static void stat_update(statistics *st, const float *values, size_t n_temps) {
+    st->count += 1;
+    for (size_t t = 0; t < n_temps; ++t) {
+        double v = (double)values[t];
+        st->aggregate[t] += (st->power == 1) ? v : v * v;
+    }
+}
+
+/* statistics/stats.rs:29-35 */
+static void stat_average(const statistics *st, double *out, size_t n_temps) {
+    if (st->count == 0) {
+        memcpy(out, st->aggregate, sizeof(double) * n_temps);
+        return;
+    }
+    double c = (double)st->count;
+    for (size_t t = 0; t < n_temps; ++t) out[t] = st->aggregate[t] / c;
+}
+
+/* ========================================================================== */
+/* Overlap-cluster moves (Houdayer group_size 2, Joerg)                        */
+/* ========================================================================== */
+
+/* ss/clusters/utils.rs:107-119 */
+static int64_t find_seed(size_t n_spins, orc_rng *rng, const int8_t *a, const int8_t *b, int joerg) {
+    for (int probe = 0; probe < 64; ++probe) {
+        size_t i = (size_t)orc_rng_gen_range_usize(rng, 0, n_spins);
+        int active = joerg ? (a[i] != b[i]) : ((int)a[i] + (int)b[i] == 0);
+        if (active) return (int64_t)i;
+    }
+    return -1;
+}
+
+/* ss/clusters/overlap.rs:35-56 (build_tasks), :153-339 (houdayer_step, group
+ * size 2) and :348-553 (jorg_step); Wolff variant = find_seed + dfs_cluster
+ * (utils.rs:125-149), SW variant = uf_bonds + per-root coin in discovery order.
+ * Update action only; observers/CSD/snapshots are out of scope. */
+static void overlap_update(const orc_lattice *lat, realization *real, size_t n_replicas,
+                           size_t n_temps, int mode, int cluster_mode) {
+    size_t n = lat->n_spins, nn = lat->n_neighbors;
+    size_t n_pairs = n_replicas / 2, group_size = 2, n_groups = n_replicas / group_size;
+    int joerg = (mode == ORC_OC_JORG);
+    uint64_t *systems = (uint64_t *)malloc(sizeof(uint64_t) * (n_temps * n_replicas + 1));
+    for (size_t t = 0; t < n_temps; ++t) {
+        for (size_t k = 0; k < n_replicas; ++k)
+            systems[t * n_replicas + k] = real->system_ids[k * n_temps + t];
+        orc_rng_shuffle_usize(&real->pair_rngs[t * n_pairs], systems + t * n_replicas, n_replicas);
+    }
+    uint8_t *in_cluster = (uint8_t *)malloc(n + 1);
+    size_t *stack = (size_t *)malloc(sizeof(size_t) * (n + 1));
+    uint32_t *parent = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
+    uint32_t *counts = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
+    uint8_t *rank = (uint8_t *)malloc(n + 1);
+
+    for (size_t task = 0; task < n_temps * n_groups; ++task) {
+        size_t t = task / n_groups, g = task % n_groups;
+        const uint64_t *grp = systems + t * n_replicas + g * group_size;
+        orc_rng *rng = &real->pair_rngs[t * n_pairs + g];
+        float temp = real->temperatures[t];
+        int8_t *a = real->spins + (size_t)grp[0] * n;
+        int8_t *b = real->spins + (size_t)grp[1] * n;
+#define ACTIVE(i) (joerg ? (a[i] != b[i]) : ((int)a[i] + (int)b[i] == 0))
+        if (cluster_mode == ORC_CLUSTER_WOLFF) {
+            int64_t seed = find_seed(n, rng, a, b, joerg);
+            if (seed < 0) continue;
+            memset(in_cluster, 0, n);
+            size_t top = 0;
+            in_cluster[seed] = 1;
+            stack[top++] = (size_t)seed;
+            while (top > 0) {
+                size_t site = stack[--top];
+                for (size_t d = 0; d < nn; ++d) {
+                    for (int dir = 0; dir < 2; ++dir) {
+                        size_t nb = dir == 0 ? lat->fwd[site * nn + d] : lat->bwd[site * nn + d];
+                        if (in_cluster[nb]) continue;
+                        int add;
+                        if (!joerg) {
+                            add = ACTIVE(site) && ACTIVE(nb);
+                        } else {
+                            add = 0;
+                            if (ACTIVE(nb)) {
+                                float coupling = dir == 0 ? real->couplings[site * nn + d]
+                                                          : real->couplings[nb * nn + d];
+                                float inter = (float)a[site] * (float)a[nb] * coupling;
+                                if (inter > 0.0f)
+                                    add = orc_rng_gen_f32(rng) < 1.0f - expf(-4.0f * inter / temp);
+                            }
+                        }
+                        if (add) {
+                            in_cluster[nb] = 1;
+                            stack[top++] = nb;
+                        }
+                    }
+                }
+            }
+            for (size_t i = 0; i < n; ++i)
+                if (in_cluster[i]) {
+                    a[i] = (int8_t)-a[i];
+                    b[i] = (int8_t)-b[i];
+                }
+        } else {
+            for (size_t i = 0; i < n; ++i) parent[i] = (uint32_t)i;
+            memset(rank, 0, n);
+            for (size_t i = 0; i < n; ++i)
+                for (size_t d = 0; d < nn; ++d) {
+                    size_t j = lat->fwd[i * nn + d];
+                    int bond = 0;
+                    if (ACTIVE(i) && ACTIVE(j)) {
+                        if (!joerg) {
+                            bond = 1;
+                        } else {
+                            float inter = (float)a[i] * (float)a[j] * real->couplings[i * nn + d];
+                            if (inter > 0.0f)
+                                bond = orc_rng_gen_f32(rng) < 1.0f - expf(-4.0f * inter / temp);
+                        }
+                    }
+                    if (bond) orc_uf_union(parent, rank, (uint32_t)i, (uint32_t)j);
+                }
+            uf_flatten_counts(parent, n, counts);
+            memset(rank, 0xFF, n);
+            for (size_t i = 0; i < n; ++i) {
+                uint32_t root = parent[i];
+                if (counts[root] > 1 && rank[root] == 0xFF)
+                    rank[root] = (uint8_t)(orc_rng_gen_f32(rng) < 0.5f);
+            }
+            for (size_t i = 0; i < n; ++i)
+                if (rank[parent[i]] == 1) {
+                    a[i] = (int8_t)-a[i];
+                    b[i] = (int8_t)-b[i];
+                }
+        }
+#undef ACTIVE
+    }
+    free(systems);
+    free(in_cluster);
+    free(stack);
+    free(parent);
+    free(counts);
+    free(rank);
+}
+
+/* ========================================================================== */
+/* Driver loop                                                                */
+/* ========================================================================== */
+
+static void result_alloc(sweep_result *res, size_t n_temps, size_t n_spins, size_t n_pairs) {
+    memset(res, 0, sizeof(*res));
+    res->moments = (double *)calloc(5 * n_temps + 1, sizeof(double));
+    if (n_pairs > 0) {
+        res->overlap = (double *)calloc(6 * n_temps + 1, sizeof(double));
+        res->histogram = (uint64_t *)calloc(n_temps * (n_spins + 1) + 1, sizeof(uint64_t));
+        res->ql_at_q_sum = (double *)calloc(n_temps * (n_spins + 1) + 1, sizeof(double));
+        res->ql2_at_q_sum = (double *)calloc(n_temps * (n_spins + 1) + 1, sizeof(double));
+    }
+}
+
+static void result_free(sweep_result *res) {
+    free(res->moments);
+    free(res->overlap);
+    free(res->histogram);
+    free(res->ql_at_q_sum);
+    free(res->ql2_at_q_sum);
+    memset(res, 0, sizeof(*res));
+}
+
+/* ss/config.rs:180-247 (the checks that apply to the options on the path). */
+static const char *validate_config(const orc_config *cfg) {
+    if (cfg->n_sweeps < 1) return "n_sweeps must be >= 1";
+    if (cfg->warmup_sweeps > cfg->n_sweeps) return "warmup_sweeps must be <= n_sweeps";
+    if (cfg->overlap_cluster_interval > 0 && cfg->n_overlap_cluster_modes < 1)
+        return "overlap_cluster modes must not be empty";
+    return NULL;
+}
+
+/* ss/simulation/mod.rs:177-858, restricted to the options on the path:
+ * sweep -> [energies(+mags)] -> [overlap collect] -> [stats] -> [overlap
+ * cluster move] -> [parallel tempering]. */
+static void run_sweep_loop(const orc_lattice *lat, realization *real, size_t n_replicas,
+                           size_t n_temps, const orc_config *cfg, sweep_result *res) {
+    size_t n = lat->n_spins, nn = lat->n_neighbors;
+    size_t n_systems = n_replicas * n_temps, n_pairs = n_replicas / 2;
+    size_t n_bonds = n * nn;
+
+    /* mod.rs:190-198 */
+    orc_lookup *lookup = NULL;
+    if (cfg->sweep_mode == ORC_SWEEP_METROPOLIS)
+        lookup = orc_lookup_new(real->couplings, n * nn, real->temperatures, n_systems, nn);
+
+    statistics mags, mags2, mags4, energies, energies2; /* mod.rs:337-341 */
+    stat_init(&mags, n_temps, 1);
+    stat_init(&mags2, n_temps, 1);
+    stat_init(&mags4, n_temps, 1);
+    stat_init(&energies, n_temps, 1);
+    stat_init(&energies2, n_temps, 2);
+    statistics ov[6]; /* overlap.rs:216-221 */
+    for (int k = 0; k < 6; ++k) stat_init(&ov[k], n_temps, 1);
+
+    float *mags_buf = (float *)calloc(n_temps + 1, sizeof(float));
+    float *mags2_buf = (float *)calloc(n_temps + 1, sizeof(float));
+    float *mags4_buf = (float *)calloc(n_temps + 1, sizeof(float));
+    float *energies_buf = (float *)calloc(n_temps + 1, sizeof(float));
+    float *ovbuf = (float *)calloc(6 * n_temps + 1, sizeof(float));
+    int64_t *magnetization_sums = (int64_t *)calloc(n_systems + 1, sizeof(int64_t));
+    orc_tempering_attempt *attempts =
+        (orc_tempering_attempt *)malloc(sizeof(orc_tempering_attempt) * (n_temps + 1));
+    size_t overlap_call_count = 0;
+
+    for (uint64_t sweep_id = 0; sweep_id < cfg->n_sweeps; ++sweep_id) {
+        int record = sweep_id >= cfg->warmup_sweeps; /* mod.rs:410 */
+
+        if (cfg->sweep_mode == ORC_SWEEP_METROPOLIS) /* mod.rs:412-432 */
+            orc_metropolis_sweep(lat, real->spins, real->couplings, real->temperatures,
+                                 real->system_ids, n_systems, real->rngs, lookup);
+        else
+            orc_gibbs_sweep(lat, real->spins, real->couplings, real->temperatures, real->system_ids,
+                            n_systems, real->rngs);
+
+        int pt_this_sweep = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0; /* :486-488 */
+
+        if (record || pt_this_sweep) /* mod.rs:492-509 */
+            orc_compute_energies(lat, real->spins, real->couplings, n_systems, real->energies,
+                                 record ? magnetization_sums : NULL, NULL);
+
+        if (record && n_pairs > 0) { /* mod.rs:527-529 -> overlap.rs:251-333 */
+            for (size_t pair_idx = 0; pair_idx < n_pairs; ++pair_idx) {
+                size_t r_a = 2 * pair_idx, r_b = 2 * pair_idx + 1;
+                for (size_t t = 0; t < n_temps; ++t) {
+                    size_t base_a = (size_t)real->system_ids[r_a * n_temps + t] * n;
+                    size_t base_b = (size_t)real->system_ids[r_b * n_temps + t] * n;
+                    int64_t dot_spin = 0, dot_link = 0;
+                    for (size_t j = 0; j < n; ++j) {
+                        int64_t q = (int64_t)real->spins[base_a + j] * (int64_t)real->spins[base_b + j];
+                        dot_spin += q;
+                        for (size_t d = 0; d < nn; ++d) {
+                            size_t k = lat->fwd[j * nn + d];
+                            int64_t neighbor_q =
+                                (int64_t)real->spins[base_a + k] * (int64_t)real->spins[base_b + k];
+                            dot_link += q * neighbor_q;
+                        }
+                    }
+                    float ql = (float)dot_link / (float)n_bonds;
+                    float q = (float)dot_spin / (float)n;
+                    float q2 = q * q;
+                    ovbuf[0 * n_temps + t] = q;
+                    ovbuf[1 * n_temps + t] = q2;
+                    ovbuf[2 * n_temps + t] = q2 * q2;
+                    float ql2 = ql * ql;
+                    ovbuf[3 * n_temps + t] = ql;
+                    ovbuf[4 * n_temps + t] = ql2;
+                    ovbuf[5 * n_temps + t] = ql2 * ql2;
+                    size_t idx = (size_t)((dot_spin + (int64_t)n) / 2);
+                    res->histogram[t * (n + 1) + idx] += 1;
+                    res->ql_at_q_sum[t * (n + 1) + idx] += (double)ql;
+                    res->ql2_at_q_sum[t * (n + 1) + idx] += (double)(ql * ql);
+                }
+                for (int k = 0; k < 6; ++k) stat_update(&ov[k], ovbuf + k * n_temps, n_temps);
+            }
+        }
+
+        if (record) { /* mod.rs:543-578 */
+            for (size_t r = 0; r < n_replicas; ++r) {
+                size_t offset = r * n_temps;
+                for (size_t t = 0; t < n_temps; ++t) {
+                    size_t system_id = (size_t)real->system_ids[offset + t];
+                    float mag = (float)magnetization_sums[system_id] / (float)n;
+                    float m2 = mag * mag;
+                    mags_buf[t] = mag;
+                    mags2_buf[t] = m2;
+                    mags4_buf[t] = m2 * m2;
+                    energies_buf[t] = real->energies[system_id];
+                }
+                stat_update(&mags, mags_buf, n_temps);
+                stat_update(&mags2, mags2_buf, n_temps);
+                stat_update(&mags4, mags4_buf, n_temps);
+                stat_update(&energies, energies_buf, n_temps);
+                stat_update(&energies2, energies_buf, n_temps);
+            }
+        }
+
+        int did_overlap_mutate = 0; /* mod.rs:597-746 */
+        if (cfg->overlap_cluster_interval > 0 && sweep_id % cfg->overlap_cluster_interval == 0) {
+            did_overlap_mutate = 1;
+            int mode = cfg->overlap_cluster_modes[overlap_call_count %
+                                                  (size_t)cfg->n_overlap_cluster_modes];
+            overlap_update(lat, real, n_replicas, n_temps, mode, cfg->overlap_cluster_mode);
+            overlap_call_count += 1;
+        }
+
+        if (pt_this_sweep) { /* mod.rs:748-796 */
+            if (did_overlap_mutate)
+                orc_compute_energies(lat, real->spins, real->couplings, n_systems, real->energies,
+                                     NULL, NULL);
+            size_t first_parity = real->pt.next_parity;
+            for (size_t r = 0; r < n_replicas; ++r) {
+                size_t offset = r * n_temps;
+                size_t count;
+                if (cfg->pt_schedule == ORC_PT_SINGLE_RANDOM_EDGE)
+                    count = orc_parallel_tempering(real->energies, real->temperatures + offset,
+                                                   real->system_ids + offset, n_temps, n,
+                                                   &real->rngs[offset], attempts);
+                else
+                    count = orc_parallel_tempering_full_ladder(
+                        real->energies, real->temperatures + offset, real->system_ids + offset,
+                        n_temps, n, &real->rngs[offset], first_parity, attempts);
+                for (size_t a = 0; a < count; ++a) pt_record_attempt(&real->pt, attempts[a]);
+            }
+            if (cfg->pt_schedule == ORC_PT_FULL_LADDER) real->pt.next_parity = 1 - real->pt.next_parity;
+        }
+    }
+
+    /* mod.rs:838-857, overlap.rs:335-354 */
+    stat_average(&mags, res->moments + 0 * n_temps, n_temps);
+    stat_average(&mags2, res->moments + 1 * n_temps, n_temps);
+    stat_average(&mags4, res->moments + 2 * n_temps, n_temps);
+    stat_average(&energies, res->moments + 3 * n_temps, n_temps);
+    stat_average(&energies2, res->moments + 4 * n_temps, n_temps);
+    if (n_pairs > 0)
+        for (int k = 0; k < 6; ++k) stat_average(&ov[k], res->overlap + k * n_temps, n_temps);
+
+    free(mags.aggregate);
+    free(mags2.aggregate);
+    free(mags4.aggregate);
+    free(energies.aggregate);
+    free(energies2.aggregate);
+    for (int k = 0; k < 6; ++k) free(ov[k].aggregate);
+    free(mags_buf);
+    free(mags2_buf);
+    free(mags4_buf);
+    free(energies_buf);
+    free(ovbuf);
+    free(magnetization_sums);
+    free(attempts);
+    orc_lookup_free(lookup);
+}
+
+/* ========================================================================== */
+/* Simulation object (src/lib.rs IsingSimulation)                             */
+/* ========================================================================== */
+
+/* src/lib.rs:108-174 */
+orc_sim *orc_sim_create(const uint64_t *shape, int n_dims, const int64_t *offsets, size_t n_offsets,
+                        const float *couplings, size_t n_realizations, const float *temperatures,
+                        size_t n_temps, size_t n_replicas, uint64_t seed) {
+    orc_sim *sim = (orc_sim *)calloc(1, sizeof(*sim));
+    sim->lattice = (offsets && n_offsets > 0)
+                       ? orc_lattice_with_offsets(shape, n_dims, offsets, n_offsets)
+                       : orc_lattice_new(shape, n_dims);
+    if (!sim->lattice) {
+        free(sim);
+        return NULL;
+    }
+    sim->n_replicas = n_replicas;
+    sim->n_temps = n_temps;
+    sim->n_realizations = n_realizations;
+    sim->constructor_seed = seed;
+    sim->realizations = (realization *)calloc(n_realizations + 1, sizeof(realization));
+    sim->results = (sweep_result *)calloc(n_realizations + 1, sizeof(sweep_result));
+    size_t chunk = sim->lattice->n_spins * sim->lattice->n_neighbors;
+    for (size_t r = 0; r < n_realizations; ++r) {
+        realization_alloc(sim->lattice, &sim->realizations[r], couplings + r * chunk, temperatures,
+                          n_replicas, n_temps);
+        realization_reset(sim->lattice, &sim->realizations[r], n_replicas, n_temps,
+                          orc_realization_seed(seed, r));
+    }
+    return sim;
+}
+
+void orc_sim_destroy(orc_sim *sim) {
+    if (!sim) return;
+    for (size_t r = 0; r < sim->n_realizations; ++r) {
+        realization_free(&sim->realizations[r]);
+        result_free(&sim->results[r]);
+    }
+    free(sim->realizations);
+    free(sim->results);
+    orc_lattice_free(sim->lattice);
+    free(sim);
+}
+
+/* src/lib.rs:624-633 */
+void orc_sim_reset(orc_sim *sim, uint64_t seed) {
+    for (size_t r = 0; r < sim->n_realizations; ++r)
+        realization_reset(sim->lattice, &sim->realizations[r], sim->n_replicas, sim->n_temps,
+                          orc_realization_seed(seed, r));
+}
+
+typedef struct {
+    orc_sim *sim;
+    const orc_config *cfg;
+    size_t begin, end;
+} worker_args;
+
+static void *worker_main(void *p) {
+    worker_args *args = (worker_args *)p;
+    for (size_t r = args->begin; r < args->end; ++r)
+        run_sweep_loop(args->sim->lattice, &args->sim->realizations[r], args->sim->n_replicas,
+                       args->sim->n_temps, args->cfg, &args->sim->results[r]);
+    return NULL;
+}
+
+/* ss/simulation/mod.rs:865-939: realisations are independent (outer rayon
+ * level); here a static split over pthreads.  Aggregation over realisations
+ * (results.rs:84-285) is left to the caller, which receives per-realisation
+ * results in realisation order. */
+int orc_sim_sample(orc_sim *sim, const orc_config *cfg) {
+    const char *problem = validate_config(cfg);
+    if (!problem && cfg->overlap_cluster_interval > 0 && sim->n_replicas < 2)
+        problem = "overlap cluster requires n_replicas >= max group_size";
+    if (problem) {
+        snprintf(sim->error, sizeof(sim->error), "%s", problem);
+        return 1;
+    }
+    size_t n_pairs = sim->n_replicas / 2;
+    for (size_t r = 0; r < sim->n_realizations; ++r) {
+        result_free(&sim->results[r]);
+        result_alloc(&sim->results[r], sim->n_temps, sim->lattice->n_spins, n_pairs);
+    }
+    size_t n_threads = cfg->n_threads > 1 ? (size_t)cfg->n_threads : 1;
+    if (n_threads > sim->n_realizations) n_threads = sim->n_realizations;
+    if (n_threads <= 1) {
+        worker_args args = {sim, cfg, 0, sim->n_realizations};
+        worker_main(&args);
+        return 0;
+    }
+    pthread_t *threads = (pthread_t *)malloc(sizeof(pthread_t) * n_threads);
+    worker_args *args = (worker_args *)malloc(sizeof(worker_args) * n_threads);
+    for (size_t k = 0; k < n_threads; ++k) {
+        args[k].sim = sim;
+        args[k].cfg = cfg;
+        args[k].begin = sim->n_realizations * k / n_threads;
+        args[k].end = sim->n_realizations * (k + 1) / n_threads;
+        pthread_create(&threads[k], NULL, worker_main, &args[k]);
+    }
+    for (size_t k = 0; k < n_threads; ++k) pthread_join(threads[k], NULL);
+    free(threads);
+    free(args);
+    return 0;
+}
+
+const char *orc_sim_last_error(const orc_sim *sim) { return sim->error; }
+uint64_t orc_sim_n_spins(const orc_sim *sim) { return sim->lattice->n_spins; }
+uint64_t orc_sim_n_neighbors(const orc_sim *sim) { return sim->lattice->n_neighbors; }
+
+void orc_sim_get_spins(const orc_sim *sim, size_t r, int8_t *out) {
+    memcpy(out, sim->realizations[r].spins, sim->n_replicas * sim->n_temps * sim->lattice->n_spins);
+}
+void orc_sim_get_system_ids(const orc_sim *sim, size_t r, uint64_t *out) {
+    memcpy(out, sim->realizations[r].system_ids, sizeof(uint64_t) * sim->n_replicas * sim->n_temps);
+}
+void orc_sim_get_energies(const orc_sim *sim, size_t r, float *out) {
+    memcpy(out, sim->realizations[r].energies, sizeof(float) * sim->n_replicas * sim->n_temps);
+}
+void orc_sim_get_rng_state(const orc_sim *sim, size_t r, size_t system, uint64_t out[4]) {
+    memcpy(out, sim->realizations[r].rngs[system].s, sizeof(uint64_t) * 4);
+}
+void orc_sim_get_pt_counters(const orc_sim *sim, size_t r, uint64_t *edge_attempts,
+                             uint64_t *edge_acceptances, uint64_t *round_trips) {
+    const pt_state *pt = &sim->realizations[r].pt;
+    size_t n_edges = sim->n_temps > 0 ? sim->n_temps - 1 : 0;
+    memcpy(edge_attempts, pt->edge_attempts, sizeof(uint64_t) * n_edges);
+    memcpy(edge_acceptances, pt->edge_acceptances, sizeof(uint64_t) * n_edges);
+    memcpy(round_trips, pt->round_trips, sizeof(uint64_t) * sim->n_replicas * sim->n_temps);
+}
+void orc_sim_get_result_moments(const orc_sim *sim, size_t r, double *out) {
+    memcpy(out, sim->results[r].moments, sizeof(double) * 5 * sim->n_temps);
+}
+int orc_sim_has_overlap(const orc_sim *sim) { return sim->n_replicas / 2 > 0; }
+void orc_sim_get_result_overlap(const orc_sim *sim, size_t r, double *out) {
+    memcpy(out, sim->results[r].overlap, sizeof(double) * 6 * sim->n_temps);
+}
+void orc_sim_get_result_histograms(const orc_sim *sim, size_t r, uint64_t *histogram,
+                                   double *ql_at_q_sum, double *ql2_at_q_sum) {
+    size_t count = sim->n_temps * (sim->lattice->n_spins + 1);
+    memcpy(histogram, sim->results[r].histogram, sizeof(uint64_t) * count);
+    memcpy(ql_at_q_sum, sim->results[r].ql_at_q_sum, sizeof(double) * count);
+    memcpy(ql2_at_q_sum, sim->results[r].ql2_at_q_sum, sizeof(double) * count);
+}

@@ -1,0 +1,189 @@
+/*
+ * peapods_amd.h -- C ABI of the MI355X-native spin-sim hot path.
+ *
+ * Drop-in boundary for ONE path of PeaBrane/peapods: the (disorder x temperature
+ * x replica) ensemble Metropolis sweep + parallel-tempering energy/swap step +
+ * replica-overlap reductions (+ Houdayer/Joerg overlap-cluster move).  The entry
+ * points are what a Rust/C/Python FFI for that path binds; they take plain
+ * pointers and sizes only.  Reference interfaces replaced (paths relative to the
+ * reference root, ss/ = spin-sim/src/):
+ *
+ *   pa_sim_create / destroy / reset / sample / get_spins
+ *        <- PyO3 class IsingSimulation {new, reset, sample, get_spins}, src/lib.rs:104-634
+ *           (which wraps spin_sim::{Lattice, Realization, run_sweep_parallel}, src/lib.rs:9-10)
+ *   pa_sim_metropolis_sweep      <- mcmc::sweep::metropolis_sweep,          ss/mcmc/sweep.rs:220-229
+ *   pa_sim_compute_energies      <- spins::energy::compute_energies_and_magnetizations_into,
+ *                                                                          ss/spins/energy.rs:59-65
+ *   pa_sim_parallel_tempering    <- mcmc::tempering::parallel_tempering(_full_ladder) as driven by
+ *                                   ss/simulation/mod.rs:748-796 (one event for every replica ladder)
+ *   pa_sim_overlap_dots          <- the integer part of OverlapAccum::collect, ss/statistics/overlap.rs:259-282
+ *   pa_sim_get_result_*          <- SweepResult / OverlapStats fields, ss/statistics/results.rs:56-77,
+ *                                   ss/statistics/overlap.rs:8-39 (per realisation, before aggregation)
+ *   pa_aggregate_*               <- SweepResult::aggregate_impl, ss/statistics/results.rs:84-285 and
+ *                                   OverlapStats::aggregate_impl, ss/statistics/overlap.rs:67-155
+ *   pa_build_metropolis_table    <- UnitCouplingMetropolisLookup::new, ss/mcmc/sweep.rs:109-139
+ *   pa_splitmix64 / pa_child_seed / pa_realization_seed
+ *                                <- ss/simulation/realization.rs:9-19, src/lib.rs:22-32
+ *
+ * All state lives on the device between calls (continuation semantics of
+ * repeated sample() calls, reference tests/test_sampling_interfaces.py:103-109).
+ * Calls on one handle are not re-entrant; handles on different devices are
+ * independent.  Every function returns PA_OK (0) or an error code; the text of
+ * the last error is available from pa_sim_last_error / the create() buffer.
+ * Options are validated before any state is touched (reference tests
+ * :145-156,197-206 require spins unchanged after a rejected call).
+ *
+ * There is no CPU fallback: without a usable HIP device create() fails with
+ * PA_ERR_DEVICE.
+ */
+#ifndef PEAPODS_AMD_H
+#define PEAPODS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    PA_OK = 0,
+    PA_ERR_INVALID = 1,     /* bad argument / option (ValueError in the reference) */
+    PA_ERR_UNSUPPORTED = 2, /* valid in the reference, not built on the device path yet */
+    PA_ERR_DEVICE = 3,      /* HIP runtime error, or no device */
+    PA_ERR_INTERRUPTED = 4
+};
+
+enum { PA_SWEEP_METROPOLIS = 0, PA_SWEEP_GIBBS = 1 };
+enum { PA_PT_SINGLE_RANDOM_EDGE = 0, PA_PT_FULL_LADDER = 1 };
+enum { PA_OC_HOUDAYER = 1, PA_OC_JORG = 2, PA_OC_CMR = 3 };
+enum { PA_CLUSTER_WOLFF = 0, PA_CLUSTER_SW = 1 };
+
+typedef struct pa_sim pa_sim;
+
+/* Constructor arguments of IsingSimulation (src/lib.rs:106-115). */
+typedef struct {
+    uint32_t n_dims;
+    const uint64_t *shape;           /* [n_dims] */
+    uint32_t n_neighbors;            /* forward directions z'; 0 = hypercubic (n_dims) */
+    const int64_t *neighbor_offsets; /* [n_neighbors][n_dims] or NULL for hypercubic */
+    const float *couplings;          /* [n_realizations][n_spins][n_neighbors], forward bonds */
+    uint64_t n_realizations;
+    const float *temperatures; /* [n_temps] */
+    uint64_t n_temps;
+    uint64_t n_replicas;
+    uint64_t seed;  /* dynamics root seed (src/lib.rs:155) */
+    int32_t device; /* HIP device ordinal */
+} pa_sim_desc;
+
+/* Keyword arguments of IsingSimulation.sample that are on the path
+ * (src/lib.rs:176-284 -> SimConfig, ss/config.rs:251-263). */
+typedef struct {
+    uint64_t n_sweeps;
+    uint64_t warmup_sweeps;
+    int32_t sweep_mode;                /* PA_SWEEP_* */
+    uint64_t pt_interval;              /* 0 = no parallel tempering */
+    int32_t pt_schedule;               /* PA_PT_* */
+    uint64_t overlap_cluster_interval; /* 0 = none */
+    int32_t overlap_cluster_modes[4];  /* PA_OC_*, round-robin per call */
+    int32_t n_overlap_cluster_modes;
+    int32_t overlap_cluster_mode; /* PA_CLUSTER_* */
+    int32_t measure_overlap;      /* 1 = collect overlap statistics on recorded sweeps (reference
+                                     behaviour whenever n_replicas >= 2); 0 only for timing runs */
+} pa_sample_config;
+
+/* ---- lifecycle ----------------------------------------------------------- */
+int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_len);
+void pa_sim_destroy(pa_sim *sim);
+int pa_sim_reset(pa_sim *sim, uint64_t seed);
+const char *pa_sim_last_error(const pa_sim *sim);
+
+/* Checks a sample configuration without touching any state (ss/config.rs:180-247).
+ * Usable without a device; `err` receives the reference's message text. */
+int pa_validate_sample_config(const pa_sample_config *cfg, uint64_t n_replicas, char *err,
+                              size_t err_len);
+
+/* ---- the driver loop (ss/simulation/mod.rs:405-797 for every realisation) -- */
+int pa_sim_sample(pa_sim *sim, const pa_sample_config *cfg);
+/* Asynchronous variant for timing: enqueue only; pa_sim_synchronize waits. */
+int pa_sim_sample_async(pa_sim *sim, const pa_sample_config *cfg);
+int pa_sim_synchronize(pa_sim *sim);
+/* Cooperative cancel, polled between kernel batches (src/lib.rs:304-308). */
+void pa_sim_request_interrupt(pa_sim *sim);
+
+/* ---- phase-level entry points (inner boundary; state stays on the device) -- */
+int pa_sim_metropolis_sweep(pa_sim *sim, uint64_t n_sweeps);
+int pa_sim_compute_energies(pa_sim *sim);
+int pa_sim_parallel_tempering(pa_sim *sim, int32_t schedule);
+/* dot_spin/dot_link: [n_realizations][n_pairs][n_temps] i64, pairs (2p, 2p+1) at slot t */
+int pa_sim_overlap_dots(pa_sim *sim, int64_t *dot_spin, int64_t *dot_link);
+
+/* ---- geometry / sizes ---------------------------------------------------- */
+uint64_t pa_sim_n_spins(const pa_sim *sim);
+uint64_t pa_sim_n_neighbors(const pa_sim *sim);
+uint64_t pa_sim_n_systems(const pa_sim *sim);
+
+/* ---- state getters (caller-allocated; reference layouts) ------------------ */
+/* spins: i8 +-1, [n_systems][n_spins] system-major for one realisation (src/lib.rs:620-622) */
+int pa_sim_get_spins(pa_sim *sim, uint64_t realization, int8_t *out);
+/* system_ids: [n_systems] slot -> system (Realization::system_ids) */
+int pa_sim_get_system_ids(pa_sim *sim, uint64_t realization, uint64_t *out);
+/* energies: f32 [n_systems] indexed by system (Realization::energies), as of the last computation */
+int pa_sim_get_energies(pa_sim *sim, uint64_t realization, float *out);
+/* magnetisation sums: i64 [n_systems] indexed by system, as of the last computation */
+int pa_sim_get_magnetization_sums(pa_sim *sim, uint64_t realization, int64_t *out);
+/* xoshiro256** state of one system's generator (Realization::rngs[system]) */
+int pa_sim_get_rng_state(pa_sim *sim, uint64_t realization, uint64_t system, uint64_t out[4]);
+/* PtState counters: edge_* [n_temps-1], round_trips [n_replicas*n_temps] by system */
+int pa_sim_get_pt_counters(pa_sim *sim, uint64_t realization, uint64_t *edge_attempts,
+                           uint64_t *edge_acceptances, uint64_t *round_trips);
+
+/* ---- per-realisation results of the last sample() ------------------------- */
+/* moments: f64 [5][n_temps] = mags, mags2, mags4, energies, energies2 */
+int pa_sim_get_result_moments(pa_sim *sim, uint64_t realization, double *out);
+/* overlap: f64 [6][n_temps] = q, q2, q4, ql, ql2, ql4 (requires n_replicas >= 2) */
+int pa_sim_get_result_overlap(pa_sim *sim, uint64_t realization, double *out);
+/* histogram u64, ql_at_q_sum f64, ql2_at_q_sum f64: each [n_temps][n_spins + 1] */
+int pa_sim_get_result_histograms(pa_sim *sim, uint64_t realization, uint64_t *histogram,
+                                 double *ql_at_q_sum, double *ql2_at_q_sum);
+/* All realisations at once, packed f64 block per realisation:
+ * [5][n_temps] moments then (if pairs) [6][n_temps] overlap moments. Used for the
+ * multi-GPU all-gather of observables. */
+uint64_t pa_sim_result_block_len(const pa_sim *sim);
+int pa_sim_get_result_blocks(pa_sim *sim, double *out /* [n_realizations][block_len] */);
+
+/* ---- host-only helpers (no device needed) --------------------------------- */
+uint64_t pa_splitmix64(uint64_t value);
+uint64_t pa_child_seed(uint64_t root, uint64_t domain, uint64_t index);
+uint64_t pa_realization_seed(uint64_t root, uint64_t realization);
+/* xoshiro256** as seeded by the reference: state from seed, then `n_skip` steps. */
+void pa_xoshiro_state(uint64_t seed, uint64_t n_skip, uint64_t out[4]);
+/* Jump-ahead used by the device generator: state advanced by `n_steps` through the
+ * GF(2) matrix machinery (must equal n_steps sequential steps). */
+void pa_xoshiro_jump(const uint64_t in[4], uint64_t n_steps, uint64_t out[4]);
+/* Acceptance table, [n_temperatures][4*n_neighbors + 1] u32; returns PA_ERR_UNSUPPORTED when the
+ * reference would decline the table (non-unit couplings / bad temperature). */
+int pa_build_metropolis_table(const float *couplings, uint64_t n_couplings,
+                              const float *temperatures, uint64_t n_temperatures,
+                              uint64_t n_neighbors, uint32_t *out);
+/* Dependency levels of the typewriter sweep: level[i] for every site; returns the level count.
+ * Sites of one level are mutually independent; executing levels in order reproduces the
+ * reference's sequential site order exactly. */
+uint64_t pa_build_sweep_levels(uint32_t n_dims, const uint64_t *shape, uint32_t n_neighbors,
+                               const int64_t *neighbor_offsets, uint32_t *level_out);
+/* Mean over realisations of per-realisation f64 vectors, summed sequentially in realisation
+ * order then divided once (results.rs:165-196,262-282). */
+void pa_aggregate_mean(const double *per_realization, uint64_t n_realizations, uint64_t len,
+                       double *out);
+void pa_aggregate_sum_u64(const uint64_t *per_realization, uint64_t n_realizations, uint64_t len,
+                          uint64_t *out);
+void pa_aggregate_sum_f64(const double *per_realization, uint64_t n_realizations, uint64_t len,
+                          double *out);
+/* Number of visible HIP devices (0 when there is none / the runtime is unusable). */
+int pa_device_count(void);
+const char *pa_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,342 @@
+"""`IsingSimulation`: the MI355X counterpart of the reference's PyO3 class
+(reference src/lib.rs:104-634).  Same constructor, `sample`, `get_spins` and
+`reset`; the ensemble lives on the GPU behind the C ABI of include/peapods_amd.h.
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nat
+
+_SWEEP_MODES = {"metropolis": 0, "gibbs": 1}
+_PT_SCHEDULES = {"single_random_edge": 0, "full_ladder": 1}
+_CLUSTER_MODES = {"wolff": 0, "sw": 1}
+_CLUSTER_ACTIONS = ("update", "observe")
+_AUTOCORR_BACKENDS = ("ring", "fft")
+_OC_MODES = {"houdayer": 1, "houd2": 1, "jorg": 2, "cmr": 3, "cmr2": 3}
+
+
+def _raise(code, text):
+    if code == nat.PA_ERR_INTERRUPTED:
+        raise KeyboardInterrupt(text)
+    if code == nat.PA_ERR_UNSUPPORTED:
+        raise NotImplementedError(text)
+    if code == nat.PA_ERR_DEVICE:
+        raise RuntimeError(text)
+    raise ValueError(text)
+
+
+def _parse_overlap_modes(text):
+    """spin-sim/src/config.rs:108-178 (parse_overlap_modes / OverlapClusterBuildMode::try_from)."""
+    modes = []
+    for part in text.split("+"):
+        name = part.strip()
+        if name in _OC_MODES:
+            modes.append(_OC_MODES[name])
+        elif name.startswith("houd"):
+            try:
+                n = int(name[4:])
+            except ValueError:
+                raise ValueError(
+                    f"invalid Houdayer group size in '{name}', expected 'houdN' with even integer N >= 2"
+                ) from None
+            if n < 2 or n % 2:
+                raise ValueError(f"Houdayer group size must be even and >= 2, got {n}")
+            raise NotImplementedError(f"houd{n} (group_size > 2) is not built on the HIP path")
+        else:
+            raise ValueError(
+                f"unknown overlap_cluster_build_mode '{name}', expected 'houdayer', 'houdN', "
+                "'jorg', or 'cmr'"
+            )
+    return modes
+
+
+class IsingSimulation:
+    def __init__(self, lattice_shape, couplings, temperatures, n_replicas=None,
+                 neighbor_offsets=None, seed=None, device=0):
+        self._lib = nat.lib()
+        self._handle = None
+        shape = [int(x) for x in lattice_shape]
+        couplings = np.ascontiguousarray(couplings, dtype=np.float32)
+        temps = np.ascontiguousarray(temperatures, dtype=np.float32)
+        if temps.ndim != 1:
+            raise ValueError("temperatures must be one-dimensional")
+        n_neighbors = len(neighbor_offsets) if neighbor_offsets is not None else len(shape)
+        expected_single = tuple(shape) + (n_neighbors,)
+        if couplings.shape == expected_single:
+            n_real = 1
+        elif couplings.ndim == len(expected_single) + 1 and couplings.shape[1:] == expected_single:
+            n_real = couplings.shape[0]
+        else:  # src/lib.rs:146-149
+            raise ValueError(
+                f"couplings shape {list(couplings.shape)} does not match lattice "
+                f"{list(expected_single)}"
+            )
+        self.lattice_shape = shape
+        self.n_replicas = 1 if n_replicas is None else int(n_replicas)
+        self.n_temps = int(temps.shape[0])
+        self.n_realizations = int(n_real)
+        self.constructor_seed = 42 if seed is None else int(seed)  # src/lib.rs:155
+
+        shape_arr = np.asarray(shape, dtype=np.uint64)
+        desc = nat.PaSimDesc()
+        desc.n_dims = len(shape)
+        desc.shape = shape_arr.ctypes.data_as(C.POINTER(C.c_uint64))
+        if neighbor_offsets is not None:
+            offsets = np.ascontiguousarray(neighbor_offsets, dtype=np.int64)
+            if offsets.ndim != 2 or offsets.shape[1] != len(shape):
+                raise ValueError("every neighbor offset must have one entry per lattice dimension")
+            desc.n_neighbors = offsets.shape[0]
+            desc.neighbor_offsets = offsets.ctypes.data_as(C.POINTER(C.c_int64))
+        else:
+            desc.n_neighbors = 0
+            desc.neighbor_offsets = None
+        desc.couplings = couplings.ctypes.data_as(C.POINTER(C.c_float))
+        desc.n_realizations = n_real
+        desc.temperatures = temps.ctypes.data_as(C.POINTER(C.c_float))
+        desc.n_temps = self.n_temps
+        desc.n_replicas = self.n_replicas
+        desc.seed = self.constructor_seed
+        desc.device = int(device)
+        handle = C.c_void_p()
+        err = C.create_string_buffer(512)
+        code = self._lib.pa_sim_create(C.byref(desc), C.byref(handle), err, len(err))
+        if code != nat.PA_OK:
+            _raise(code, err.value.decode())
+        self._handle = handle
+        self.n_spins = int(self._lib.pa_sim_n_spins(handle))
+        self.n_neighbors = int(self._lib.pa_sim_n_neighbors(handle))
+        self.n_systems = int(self._lib.pa_sim_n_systems(handle))
+
+    def __del__(self):
+        if getattr(self, "_handle", None):
+            self._lib.pa_sim_destroy(self._handle)
+            self._handle = None
+
+    def _check(self, code):
+        if code != nat.PA_OK:
+            _raise(code, self._lib.pa_sim_last_error(self._handle).decode())
+
+    # ---- configuration ----------------------------------------------------
+    def make_config(self, n_sweeps, sweep_mode, cluster_update_interval=None, cluster_mode=None,
+                    cluster_action=None, pt_interval=None, pt_schedule=None,
+                    overlap_cluster_update_interval=None, overlap_cluster_build_mode=None,
+                    overlap_cluster_mode=None, overlap_cluster_action=None, warmup_ratio=None,
+                    collect_cluster_stats=None, autocorrelation_max_lag=None,
+                    autocorrelation_backend=None, sequential=None, equilibration_diagnostic=None,
+                    snapshot_interval=None, measure_overlap=True):
+        """Validates the keyword arguments of `sample` (src/lib.rs:219-284, config.rs:180-247)
+        without touching any state and returns the C configuration."""
+        warmup = 0.25 if warmup_ratio is None else float(warmup_ratio)
+        cfg = nat.PaSampleConfig()
+        cfg.n_sweeps = int(n_sweeps)
+        cfg.warmup_sweeps = int(np.floor(n_sweeps * warmup + 0.5))  # f64::round, src/lib.rs:220
+        if sweep_mode not in _SWEEP_MODES:
+            raise ValueError(f"unknown sweep_mode '{sweep_mode}', expected 'metropolis' or 'gibbs'")
+        cfg.sweep_mode = _SWEEP_MODES[sweep_mode]
+        schedule = "single_random_edge" if pt_schedule is None else pt_schedule
+        if schedule not in _PT_SCHEDULES:
+            raise ValueError(
+                f"unknown pt_schedule '{schedule}', expected 'single_random_edge' or 'full_ladder'"
+            )
+        cfg.pt_schedule = _PT_SCHEDULES[schedule]
+        backend = "ring" if autocorrelation_backend is None else autocorrelation_backend
+        if backend not in _AUTOCORR_BACKENDS:
+            raise ValueError(
+                f"unknown autocorrelation_backend '{backend}', expected 'ring' or 'fft'"
+            )
+        if backend == "fft" and autocorrelation_max_lag is None:
+            raise ValueError("autocorrelation_backend='fft' requires autocorrelation_max_lag")
+        if pt_interval is not None and pt_interval < 1:
+            raise ValueError("pt_interval must be >= 1")
+        cfg.pt_interval = 0 if pt_interval is None else int(pt_interval)
+        if cluster_update_interval is not None:
+            mode = "sw" if cluster_mode is None else cluster_mode
+            if mode not in _CLUSTER_MODES:
+                raise ValueError(f"unknown cluster_mode '{mode}', expected 'wolff' or 'sw'")
+            action = "update" if cluster_action is None else cluster_action
+            if action not in _CLUSTER_ACTIONS:
+                raise ValueError(f"unknown cluster action '{action}', expected 'update' or 'observe'")
+            if cluster_update_interval < 1:
+                raise ValueError("cluster_update interval must be >= 1")
+            if action == "observe" and mode == "wolff":
+                raise ValueError("cluster_action='observe' requires cluster_mode='sw'")
+            raise NotImplementedError(
+                "FK cluster updates (cluster_update_interval) are outside the HIP hot path"
+            )
+        if overlap_cluster_update_interval is not None:
+            modes = _parse_overlap_modes(
+                "houdayer" if overlap_cluster_build_mode is None else overlap_cluster_build_mode
+            )
+            oc_mode = "wolff" if overlap_cluster_mode is None else overlap_cluster_mode
+            if oc_mode not in _CLUSTER_MODES:
+                raise ValueError(f"unknown cluster_mode '{oc_mode}', expected 'wolff' or 'sw'")
+            action = "update" if overlap_cluster_action is None else overlap_cluster_action
+            if action not in _CLUSTER_ACTIONS:
+                raise ValueError(f"unknown cluster action '{action}', expected 'update' or 'observe'")
+            if overlap_cluster_update_interval < 1:
+                raise ValueError("overlap_cluster interval must be >= 1")
+            if action == "observe":
+                if oc_mode == "wolff":
+                    raise ValueError(
+                        "overlap_cluster_action='observe' requires overlap_cluster_mode='sw'"
+                    )
+                raise NotImplementedError("cluster observers are outside the HIP hot path")
+            if len(modes) > 4:
+                raise NotImplementedError("at most 4 alternating overlap modes are supported")
+            cfg.overlap_cluster_interval = int(overlap_cluster_update_interval)
+            for k, m in enumerate(modes):
+                cfg.overlap_cluster_modes[k] = m
+            cfg.n_overlap_cluster_modes = len(modes)
+            cfg.overlap_cluster_mode = _CLUSTER_MODES[oc_mode]
+        if autocorrelation_max_lag is not None:
+            raise NotImplementedError("autocorrelation diagnostics are outside the HIP hot path")
+        if equilibration_diagnostic:
+            raise NotImplementedError("equilibration diagnostics are outside the HIP hot path")
+        cfg.measure_overlap = 1 if measure_overlap else 0
+        err = C.create_string_buffer(512)
+        code = self._lib.pa_validate_sample_config(C.byref(cfg), self.n_replicas, err, len(err))
+        if code != nat.PA_OK:
+            _raise(code, err.value.decode())
+        return cfg
+
+    # ---- hot path ---------------------------------------------------------
+    def run(self, cfg, wait=True):
+        fn = self._lib.pa_sim_sample if wait else self._lib.pa_sim_sample_async
+        self._check(fn(self._handle, C.byref(cfg)))
+
+    def synchronize(self):
+        self._check(self._lib.pa_sim_synchronize(self._handle))
+
+    def metropolis_sweep(self, n_sweeps=1):
+        self._check(self._lib.pa_sim_metropolis_sweep(self._handle, int(n_sweeps)))
+
+    def compute_energies(self):
+        self._check(self._lib.pa_sim_compute_energies(self._handle))
+
+    def parallel_tempering(self, schedule="single_random_edge"):
+        if schedule not in _PT_SCHEDULES:
+            raise ValueError(
+                f"unknown pt_schedule '{schedule}', expected 'single_random_edge' or 'full_ladder'"
+            )
+        self._check(self._lib.pa_sim_parallel_tempering(self._handle, _PT_SCHEDULES[schedule]))
+
+    def overlap_dots(self):
+        n_pairs = self.n_replicas // 2
+        shape = (self.n_realizations, n_pairs, self.n_temps)
+        dot_spin = np.zeros(shape, dtype=np.int64)
+        dot_link = np.zeros(shape, dtype=np.int64)
+        self._check(self._lib.pa_sim_overlap_dots(self._handle, nat.ptr(dot_spin), nat.ptr(dot_link)))
+        return dot_spin, dot_link
+
+    # ---- state ------------------------------------------------------------
+    def get_spins(self, realization=0):
+        out = np.empty(self.n_systems * self.n_spins, dtype=np.int8)
+        self._check(self._lib.pa_sim_get_spins(self._handle, realization, nat.ptr(out)))
+        return out
+
+    def get_system_ids(self, realization=0):
+        out = np.empty(self.n_systems, dtype=np.uint64)
+        self._check(self._lib.pa_sim_get_system_ids(self._handle, realization, nat.ptr(out)))
+        return out
+
+    def get_energies(self, realization=0):
+        out = np.empty(self.n_systems, dtype=np.float32)
+        self._check(self._lib.pa_sim_get_energies(self._handle, realization, nat.ptr(out)))
+        return out
+
+    def get_magnetization_sums(self, realization=0):
+        out = np.empty(self.n_systems, dtype=np.int64)
+        self._check(self._lib.pa_sim_get_magnetization_sums(self._handle, realization, nat.ptr(out)))
+        return out
+
+    def get_rng_state(self, realization, system):
+        out = np.empty(4, dtype=np.uint64)
+        self._check(self._lib.pa_sim_get_rng_state(self._handle, realization, system, nat.ptr(out)))
+        return out
+
+    def get_pt_counters(self, realization=0):
+        n_edges = max(self.n_temps - 1, 0)
+        attempts = np.zeros(max(n_edges, 1), dtype=np.uint64)
+        acceptances = np.zeros(max(n_edges, 1), dtype=np.uint64)
+        trips = np.zeros(self.n_systems, dtype=np.uint64)
+        self._check(self._lib.pa_sim_get_pt_counters(
+            self._handle, realization, nat.ptr(attempts), nat.ptr(acceptances), nat.ptr(trips)))
+        return attempts[:n_edges], acceptances[:n_edges], trips.reshape(self.n_replicas, self.n_temps)
+
+    def reset(self, seed=None):
+        self._check(self._lib.pa_sim_reset(
+            self._handle, self.constructor_seed if seed is None else int(seed)))
+
+    # ---- results ----------------------------------------------------------
+    def result_blocks(self):
+        """[n_realizations][block] f64: the per-realisation moments (and overlap moments)."""
+        length = int(self._lib.pa_sim_result_block_len(self._handle))
+        out = np.empty((self.n_realizations, length), dtype=np.float64)
+        self._check(self._lib.pa_sim_get_result_blocks(self._handle, nat.ptr(out)))
+        return out
+
+    def result_histograms(self):
+        n_bins = self.n_spins + 1
+        shape = (self.n_realizations, self.n_temps, n_bins)
+        hist = np.empty(shape, dtype=np.uint64)
+        qlq = np.empty(shape, dtype=np.float64)
+        ql2q = np.empty(shape, dtype=np.float64)
+        for r in range(self.n_realizations):
+            self._check(self._lib.pa_sim_get_result_histograms(
+                self._handle, r, nat.ptr(hist[r]), nat.ptr(qlq[r]), nat.ptr(ql2q[r])))
+        return hist, qlq, ql2q
+
+    def pt_diagnostics(self):
+        att, acc, trips = zip(*(self.get_pt_counters(r) for r in range(self.n_realizations)))
+        return {
+            "edge_attempts": np.stack(att),
+            "edge_acceptances": np.stack(acc),
+            "round_trips": np.stack(trips),
+        }
+
+    def sample(self, n_sweeps, sweep_mode, **kwargs):
+        """Runs the sweeps and returns the reference's result dictionary (src/lib.rs:337-617)."""
+        cfg = self.make_config(n_sweeps, sweep_mode, **kwargs)
+        self.run(cfg)
+        return assemble_results(
+            self._lib, self.result_blocks(),
+            self.result_histograms() if self.n_replicas >= 2 else None,
+            self.pt_diagnostics() if kwargs.get("pt_interval") is not None else None,
+            self.n_temps, self.n_replicas // 2,
+        )
+
+
+def assemble_results(lib, blocks, histograms, pt, n_temps, n_pairs):
+    """Disorder aggregation (statistics/results.rs:165-282, overlap.rs:106-152, mod.rs:905-921)
+    of per-realisation blocks, in realisation order, into the reference's dictionary."""
+    n_real = blocks.shape[0]
+    blocks = np.ascontiguousarray(blocks)
+    mean = np.empty(blocks.shape[1], dtype=np.float64)
+    lib.pa_aggregate_mean(nat.ptr(blocks), n_real, blocks.shape[1], nat.ptr(mean))
+    out = {}
+    for k, key in enumerate(["mags", "mags2", "mags4", "energies", "energies2"]):
+        out[key] = mean[k * n_temps:(k + 1) * n_temps].copy()
+    if n_pairs > 0:
+        keys = ["overlap", "overlap2", "overlap4", "link_overlap", "link_overlap2", "link_overlap4"]
+        for k, key in enumerate(keys):
+            out[key] = mean[(5 + k) * n_temps:(6 + k) * n_temps].copy()
+        hist, qlq, ql2q = (np.ascontiguousarray(a) for a in histograms)
+        per = hist[0].size
+        hist_sum = np.empty(hist.shape[1:], dtype=np.uint64)
+        qlq_sum = np.empty(qlq.shape[1:], dtype=np.float64)
+        ql2q_sum = np.empty(ql2q.shape[1:], dtype=np.float64)
+        lib.pa_aggregate_sum_u64(nat.ptr(hist), n_real, per, nat.ptr(hist_sum))
+        lib.pa_aggregate_sum_f64(nat.ptr(qlq), n_real, per, nat.ptr(qlq_sum))
+        lib.pa_aggregate_sum_f64(nat.ptr(ql2q), n_real, per, nat.ptr(ql2q_sum))
+        out["overlap_histogram"] = [hist_sum[t].copy() for t in range(n_temps)]
+        out["ql_at_q_sum"] = qlq_sum
+        out["ql2_at_q_sum"] = ql2q_sum
+        if n_real > 1:
+            out["per_sample_overlap_histogram"] = hist
+            out["per_sample_ql_at_q_sum"] = qlq
+            out["per_sample_ql2_at_q_sum"] = ql2q
+    if pt is not None:
+        out["per_disorder"] = {"parallel_tempering": pt}
+    return out

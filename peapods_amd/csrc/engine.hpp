@@ -1,0 +1,91 @@
+// Device-visible layout of one simulation (pa_sim) and the kernel launchers.
+//
+// Representation ("slot-sliced multispin coding"):
+//   * One TILE per disorder realisation.  Bit k of a tile word belongs to
+//     temperature SLOT k = replica * n_temps + t; a tile has W = ceil(n_sys/32)
+//     words per lattice site.  S[real][site][w] holds the spins (bit = 1 <=> -1)
+//     of 32 slots at one site, so every bitwise instruction advances 32 systems
+//     that share the realisation's couplings.
+//   * The reference's typewriter order is kept exactly: sites are grouped into
+//     dependency levels (host_util.hpp) and levels run in order.
+//   * The reference's per-system xoshiro256** stream is kept exactly: each
+//     (slot, block-of-sites) lane enters its block by GF(2) jump-ahead from the
+//     slot's cursor, draws sequentially, and a wave ballot transposes the 32
+//     per-slot decisions of one site into the tile word the sweep consumes.
+//   * Parallel tempering swaps bit columns (and cursors); system_ids/slot_of
+//     keep the reference's slot->system permutation for every getter.
+#pragma once
+
+#include <cstdint>
+#include <hip/hip_runtime.h>
+
+namespace pa {
+
+struct SimDims {
+    uint32_t N;          // sites
+    uint32_t W;          // words per site
+    uint32_t SP;         // W * 32 (padded slot count)
+    uint32_t n_sys;      // n_replicas * n_temps
+    uint32_t n_temps;
+    uint32_t n_replicas;
+    uint32_t n_pairs;    // n_replicas / 2
+    uint32_t n_real;
+    uint32_t nn;         // forward directions z' (<= 3)
+    uint32_t B;          // RNG blocks per sweep
+    uint32_t BS;         // sites per RNG block
+    uint32_t BP;         // ceil(B / 2): block pairs (one wave handles two blocks x 32 slots)
+    uint32_t n_levels;
+    uint32_t MW;         // ceil(N / 32): words of the per-site parity bitmap
+    uint32_t has_odd;    // 1 if any site has an odd number of non-zero bonds
+    uint32_t n_edges;    // max(n_temps - 1, 1) (allocation stride of the PT edge counters)
+};
+
+struct DevPtrs {
+    uint32_t *S;             // [n_real][N][W]
+    uint2 *planes;           // [n_real][N][W]  .x/.y = bit 0/1 of the acceptance level
+    uint32_t *cursor;        // [n_real][8][SP]  xoshiro state of the system in each slot
+    uint32_t *system_ids;    // [n_real][n_sys]  slot -> system
+    uint32_t *slot_of;       // [n_real][n_sys]  system -> slot
+    const uint32_t *thr;     // [2][3][n_temps]  thresholds: even set (dE=-2,-4,-6), odd set (-1,-3,-5)
+    const uint32_t *mpar;    // [n_real][MW]     parity of the non-zero bond count per site
+    const uint32_t *sched;   // [N][8]  schedule order: site, f0, b0, f1, b1, f2, b2, pad
+    const uint16_t *jmeta;   // [n_real][N] schedule order: neg[0..5] | nz[6..11] | h[12..13]
+    const uint32_t *level_start; // [n_levels + 1]
+    const uint32_t *jump;    // [B][64][16][8] nibble tables of T^(b*BS)
+    int32_t *Esum;           // [n_real][n_sys] by slot: sum_{i,d} J s s (exact integer)
+    int32_t *Msum;           // [n_real][n_sys] by slot: sum_i s_i
+    const int32_t *nz_bonds; // [n_real] number of non-zero forward bonds
+    int32_t *dot_spin;       // [n_real][n_pairs][n_temps]
+    int32_t *dot_link;       // [n_real][n_pairs][n_temps]
+    double *mom;             // [n_real][5][n_temps] running f64 sums
+    double *ovm;             // [n_real][6][n_temps]
+    uint64_t *hist;          // [n_real][n_temps][N + 1]
+    double *qlq;             // [n_real][n_temps][N + 1]
+    double *ql2q;            // [n_real][n_temps][N + 1]
+    uint64_t *edge_att;      // [n_real][n_edges]
+    uint64_t *edge_acc;      // [n_real][n_edges]
+    uint64_t *round_trips;   // [n_real][n_sys] by system
+    uint8_t *trip_state;     // [n_real][n_sys] by system
+    const float *ln_table;   // [2^24] ln(k * 2^-24) as computed by the host libm
+    const float *dbeta;      // [n_edges] 1/T[t] - 1/T[t+1] (f32)
+    uint32_t *swap_masks;    // [n_real][2][W] scratch of the PT kernel
+};
+
+struct PtParams {
+    int32_t schedule;     // PA_PT_*
+    uint32_t first_parity;
+    uint32_t hot_slot, cold_slot;
+};
+
+// All launchers enqueue on `stream` and return the hipGetLastError() of the launch.
+hipError_t launch_rng(const SimDims &d, const DevPtrs &p, hipStream_t stream);
+hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,
+                        hipStream_t stream);
+hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream);
+hipError_t launch_accumulate(const SimDims &d, const DevPtrs &p, bool with_overlap,
+                             hipStream_t stream);
+hipError_t launch_pt(const SimDims &d, const DevPtrs &p, const PtParams &pt, hipStream_t stream);
+size_t sweep_lds_bytes(const SimDims &d);
+hipError_t configure_kernels(const SimDims &d);
+
+} // namespace pa

@@ -1,0 +1,231 @@
+#include "host_util.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace pa {
+
+// reference: spin-sim/src/simulation/realization.rs:9-15 (same body as src/lib.rs:22-28)
+uint64_t splitmix64(uint64_t value) {
+    value += 0x9E3779B97F4A7C15ULL;
+    uint64_t z = value;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// realization.rs:17-19
+uint64_t child_seed(uint64_t root, uint64_t domain, uint64_t index) {
+    return splitmix64(root ^ domain ^ splitmix64(index));
+}
+
+// src/lib.rs:30-32
+uint64_t realization_seed(uint64_t root, uint64_t realization) {
+    return splitmix64(root ^ splitmix64(realization));
+}
+
+// rand_xoshiro 0.6.0 seed_from_u64: four SplitMix64 outputs from state `seed`.
+Xoshiro Xoshiro::from_seed_u64(uint64_t seed) {
+    Xoshiro rng;
+    uint64_t state = seed;
+    for (int i = 0; i < 4; ++i) {
+        rng.s[i] = splitmix64(state);
+        state += 0x9E3779B97F4A7C15ULL;
+    }
+    return rng;
+}
+
+// ---------------------------------------------------------------------------
+// GF(2) jump-ahead.  One xoshiro step is linear over GF(2) in the 256 state
+// bits, so n steps are a 256x256 bit matrix T^n; the device splits each
+// system's stream into blocks and enters block b with T^(b*block) * cursor.
+// ---------------------------------------------------------------------------
+
+JumpMatrix JumpMatrix::identity() {
+    JumpMatrix m;
+    m.cols.assign(256 * 4, 0);
+    for (int j = 0; j < 256; ++j) m.cols[j * 4 + j / 64] = 1ULL << (j % 64);
+    return m;
+}
+
+void JumpMatrix::apply(const uint64_t in[4], uint64_t out[4]) const {
+    uint64_t acc[4] = {0, 0, 0, 0};
+    for (int w = 0; w < 4; ++w) {
+        uint64_t bits = in[w];
+        while (bits) {
+            int b = __builtin_ctzll(bits);
+            bits &= bits - 1;
+            const uint64_t *col = &cols[(w * 64 + b) * 4];
+            acc[0] ^= col[0];
+            acc[1] ^= col[1];
+            acc[2] ^= col[2];
+            acc[3] ^= col[3];
+        }
+    }
+    std::memcpy(out, acc, sizeof(acc));
+}
+
+JumpMatrix JumpMatrix::compose(const JumpMatrix &first) const {
+    JumpMatrix r;
+    r.cols.resize(256 * 4);
+    for (int j = 0; j < 256; ++j) apply(&first.cols[j * 4], &r.cols[j * 4]);
+    return r;
+}
+
+JumpMatrix JumpMatrix::steps(uint64_t n_steps) {
+    // single-step matrix: images of the unit vectors under one generator step
+    JumpMatrix one;
+    one.cols.resize(256 * 4);
+    for (int j = 0; j < 256; ++j) {
+        Xoshiro g;
+        g.s[0] = g.s[1] = g.s[2] = g.s[3] = 0;
+        g.s[j / 64] = 1ULL << (j % 64);
+        g.next_u64();
+        std::memcpy(&one.cols[j * 4], g.s, 32);
+    }
+    JumpMatrix result = identity();
+    JumpMatrix power = one;
+    while (n_steps) {
+        if (n_steps & 1) result = power.compose(result);
+        n_steps >>= 1;
+        if (n_steps) power = power.compose(power);
+    }
+    return result;
+}
+
+void JumpMatrix::nibble_table(uint32_t *out) const {
+    for (int p = 0; p < 64; ++p) {
+        for (int v = 0; v < 16; ++v) {
+            uint64_t acc[4] = {0, 0, 0, 0};
+            for (int i = 0; i < 4; ++i)
+                if (v & (1 << i)) {
+                    const uint64_t *col = &cols[(p * 4 + i) * 4];
+                    acc[0] ^= col[0];
+                    acc[1] ^= col[1];
+                    acc[2] ^= col[2];
+                    acc[3] ^= col[3];
+                }
+            uint32_t *dst = out + (static_cast<size_t>(p) * 16 + v) * 8;
+            for (int w = 0; w < 4; ++w) {
+                dst[2 * w] = static_cast<uint32_t>(acc[w]);
+                dst[2 * w + 1] = static_cast<uint32_t>(acc[w] >> 32);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Lattice: row-major sites, periodic wrap with Euclidean remainder
+// (spin-sim/src/geometry/lattice.rs:44-99).
+// ---------------------------------------------------------------------------
+
+LatticeTables LatticeTables::build(uint32_t n_dims, const uint64_t *shape, uint32_t n_neighbors,
+                                   const int64_t *offsets) {
+    LatticeTables lat;
+    lat.n_dims = n_dims;
+    lat.shape.assign(shape, shape + n_dims);
+    lat.strides.assign(n_dims, 1);
+    for (int d = static_cast<int>(n_dims) - 2; d >= 0; --d)
+        lat.strides[d] = lat.strides[d + 1] * lat.shape[d + 1];
+    lat.n_spins = 1;
+    for (uint32_t d = 0; d < n_dims; ++d) lat.n_spins *= lat.shape[d];
+
+    std::vector<int64_t> unit;
+    if (!offsets) {
+        n_neighbors = n_dims;
+        unit.assign(static_cast<size_t>(n_dims) * n_dims, 0);
+        for (uint32_t d = 0; d < n_dims; ++d) unit[d * n_dims + d] = 1;
+        offsets = unit.data();
+    }
+    lat.n_neighbors = n_neighbors;
+    lat.fwd.resize(lat.n_spins * n_neighbors);
+    lat.bwd.resize(lat.n_spins * n_neighbors);
+    std::vector<int64_t> coords(n_dims);
+    for (uint64_t site = 0; site < lat.n_spins; ++site) {
+        for (uint32_t d = 0; d < n_dims; ++d)
+            coords[d] = static_cast<int64_t>((site / lat.strides[d]) % lat.shape[d]);
+        for (uint32_t k = 0; k < n_neighbors; ++k) {
+            uint64_t plus = 0, minus = 0;
+            for (uint32_t d = 0; d < n_dims; ++d) {
+                const int64_t extent = static_cast<int64_t>(lat.shape[d]);
+                int64_t up = (coords[d] + offsets[k * n_dims + d]) % extent;
+                int64_t down = (coords[d] - offsets[k * n_dims + d]) % extent;
+                if (up < 0) up += extent;
+                if (down < 0) down += extent;
+                plus += static_cast<uint64_t>(up) * lat.strides[d];
+                minus += static_cast<uint64_t>(down) * lat.strides[d];
+            }
+            lat.fwd[site * n_neighbors + k] = static_cast<uint32_t>(plus);
+            lat.bwd[site * n_neighbors + k] = static_cast<uint32_t>(minus);
+        }
+    }
+    return lat;
+}
+
+// ---------------------------------------------------------------------------
+// Acceptance table (spin-sim/src/mcmc/sweep.rs:99-167): number of 24-bit draws
+// accepted at (T, dE), found by bisection on the reference's f32 predicate.
+// logf is the platform libm, as for the reference's f32::ln.
+// ---------------------------------------------------------------------------
+
+static inline bool log_rule_accepts(float temperature, int32_t energy_change, uint32_t draw) {
+    const float uniform = static_cast<float>(draw) / 16777216.0f;
+    return static_cast<float>(energy_change) >= (temperature / 2.0f) * logf(uniform);
+}
+
+uint32_t accepted_count(float temperature, int32_t energy_change) {
+    uint32_t lo = 0, hi = 1u << 24;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (log_rule_accepts(temperature, energy_change, mid))
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+bool build_metropolis_table(const float *couplings, uint64_t n_couplings, const float *temps,
+                            uint64_t n_temps, uint64_t n_neighbors, std::vector<uint32_t> &out) {
+    for (uint64_t i = 0; i < n_couplings; ++i) {
+        const float c = couplings[i];
+        if (!(c == -1.0f || c == 0.0f || c == 1.0f)) return false;
+    }
+    for (uint64_t t = 0; t < n_temps; ++t)
+        if (!(std::isfinite(temps[t]) && temps[t] / 2.0f > 0.0f)) return false;
+    const int32_t offset = static_cast<int32_t>(2 * n_neighbors);
+    const uint64_t width = 4 * n_neighbors + 1;
+    out.resize(n_temps * width);
+    for (uint64_t t = 0; t < n_temps; ++t)
+        for (int32_t e = -offset; e <= offset; ++e)
+            out[t * width + static_cast<uint64_t>(e + offset)] = accepted_count(temps[t], e);
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// Dependency levels.  In the reference a sweep visits sites 0..N-1 in order
+// (sweep.rs:58-61); site i therefore sees the NEW value of every neighbour
+// j < i and the OLD value of every neighbour j > i.  Any schedule in which
+// each site runs after all its smaller neighbours and before all its larger
+// ones gives the identical result; the longest-path layering below is the
+// shortest such schedule (hyperplanes x+y+z = const on a hypercubic lattice).
+// ---------------------------------------------------------------------------
+
+uint32_t build_levels(const LatticeTables &lat, std::vector<uint32_t> &level) {
+    level.assign(lat.n_spins, 0);
+    uint32_t n_levels = lat.n_spins ? 1 : 0;
+    for (uint64_t site = 0; site < lat.n_spins; ++site) {
+        uint32_t lvl = 0;
+        for (uint32_t k = 0; k < lat.n_neighbors; ++k) {
+            const uint32_t a = lat.fwd[site * lat.n_neighbors + k];
+            const uint32_t b = lat.bwd[site * lat.n_neighbors + k];
+            if (a < site && level[a] + 1 > lvl) lvl = level[a] + 1;
+            if (b < site && level[b] + 1 > lvl) lvl = level[b] + 1;
+        }
+        level[site] = lvl;
+        if (lvl + 1 > n_levels) n_levels = lvl + 1;
+    }
+    return n_levels;
+}
+
+} // namespace pa

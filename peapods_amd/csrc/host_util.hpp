@@ -1,0 +1,75 @@
+// Host-side building blocks of the MI355X spin-sim engine: seed tree, the
+// xoshiro256** generator (stepping and GF(2) jump-ahead), lattice neighbour
+// tables, the Metropolis acceptance table and the dependency levels that turn
+// the reference's sequential typewriter sweep into parallel wavefront steps.
+// Pure C++ (no device code); unit-tested on CPU through the C ABI.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace pa {
+
+constexpr uint64_t kSystemSeedDomain = 0x53A917E14C2D8B6FULL; // realization.rs:6
+constexpr uint64_t kPairSeedDomain = 0xA1475EED91C302D7ULL;   // realization.rs:7
+
+uint64_t splitmix64(uint64_t value);
+uint64_t child_seed(uint64_t root, uint64_t domain, uint64_t index);
+uint64_t realization_seed(uint64_t root, uint64_t realization);
+
+// xoshiro256** with the rand / rand_xoshiro sampling rules the reference relies on.
+struct Xoshiro {
+    uint64_t s[4];
+    static Xoshiro from_seed_u64(uint64_t seed);
+    inline uint64_t next_u64() {
+        const uint64_t mul5 = s[1] * 5;
+        const uint64_t result = ((mul5 << 7) | (mul5 >> 57)) * 9;
+        const uint64_t t = s[1] << 17;
+        s[2] ^= s[0];
+        s[3] ^= s[1];
+        s[1] ^= s[2];
+        s[0] ^= s[3];
+        s[2] ^= t;
+        s[3] = (s[3] << 45) | (s[3] >> 19);
+        return result;
+    }
+    inline uint32_t next_u32() { return static_cast<uint32_t>(next_u64() >> 32); }
+    inline uint32_t next_draw24() { return static_cast<uint32_t>(next_u64() >> 40); }
+};
+
+// 256x256 matrix over GF(2) acting on the xoshiro state, stored as the images of
+// the 256 unit vectors (column j = M * e_j, 4 x u64 each).
+struct JumpMatrix {
+    std::vector<uint64_t> cols; // [256][4]
+    static JumpMatrix identity();
+    static JumpMatrix steps(uint64_t n_steps); // T^n by repeated squaring
+    JumpMatrix compose(const JumpMatrix &first) const; // this * first
+    void apply(const uint64_t in[4], uint64_t out[4]) const;
+    // Nibble tables used on the device: entry [p][v] (p = 0..63, v = 0..15) is
+    // M * (v << 4p) as 8 little-endian dwords.
+    void nibble_table(uint32_t *out /* [64][16][8] */) const;
+};
+
+struct LatticeTables {
+    uint32_t n_dims = 0;
+    std::vector<uint64_t> shape, strides;
+    uint64_t n_spins = 0;
+    uint32_t n_neighbors = 0;
+    std::vector<uint32_t> fwd, bwd; // [n_spins][n_neighbors]
+    // offsets == nullptr -> hypercubic unit vectors (lattice.rs:31-38, offsets.rs:4-13)
+    static LatticeTables build(uint32_t n_dims, const uint64_t *shape, uint32_t n_neighbors,
+                               const int64_t *offsets);
+};
+
+// UnitCouplingMetropolisLookup (sweep.rs:99-167).  Returns false when the
+// reference declines to build the table.
+bool build_metropolis_table(const float *couplings, uint64_t n_couplings, const float *temps,
+                            uint64_t n_temps, uint64_t n_neighbors, std::vector<uint32_t> &out);
+uint32_t accepted_count(float temperature, int32_t energy_change);
+
+// level[i] = 1 + max(level[j]) over neighbours j < i (0 if none).  Returns level count.
+uint32_t build_levels(const LatticeTables &lat, std::vector<uint32_t> &level);
+
+} // namespace pa

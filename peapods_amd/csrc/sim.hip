@@ -1,0 +1,842 @@
+// pa_sim: the device-resident ensemble and the C ABI (include/peapods_amd.h).
+//
+// Host orchestration only: builds the static tables (neighbour schedule,
+// acceptance thresholds, jump tables), seeds the ensemble the way the
+// reference does (src/lib.rs:157-164, realization.rs:155-211), and sequences
+// the kernels of kernels.hip in the reference's per-sweep phase order
+// (spin-sim/src/simulation/mod.rs:405-797).  No arithmetic of the hot path
+// runs on the host after create()/reset().
+#include "../../include/peapods_amd.h"
+#include "engine.hpp"
+#include "host_util.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace pa;
+
+namespace {
+
+struct DeviceBuffers {
+    std::vector<void *> allocations;
+    template <typename T> hipError_t alloc(T **ptr, size_t count) {
+        void *raw = nullptr;
+        hipError_t e = hipMalloc(&raw, std::max<size_t>(count, 1) * sizeof(T));
+        if (e != hipSuccess) return e;
+        allocations.push_back(raw);
+        *ptr = static_cast<T *>(raw);
+        return hipSuccess;
+    }
+    void release() {
+        for (void *a : allocations) (void)hipFree(a);
+        allocations.clear();
+    }
+};
+
+std::mutex g_ln_mutex;
+std::map<int, float *> g_ln_tables; // per device, lives for the process
+
+} // namespace
+
+struct pa_sim {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    LatticeTables lat;
+    SimDims d{};
+    DevPtrs p{};
+    DeviceBuffers buffers;
+    std::vector<float> temps;
+    uint64_t n_replicas = 0, n_temps = 0, n_real = 0;
+    uint64_t constructor_seed = 0;
+    uint32_t hot_slot = 0, cold_slot = 0;
+    uint32_t next_parity = 0;
+    // non-const aliases of the static tables (filled once in create)
+    uint32_t *thr = nullptr, *mpar = nullptr, *sched = nullptr, *level_start = nullptr,
+             *jump = nullptr;
+    uint16_t *jmeta = nullptr;
+    int32_t *nz_bonds = nullptr;
+    float *dbeta = nullptr;
+    // bookkeeping of the last sample()
+    uint64_t n_recorded = 0;
+    bool overlap_collected = false;
+    std::atomic<bool> interrupt{false};
+    std::string error;
+};
+
+namespace {
+
+int fail(pa_sim *sim, int code, const std::string &msg) {
+    if (sim) sim->error = msg;
+    return code;
+}
+
+#define PA_HIP(sim, expr)                                                                          \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(sim, PA_ERR_DEVICE,                                                        \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                        \
+    } while (0)
+
+void write_err(char *err, size_t len, const std::string &msg) {
+    if (err && len) std::snprintf(err, len, "%s", msg.c_str());
+}
+
+// ln(k * 2^-24) for every 24-bit k, with the host libm: the parallel-tempering
+// criterion compares against ln(gen::<f32>()) (tempering.rs:88-91) and the
+// device must see the host's logf bit for bit.  64 MiB, once per device.
+int ensure_ln_table(pa_sim *sim) {
+    std::lock_guard<std::mutex> lock(g_ln_mutex);
+    auto it = g_ln_tables.find(sim->device);
+    if (it == g_ln_tables.end()) {
+        std::vector<float> table(1u << 24);
+        const unsigned n_threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> workers;
+        for (unsigned k = 0; k < n_threads; ++k)
+            workers.emplace_back([&, k] {
+                const uint32_t lo = static_cast<uint32_t>((1ull << 24) * k / n_threads);
+                const uint32_t hi = static_cast<uint32_t>((1ull << 24) * (k + 1) / n_threads);
+                for (uint32_t v = lo; v < hi; ++v)
+                    table[v] = logf(static_cast<float>(v) * (1.0f / 16777216.0f));
+            });
+        for (auto &t : workers) t.join();
+        float *dev = nullptr;
+        PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&dev), sizeof(float) << 24));
+        PA_HIP(sim, hipMemcpy(dev, table.data(), sizeof(float) << 24, hipMemcpyHostToDevice));
+        it = g_ln_tables.emplace(sim->device, dev).first;
+    }
+    sim->p.ln_table = it->second;
+    return PA_OK;
+}
+
+template <typename T> int upload(pa_sim *sim, T *dst, const std::vector<T> &src) {
+    if (src.empty()) return PA_OK;
+    PA_HIP(sim, hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice,
+                               sim->stream));
+    PA_HIP(sim, hipStreamSynchronize(sim->stream));
+    return PA_OK;
+}
+
+template <typename T> int download(pa_sim *sim, std::vector<T> &dst, const T *src, size_t count) {
+    dst.resize(count);
+    if (!count) return PA_OK;
+    PA_HIP(sim, hipMemcpyAsync(dst.data(), src, count * sizeof(T), hipMemcpyDeviceToHost,
+                               sim->stream));
+    PA_HIP(sim, hipStreamSynchronize(sim->stream));
+    return PA_OK;
+}
+
+// Seeds every realisation exactly as Realization::new / reset do, packs the
+// spins slot-major and uploads the dynamic state.
+int seed_state(pa_sim *sim, uint64_t seed) {
+    const SimDims &d = sim->d;
+    const size_t tile_words = static_cast<size_t>(d.N) * d.W;
+    std::vector<uint32_t> S(tile_words * d.n_real, 0u);
+    std::vector<uint32_t> cursor(static_cast<size_t>(d.n_real) * 8 * d.SP, 0u);
+    const unsigned n_threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> workers;
+    for (unsigned k = 0; k < n_threads; ++k)
+        workers.emplace_back([&, k] {
+            for (uint32_t real = k; real < d.n_real; real += n_threads) {
+                const uint64_t base = realization_seed(seed, real); // src/lib.rs:160
+                uint32_t *tile = S.data() + tile_words * real;
+                for (uint32_t sys = 0; sys < d.n_sys; ++sys) {
+                    Xoshiro rng = Xoshiro::from_seed_u64(child_seed(base, kSystemSeedDomain, sys));
+                    const uint32_t word = sys >> 5, bit = 1u << (sys & 31u);
+                    for (uint32_t site = 0; site < d.N; ++site) // gen::<f32>() < 0.5 -> -1
+                        if (rng.next_draw24() < (1u << 23)) tile[static_cast<size_t>(site) * d.W + word] |= bit;
+                    for (int w = 0; w < 4; ++w) {
+                        cursor[(static_cast<size_t>(real) * 8 + 2 * w) * d.SP + sys] =
+                            static_cast<uint32_t>(rng.s[w]);
+                        cursor[(static_cast<size_t>(real) * 8 + 2 * w + 1) * d.SP + sys] =
+                            static_cast<uint32_t>(rng.s[w] >> 32);
+                    }
+                }
+            }
+        });
+    for (auto &t : workers) t.join();
+
+    std::vector<uint32_t> ids(static_cast<size_t>(d.n_real) * d.n_sys);
+    for (size_t i = 0; i < ids.size(); ++i) ids[i] = static_cast<uint32_t>(i % d.n_sys);
+    std::vector<uint8_t> trip(static_cast<size_t>(d.n_real) * d.n_sys, 0);
+    for (uint32_t real = 0; real < d.n_real; ++real) // PtState::reset, realization.rs:46-71
+        for (uint32_t rep = 0; rep < d.n_replicas; ++rep)
+            trip[static_cast<size_t>(real) * d.n_sys + rep * d.n_temps + sim->hot_slot] = 1;
+
+    int rc;
+    if ((rc = upload(sim, sim->p.S, S))) return rc;
+    if ((rc = upload(sim, sim->p.cursor, cursor))) return rc;
+    if ((rc = upload(sim, sim->p.system_ids, ids))) return rc;
+    if ((rc = upload(sim, sim->p.slot_of, ids))) return rc;
+    if ((rc = upload(sim, sim->p.trip_state, trip))) return rc;
+    PA_HIP(sim, hipMemsetAsync(sim->p.edge_att, 0, sizeof(uint64_t) * d.n_real * d.n_edges, sim->stream));
+    PA_HIP(sim, hipMemsetAsync(sim->p.edge_acc, 0, sizeof(uint64_t) * d.n_real * d.n_edges, sim->stream));
+    PA_HIP(sim, hipMemsetAsync(sim->p.round_trips, 0, sizeof(uint64_t) * d.n_real * d.n_sys, sim->stream));
+    sim->next_parity = 0;
+    // Realization::new computes the initial energies (realization.rs:196-197)
+    PA_HIP(sim, launch_sweep(sim->d, sim->p, true, false, sim->stream));
+    PA_HIP(sim, hipStreamSynchronize(sim->stream));
+    return PA_OK;
+}
+
+int zero_accumulators(pa_sim *sim) {
+    const SimDims &d = sim->d;
+    PA_HIP(sim, hipMemsetAsync(sim->p.mom, 0, sizeof(double) * d.n_real * 5 * d.n_temps, sim->stream));
+    if (d.n_pairs) {
+        const size_t bins = static_cast<size_t>(d.n_real) * d.n_temps * (d.N + 1);
+        PA_HIP(sim, hipMemsetAsync(sim->p.ovm, 0, sizeof(double) * d.n_real * 6 * d.n_temps, sim->stream));
+        PA_HIP(sim, hipMemsetAsync(sim->p.hist, 0, sizeof(uint64_t) * bins, sim->stream));
+        PA_HIP(sim, hipMemsetAsync(sim->p.qlq, 0, sizeof(double) * bins, sim->stream));
+        PA_HIP(sim, hipMemsetAsync(sim->p.ql2q, 0, sizeof(double) * bins, sim->stream));
+    }
+    return PA_OK;
+}
+
+std::string validate_text(const pa_sample_config *cfg, uint64_t n_replicas, int *code) {
+    *code = PA_ERR_INVALID;
+    // spin-sim/src/config.rs:180-247 (message texts are the reference's)
+    if (cfg->n_sweeps < 1) return "n_sweeps must be >= 1";
+    if (cfg->warmup_sweeps > cfg->n_sweeps) return "warmup_sweeps must be <= n_sweeps";
+    if (cfg->sweep_mode != PA_SWEEP_METROPOLIS && cfg->sweep_mode != PA_SWEEP_GIBBS)
+        return "unknown sweep_mode, expected 'metropolis' or 'gibbs'";
+    if (cfg->pt_schedule != PA_PT_SINGLE_RANDOM_EDGE && cfg->pt_schedule != PA_PT_FULL_LADDER)
+        return "unknown pt_schedule, expected 'single_random_edge' or 'full_ladder'";
+    if (cfg->overlap_cluster_interval > 0) {
+        if (cfg->n_overlap_cluster_modes < 1) return "overlap_cluster modes must not be empty";
+        // simulation/mod.rs:207-214
+        if (n_replicas < 2)
+            return "overlap cluster requires n_replicas >= max group_size (" +
+                   std::to_string(n_replicas) + " < 2)";
+    }
+    *code = PA_ERR_UNSUPPORTED;
+    if (cfg->sweep_mode == PA_SWEEP_GIBBS)
+        return "sweep_mode='gibbs' is not built on the HIP path yet";
+    if (cfg->overlap_cluster_interval > 0)
+        return "overlap cluster moves are not built on the HIP path yet";
+    *code = PA_OK;
+    return "";
+}
+
+int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
+    const SimDims &d = sim->d;
+    int rc = zero_accumulators(sim);
+    if (rc) return rc;
+    const bool want_overlap = d.n_pairs > 0 && cfg->measure_overlap;
+    sim->n_recorded = 0;
+    sim->overlap_collected = want_overlap;
+    for (uint64_t sweep_id = 0; sweep_id < cfg->n_sweeps; ++sweep_id) {
+        if ((sweep_id & 31u) == 0 && sim->interrupt.load(std::memory_order_relaxed)) {
+            (void)hipStreamSynchronize(sim->stream);
+            sim->interrupt.store(false);
+            return fail(sim, PA_ERR_INTERRUPTED, "interrupted");
+        }
+        const bool record = sweep_id >= cfg->warmup_sweeps; // mod.rs:410
+        const bool pt_this = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0; // :486-488
+        PA_HIP(sim, launch_rng(d, sim->p, sim->stream));                                // :412-432
+        PA_HIP(sim, launch_sweep(d, sim->p, record || pt_this, true, sim->stream));     // :492-509
+        if (record) {
+            if (want_overlap) PA_HIP(sim, launch_overlap(d, sim->p, sim->stream));      // :527-529
+            PA_HIP(sim, launch_accumulate(d, sim->p, want_overlap, sim->stream));       // :543-578
+            sim->n_recorded += 1;
+        }
+        if (pt_this) {                                                                  // :748-796
+            PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
+            PA_HIP(sim, launch_pt(d, sim->p, pt, sim->stream));
+            if (cfg->pt_schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
+        }
+    }
+    return PA_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *pa_version(void) { return "peapods_amd 0.1 (gfx950)"; }
+
+int pa_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+uint64_t pa_splitmix64(uint64_t value) { return splitmix64(value); }
+uint64_t pa_child_seed(uint64_t root, uint64_t domain, uint64_t index) {
+    return child_seed(root, domain, index);
+}
+uint64_t pa_realization_seed(uint64_t root, uint64_t realization) {
+    return realization_seed(root, realization);
+}
+
+void pa_xoshiro_state(uint64_t seed, uint64_t n_skip, uint64_t out[4]) {
+    Xoshiro rng = Xoshiro::from_seed_u64(seed);
+    for (uint64_t i = 0; i < n_skip; ++i) rng.next_u64();
+    std::memcpy(out, rng.s, 32);
+}
+
+void pa_xoshiro_jump(const uint64_t in[4], uint64_t n_steps, uint64_t out[4]) {
+    // through the same nibble-table form the device consumes
+    JumpMatrix m = JumpMatrix::steps(n_steps);
+    std::vector<uint32_t> table(64 * 16 * 8);
+    m.nibble_table(table.data());
+    uint32_t st[8], acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int w = 0; w < 4; ++w) {
+        st[2 * w] = static_cast<uint32_t>(in[w]);
+        st[2 * w + 1] = static_cast<uint32_t>(in[w] >> 32);
+    }
+    for (int p = 0; p < 64; ++p) {
+        const uint32_t nib = (st[p >> 3] >> ((p & 7) * 4)) & 15u;
+        for (int j = 0; j < 8; ++j) acc[j] ^= table[(p * 16 + nib) * 8 + j];
+    }
+    for (int w = 0; w < 4; ++w) out[w] = (static_cast<uint64_t>(acc[2 * w + 1]) << 32) | acc[2 * w];
+}
+
+int pa_build_metropolis_table(const float *couplings, uint64_t n_couplings,
+                              const float *temperatures, uint64_t n_temperatures,
+                              uint64_t n_neighbors, uint32_t *out) {
+    std::vector<uint32_t> table;
+    if (!build_metropolis_table(couplings, n_couplings, temperatures, n_temperatures, n_neighbors,
+                                table))
+        return PA_ERR_UNSUPPORTED;
+    std::memcpy(out, table.data(), table.size() * sizeof(uint32_t));
+    return PA_OK;
+}
+
+uint64_t pa_build_sweep_levels(uint32_t n_dims, const uint64_t *shape, uint32_t n_neighbors,
+                               const int64_t *neighbor_offsets, uint32_t *level_out) {
+    LatticeTables lat = LatticeTables::build(n_dims, shape, n_neighbors, neighbor_offsets);
+    std::vector<uint32_t> level;
+    const uint32_t n_levels = build_levels(lat, level);
+    std::memcpy(level_out, level.data(), level.size() * sizeof(uint32_t));
+    return n_levels;
+}
+
+void pa_aggregate_mean(const double *per_realization, uint64_t n_realizations, uint64_t len,
+                       double *out) {
+    for (uint64_t i = 0; i < len; ++i) out[i] = 0.0;
+    for (uint64_t r = 0; r < n_realizations; ++r)
+        for (uint64_t i = 0; i < len; ++i) out[i] += per_realization[r * len + i];
+    if (n_realizations > 1) { // a single realisation is returned as is (mod.rs:874-885)
+        const double n = static_cast<double>(n_realizations);
+        for (uint64_t i = 0; i < len; ++i) out[i] /= n;
+    }
+}
+
+void pa_aggregate_sum_u64(const uint64_t *per_realization, uint64_t n_realizations, uint64_t len,
+                          uint64_t *out) {
+    for (uint64_t i = 0; i < len; ++i) out[i] = 0;
+    for (uint64_t r = 0; r < n_realizations; ++r)
+        for (uint64_t i = 0; i < len; ++i) out[i] += per_realization[r * len + i];
+}
+
+void pa_aggregate_sum_f64(const double *per_realization, uint64_t n_realizations, uint64_t len,
+                          double *out) {
+    for (uint64_t i = 0; i < len; ++i) out[i] = 0.0;
+    for (uint64_t r = 0; r < n_realizations; ++r)
+        for (uint64_t i = 0; i < len; ++i) out[i] += per_realization[r * len + i];
+}
+
+int pa_validate_sample_config(const pa_sample_config *cfg, uint64_t n_replicas, char *err,
+                              size_t err_len) {
+    int code;
+    const std::string text = validate_text(cfg, n_replicas, &code);
+    if (code != PA_OK) write_err(err, err_len, text);
+    return code;
+}
+
+int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_len) {
+    *out = nullptr;
+    auto reject = [&](int code, const std::string &msg) {
+        write_err(err, err_len, msg);
+        return code;
+    };
+    if (!desc || desc->n_dims < 1 || desc->n_dims > 8 || !desc->shape)
+        return reject(PA_ERR_INVALID, "lattice_shape must have 1..8 dimensions");
+    for (uint32_t k = 0; k < desc->n_dims; ++k)
+        if (desc->shape[k] < 1) return reject(PA_ERR_INVALID, "lattice extents must be >= 1");
+    if (desc->n_temps < 1) return reject(PA_ERR_INVALID, "temperatures must not be empty");
+    if (desc->n_replicas < 1) return reject(PA_ERR_INVALID, "n_replicas must be >= 1");
+    if (desc->n_realizations < 1 || !desc->couplings || !desc->temperatures)
+        return reject(PA_ERR_INVALID, "couplings and temperatures are required");
+
+    int n_devices = 0;
+    if (hipGetDeviceCount(&n_devices) != hipSuccess || n_devices < 1)
+        return reject(PA_ERR_DEVICE, "no HIP device available (this engine has no CPU fallback)");
+    if (desc->device < 0 || desc->device >= n_devices)
+        return reject(PA_ERR_DEVICE, "HIP device ordinal out of range");
+
+    pa_sim *sim = new pa_sim();
+    auto bail = [&](int code) {
+        write_err(err, err_len, sim->error);
+        pa_sim_destroy(sim);
+        return code;
+    };
+    sim->device = desc->device;
+    sim->lat = LatticeTables::build(desc->n_dims, desc->shape,
+                                    desc->neighbor_offsets ? desc->n_neighbors : desc->n_dims,
+                                    desc->neighbor_offsets);
+    const LatticeTables &lat = sim->lat;
+    if (lat.n_neighbors > 3) {
+        sim->error = "more than 3 forward directions are not built on the HIP path yet";
+        return bail(PA_ERR_UNSUPPORTED);
+    }
+    if (lat.n_spins > 40000) {
+        sim->error = "lattices above 40000 sites are not built on the HIP path yet";
+        return bail(PA_ERR_UNSUPPORTED);
+    }
+    sim->n_replicas = desc->n_replicas;
+    sim->n_temps = desc->n_temps;
+    sim->n_real = desc->n_realizations;
+    sim->constructor_seed = desc->seed;
+    sim->temps.assign(desc->temperatures, desc->temperatures + desc->n_temps);
+
+    SimDims &d = sim->d;
+    d.N = static_cast<uint32_t>(lat.n_spins);
+    d.n_sys = static_cast<uint32_t>(desc->n_replicas * desc->n_temps);
+    d.W = (d.n_sys + 31) / 32;
+    d.SP = d.W * 32;
+    d.n_temps = static_cast<uint32_t>(desc->n_temps);
+    d.n_replicas = static_cast<uint32_t>(desc->n_replicas);
+    d.n_pairs = d.n_replicas / 2;
+    d.n_real = static_cast<uint32_t>(desc->n_realizations);
+    d.nn = lat.n_neighbors;
+    d.B = std::max<uint32_t>(1, (d.N + 128) / 256);
+    d.BS = (d.N + d.B - 1) / d.B;
+    d.B = (d.N + d.BS - 1) / d.BS;
+    d.BP = (d.B + 1) / 2;
+    d.MW = (d.N + 31) / 32;
+    d.n_edges = std::max<uint32_t>(1, d.n_temps - 1);
+    if (d.W > 64) {
+        sim->error = "more than 2048 systems per realisation are not built on the HIP path yet";
+        return bail(PA_ERR_UNSUPPORTED);
+    }
+
+    // ---- acceptance thresholds (sweep.rs:109-139); all realisations must take the table path
+    const size_t n_coup = static_cast<size_t>(d.N) * d.nn;
+    std::vector<uint32_t> table;
+    if (!build_metropolis_table(desc->couplings, n_coup * d.n_real, sim->temps.data(), d.n_temps,
+                                d.nn, table)) {
+        sim->error = "couplings outside {-1,0,+1} or non-positive temperatures need the "
+                     "reference's logarithmic path, which is not built on the HIP path yet";
+        return bail(PA_ERR_UNSUPPORTED);
+    }
+    const uint32_t width = 4 * d.nn + 1, off = 2 * d.nn;
+    std::vector<uint32_t> thr(6 * d.n_temps, 0u);
+    for (uint32_t t = 0; t < d.n_temps; ++t) {
+        for (uint32_t j = 0; j < 3; ++j) {
+            const uint32_t even_e = 2 * (j + 1), odd_e = 2 * j + 1; // |dE|
+            if (even_e <= off) thr[(0 + j) * d.n_temps + t] = table[t * width + off - even_e];
+            if (odd_e <= off) thr[(3 + j) * d.n_temps + t] = table[t * width + off - odd_e];
+        }
+        for (uint32_t e = 1; e <= off; ++e) // levels need thresholds that fall with |dE|
+            if (table[t * width + off - e] > table[t * width + off - e + 1]) {
+                sim->error = "acceptance table is not monotone in the energy change";
+                return bail(PA_ERR_UNSUPPORTED);
+            }
+    }
+
+    // ---- dependency levels -> schedule order
+    std::vector<uint32_t> level;
+    d.n_levels = build_levels(lat, level);
+    std::vector<uint32_t> order(d.N);
+    for (uint32_t i = 0; i < d.N; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(),
+                     [&](uint32_t a, uint32_t b) { return level[a] < level[b]; });
+    std::vector<uint32_t> level_start(d.n_levels + 1, 0);
+    for (uint32_t i = 0; i < d.N; ++i) level_start[level[i] + 1] += 1;
+    for (uint32_t l = 0; l < d.n_levels; ++l) level_start[l + 1] += level_start[l];
+    std::vector<uint32_t> sched(static_cast<size_t>(d.N) * 8, 0u);
+    for (uint32_t pos = 0; pos < d.N; ++pos) {
+        const uint32_t site = order[pos];
+        uint32_t *rec = &sched[static_cast<size_t>(pos) * 8];
+        rec[0] = site;
+        for (uint32_t k = 0; k < 3; ++k) {
+            rec[1 + 2 * k] = k < d.nn ? lat.fwd[site * d.nn + k] : site;
+            rec[2 + 2 * k] = k < d.nn ? lat.bwd[site * d.nn + k] : site;
+        }
+    }
+
+    // ---- per-realisation coupling metadata in schedule order
+    std::vector<uint16_t> jmeta(static_cast<size_t>(d.n_real) * d.N, 0);
+    std::vector<uint32_t> mpar(static_cast<size_t>(d.n_real) * d.MW, 0u);
+    std::vector<int32_t> nz_bonds(d.n_real, 0);
+    d.has_odd = 0;
+    for (uint32_t real = 0; real < d.n_real; ++real) {
+        const float *J = desc->couplings + n_coup * real;
+        for (uint32_t pos = 0; pos < d.N; ++pos) {
+            const uint32_t site = order[pos];
+            uint32_t neg = 0, nz = 0, m = 0;
+            for (uint32_t k = 0; k < d.nn; ++k) {
+                const float jf = J[site * d.nn + k];                  // bond site -> fwd
+                const float jb = J[lat.bwd[site * d.nn + k] * d.nn + k]; // owned by the bwd neighbour
+                if (jf != 0.0f) { nz |= 1u << (2 * k); m += 1; nz_bonds[real] += 1; }
+                if (jf < 0.0f) neg |= 1u << (2 * k);
+                if (jb != 0.0f) { nz |= 1u << (2 * k + 1); m += 1; }
+                if (jb < 0.0f) neg |= 1u << (2 * k + 1);
+            }
+            const uint32_t h = (m + 1) / 2;
+            jmeta[static_cast<size_t>(real) * d.N + pos] =
+                static_cast<uint16_t>(neg | (nz << 6) | (h << 12));
+            if (m & 1u) {
+                mpar[static_cast<size_t>(real) * d.MW + (site >> 5)] |= 1u << (site & 31u);
+                d.has_odd = 1;
+            }
+        }
+    }
+
+    // ---- jump tables T^(b*BS), b = 0..B-1
+    std::vector<uint32_t> jump(static_cast<size_t>(d.B) * 64 * 16 * 8);
+    {
+        JumpMatrix step = JumpMatrix::steps(d.BS);
+        JumpMatrix acc = JumpMatrix::identity();
+        for (uint32_t b = 0; b < d.B; ++b) {
+            acc.nibble_table(&jump[static_cast<size_t>(b) * 64 * 16 * 8]);
+            if (b + 1 < d.B) acc = step.compose(acc);
+        }
+    }
+
+    // ---- PT constants
+    std::vector<float> dbeta(d.n_edges, 0.0f);
+    for (uint32_t t = 0; t + 1 < d.n_temps; ++t)
+        dbeta[t] = 1.0f / sim->temps[t] - 1.0f / sim->temps[t + 1]; // tempering.rs:88
+    sim->cold_slot = sim->hot_slot = 0; // realization.rs:92-107
+    for (uint32_t t = 1; t < d.n_temps; ++t) {
+        if (sim->temps[t] < sim->temps[sim->cold_slot]) sim->cold_slot = t;
+        if (sim->temps[t] > sim->temps[sim->hot_slot]) sim->hot_slot = t;
+    }
+
+    // ---- device
+    if (hipSetDevice(sim->device) != hipSuccess) {
+        sim->error = "hipSetDevice failed";
+        return bail(PA_ERR_DEVICE);
+    }
+    if (hipStreamCreate(&sim->stream) != hipSuccess) {
+        sim->error = "hipStreamCreate failed";
+        return bail(PA_ERR_DEVICE);
+    }
+    int rc = ensure_ln_table(sim);
+    if (rc) return bail(rc);
+
+    DevPtrs &p = sim->p;
+    DeviceBuffers &bufs = sim->buffers;
+    const size_t tile_words = static_cast<size_t>(d.N) * d.W;
+    const size_t bins = d.n_pairs ? static_cast<size_t>(d.n_real) * d.n_temps * (d.N + 1) : 0;
+    const size_t n_pair_slots = static_cast<size_t>(d.n_real) * d.n_pairs * d.n_temps;
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) {
+        if (e == hipSuccess) e = r;
+    };
+    ok(bufs.alloc(&p.S, tile_words * d.n_real));
+    ok(bufs.alloc(&p.planes, tile_words * d.n_real));
+    ok(bufs.alloc(&p.cursor, static_cast<size_t>(d.n_real) * 8 * d.SP));
+    ok(bufs.alloc(&p.system_ids, static_cast<size_t>(d.n_real) * d.n_sys));
+    ok(bufs.alloc(&p.slot_of, static_cast<size_t>(d.n_real) * d.n_sys));
+    ok(bufs.alloc(&sim->thr, thr.size()));
+    ok(bufs.alloc(&sim->mpar, mpar.size()));
+    ok(bufs.alloc(&sim->sched, sched.size()));
+    ok(bufs.alloc(&sim->jmeta, jmeta.size()));
+    ok(bufs.alloc(&sim->level_start, level_start.size()));
+    ok(bufs.alloc(&sim->jump, jump.size()));
+    ok(bufs.alloc(&p.Esum, static_cast<size_t>(d.n_real) * d.n_sys));
+    ok(bufs.alloc(&p.Msum, static_cast<size_t>(d.n_real) * d.n_sys));
+    ok(bufs.alloc(&sim->nz_bonds, nz_bonds.size()));
+    ok(bufs.alloc(&p.dot_spin, n_pair_slots));
+    ok(bufs.alloc(&p.dot_link, n_pair_slots));
+    ok(bufs.alloc(&p.mom, static_cast<size_t>(d.n_real) * 5 * d.n_temps));
+    ok(bufs.alloc(&p.ovm, static_cast<size_t>(d.n_real) * 6 * d.n_temps));
+    ok(bufs.alloc(&p.hist, bins));
+    ok(bufs.alloc(&p.qlq, bins));
+    ok(bufs.alloc(&p.ql2q, bins));
+    ok(bufs.alloc(&p.edge_att, static_cast<size_t>(d.n_real) * d.n_edges));
+    ok(bufs.alloc(&p.edge_acc, static_cast<size_t>(d.n_real) * d.n_edges));
+    ok(bufs.alloc(&p.round_trips, static_cast<size_t>(d.n_real) * d.n_sys));
+    ok(bufs.alloc(&p.trip_state, static_cast<size_t>(d.n_real) * d.n_sys));
+    ok(bufs.alloc(&sim->dbeta, dbeta.size()));
+    ok(bufs.alloc(&p.swap_masks, static_cast<size_t>(d.n_real) * 2 * d.W));
+    if (e != hipSuccess) {
+        sim->error = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return bail(PA_ERR_DEVICE);
+    }
+    p.thr = sim->thr;
+    p.mpar = sim->mpar;
+    p.sched = sim->sched;
+    p.jmeta = sim->jmeta;
+    p.level_start = sim->level_start;
+    p.jump = sim->jump;
+    p.nz_bonds = sim->nz_bonds;
+    p.dbeta = sim->dbeta;
+    if ((rc = upload(sim, sim->thr, thr)) || (rc = upload(sim, sim->mpar, mpar)) ||
+        (rc = upload(sim, sim->sched, sched)) || (rc = upload(sim, sim->jmeta, jmeta)) ||
+        (rc = upload(sim, sim->level_start, level_start)) || (rc = upload(sim, sim->jump, jump)) ||
+        (rc = upload(sim, sim->nz_bonds, nz_bonds)) || (rc = upload(sim, sim->dbeta, dbeta)))
+        return bail(rc);
+    if (configure_kernels(d) != hipSuccess) {
+        sim->error = "kernel LDS configuration failed";
+        return bail(PA_ERR_DEVICE);
+    }
+    if ((rc = zero_accumulators(sim))) return bail(rc);
+    if ((rc = seed_state(sim, desc->seed))) return bail(rc);
+    *out = sim;
+    return PA_OK;
+}
+
+void pa_sim_destroy(pa_sim *sim) {
+    if (!sim) return;
+    if (sim->stream) {
+        (void)hipSetDevice(sim->device);
+        (void)hipStreamSynchronize(sim->stream);
+        sim->buffers.release();
+        (void)hipStreamDestroy(sim->stream);
+    }
+    delete sim;
+}
+
+const char *pa_sim_last_error(const pa_sim *sim) { return sim ? sim->error.c_str() : ""; }
+
+int pa_sim_reset(pa_sim *sim, uint64_t seed) {
+    PA_HIP(sim, hipSetDevice(sim->device));
+    return seed_state(sim, seed);
+}
+
+void pa_sim_request_interrupt(pa_sim *sim) { sim->interrupt.store(true); }
+
+int pa_sim_synchronize(pa_sim *sim) {
+    PA_HIP(sim, hipSetDevice(sim->device));
+    PA_HIP(sim, hipStreamSynchronize(sim->stream));
+    return PA_OK;
+}
+
+int pa_sim_sample_async(pa_sim *sim, const pa_sample_config *cfg) {
+    int code;
+    const std::string text = validate_text(cfg, sim->n_replicas, &code);
+    if (code != PA_OK) return fail(sim, code, text);
+    PA_HIP(sim, hipSetDevice(sim->device));
+    return run_sweeps(sim, cfg);
+}
+
+int pa_sim_sample(pa_sim *sim, const pa_sample_config *cfg) {
+    int rc = pa_sim_sample_async(sim, cfg);
+    if (rc) return rc;
+    return pa_sim_synchronize(sim);
+}
+
+int pa_sim_metropolis_sweep(pa_sim *sim, uint64_t n_sweeps) {
+    PA_HIP(sim, hipSetDevice(sim->device));
+    for (uint64_t k = 0; k < n_sweeps; ++k) {
+        PA_HIP(sim, launch_rng(sim->d, sim->p, sim->stream));
+        PA_HIP(sim, launch_sweep(sim->d, sim->p, false, true, sim->stream));
+    }
+    return pa_sim_synchronize(sim);
+}
+
+int pa_sim_compute_energies(pa_sim *sim) {
+    PA_HIP(sim, hipSetDevice(sim->device));
+    PA_HIP(sim, launch_sweep(sim->d, sim->p, true, false, sim->stream));
+    return pa_sim_synchronize(sim);
+}
+
+int pa_sim_parallel_tempering(pa_sim *sim, int32_t schedule) {
+    if (schedule != PA_PT_SINGLE_RANDOM_EDGE && schedule != PA_PT_FULL_LADDER)
+        return fail(sim, PA_ERR_INVALID,
+                    "unknown pt_schedule, expected 'single_random_edge' or 'full_ladder'");
+    PA_HIP(sim, hipSetDevice(sim->device));
+    PA_HIP(sim, launch_sweep(sim->d, sim->p, true, false, sim->stream));
+    PtParams pt{schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
+    PA_HIP(sim, launch_pt(sim->d, sim->p, pt, sim->stream));
+    if (schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
+    return pa_sim_synchronize(sim);
+}
+
+int pa_sim_overlap_dots(pa_sim *sim, int64_t *dot_spin, int64_t *dot_link) {
+    const SimDims &d = sim->d;
+    if (d.n_pairs == 0) return fail(sim, PA_ERR_INVALID, "overlap needs n_replicas >= 2");
+    PA_HIP(sim, hipSetDevice(sim->device));
+    PA_HIP(sim, launch_overlap(d, sim->p, sim->stream));
+    const size_t count = static_cast<size_t>(d.n_real) * d.n_pairs * d.n_temps;
+    std::vector<int32_t> a, b;
+    int rc;
+    if ((rc = download(sim, a, sim->p.dot_spin, count)) || (rc = download(sim, b, sim->p.dot_link, count)))
+        return rc;
+    for (size_t i = 0; i < count; ++i) {
+        dot_spin[i] = a[i];
+        dot_link[i] = b[i];
+    }
+    return PA_OK;
+}
+
+uint64_t pa_sim_n_spins(const pa_sim *sim) { return sim->d.N; }
+uint64_t pa_sim_n_neighbors(const pa_sim *sim) { return sim->d.nn; }
+uint64_t pa_sim_n_systems(const pa_sim *sim) { return sim->d.n_sys; }
+
+#define PA_CHECK_REAL(sim, r)                                                                      \
+    if ((r) >= (sim)->d.n_real) return fail(sim, PA_ERR_INVALID, "realization index out of range")
+
+int pa_sim_get_spins(pa_sim *sim, uint64_t realization, int8_t *out) {
+    PA_CHECK_REAL(sim, realization);
+    PA_HIP(sim, hipSetDevice(sim->device));
+    const SimDims &d = sim->d;
+    std::vector<uint32_t> S, slot_of;
+    int rc;
+    const size_t tile_words = static_cast<size_t>(d.N) * d.W;
+    if ((rc = download(sim, S, sim->p.S + tile_words * realization, tile_words))) return rc;
+    if ((rc = download(sim, slot_of, sim->p.slot_of + d.n_sys * realization, d.n_sys))) return rc;
+    for (uint32_t sys = 0; sys < d.n_sys; ++sys) {
+        const uint32_t slot = slot_of[sys], word = slot >> 5, bit = slot & 31u;
+        int8_t *dst = out + static_cast<size_t>(sys) * d.N;
+        for (uint32_t site = 0; site < d.N; ++site)
+            dst[site] = ((S[static_cast<size_t>(site) * d.W + word] >> bit) & 1u) ? -1 : 1;
+    }
+    return PA_OK;
+}
+
+int pa_sim_get_system_ids(pa_sim *sim, uint64_t realization, uint64_t *out) {
+    PA_CHECK_REAL(sim, realization);
+    PA_HIP(sim, hipSetDevice(sim->device));
+    std::vector<uint32_t> ids;
+    int rc = download(sim, ids, sim->p.system_ids + sim->d.n_sys * realization, sim->d.n_sys);
+    if (rc) return rc;
+    for (uint32_t k = 0; k < sim->d.n_sys; ++k) out[k] = ids[k];
+    return PA_OK;
+}
+
+int pa_sim_get_energies(pa_sim *sim, uint64_t realization, float *out) {
+    PA_CHECK_REAL(sim, realization);
+    PA_HIP(sim, hipSetDevice(sim->device));
+    const SimDims &d = sim->d;
+    std::vector<int32_t> E;
+    std::vector<uint32_t> slot_of;
+    int rc;
+    if ((rc = download(sim, E, sim->p.Esum + d.n_sys * realization, d.n_sys))) return rc;
+    if ((rc = download(sim, slot_of, sim->p.slot_of + d.n_sys * realization, d.n_sys))) return rc;
+    for (uint32_t sys = 0; sys < d.n_sys; ++sys) // energy.rs:108: total / n_spins as f32
+        out[sys] = static_cast<float>(E[slot_of[sys]]) / static_cast<float>(d.N);
+    return PA_OK;
+}
+
+int pa_sim_get_magnetization_sums(pa_sim *sim, uint64_t realization, int64_t *out) {
+    PA_CHECK_REAL(sim, realization);
+    PA_HIP(sim, hipSetDevice(sim->device));
+    const SimDims &d = sim->d;
+    std::vector<int32_t> M;
+    std::vector<uint32_t> slot_of;
+    int rc;
+    if ((rc = download(sim, M, sim->p.Msum + d.n_sys * realization, d.n_sys))) return rc;
+    if ((rc = download(sim, slot_of, sim->p.slot_of + d.n_sys * realization, d.n_sys))) return rc;
+    for (uint32_t sys = 0; sys < d.n_sys; ++sys) out[sys] = M[slot_of[sys]];
+    return PA_OK;
+}
+
+int pa_sim_get_rng_state(pa_sim *sim, uint64_t realization, uint64_t system, uint64_t out[4]) {
+    PA_CHECK_REAL(sim, realization);
+    if (system >= sim->d.n_sys) return fail(sim, PA_ERR_INVALID, "system index out of range");
+    PA_HIP(sim, hipSetDevice(sim->device));
+    const SimDims &d = sim->d;
+    std::vector<uint32_t> slot_of, cur;
+    int rc;
+    if ((rc = download(sim, slot_of, sim->p.slot_of + d.n_sys * realization, d.n_sys))) return rc;
+    if ((rc = download(sim, cur, sim->p.cursor + static_cast<size_t>(realization) * 8 * d.SP,
+                       static_cast<size_t>(8) * d.SP)))
+        return rc;
+    const uint32_t slot = slot_of[system];
+    for (int w = 0; w < 4; ++w)
+        out[w] = (static_cast<uint64_t>(cur[(2 * w + 1) * d.SP + slot]) << 32) | cur[(2 * w) * d.SP + slot];
+    return PA_OK;
+}
+
+int pa_sim_get_pt_counters(pa_sim *sim, uint64_t realization, uint64_t *edge_attempts,
+                           uint64_t *edge_acceptances, uint64_t *round_trips) {
+    PA_CHECK_REAL(sim, realization);
+    PA_HIP(sim, hipSetDevice(sim->device));
+    const SimDims &d = sim->d;
+    std::vector<uint64_t> a, b, c;
+    int rc;
+    if ((rc = download(sim, a, sim->p.edge_att + d.n_edges * realization, d.n_edges)) ||
+        (rc = download(sim, b, sim->p.edge_acc + d.n_edges * realization, d.n_edges)) ||
+        (rc = download(sim, c, sim->p.round_trips + d.n_sys * realization, d.n_sys)))
+        return rc;
+    for (uint32_t k = 0; k + 1 < d.n_temps; ++k) {
+        edge_attempts[k] = a[k];
+        edge_acceptances[k] = b[k];
+    }
+    std::memcpy(round_trips, c.data(), sizeof(uint64_t) * d.n_sys);
+    return PA_OK;
+}
+
+// Statistics::average (stats.rs:29-35): sum / count, or the raw sums when nothing was recorded.
+static void average_into(double *dst, const double *sums, size_t n, uint64_t count) {
+    if (count == 0) {
+        std::memcpy(dst, sums, sizeof(double) * n);
+        return;
+    }
+    const double c = static_cast<double>(count);
+    for (size_t i = 0; i < n; ++i) dst[i] = sums[i] / c;
+}
+
+int pa_sim_get_result_moments(pa_sim *sim, uint64_t realization, double *out) {
+    PA_CHECK_REAL(sim, realization);
+    PA_HIP(sim, hipSetDevice(sim->device));
+    const SimDims &d = sim->d;
+    std::vector<double> sums;
+    int rc = download(sim, sums, sim->p.mom + static_cast<size_t>(realization) * 5 * d.n_temps,
+                      static_cast<size_t>(5) * d.n_temps);
+    if (rc) return rc;
+    average_into(out, sums.data(), sums.size(), sim->n_recorded * d.n_replicas);
+    return PA_OK;
+}
+
+int pa_sim_get_result_overlap(pa_sim *sim, uint64_t realization, double *out) {
+    PA_CHECK_REAL(sim, realization);
+    const SimDims &d = sim->d;
+    if (d.n_pairs == 0) return fail(sim, PA_ERR_INVALID, "overlap needs n_replicas >= 2");
+    PA_HIP(sim, hipSetDevice(sim->device));
+    std::vector<double> sums;
+    int rc = download(sim, sums, sim->p.ovm + static_cast<size_t>(realization) * 6 * d.n_temps,
+                      static_cast<size_t>(6) * d.n_temps);
+    if (rc) return rc;
+    average_into(out, sums.data(), sums.size(),
+                 sim->overlap_collected ? sim->n_recorded * d.n_pairs : 0);
+    return PA_OK;
+}
+
+int pa_sim_get_result_histograms(pa_sim *sim, uint64_t realization, uint64_t *histogram,
+                                 double *ql_at_q_sum, double *ql2_at_q_sum) {
+    PA_CHECK_REAL(sim, realization);
+    const SimDims &d = sim->d;
+    if (d.n_pairs == 0) return fail(sim, PA_ERR_INVALID, "overlap needs n_replicas >= 2");
+    PA_HIP(sim, hipSetDevice(sim->device));
+    const size_t bins = static_cast<size_t>(d.n_temps) * (d.N + 1);
+    PA_HIP(sim, hipMemcpyAsync(histogram, sim->p.hist + bins * realization, bins * sizeof(uint64_t),
+                               hipMemcpyDeviceToHost, sim->stream));
+    PA_HIP(sim, hipMemcpyAsync(ql_at_q_sum, sim->p.qlq + bins * realization, bins * sizeof(double),
+                               hipMemcpyDeviceToHost, sim->stream));
+    PA_HIP(sim, hipMemcpyAsync(ql2_at_q_sum, sim->p.ql2q + bins * realization, bins * sizeof(double),
+                               hipMemcpyDeviceToHost, sim->stream));
+    PA_HIP(sim, hipStreamSynchronize(sim->stream));
+    return PA_OK;
+}
+
+uint64_t pa_sim_result_block_len(const pa_sim *sim) {
+    return static_cast<uint64_t>(sim->d.n_temps) * (sim->d.n_pairs ? 11 : 5);
+}
+
+int pa_sim_get_result_blocks(pa_sim *sim, double *out) {
+    const SimDims &d = sim->d;
+    const uint64_t len = pa_sim_result_block_len(sim);
+    for (uint32_t real = 0; real < d.n_real; ++real) {
+        int rc = pa_sim_get_result_moments(sim, real, out + real * len);
+        if (rc) return rc;
+        if (d.n_pairs && (rc = pa_sim_get_result_overlap(sim, real, out + real * len + 5 * d.n_temps)))
+            return rc;
+    }
+    return PA_OK;
+}
+
+} // extern "C"

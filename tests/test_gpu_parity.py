@@ -1,0 +1,213 @@
+"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Integer and index results must be bit-exact; floating-point
+observables are compared bit for bit too (they are one IEEE division / f64 running
+sums of exact integers), which is tighter than the 1e-6 the north star allows.
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bimodal(shape, nn, n_dis, seed):
+    rng = np.random.default_rng(seed)
+    full = (n_dis,) + tuple(shape) + (nn,) if n_dis > 1 else tuple(shape) + (nn,)
+    return (2 * rng.integers(0, 2, size=full) - 1).astype(np.float32)
+
+
+def make_pair(oracle, shape, couplings, temps, n_replicas, seed, offsets=None):
+    from peapods_amd import IsingSimulation
+
+    temps = np.asarray(temps, dtype=np.float32)
+    gpu = IsingSimulation(list(shape), couplings, temps, n_replicas, offsets, seed)
+    cpu = oracle.OracleSimulation(list(shape), couplings, temps, n_replicas, offsets, seed)
+    return gpu, cpu
+
+
+def assert_state_equal(gpu, cpu, check_energy=True):
+    for r in range(gpu.n_realizations):
+        np.testing.assert_array_equal(gpu.get_spins(r), cpu.get_spins(r))
+        np.testing.assert_array_equal(gpu.get_system_ids(r), cpu.get_system_ids(r))
+        for s in range(gpu.n_systems):
+            np.testing.assert_array_equal(gpu.get_rng_state(r, s), cpu.get_rng_state(r, s))
+        if check_energy:
+            np.testing.assert_array_equal(gpu.get_energies(r), cpu.get_energies(r))
+
+
+def assert_results_equal(a, b):
+    assert set(a.keys()) == set(b.keys())
+    for key in a:
+        if key == "per_disorder":
+            for k2 in a[key]["parallel_tempering"]:
+                np.testing.assert_array_equal(a[key]["parallel_tempering"][k2],
+                                              b[key]["parallel_tempering"][k2], err_msg=k2)
+        elif key == "overlap_histogram":
+            for x, y in zip(a[key], b[key]):
+                np.testing.assert_array_equal(x, y)
+        else:
+            np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+
+
+CASES = [
+    # shape, n_temps, n_replicas, n_disorder, offsets
+    ((4, 4), 2, 2, 1, None),
+    ((3, 5), 3, 1, 2, None),            # odd extents: no checkerboard exists, levels still do
+    ((8, 8), 3, 1, 1, [[1, 0], [0, 1]]),
+    ((4, 4), 2, 2, 1, [[1, 0], [0, 1], [1, -1]]),  # triangular
+    ((2, 3, 4), 4, 2, 2, None),         # extent-2 dimension: fwd and bwd bonds coincide in site
+    ((6, 6, 6), 5, 4, 3, None),
+    ((12,), 3, 2, 1, None),
+]
+
+
+@pytest.mark.parametrize("shape,n_temps,n_rep,n_dis,offsets", CASES)
+def test_initial_state_and_sweep_trajectory(oracle, shape, n_temps, n_rep, n_dis, offsets):
+    nn = len(offsets) if offsets else len(shape)
+    couplings = bimodal(shape, nn, n_dis, 5)
+    temps = np.linspace(0.8, 2.4, n_temps)
+    gpu, cpu = make_pair(oracle, shape, couplings, temps, n_rep, 1234, offsets)
+    assert_state_equal(gpu, cpu)
+    gpu.metropolis_sweep(7)
+    cpu.sample(7, "metropolis", warmup_ratio=1.0)
+    gpu.compute_energies()
+    assert_state_equal(gpu, cpu, check_energy=False)
+
+
+def test_unit_lookup_case_with_zero_couplings(oracle):
+    # the reference's own table test pattern (sweep.rs:382-442): couplings cycle -1, 0, +1
+    shape = (8, 8)
+    n = 64
+    couplings = np.array([[-1.0, 0.0, 1.0][i % 3] for i in range(n * 2)], np.float32).reshape(8, 8, 2)
+    gpu, cpu = make_pair(oracle, shape, couplings, [0.7, 2.0, 5.0], 2, 71)
+    gpu.metropolis_sweep(20)
+    cpu.sample(20, "metropolis", warmup_ratio=1.0)
+    assert_state_equal(gpu, cpu, check_energy=False)
+    gpu.compute_energies()
+    cpu_e = cpu.get_energies()
+    # oracle energies after sample() are those of the last PT/record sweep; recompute by a
+    # recorded sweep-less call is not available, so compare through the energy definition
+    spins = gpu.get_spins().reshape(gpu.n_systems, n).astype(np.float32)
+    lat = oracle.Lattice(shape)
+    J = couplings.reshape(n, 2)
+    for s in range(gpu.n_systems):
+        total = np.float32(0)
+        for i in range(n):
+            for d in range(2):
+                total = np.float32(total + spins[s, i] * spins[s, lat.neighbor_fwd(i, d)] * J[i, d])
+        assert gpu.get_energies()[s] == np.float32(total / np.float32(n))
+    del cpu_e
+
+
+@pytest.mark.parametrize("schedule", ["single_random_edge", "full_ladder"])
+@pytest.mark.parametrize("shape,n_temps,n_rep,n_dis", [((4, 4), 3, 2, 1), ((4, 4, 4), 6, 4, 3),
+                                                       ((6, 6, 6), 24, 4, 2)])
+def test_sample_matches_oracle(oracle, schedule, shape, n_temps, n_rep, n_dis):
+    couplings = bimodal(shape, len(shape), n_dis, 11)
+    temps = np.linspace(0.8, 1.6, n_temps)
+    gpu, cpu = make_pair(oracle, shape, couplings, temps, n_rep, 99)
+    kwargs = dict(pt_interval=1, pt_schedule=schedule, warmup_ratio=0.25)
+    a = gpu.sample(24, "metropolis", **kwargs)
+    b = cpu.sample(24, "metropolis", **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+    # continuation semantics: a second call continues the chain and the PT counters
+    a = gpu.sample(9, "metropolis", pt_interval=2, pt_schedule=schedule, warmup_ratio=0.0)
+    b = cpu.sample(9, "metropolis", pt_interval=2, pt_schedule=schedule, warmup_ratio=0.0)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+
+
+def test_ferromagnet_without_replicas_or_pt(oracle):
+    shape = (8, 8)
+    couplings = np.ones(shape + (2,), np.float32)
+    gpu, cpu = make_pair(oracle, shape, couplings, np.linspace(1.969, 2.569, 8), 1, 3)
+    a = gpu.sample(40, "metropolis")
+    b = cpu.sample(40, "metropolis")
+    assert_results_equal(a, b)
+    assert "overlap" not in a
+
+
+def test_reset_replays_and_reseeds(oracle):
+    shape = (4, 4)
+    couplings = bimodal(shape, 2, 1, 3)
+    gpu, cpu = make_pair(oracle, shape, couplings, [1.0, 2.0], 2, 41)
+    initial = gpu.get_spins().copy()
+    gpu.sample(2, "metropolis", warmup_ratio=0)
+    gpu.reset()
+    np.testing.assert_array_equal(gpu.get_spins(), initial)
+    gpu.reset(seed=99)
+    cpu.reset(seed=99)
+    assert_state_equal(gpu, cpu)
+    gpu.reset()
+    np.testing.assert_array_equal(gpu.get_spins(), initial)
+
+
+def test_overlap_dots_entry_point(oracle):
+    shape = (4, 4, 4)
+    couplings = bimodal(shape, 3, 2, 8)
+    gpu, cpu = make_pair(oracle, shape, couplings, np.linspace(0.9, 1.5, 5), 4, 17)
+    gpu.metropolis_sweep(3)
+    dot_spin, dot_link = gpu.overlap_dots()
+    n = 64
+    lat = oracle.Lattice(shape)
+    for r in range(2):
+        spins = gpu.get_spins(r).reshape(gpu.n_systems, n).astype(np.int64)
+        ids = gpu.get_system_ids(r)
+        for p in range(2):
+            for t in range(5):
+                a = spins[int(ids[(2 * p) * 5 + t])]
+                b = spins[int(ids[(2 * p + 1) * 5 + t])]
+                q = a * b
+                assert dot_spin[r, p, t] == q.sum()
+                link = sum(int(q[i] * q[lat.neighbor_fwd(i, d)]) for i in range(n) for d in range(3))
+                assert dot_link[r, p, t] == link
+
+
+def test_invalid_options_fail_before_mutation():
+    from peapods_amd import Ising
+
+    model = Ising((4, 4), temperatures=np.array([2.0]), seed=13)
+    before = model._sim.get_spins().copy()
+    with pytest.raises(ValueError, match="requires cluster_mode='sw'"):
+        model.sample(1, cluster_update_interval=1, cluster_mode="wolff", cluster_action="observe",
+                     warmup_ratio=0)
+    with pytest.raises(ValueError, match="must be 'ring' or 'fft'"):
+        model.sample(4, autocorrelation_backend="other", warmup_ratio=0)
+    with pytest.raises(ValueError, match="requires autocorrelation_max_lag"):
+        model.sample(4, autocorrelation_backend="fft", warmup_ratio=0)
+    with pytest.raises(ValueError, match="sweep_mode"):
+        model.sample(4, sweep_mode="heatbath")
+    np.testing.assert_array_equal(model._sim.get_spins(), before)
+
+
+def test_ising_surface_seed_determinism_and_keys():
+    # reference tests/test_sampling_interfaces.py:12-48,75-118
+    from peapods_amd import Ising
+
+    temps = np.array([1.0, 2.0, 4.0], dtype=np.float32)
+    first = Ising((4, 4), couplings="bimodal", temperatures=temps, n_replicas=2, seed=41)
+    second = Ising((4, 4), couplings="bimodal", temperatures=temps, n_replicas=2, seed=41)
+    np.testing.assert_array_equal(first.couplings, second.couplings)
+    np.testing.assert_array_equal(first._sim.get_spins(), second._sim.get_spins())
+    one = Ising((4, 4), couplings="bimodal", n_disorder=1, seed=7)
+    many = Ising((4, 4), couplings="bimodal", n_disorder=3, seed=7)
+    np.testing.assert_array_equal(one.couplings, many.couplings[0])
+
+    result = first.sample(2, pt_interval=1, pt_schedule="full_ladder", warmup_ratio=0)
+    pt = result["per_disorder"]["parallel_tempering"]
+    assert pt["edge_attempts"].shape == (1, 2) and np.all(pt["edge_attempts"] == 4)
+    assert pt["edge_attempts"].dtype == np.uint64
+    assert pt["round_trips"].shape == (1, 2, 3)
+    for key in ("mags", "mags2", "mags4", "energies", "energies2", "overlap", "overlap2",
+                "overlap4", "link_overlap", "link_overlap2", "link_overlap4"):
+        assert result[key].shape == (3,) and result[key].dtype == np.float64
+    assert len(result["overlap_histogram"]) == 3 and result["overlap_histogram"][0].shape == (17,)
+    assert result["ql_at_q_sum"].shape == (3, 17)
+    assert first.sg_binder.shape == (3,) and first.heat_capacity.shape == (3,)
+    continued = first.sample(1, pt_interval=1, pt_schedule="full_ladder", warmup_ratio=0)
+    assert np.all(continued["per_disorder"]["parallel_tempering"]["edge_attempts"] == 6)
+    first.reset()
+    again = first.sample(1, pt_interval=1, pt_schedule="full_ladder", warmup_ratio=0)
+    assert np.all(again["per_disorder"]["parallel_tempering"]["edge_attempts"] == 2)
+    assert many.sample(4)["mags"].shape == (32,)

@@ -74,6 +74,10 @@ typedef struct {
     uint64_t n_replicas;
     uint64_t seed;  /* dynamics root seed (src/lib.rs:155) */
     int32_t device; /* HIP device ordinal */
+    /* Global index of this handle's realisation 0.  Realisation seeds depend only on the global
+     * index (src/lib.rs:30-32), so a disorder ensemble sharded over several handles / GPUs gives
+     * the same per-realisation results as one handle holding all of them. */
+    uint64_t first_realization;
 } pa_sim_desc;
 
 /* Keyword arguments of IsingSimulation.sample that are on the path
@@ -110,6 +114,12 @@ int pa_sim_sample_async(pa_sim *sim, const pa_sample_config *cfg);
 int pa_sim_synchronize(pa_sim *sim);
 /* Cooperative cancel, polled between kernel batches (src/lib.rs:304-308). */
 void pa_sim_request_interrupt(pa_sim *sim);
+
+/* Per-kernel device time of the sweep pipeline, measured with HIP events on the handle's stream
+ * while running `n_sweeps` sweeps of `cfg`'s protocol (state advances like sample()).
+ * ms_out[5] = average milliseconds per launch of: rng, sweep, overlap, accumulate, tempering. */
+int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_sweeps,
+                           double ms_out[5]);
 
 /* ---- phase-level entry points (inner boundary; state stays on the device) -- */
 int pa_sim_metropolis_sweep(pa_sim *sim, uint64_t n_sweeps);

@@ -54,7 +54,7 @@ def _parse_overlap_modes(text):
 
 class IsingSimulation:
     def __init__(self, lattice_shape, couplings, temperatures, n_replicas=None,
-                 neighbor_offsets=None, seed=None, device=0):
+                 neighbor_offsets=None, seed=None, device=0, first_realization=0):
         self._lib = nat.lib()
         self._handle = None
         shape = [int(x) for x in lattice_shape]
@@ -99,6 +99,7 @@ class IsingSimulation:
         desc.n_replicas = self.n_replicas
         desc.seed = self.constructor_seed
         desc.device = int(device)
+        desc.first_realization = int(first_realization)
         handle = C.c_void_p()
         err = C.create_string_buffer(512)
         code = self._lib.pa_sim_create(C.byref(desc), C.byref(handle), err, len(err))
@@ -205,6 +206,13 @@ class IsingSimulation:
     def run(self, cfg, wait=True):
         fn = self._lib.pa_sim_sample if wait else self._lib.pa_sim_sample_async
         self._check(fn(self._handle, C.byref(cfg)))
+
+    def profile_kernels(self, cfg, n_sweeps):
+        """Average device milliseconds per launch of (rng, sweep, overlap, accumulate, tempering)."""
+        out = np.zeros(5, dtype=np.float64)
+        self._check(self._lib.pa_sim_profile_kernels(self._handle, C.byref(cfg), int(n_sweeps),
+                                                     nat.ptr(out)))
+        return dict(zip(("k_rng", "k_sweep", "k_overlap", "k_accumulate", "k_pt"), out.tolist()))
 
     def synchronize(self):
         self._check(self._lib.pa_sim_synchronize(self._handle))

@@ -26,6 +26,7 @@ class PaSimDesc(C.Structure):
         ("n_replicas", C.c_uint64),
         ("seed", C.c_uint64),
         ("device", C.c_int32),
+        ("first_realization", C.c_uint64),
     ]
 
 
@@ -57,6 +58,7 @@ SIGNATURES = {
     "pa_sim_sample_async": (C.c_int, [_vp, C.POINTER(PaSampleConfig)]),
     "pa_sim_synchronize": (C.c_int, [_vp]),
     "pa_sim_request_interrupt": (None, [_vp]),
+    "pa_sim_profile_kernels": (C.c_int, [_vp, C.POINTER(PaSampleConfig), _u64, _vp]),
     "pa_sim_metropolis_sweep": (C.c_int, [_vp, _u64]),
     "pa_sim_compute_energies": (C.c_int, [_vp]),
     "pa_sim_parallel_tempering": (C.c_int, [_vp, _i32]),

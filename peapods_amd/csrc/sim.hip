@@ -56,6 +56,7 @@ struct pa_sim {
     std::vector<float> temps;
     uint64_t n_replicas = 0, n_temps = 0, n_real = 0;
     uint64_t constructor_seed = 0;
+    uint64_t first_realization = 0;
     uint32_t hot_slot = 0, cold_slot = 0;
     uint32_t next_parity = 0;
     // non-const aliases of the static tables (filled once in create)
@@ -146,7 +147,7 @@ int seed_state(pa_sim *sim, uint64_t seed) {
     for (unsigned k = 0; k < n_threads; ++k)
         workers.emplace_back([&, k] {
             for (uint32_t real = k; real < d.n_real; real += n_threads) {
-                const uint64_t base = realization_seed(seed, real); // src/lib.rs:160
+                const uint64_t base = realization_seed(seed, sim->first_realization + real); // src/lib.rs:160
                 uint32_t *tile = S.data() + tile_words * real;
                 for (uint32_t sys = 0; sys < d.n_sys; ++sys) {
                     Xoshiro rng = Xoshiro::from_seed_u64(child_seed(base, kSystemSeedDomain, sys));
@@ -396,6 +397,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     sim->n_temps = desc->n_temps;
     sim->n_real = desc->n_realizations;
     sim->constructor_seed = desc->seed;
+    sim->first_realization = desc->first_realization;
     sim->temps.assign(desc->temperatures, desc->temperatures + desc->n_temps);
 
     SimDims &d = sim->d;
@@ -626,6 +628,63 @@ int pa_sim_sample(pa_sim *sim, const pa_sample_config *cfg) {
     int rc = pa_sim_sample_async(sim, cfg);
     if (rc) return rc;
     return pa_sim_synchronize(sim);
+}
+
+int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_sweeps,
+                           double ms_out[5]) {
+    int code;
+    const std::string text = validate_text(cfg, sim->n_replicas, &code);
+    if (code != PA_OK) return fail(sim, code, text);
+    PA_HIP(sim, hipSetDevice(sim->device));
+    const SimDims &d = sim->d;
+    int rc = zero_accumulators(sim);
+    if (rc) return rc;
+    const bool want_overlap = d.n_pairs > 0 && cfg->measure_overlap;
+    sim->n_recorded = 0;
+    sim->overlap_collected = want_overlap;
+    hipEvent_t ev[6];
+    for (auto &e : ev) PA_HIP(sim, hipEventCreate(&e));
+    double total[5] = {0, 0, 0, 0, 0};
+    uint64_t count[5] = {0, 0, 0, 0, 0};
+    for (uint64_t sweep_id = 0; sweep_id < n_sweeps; ++sweep_id) {
+        const bool record = sweep_id >= cfg->warmup_sweeps;
+        const bool pt_this = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0;
+        bool ran[5] = {true, true, false, false, false};
+        PA_HIP(sim, hipEventRecord(ev[0], sim->stream));
+        PA_HIP(sim, launch_rng(d, sim->p, sim->stream));
+        PA_HIP(sim, hipEventRecord(ev[1], sim->stream));
+        PA_HIP(sim, launch_sweep(d, sim->p, record || pt_this, true, sim->stream));
+        PA_HIP(sim, hipEventRecord(ev[2], sim->stream));
+        if (record && want_overlap) {
+            PA_HIP(sim, launch_overlap(d, sim->p, sim->stream));
+            ran[2] = true;
+        }
+        PA_HIP(sim, hipEventRecord(ev[3], sim->stream));
+        if (record) {
+            PA_HIP(sim, launch_accumulate(d, sim->p, want_overlap, sim->stream));
+            sim->n_recorded += 1;
+            ran[3] = true;
+        }
+        PA_HIP(sim, hipEventRecord(ev[4], sim->stream));
+        if (pt_this) {
+            PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
+            PA_HIP(sim, launch_pt(d, sim->p, pt, sim->stream));
+            if (cfg->pt_schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
+            ran[4] = true;
+        }
+        PA_HIP(sim, hipEventRecord(ev[5], sim->stream));
+        PA_HIP(sim, hipEventSynchronize(ev[5]));
+        for (int k = 0; k < 5; ++k) {
+            if (!ran[k]) continue;
+            float ms = 0.f;
+            PA_HIP(sim, hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+            total[k] += ms;
+            count[k] += 1;
+        }
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    for (int k = 0; k < 5; ++k) ms_out[k] = count[k] ? total[k] / static_cast<double>(count[k]) : 0.0;
+    return PA_OK;
 }
 
 int pa_sim_metropolis_sweep(pa_sim *sim, uint64_t n_sweeps) {

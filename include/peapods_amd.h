@@ -117,9 +117,10 @@ void pa_sim_request_interrupt(pa_sim *sim);
 
 /* Per-kernel device time of the sweep pipeline, measured with HIP events on the handle's stream
  * while running `n_sweeps` sweeps of `cfg`'s protocol (state advances like sample()).
- * ms_out[5] = average milliseconds per launch of: rng, sweep, overlap, accumulate, tempering. */
+ * ms_out[3] = average milliseconds per launch of: k_rng (random stream -> acceptance levels),
+ * k_sweep (level-ordered Metropolis sweep + energies), k_measure (overlap + statistics + tempering). */
 int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_sweeps,
-                           double ms_out[5]);
+                           double ms_out[3]);
 
 /* ---- phase-level entry points (inner boundary; state stays on the device) -- */
 int pa_sim_metropolis_sweep(pa_sim *sim, uint64_t n_sweeps);

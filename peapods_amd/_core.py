@@ -208,11 +208,11 @@ class IsingSimulation:
         self._check(fn(self._handle, C.byref(cfg)))
 
     def profile_kernels(self, cfg, n_sweeps):
-        """Average device milliseconds per launch of (rng, sweep, overlap, accumulate, tempering)."""
-        out = np.zeros(5, dtype=np.float64)
+        """Average device milliseconds per launch of (k_rng, k_sweep, k_measure)."""
+        out = np.zeros(3, dtype=np.float64)
         self._check(self._lib.pa_sim_profile_kernels(self._handle, C.byref(cfg), int(n_sweeps),
                                                      nat.ptr(out)))
-        return dict(zip(("k_rng", "k_sweep", "k_overlap", "k_accumulate", "k_pt"), out.tolist()))
+        return dict(zip(("k_rng", "k_sweep", "k_measure"), out.tolist()))
 
     def synchronize(self):
         self._check(self._lib.pa_sim_synchronize(self._handle))

@@ -3,7 +3,7 @@
 // Representation ("slot-sliced multispin coding"):
 //   * One TILE per disorder realisation.  Bit k of a tile word belongs to
 //     temperature SLOT k = replica * n_temps + t; a tile has W = ceil(n_sys/32)
-//     words per lattice site.  S[real][site][w] holds the spins (bit = 1 <=> -1)
+//     words per lattice site.  S[real][w][site] holds the spins (bit = 1 <=> -1)
 //     of 32 slots at one site, so every bitwise instruction advances 32 systems
 //     that share the realisation's couplings.
 //   * The reference's typewriter order is kept exactly: sites are grouped into
@@ -34,23 +34,23 @@ struct SimDims {
     uint32_t B;          // RNG blocks per sweep
     uint32_t BS;         // sites per RNG block
     uint32_t BP;         // ceil(B / 2): block pairs (one wave handles two blocks x 32 slots)
-    uint32_t n_levels;
+    uint32_t n_passes;   // schedule passes: dependency levels cut into chunks of <= 256 sites
     uint32_t MW;         // ceil(N / 32): words of the per-site parity bitmap
     uint32_t has_odd;    // 1 if any site has an odd number of non-zero bonds
     uint32_t n_edges;    // max(n_temps - 1, 1) (allocation stride of the PT edge counters)
 };
 
 struct DevPtrs {
-    uint32_t *S;             // [n_real][N][W]
-    uint2 *planes;           // [n_real][N][W]  .x/.y = bit 0/1 of the acceptance level
+    uint32_t *S;             // [n_real][W][N]
+    uint2 *planes;           // [n_real][W][N]  .x/.y = bit 0/1 of the acceptance level
     uint32_t *cursor;        // [n_real][8][SP]  xoshiro state of the system in each slot
     uint32_t *system_ids;    // [n_real][n_sys]  slot -> system
     uint32_t *slot_of;       // [n_real][n_sys]  system -> slot
     const uint32_t *thr;     // [2][3][n_temps]  thresholds: even set (dE=-2,-4,-6), odd set (-1,-3,-5)
     const uint32_t *mpar;    // [n_real][MW]     parity of the non-zero bond count per site
-    const uint32_t *sched;   // [N][8]  schedule order: site, f0, b0, f1, b1, f2, b2, pad
-    const uint16_t *jmeta;   // [n_real][N] schedule order: neg[0..5] | nz[6..11] | h[12..13]
-    const uint32_t *level_start; // [n_levels + 1]
+    const uint4 *rec;        // [n_real][N] schedule order, 16-bit fields: site,f0 | b0,f1 | b1,f2 | b2,jmeta
+                             //   jmeta = neg[0..5] | nz[6..11] | h[12..13] for bonds f0,b0,f1,b1,f2,b2
+    const uint32_t *pass_start; // [n_passes + 1]
     const uint32_t *jump;    // [B][64][16][8] nibble tables of T^(b*BS)
     int32_t *Esum;           // [n_real][n_sys] by slot: sum_{i,d} J s s (exact integer)
     int32_t *Msum;           // [n_real][n_sys] by slot: sum_i s_i
@@ -81,11 +81,12 @@ struct PtParams {
 hipError_t launch_rng(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,
                         hipStream_t stream);
-hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream);
-hipError_t launch_accumulate(const SimDims &d, const DevPtrs &p, bool with_overlap,
-                             hipStream_t stream);
-hipError_t launch_pt(const SimDims &d, const DevPtrs &p, const PtParams &pt, hipStream_t stream);
+hipError_t launch_sweep_stamped(const SimDims &d, const DevPtrs &p, unsigned long long *stamps,
+                                hipStream_t stream);
+hipError_t launch_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_overlap,
+                          bool do_accum, bool accum_overlap, bool do_pt, hipStream_t stream);
 size_t sweep_lds_bytes(const SimDims &d);
+size_t measure_lds_bytes(const SimDims &d);
 hipError_t configure_kernels(const SimDims &d);
 
 } // namespace pa

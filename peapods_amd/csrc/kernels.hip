@@ -12,6 +12,10 @@
 // explicit IEEE intrinsics so nothing is contracted or reassociated.
 #include "engine.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+#include <utility>
+
 namespace pa {
 
 // ---------------------------------------------------------------------------
@@ -68,37 +72,130 @@ __device__ __forceinline__ void jump_state(uint32_t st[8], const uint32_t *__res
 }
 
 // ---------------------------------------------------------------------------
-// k_rng: one wave = 32 slots of one tile word x 2 consecutive site blocks.
-// Lane l: slot bit = l & 31, block = 2*bp + (l >> 5).  Every lane walks its
+// xoshiro256** in 32-bit halves: every operation is a full-rate VALU op (no
+// 64-bit multiply); only the top 24 bits of the output are formed, which is
+// all the reference uses (next_u32 >> 8 of next_u64 >> 32, sweep.rs:181).
+// ---------------------------------------------------------------------------
+struct Rng32 {
+    uint32_t a0, a1, b0, b1, c0, c1, d0, d1; // s0 = a1:a0, s1 = b1:b0, s2 = c1:c0, s3 = d1:d0
+    __device__ __forceinline__ void load(const uint32_t st[8]) {
+        a0 = st[0]; a1 = st[1]; b0 = st[2]; b1 = st[3];
+        c0 = st[4]; c1 = st[5]; d0 = st[6]; d1 = st[7];
+    }
+    __device__ __forceinline__ void store(uint32_t st[8]) const {
+        st[0] = a0; st[1] = a1; st[2] = b0; st[3] = b1;
+        st[4] = c0; st[5] = c1; st[6] = d0; st[7] = d1;
+    }
+    __device__ __forceinline__ uint32_t next24() {
+        // P = s1 * 5 = (s1 << 2) + s1
+        const uint32_t q = b0 << 2;
+        const uint32_t plo = q + b0;
+        const uint32_t phi = ((b1 << 2) + b1) + (b0 >> 30) + (plo < q ? 1u : 0u);
+        // R = rotl(P, 7)
+        const uint32_t rhi = __builtin_amdgcn_alignbit(phi, plo, 25);
+        const uint32_t rlo = __builtin_amdgcn_alignbit(plo, phi, 25);
+        // high word of R * 9 = rhi * 9 + mulhi(rlo, 9)
+        const uint32_t e = rlo << 3;
+        const uint32_t f = e + rlo;
+        const uint32_t top = ((rhi << 3) + rhi) + (rlo >> 29) + (f < e ? 1u : 0u);
+        // state transition
+        const uint32_t t0 = b0 << 17;
+        const uint32_t t1 = __builtin_amdgcn_alignbit(b1, b0, 15);
+        c0 ^= a0; c1 ^= a1;
+        d0 ^= b0; d1 ^= b1;
+        b0 ^= c0; b1 ^= c1;
+        a0 ^= d0; a1 ^= d1;
+        c0 ^= t0; c1 ^= t1;
+        const uint32_t nd1 = __builtin_amdgcn_alignbit(d0, d1, 19); // rotl(s3, 45)
+        const uint32_t nd0 = __builtin_amdgcn_alignbit(d1, d0, 19);
+        d0 = nd0; d1 = nd1;
+        return top >> 8;
+    }
+};
+
+// state <- M * state with M as nibble tables [64][16][8] in LDS.
+__device__ __forceinline__ void jump_state_lds(uint32_t st[8], const uint32_t *tab) {
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int p = 0; p < 64; ++p) {
+        const uint32_t nib = (st[p >> 3] >> ((p & 7) * 4)) & 15u;
+        const uint4 *e = reinterpret_cast<const uint4 *>(tab + (p * 16 + nib) * 8);
+        const uint4 a = e[0], b = e[1];
+        acc[0] ^= a.x; acc[1] ^= a.y; acc[2] ^= a.z; acc[3] ^= a.w;
+        acc[4] ^= b.x; acc[5] ^= b.y; acc[6] ^= b.z; acc[7] ^= b.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) st[j] = acc[j];
+}
+
+// v_writelane_b32: park a wave-uniform (SGPR) value in one lane of a VGPR.  hipcc has no
+// builtin for it; the lane select is an inline constant, so no manual wait states apply
+// (the ISA's writelane hazard concerns a VALU-written lane-select SGPR only).
+template <int LANE> __device__ __forceinline__ uint32_t park_in_lane(uint32_t vec, uint32_t value) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(vec) : "s"(value), "n"(LANE));
+    return vec;
+}
+
+template <int JJ>
+__device__ __forceinline__ void rng_step(Rng32 &rng, uint32_t ca0, uint32_t ca1, uint32_t ca2,
+                                         uint32_t &keep0, uint32_t &keep1) {
+    const uint32_t draw = rng.next24();
+    // thresholds fall with |dE| (checked on the host): level bit1 = (draw < c1),
+    // bit0 = (draw < c0) ^ (draw < c1) ^ (draw < c2)
+    const unsigned long long l0 = __ballot(draw < ca0);
+    const unsigned long long l1 = __ballot(draw < ca1);
+    const unsigned long long l2 = __ballot(draw < ca2);
+    const unsigned long long m0 = l0 ^ l1 ^ l2;
+    keep0 = park_in_lane<JJ>(keep0, static_cast<uint32_t>(m0));
+    keep0 = park_in_lane<JJ + 32>(keep0, static_cast<uint32_t>(m0 >> 32));
+    keep1 = park_in_lane<JJ>(keep1, static_cast<uint32_t>(l1));
+    keep1 = park_in_lane<JJ + 32>(keep1, static_cast<uint32_t>(l1 >> 32));
+}
+
+template <int... JJ>
+__device__ __forceinline__ void rng_chunk32(Rng32 &rng, uint32_t ca0, uint32_t ca1, uint32_t ca2,
+                                            uint32_t &keep0, uint32_t &keep1,
+                                            std::integer_sequence<int, JJ...>) {
+    (rng_step<JJ>(rng, ca0, ca1, ca2, keep0, keep1), ...);
+}
+
+// ---------------------------------------------------------------------------
+// k_rng: workgroup = 4 waves that share ONE site block b (so one jump table,
+// staged in LDS); each wave serves two tile words: lanes 0-31 the 32 slots of
+// tile word 2k, lanes 32-63 those of tile word 2k+1.  Every lane walks the
 // block's sites in order, drawing the reference's next 24-bit value for its
 // slot (sweep.rs:181) and comparing it with the slot's three thresholds; the
-// ballot of those comparisons IS the 32-slot word of that site.
+// wave ballots of the comparisons ARE the 32-slot words of that site.  Ballot
+// words are parked in lane (site & 31) with v_writelane and stored 32 sites at
+// a time, fully coalesced.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_rng(SimDims d, DevPtrs p) {
-    const uint32_t task = blockIdx.x;
-    const uint32_t bp = task % d.BP;
-    const uint32_t w = (task / d.BP) % d.W;
-    const uint32_t real = task / (d.BP * d.W);
-    const uint32_t lane = threadIdx.x;
+__global__ __launch_bounds__(256) void k_rng(SimDims d, DevPtrs p) {
+    extern __shared__ uint32_t tab[]; // [64 * 16 * 8] (+ padding that caps workgroups per CU)
+    const uint32_t block = blockIdx.x % d.B;
+    const uint32_t group = blockIdx.x / d.B;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t bit = lane & 31u, half = lane >> 5;
-    const uint32_t block = 2 * bp + half;
+    const uint32_t n_tw = d.n_real * d.W;
+    const uint32_t tw = (group * 4 + wave) * 2 + half;
+    const bool tw_ok = tw < n_tw;
+    const uint32_t real = tw_ok ? tw / d.W : 0, w = tw_ok ? tw % d.W : 0;
     const uint32_t slot = w * 32 + bit;
-    const bool slot_ok = slot < d.n_sys;
-    const bool active = slot_ok && block < d.B;
+    const bool active = tw_ok && slot < d.n_sys;
 
-    uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (active) {
-        load_cursor(p.cursor, real, d.SP, slot, st);
-        if (block > 0) jump_state(st, p.jump + static_cast<size_t>(block) * (64 * 16 * 8));
+    if (block > 0) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.jump + static_cast<size_t>(block) * (64 * 16 * 8));
+        uint4 *dst = reinterpret_cast<uint4 *>(tab);
+        for (uint32_t i = tid; i < 64 * 16 * 2; i += 256) dst[i] = src[i];
     }
-    DevRng rng;
-    rng.s0 = (static_cast<uint64_t>(st[1]) << 32) | st[0];
-    rng.s1 = (static_cast<uint64_t>(st[3]) << 32) | st[2];
-    rng.s2 = (static_cast<uint64_t>(st[5]) << 32) | st[4];
-    rng.s3 = (static_cast<uint64_t>(st[7]) << 32) | st[6];
+    uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (active) load_cursor(p.cursor, real, d.SP, slot, st);
+    __syncthreads();
+    if (block > 0) jump_state_lds(st, tab);
+    Rng32 rng;
+    rng.load(st);
 
     uint32_t ca0 = 0, ca1 = 0, ca2 = 0, cb0 = 0, cb1 = 0, cb2 = 0;
-    if (slot_ok) {
+    if (active) {
         const uint32_t t = slot % d.n_temps;
         ca0 = p.thr[0 * d.n_temps + t];
         ca1 = p.thr[1 * d.n_temps + t];
@@ -107,45 +204,43 @@ __global__ __launch_bounds__(64) void k_rng(SimDims d, DevPtrs p) {
         cb1 = p.thr[4 * d.n_temps + t];
         cb2 = p.thr[5 * d.n_temps + t];
     }
-
     const uint32_t begin = block * d.BS;
-    const uint32_t end = active ? min(d.N, begin + d.BS) : begin;
-    uint2 *planes = p.planes + static_cast<size_t>(real) * d.N * d.W;
+    const uint32_t len = min(d.BS, d.N - begin); // uniform over the workgroup
+    uint2 *planes = p.planes + static_cast<size_t>(tw_ok ? tw : 0) * d.N;
     const uint32_t *mpar = p.mpar + static_cast<size_t>(real) * d.MW;
 
-    for (uint32_t j = 0; j < d.BS; ++j) {
-        const uint32_t site = begin + j;
-        const bool valid = site < end; // false for idle lanes and past a short last block
-        uint32_t level = 0;
-        if (valid) {
-            const uint32_t draw = static_cast<uint32_t>(rng.next() >> 40);
-            uint32_t c0 = ca0, c1 = ca1, c2 = ca2;
-            if (d.has_odd && ((mpar[site >> 5] >> (site & 31u)) & 1u)) {
-                c0 = cb0;
-                c1 = cb1;
-                c2 = cb2;
+    for (uint32_t j0 = 0; j0 < len; j0 += 32) {
+        uint32_t keep0 = 0, keep1 = 0;
+        const uint32_t chunk = min(32u, len - j0);
+        if (chunk == 32 && !d.has_odd) {
+            rng_chunk32(rng, ca0, ca1, ca2, keep0, keep1, std::make_integer_sequence<int, 32>{});
+        } else {
+            for (uint32_t jj = 0; jj < chunk; ++jj) {
+                const uint32_t site = begin + j0 + jj;
+                const uint32_t draw = rng.next24();
+                uint32_t c0 = ca0, c1 = ca1, c2 = ca2;
+                if (d.has_odd && ((mpar[site >> 5] >> (site & 31u)) & 1u)) {
+                    c0 = cb0;
+                    c1 = cb1;
+                    c2 = cb2;
+                }
+                const unsigned long long l0 = __ballot(draw < c0);
+                const unsigned long long l1 = __ballot(draw < c1);
+                const unsigned long long l2 = __ballot(draw < c2);
+                const unsigned long long m0 = l0 ^ l1 ^ l2;
+                const uint32_t x = half ? static_cast<uint32_t>(m0 >> 32) : static_cast<uint32_t>(m0);
+                const uint32_t y = half ? static_cast<uint32_t>(l1 >> 32) : static_cast<uint32_t>(l1);
+                if (bit == jj) {
+                    keep0 = x;
+                    keep1 = y;
+                }
             }
-            level = (draw < c0) + (draw < c1) + (draw < c2);
         }
-        const unsigned long long m0 = __ballot(level & 1u);
-        const unsigned long long m1 = __ballot(level & 2u);
-        if (bit == 0 && valid) {
-            const uint32_t x = half ? static_cast<uint32_t>(m0 >> 32) : static_cast<uint32_t>(m0);
-            const uint32_t y = half ? static_cast<uint32_t>(m1 >> 32) : static_cast<uint32_t>(m1);
-            planes[static_cast<size_t>(site) * d.W + w] = make_uint2(x, y);
-        }
+        if (tw_ok && bit < chunk) planes[begin + j0 + bit] = make_uint2(keep0, keep1);
     }
     // The last block ends exactly N draws after the cursor: that is the next cursor.
     if (active && block == d.B - 1) {
-        // (a short last block drew only its own sites, see `valid` above)
-        st[0] = static_cast<uint32_t>(rng.s0);
-        st[1] = static_cast<uint32_t>(rng.s0 >> 32);
-        st[2] = static_cast<uint32_t>(rng.s1);
-        st[3] = static_cast<uint32_t>(rng.s1 >> 32);
-        st[4] = static_cast<uint32_t>(rng.s2);
-        st[5] = static_cast<uint32_t>(rng.s2 >> 32);
-        st[6] = static_cast<uint32_t>(rng.s3);
-        st[7] = static_cast<uint32_t>(rng.s3 >> 32);
+        rng.store(st);
         store_cursor(p.cursor, real, d.SP, slot, st);
     }
 }
@@ -189,26 +284,35 @@ __device__ __forceinline__ void byte_count(uint32_t c[8], uint32_t x) {
     for (int j = 0; j < 8; ++j) c[j] += (x >> j) & 0x01010101u;
 }
 
-// Reduce NSET sets of byte counters over the 256-thread block.  Thread b < 32
-// receives in out[set] the total for bit b.  scratch: [4][NSET*16] dwords of LDS.
+// Sum over the 16 lanes of a DPP row, result in every lane of the row (row_ror 8, 4, 2, 1).
+// DPP adds are plain VALU instructions: unlike __shfl_xor (ds_bpermute) they do not touch the
+// LDS pipe, which the 48-register reductions below would otherwise saturate.
+__device__ __forceinline__ uint32_t row_sum16(uint32_t v) {
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x128, 0xF, 0xF, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x124, 0xF, 0xF, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x122, 0xF, 0xF, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x121, 0xF, 0xF, false));
+    return v;
+}
+
+// Reduce NSET sets of byte counters over the workgroup (blockDim.x / 64 waves).  Thread b < 32
+// receives in out[set] the total for bit b.  scratch: [n_waves * 4][NSET*16] dwords of LDS.
 template <int NSET>
 __device__ __forceinline__ void block_bit_totals(const uint32_t (*c)[8], uint32_t *scratch,
                                                  uint32_t out[NSET]) {
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t n_rows = blockDim.x >> 4;
+    const uint32_t row = tid >> 4;
 #pragma unroll
     for (int s = 0; s < NSET; ++s) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            uint32_t lo = c[s][j] & 0x00FF00FFu;        // bits j (low half), j+16 (high half)
-            uint32_t hi = (c[s][j] >> 8) & 0x00FF00FFu; // bits j+8, j+24
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                lo += __shfl_xor(lo, off);
-                hi += __shfl_xor(hi, off);
-            }
-            if (lane == 0) {
-                scratch[wave * (NSET * 16) + s * 16 + j * 2 + 0] = lo;
-                scratch[wave * (NSET * 16) + s * 16 + j * 2 + 1] = hi;
+            // widen the four byte counters to 16 bits (two registers) before summing lanes
+            const uint32_t lo = row_sum16(c[s][j] & 0x00FF00FFu);        // bits j, j+16
+            const uint32_t hi = row_sum16((c[s][j] >> 8) & 0x00FF00FFu); // bits j+8, j+24
+            if ((lane & 15u) == 0) {
+                scratch[row * (NSET * 16) + s * 16 + j * 2 + 0] = lo;
+                scratch[row * (NSET * 16) + s * 16 + j * 2 + 1] = hi;
             }
         }
     }
@@ -218,8 +322,8 @@ __device__ __forceinline__ void block_bit_totals(const uint32_t (*c)[8], uint32_
 #pragma unroll
         for (int s = 0; s < NSET; ++s) {
             uint32_t total = 0;
-            for (int wv = 0; wv < 4; ++wv) {
-                const uint32_t v = scratch[wv * (NSET * 16) + s * 16 + j * 2 + (byte & 1u)];
+            for (uint32_t rw = 0; rw < n_rows; ++rw) {
+                const uint32_t v = scratch[rw * (NSET * 16) + s * 16 + j * 2 + (byte & 1u)];
                 total += (byte >> 1) ? (v >> 16) : (v & 0xFFFFu);
             }
             out[s] = total;
@@ -228,52 +332,93 @@ __device__ __forceinline__ void block_bit_totals(const uint32_t (*c)[8], uint32_
     __syncthreads();
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which
+// would stall every schedule pass on the global prefetch issued just before it.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Schedule record of one site (uint4, 16-bit fields):
+//   x = site | f0 << 16,  y = b0 | f1 << 16,  z = b1 | f2 << 16,  w = b2 | jmeta << 16
+struct SiteRec {
+    uint32_t site, nb[6], jm;
+    __device__ __forceinline__ explicit SiteRec(const uint4 r) {
+        site = r.x & 0xFFFFu;
+        nb[0] = r.x >> 16;
+        nb[1] = r.y & 0xFFFFu;
+        nb[2] = r.y >> 16;
+        nb[3] = r.z & 0xFFFFu;
+        nb[4] = r.z >> 16;
+        nb[5] = r.w & 0xFFFFu;
+        jm = r.w >> 16;
+    }
+};
+
 // ---------------------------------------------------------------------------
-// k_sweep: workgroup = (tile, word).  The word's N site values live in LDS; the
-// dependency levels run in order with one barrier each, which reproduces the
-// reference's sequential site order (sweep.rs:58-61) bit for bit.
+// k_sweep: workgroup = (tile, word).  The word's N site values and the two
+// acceptance-level planes live in LDS; the schedule passes (dependency levels
+// cut into chunks of <= 256 sites) run in order with one barrier each, which
+// reproduces the reference's sequential site order (sweep.rs:58-61) bit for
+// bit.  The next pass's site record is prefetched while the current one runs.
 // Epilogue: energy sum_{i,d} J s_i s_fwd and magnetisation sum_i s_i for the
 // word's 32 slots (energy.rs:92-109), by byte-sliced vertical counters.
 // ---------------------------------------------------------------------------
+#define PA_STAMP(k)                                                                                \
+    if (STAMPS && blockIdx.x == 0 && threadIdx.x == 0) stamps[k] = clock64();
+
+template <bool STAMPS>
 __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_energy,
-                                               int do_sweep) {
+                                               int do_sweep, unsigned long long *stamps) {
     extern __shared__ uint32_t lds[];
-    uint32_t *sw = lds;               // [N]
-    uint32_t *scratch = lds + d.N;    // [4 * 48]
+    PA_STAMP(0)
+    const uint32_t n_pad = (d.N + 1u) & ~1u;
+    uint32_t *sw = lds;                                        // [N] spins of this word
+    uint2 *pl = reinterpret_cast<uint2 *>(lds + n_pad);        // [N] acceptance-level planes
+    uint32_t *scratch = lds + n_pad + 2 * static_cast<size_t>(d.N); // [16 rows][48]
     const uint32_t real = blockIdx.x / d.W, w = blockIdx.x % d.W;
     const uint32_t tid = threadIdx.x;
-    uint32_t *Sg = p.S + static_cast<size_t>(real) * d.N * d.W;
-    for (uint32_t i = tid; i < d.N; i += 256) sw[i] = Sg[static_cast<size_t>(i) * d.W + w];
+    uint32_t *Sg = p.S + (static_cast<size_t>(real) * d.W + w) * d.N; // this word's N sites
+    const uint4 *rec = p.rec + static_cast<size_t>(real) * d.N;
+    for (uint32_t i = tid; i < d.N; i += 256) sw[i] = Sg[i];
+    if (do_sweep) {
+        const uint2 *planes = p.planes + (static_cast<size_t>(real) * d.W + w) * d.N;
+        for (uint32_t i = tid; i < d.N; i += 256) pl[i] = planes[i];
+    }
     const uint32_t live = d.n_sys - w * 32;
     const uint32_t valid_bits = live >= 32 ? 0xFFFFFFFFu : ((1u << live) - 1u);
-    const uint2 *planes = p.planes + static_cast<size_t>(real) * d.N * d.W;
-    const uint16_t *jmeta = p.jmeta + static_cast<size_t>(real) * d.N;
-    const uint4 *sched = reinterpret_cast<const uint4 *>(p.sched);
     __syncthreads();
+    PA_STAMP(1)
 
     if (do_sweep) {
-        for (uint32_t lvl = 0; lvl < d.n_levels; ++lvl) {
-            const uint32_t begin = p.level_start[lvl], end = p.level_start[lvl + 1];
-            for (uint32_t pos = begin + tid; pos < end; pos += 256) {
-                const uint4 r0 = sched[2 * pos], r1 = sched[2 * pos + 1];
-                const uint32_t site = r0.x;
-                const uint32_t jm = jmeta[pos];
-                const uint2 lv = planes[static_cast<size_t>(site) * d.W + w];
+        uint32_t begin = p.pass_start[0];
+        uint32_t end = p.pass_start[1];
+        uint4 cur = make_uint4(0, 0, 0, 0);
+        if (begin + tid < end) cur = rec[begin + tid];
+        for (uint32_t pass = 0; pass < d.n_passes; ++pass) {
+            const bool active = begin + tid < end;
+            const uint32_t nbegin = end;
+            const uint32_t nend = pass + 1 < d.n_passes ? p.pass_start[pass + 2] : end;
+            uint4 nxt = make_uint4(0, 0, 0, 0);
+            if (nbegin + tid < nend) nxt = rec[nbegin + tid]; // prefetch
+            if (active) {
+                const SiteRec r(cur);
                 uint32_t nb[6];
-                nb[0] = sw[r0.y];
-                nb[1] = sw[r0.z];
-                nb[2] = sw[r0.w];
-                nb[3] = sw[r1.x];
-                nb[4] = sw[r1.y];
-                nb[5] = sw[r1.z];
-                const uint32_t s = sw[site];
-                const uint32_t acc = accept_mask(s, nb, jm, lv.x, lv.y) & valid_bits;
-                sw[site] = s ^ acc;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) nb[k] = sw[r.nb[k]];
+                const uint32_t s = sw[r.site];
+                const uint2 lv = pl[r.site];
+                const uint32_t acc = accept_mask(s, nb, r.jm, lv.x, lv.y) & valid_bits;
+                sw[r.site] = s ^ acc;
             }
-            __syncthreads();
+            lds_barrier();
+            cur = nxt;
+            begin = nbegin;
+            end = nend;
         }
-        for (uint32_t i = tid; i < d.N; i += 256) Sg[static_cast<size_t>(i) * d.W + w] = sw[i];
+        PA_STAMP(2)
+        for (uint32_t i = tid; i < d.N; i += 256) Sg[i] = sw[i];
     }
+    PA_STAMP(3)
 
     if (with_energy) {
         uint32_t c[3][8];
@@ -281,11 +426,12 @@ __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_en
         for (int s = 0; s < 3; ++s)
 #pragma unroll
             for (int j = 0; j < 8; ++j) c[s][j] = 0;
+#pragma unroll 4
         for (uint32_t pos = tid; pos < d.N; pos += 256) {
-            const uint4 r0 = sched[2 * pos], r1 = sched[2 * pos + 1];
-            const uint32_t jm = jmeta[pos];
-            const uint32_t s = sw[r0.x];
-            const uint32_t f0 = sw[r0.y], f1 = sw[r0.w], f2 = sw[r1.y];
+            const SiteRec r(rec[pos]);
+            const uint32_t jm = r.jm;
+            const uint32_t s = sw[r.site];
+            const uint32_t f0 = sw[r.nb[0]], f1 = sw[r.nb[2]], f2 = sw[r.nb[4]];
             const uint32_t u0 = (s ^ f0 ^ (0u - ((jm >> 0) & 1u))) & (0u - ((jm >> 6) & 1u));
             const uint32_t u1 = (s ^ f1 ^ (0u - ((jm >> 2) & 1u))) & (0u - ((jm >> 8) & 1u));
             const uint32_t u2 = (s ^ f2 ^ (0u - ((jm >> 4) & 1u))) & (0u - ((jm >> 10) & 1u));
@@ -293,6 +439,7 @@ __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_en
             byte_count(c[1], maj3(u0, u1, u2));  // weight 2
             byte_count(c[2], s);                 // spins equal to -1
         }
+        PA_STAMP(4)
         uint32_t tot[3];
         block_bit_totals<3>(c, scratch, tot);
         if (tid < 32 && w * 32 + tid < d.n_sys) {
@@ -303,321 +450,411 @@ __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_en
                 static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(tot[2]);
         }
     }
+    PA_STAMP(5)
 }
 
 // ---------------------------------------------------------------------------
-// k_overlap: workgroup = (tile, word).  Replica 2p and 2p+1 at temperature t sit
-// n_temps bit positions apart, so Y = V ^ (V >> n_temps) lines every pair up in
-// the bits of the even replica.  V = S gives q_i; V = S ^ S(fwd_d) gives the
-// bond products, and (q_i q_k) = +1 <=> the two replicas agree on the bond
-// (overlap.rs:259-282).  Counts per bit by byte-sliced counters.
+// k_measure: workgroup = tile (one disorder realisation), 1024 threads.  Fuses
+// the three per-tile phases that follow a sweep in the reference's order:
+//
+//  (1) overlap  Replica 2p and 2p+1 at temperature t sit n_temps bit positions
+//      apart, so Y = V ^ (V >> n_temps) lines every pair up in the bits of the
+//      even replica.  V = S gives q_i; V = S ^ S(fwd_d) gives the bond products,
+//      and q_i q_k = +1 <=> both replicas agree on the bond (overlap.rs:259-282).
+//  (2) statistics  the reference's f64 running sums in its order: replica by
+//      replica, pair by pair (mod.rs:555-578, overlap.rs:283-325, stats.rs:17-27).
+//  (3) parallel tempering  one lane per replica ladder replays the reference's
+//      event (mod.rs:766-792, tempering.rs:20-102, realization.rs:73-120) with
+//      the generator of system r*n_temps; accepted swaps exchange adjacent bit
+//      columns of the tile, and the slot cursors are permuted accordingly.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_overlap(SimDims d, DevPtrs p) {
+struct MeasureLds {
+    uint32_t *tile;    // [W][N]
+    uint32_t *scratch; // [64 rows][48]
+    int32_t *dot_spin; // [n_sys]
+    int32_t *dot_link; // [n_sys]
+    int32_t *E;        // [n_sys] by slot
+    int32_t *M;        // [n_sys]
+    uint32_t *sid;     // [n_sys] slot -> system
+    uint32_t *sid0;    // [n_sys] before the event
+    uint32_t *sof0;    // [n_sys] system -> slot before the event
+    uint32_t *att;     // [n_edges]
+    uint32_t *acc;     // [n_edges]
+    uint32_t *masks;   // [2][W]
+    uint32_t *flags;   // [1] any swap
+};
+
+__host__ __device__ inline size_t measure_lds_words(const SimDims &d) {
+    return static_cast<size_t>(d.N) * d.W + 64 * 48 + 7 * static_cast<size_t>(d.n_sys) +
+           2 * static_cast<size_t>(d.n_edges) + 2 * static_cast<size_t>(d.W) + 4;
+}
+
+__global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams pt, int do_overlap,
+                                                  int do_accum, int accum_overlap, int do_pt) {
     extern __shared__ uint32_t lds[];
-    uint32_t *A = lds;             // word w
-    uint32_t *B0 = lds + d.N;      // word w + q
-    uint32_t *B1 = lds + 2 * d.N;  // word w + q + 1
-    uint32_t *scratch = lds + 3 * d.N;
-    const uint32_t real = blockIdx.x / d.W, w = blockIdx.x % d.W;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t q = d.n_temps >> 5, r = d.n_temps & 31u;
-    const uint32_t *Sg = p.S + static_cast<size_t>(real) * d.N * d.W;
-    const uint32_t wa = w + q, wb = w + q + 1;
-    for (uint32_t i = tid; i < d.N; i += 256) {
-        A[i] = Sg[static_cast<size_t>(i) * d.W + w];
-        B0[i] = wa < d.W ? Sg[static_cast<size_t>(i) * d.W + wa] : 0u;
-        B1[i] = wb < d.W ? Sg[static_cast<size_t>(i) * d.W + wb] : 0u;
+    MeasureLds m;
+    {
+        uint32_t *q = lds;
+        m.tile = q; q += static_cast<size_t>(d.N) * d.W;
+        m.scratch = q; q += 64 * 48;
+        m.dot_spin = reinterpret_cast<int32_t *>(q); q += d.n_sys;
+        m.dot_link = reinterpret_cast<int32_t *>(q); q += d.n_sys;
+        m.E = reinterpret_cast<int32_t *>(q); q += d.n_sys;
+        m.M = reinterpret_cast<int32_t *>(q); q += d.n_sys;
+        m.sid = q; q += d.n_sys;
+        m.sid0 = q; q += d.n_sys;
+        m.sof0 = q; q += d.n_sys;
+        m.att = q; q += d.n_edges;
+        m.acc = q; q += d.n_edges;
+        m.masks = q; q += 2 * d.W;
+        m.flags = q;
     }
+    const uint32_t real = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
+    uint32_t *Sg = p.S + static_cast<size_t>(real) * d.N * d.W;
+    const uint4 *rec = p.rec + static_cast<size_t>(real) * d.N;
+    const size_t tile_words = static_cast<size_t>(d.N) * d.W;
+    int32_t *Eg = p.Esum + static_cast<size_t>(real) * d.n_sys;
+    int32_t *Mg = p.Msum + static_cast<size_t>(real) * d.n_sys;
+    uint32_t *sidg = p.system_ids + static_cast<size_t>(real) * d.n_sys;
+    uint32_t *sofg = p.slot_of + static_cast<size_t>(real) * d.n_sys;
+
+    bool tile_loaded = false;
+    if (do_overlap) {
+        for (size_t i = tid; i < tile_words; i += nthreads) m.tile[i] = Sg[i];
+        tile_loaded = true;
+    }
+    for (uint32_t k = tid; k < d.n_sys; k += nthreads) {
+        m.E[k] = Eg[k];
+        m.M[k] = Mg[k];
+        const uint32_t sys = sidg[k];
+        m.sid[k] = sys;
+        m.sid0[k] = sys;
+        m.sof0[k] = sofg[k];
+    }
+    for (uint32_t k = tid; k < d.n_edges; k += nthreads) {
+        m.att[k] = 0;
+        m.acc[k] = 0;
+    }
+    if (tid < 2 * d.W) m.masks[tid] = 0;
+    if (tid == 0) m.flags[0] = 0;
     __syncthreads();
-    const uint4 *sched = reinterpret_cast<const uint4 *>(p.sched);
-    uint32_t c[3][8];
+
+    // ---- (1) overlap dots ---------------------------------------------------
+    if (do_overlap && d.n_pairs) {
+        const uint32_t q = d.n_temps >> 5, r = d.n_temps & 31u;
+        for (uint32_t w = 0; w < d.W; ++w) {
+            const uint32_t wa = w + q, wb = w + q + 1;
+            uint32_t c[3][8];
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+            for (int s = 0; s < 3; ++s)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) c[s][j] = 0;
-    for (uint32_t pos = tid; pos < d.N; pos += 256) {
-        const uint4 r0 = sched[2 * pos], r1 = sched[2 * pos + 1];
-        const uint32_t site = r0.x;
-        const uint32_t fw[3] = {r0.y, r0.w, r1.y};
-        const uint32_t a = A[site];
-        const uint32_t sh = r ? ((B0[site] >> r) | (B1[site] << (32 - r))) : B0[site];
-        const uint32_t y = a ^ sh; // 1 where the pair disagrees at this site
-        uint32_t z[3];
+                for (int j = 0; j < 8; ++j) c[s][j] = 0;
+            for (uint32_t pos = tid; pos < d.N; pos += nthreads) {
+                const SiteRec sr(rec[pos]);
+                const uint32_t a = m.tile[w * d.N + sr.site];
+                const uint32_t b0 = wa < d.W ? m.tile[wa * d.N + sr.site] : 0u;
+                const uint32_t b1 = wb < d.W ? m.tile[wb * d.N + sr.site] : 0u;
+                const uint32_t sh = r ? ((b0 >> r) | (b1 << (32 - r))) : b0;
+                const uint32_t y = a ^ sh; // 1 where the pair disagrees at this site
+                uint32_t z[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (k < static_cast<int>(d.nn)) {
-                const uint32_t fa = A[fw[k]];
-                const uint32_t fsh = r ? ((B0[fw[k]] >> r) | (B1[fw[k]] << (32 - r))) : B0[fw[k]];
-                z[k] = y ^ fa ^ fsh; // 1 where q_i * q_k = -1
-            } else {
-                z[k] = 0;
+                for (int k = 0; k < 3; ++k) {
+                    z[k] = 0;
+                    if (k < static_cast<int>(d.nn)) {
+                        const uint32_t nbr = sr.nb[2 * k];
+                        const uint32_t fa = m.tile[w * d.N + nbr];
+                        const uint32_t f0 = wa < d.W ? m.tile[wa * d.N + nbr] : 0u;
+                        const uint32_t f1 = wb < d.W ? m.tile[wb * d.N + nbr] : 0u;
+                        const uint32_t fsh = r ? ((f0 >> r) | (f1 << (32 - r))) : f0;
+                        z[k] = y ^ fa ^ fsh; // 1 where q_i * q_k = -1
+                    }
+                }
+                byte_count(c[0], y);
+                byte_count(c[1], z[0] ^ z[1] ^ z[2]);
+                byte_count(c[2], maj3(z[0], z[1], z[2]));
+            }
+            uint32_t tot[3];
+            block_bit_totals<3>(c, m.scratch, tot);
+            if (tid < 32) {
+                const uint32_t k = w * 32 + tid;
+                const uint32_t rep = k / d.n_temps, t = k % d.n_temps;
+                if (k < d.n_sys && (rep & 1u) == 0 && rep + 1 < d.n_replicas) {
+                    const uint32_t o = (rep >> 1) * d.n_temps + t;
+                    const int32_t ds = static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(tot[0]);
+                    const int32_t dl = static_cast<int32_t>(d.N * d.nn) -
+                                       2 * static_cast<int32_t>(tot[1] + 2 * tot[2]);
+                    m.dot_spin[o] = ds;
+                    m.dot_link[o] = dl;
+                    const size_t g = static_cast<size_t>(real) * d.n_pairs * d.n_temps + o;
+                    p.dot_spin[g] = ds;
+                    p.dot_link[g] = dl;
+                }
             }
         }
-        byte_count(c[0], y);
-        byte_count(c[1], z[0] ^ z[1] ^ z[2]);
-        byte_count(c[2], maj3(z[0], z[1], z[2]));
+        __syncthreads();
     }
-    uint32_t tot[3];
-    block_bit_totals<3>(c, scratch, tot);
-    if (tid < 32) {
-        const uint32_t k = w * 32 + tid;
-        const uint32_t rep = k / d.n_temps, t = k % d.n_temps;
-        if ((rep & 1u) == 0 && rep + 1 < d.n_replicas && (rep >> 1) < d.n_pairs) {
-            const size_t o = (static_cast<size_t>(real) * d.n_pairs + (rep >> 1)) * d.n_temps + t;
-            p.dot_spin[o] = static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(tot[0]);
-            p.dot_link[o] = static_cast<int32_t>(d.N * d.nn) -
-                            2 * static_cast<int32_t>(tot[1] + 2 * tot[2]);
+
+    // ---- (2) running statistics ---------------------------------------------
+    if (do_accum && tid < d.n_temps) {
+        const uint32_t t = tid;
+        const float n_f = static_cast<float>(d.N);
+        double *mom = p.mom + static_cast<size_t>(real) * 5 * d.n_temps;
+        double m0 = mom[0 * d.n_temps + t], m1 = mom[1 * d.n_temps + t], m2s = mom[2 * d.n_temps + t];
+        double e0 = mom[3 * d.n_temps + t], e1 = mom[4 * d.n_temps + t];
+        for (uint32_t rep = 0; rep < d.n_replicas; ++rep) {
+            const uint32_t slot = rep * d.n_temps + t;
+            const float mag = __fdiv_rn(static_cast<float>(m.M[slot]), n_f);
+            const float mag2 = __fmul_rn(mag, mag);
+            const float mag4 = __fmul_rn(mag2, mag2);
+            const float energy = __fdiv_rn(static_cast<float>(m.E[slot]), n_f);
+            const double ed = static_cast<double>(energy);
+            m0 = __dadd_rn(m0, static_cast<double>(mag));
+            m1 = __dadd_rn(m1, static_cast<double>(mag2));
+            m2s = __dadd_rn(m2s, static_cast<double>(mag4));
+            e0 = __dadd_rn(e0, ed);
+            e1 = __dadd_rn(e1, __dmul_rn(ed, ed));
+        }
+        mom[0 * d.n_temps + t] = m0;
+        mom[1 * d.n_temps + t] = m1;
+        mom[2 * d.n_temps + t] = m2s;
+        mom[3 * d.n_temps + t] = e0;
+        mom[4 * d.n_temps + t] = e1;
+        if (accum_overlap && d.n_pairs) {
+            double *ovm = p.ovm + static_cast<size_t>(real) * 6 * d.n_temps;
+            double o[6];
+            for (int k = 0; k < 6; ++k) o[k] = ovm[k * d.n_temps + t];
+            const float n_bonds_f = static_cast<float>(d.N * d.nn);
+            const size_t hbase = (static_cast<size_t>(real) * d.n_temps + t) * (d.N + 1);
+            for (uint32_t pr = 0; pr < d.n_pairs; ++pr) {
+                const int32_t dot_spin = m.dot_spin[pr * d.n_temps + t];
+                const int32_t dot_link = m.dot_link[pr * d.n_temps + t];
+                const float ql = __fdiv_rn(static_cast<float>(dot_link), n_bonds_f);
+                const float qv = __fdiv_rn(static_cast<float>(dot_spin), n_f);
+                const float q2 = __fmul_rn(qv, qv);
+                const float q4 = __fmul_rn(q2, q2);
+                const float ql2 = __fmul_rn(ql, ql);
+                const float ql4 = __fmul_rn(ql2, ql2);
+                o[0] = __dadd_rn(o[0], static_cast<double>(qv));
+                o[1] = __dadd_rn(o[1], static_cast<double>(q2));
+                o[2] = __dadd_rn(o[2], static_cast<double>(q4));
+                o[3] = __dadd_rn(o[3], static_cast<double>(ql));
+                o[4] = __dadd_rn(o[4], static_cast<double>(ql2));
+                o[5] = __dadd_rn(o[5], static_cast<double>(ql4));
+                const size_t bin =
+                    hbase + static_cast<size_t>((dot_spin + static_cast<int32_t>(d.N)) / 2);
+                p.hist[bin] += 1;
+                p.qlq[bin] = __dadd_rn(p.qlq[bin], static_cast<double>(ql));
+                p.ql2q[bin] = __dadd_rn(p.ql2q[bin], static_cast<double>(ql2));
+            }
+            for (int k = 0; k < 6; ++k) ovm[k * d.n_temps + t] = o[k];
         }
     }
-}
-
-// ---------------------------------------------------------------------------
-// k_accumulate: one thread per (tile, temperature); the reference's f64 running
-// sums in its order (replica by replica, pair by pair: mod.rs:555-578,
-// overlap.rs:259-325, stats.rs:17-27).
-// ---------------------------------------------------------------------------
-__global__ void k_accumulate(SimDims d, DevPtrs p, int with_overlap) {
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= d.n_real * d.n_temps) return;
-    const uint32_t real = idx / d.n_temps, t = idx % d.n_temps;
-    const float n_f = static_cast<float>(d.N);
-    double *mom = p.mom + static_cast<size_t>(real) * 5 * d.n_temps;
-    double m0 = mom[0 * d.n_temps + t], m1 = mom[1 * d.n_temps + t], m2s = mom[2 * d.n_temps + t];
-    double e0 = mom[3 * d.n_temps + t], e1 = mom[4 * d.n_temps + t];
-    for (uint32_t rep = 0; rep < d.n_replicas; ++rep) {
-        const size_t slot = static_cast<size_t>(real) * d.n_sys + rep * d.n_temps + t;
-        const float mag = __fdiv_rn(static_cast<float>(p.Msum[slot]), n_f);
-        const float mag2 = __fmul_rn(mag, mag);
-        const float mag4 = __fmul_rn(mag2, mag2);
-        const float energy = __fdiv_rn(static_cast<float>(p.Esum[slot]), n_f);
-        const double ed = static_cast<double>(energy);
-        m0 = __dadd_rn(m0, static_cast<double>(mag));
-        m1 = __dadd_rn(m1, static_cast<double>(mag2));
-        m2s = __dadd_rn(m2s, static_cast<double>(mag4));
-        e0 = __dadd_rn(e0, ed);
-        e1 = __dadd_rn(e1, __dmul_rn(ed, ed));
-    }
-    mom[0 * d.n_temps + t] = m0;
-    mom[1 * d.n_temps + t] = m1;
-    mom[2 * d.n_temps + t] = m2s;
-    mom[3 * d.n_temps + t] = e0;
-    mom[4 * d.n_temps + t] = e1;
-
-    if (!with_overlap || d.n_pairs == 0) return;
-    double *ovm = p.ovm + static_cast<size_t>(real) * 6 * d.n_temps;
-    double o[6];
-    for (int k = 0; k < 6; ++k) o[k] = ovm[k * d.n_temps + t];
-    const float n_bonds_f = static_cast<float>(d.N * d.nn);
-    const size_t hbase = (static_cast<size_t>(real) * d.n_temps + t) * (d.N + 1);
-    for (uint32_t pr = 0; pr < d.n_pairs; ++pr) {
-        const size_t oidx = (static_cast<size_t>(real) * d.n_pairs + pr) * d.n_temps + t;
-        const int32_t dot_spin = p.dot_spin[oidx], dot_link = p.dot_link[oidx];
-        const float ql = __fdiv_rn(static_cast<float>(dot_link), n_bonds_f);
-        const float qv = __fdiv_rn(static_cast<float>(dot_spin), n_f);
-        const float q2 = __fmul_rn(qv, qv);
-        const float q4 = __fmul_rn(q2, q2);
-        const float ql2 = __fmul_rn(ql, ql);
-        const float ql4 = __fmul_rn(ql2, ql2);
-        o[0] = __dadd_rn(o[0], static_cast<double>(qv));
-        o[1] = __dadd_rn(o[1], static_cast<double>(q2));
-        o[2] = __dadd_rn(o[2], static_cast<double>(q4));
-        o[3] = __dadd_rn(o[3], static_cast<double>(ql));
-        o[4] = __dadd_rn(o[4], static_cast<double>(ql2));
-        o[5] = __dadd_rn(o[5], static_cast<double>(ql4));
-        const size_t bin = hbase + static_cast<size_t>((dot_spin + static_cast<int32_t>(d.N)) / 2);
-        p.hist[bin] += 1;
-        p.qlq[bin] = __dadd_rn(p.qlq[bin], static_cast<double>(ql));
-        p.ql2q[bin] = __dadd_rn(p.ql2q[bin], static_cast<double>(ql2));
-    }
-    for (int k = 0; k < 6; ++k) ovm[k * d.n_temps + t] = o[k];
-}
-
-// ---------------------------------------------------------------------------
-// k_pt: one workgroup per tile.  Thread 0 replays the reference's tempering
-// event for every replica ladder in order (mod.rs:766-792, tempering.rs:20-102,
-// realization.rs:73-120), drawing from the generator of system r*n_temps; the
-// accepted swaps are then applied to the tile as adjacent bit-column exchanges
-// by all threads.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void swap_u32(uint32_t *a, uint32_t *b) {
-    const uint32_t t = *a;
-    *a = *b;
-    *b = t;
-}
-
-__global__ __launch_bounds__(256) void k_pt(SimDims d, DevPtrs p, PtParams pt) {
-    __shared__ uint32_t masks[2][64]; // up to 2048 slots per tile
-    const uint32_t real = blockIdx.x, tid = threadIdx.x;
-    if (tid < 64) {
-        masks[0][tid] = 0;
-        masks[1][tid] = 0;
-    }
+    if (!do_pt || d.n_temps < 2) return;
     __syncthreads();
-    if (tid == 0 && d.n_temps >= 2) {
-        uint32_t *sid = p.system_ids + static_cast<size_t>(real) * d.n_sys;
-        uint32_t *sof = p.slot_of + static_cast<size_t>(real) * d.n_sys;
-        int32_t *E = p.Esum + static_cast<size_t>(real) * d.n_sys;
-        int32_t *M = p.Msum + static_cast<size_t>(real) * d.n_sys;
-        uint64_t *att = p.edge_att + static_cast<size_t>(real) * d.n_edges;
-        uint64_t *accn = p.edge_acc + static_cast<size_t>(real) * d.n_edges;
+
+    // ---- (3) parallel tempering: one lane per replica ladder -------------------
+    DevRng rng;
+    rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
+    if (tid < d.n_replicas) {
+        const uint32_t rep = tid, offset = rep * d.n_temps;
         uint64_t *trips = p.round_trips + static_cast<size_t>(real) * d.n_sys;
         uint8_t *trip = p.trip_state + static_cast<size_t>(real) * d.n_sys;
+        uint32_t st[8];
+        load_cursor(p.cursor, real, d.SP, m.sof0[offset], st);
+        rng.s0 = (static_cast<uint64_t>(st[1]) << 32) | st[0];
+        rng.s1 = (static_cast<uint64_t>(st[3]) << 32) | st[2];
+        rng.s2 = (static_cast<uint64_t>(st[5]) << 32) | st[4];
+        rng.s3 = (static_cast<uint64_t>(st[7]) << 32) | st[6];
         const float n_f = static_cast<float>(d.N);
-        for (uint32_t rep = 0; rep < d.n_replicas; ++rep) {
-            const uint32_t offset = rep * d.n_temps;
-            uint32_t st[8];
-            load_cursor(p.cursor, real, d.SP, sof[offset], st);
-            DevRng rng;
-            rng.s0 = (static_cast<uint64_t>(st[1]) << 32) | st[0];
-            rng.s1 = (static_cast<uint64_t>(st[3]) << 32) | st[2];
-            rng.s2 = (static_cast<uint64_t>(st[5]) << 32) | st[4];
-            rng.s3 = (static_cast<uint64_t>(st[7]) << 32) | st[6];
-            const uint32_t n_edges = d.n_temps - 1;
-            const uint32_t n_attempts = pt.schedule == 0 ? 1u : n_edges;
-            for (uint32_t a = 0; a < n_attempts; ++a) {
-                uint32_t edge;
-                uint32_t round = 0;
-                if (pt.schedule == 0) {
-                    // rand 0.8.5 gen_range(0..n_temps-1) on usize: widening multiply + zone
-                    const uint64_t range = n_edges;
-                    const uint64_t zone = (range << __clzll(range)) - 1;
-                    for (;;) {
-                        const uint64_t v = rng.next();
-                        const uint64_t lo = v * range;
-                        if (lo <= zone) {
-                            edge = static_cast<uint32_t>(__umul64hi(v, range));
-                            break;
-                        }
-                    }
-                } else {
-                    // edges of parity p first, then 1-p (tempering.rs:59-70)
-                    const uint32_t n_first = (n_edges + 1 - pt.first_parity) / 2; // edges p, p+2, ...
-                    if (a < n_first) {
-                        edge = pt.first_parity + 2 * a;
-                    } else {
-                        edge = (1 - pt.first_parity) + 2 * (a - n_first);
-                        round = 1;
+        const uint32_t n_edges = d.n_temps - 1;
+        const uint32_t n_attempts = pt.schedule == 0 ? 1u : n_edges;
+        for (uint32_t a = 0; a < n_attempts; ++a) {
+            uint32_t edge, round = 0;
+            if (pt.schedule == 0) {
+                // rand 0.8.5 gen_range(0..n_temps-1) on usize: widening multiply + zone
+                const uint64_t range = n_edges;
+                const uint64_t zone = (range << __clzll(range)) - 1;
+                for (;;) {
+                    const uint64_t v = rng.next();
+                    if (v * range <= zone) {
+                        edge = static_cast<uint32_t>(__umul64hi(v, range));
+                        break;
                     }
                 }
-                const uint32_t sl = offset + edge, sr = offset + edge + 1;
-                const uint32_t left = sid[sl], right = sid[sr];
-                const float e1 = __fdiv_rn(static_cast<float>(E[sl]), n_f);
-                const float e2 = __fdiv_rn(static_cast<float>(E[sr]), n_f);
-                const float delta =
-                    __fmul_rn(__fmul_rn(n_f, __fsub_rn(e2, e1)), p.dbeta[edge]);
-                const uint32_t draw = static_cast<uint32_t>(rng.next() >> 40);
-                const float log_rand = p.ln_table[draw];
-                const bool accepted = delta >= log_rand;
-                att[edge] += 1;
-                if (accepted) {
-                    accn[edge] += 1;
-                    // record_arrival(left, edge + 1), record_arrival(right, edge)
-                    const uint32_t arr_sys[2] = {left, right};
-                    const uint32_t arr_slot[2] = {edge + 1, edge};
-                    for (int k = 0; k < 2; ++k) {
-                        const uint32_t sys = arr_sys[k], slt = arr_slot[k];
-                        if (slt == pt.hot_slot) {
-                            if (trip[sys] == 2) trips[sys] += 1;
-                            trip[sys] = 1;
-                        } else if (slt == pt.cold_slot && trip[sys] == 1) {
-                            trip[sys] = 2;
-                        }
-                    }
-                    sid[sl] = right;
-                    sid[sr] = left;
-                    sof[right] = sl;
-                    sof[left] = sr;
-                    const int32_t te = E[sl];
-                    E[sl] = E[sr];
-                    E[sr] = te;
-                    const int32_t tm = M[sl];
-                    M[sl] = M[sr];
-                    M[sr] = tm;
-                    for (int j = 0; j < 8; ++j)
-                        swap_u32(&p.cursor[(static_cast<size_t>(real) * 8 + j) * d.SP + sl],
-                                 &p.cursor[(static_cast<size_t>(real) * 8 + j) * d.SP + sr]);
-                    masks[round][sl >> 5] |= 1u << (sl & 31u);
+            } else {
+                // edges of parity p first, then 1-p (tempering.rs:59-70)
+                const uint32_t n_first = (n_edges + 1 - pt.first_parity) / 2;
+                if (a < n_first) {
+                    edge = pt.first_parity + 2 * a;
+                } else {
+                    edge = (1 - pt.first_parity) + 2 * (a - n_first);
+                    round = 1;
                 }
             }
-            st[0] = static_cast<uint32_t>(rng.s0);
-            st[1] = static_cast<uint32_t>(rng.s0 >> 32);
-            st[2] = static_cast<uint32_t>(rng.s1);
-            st[3] = static_cast<uint32_t>(rng.s1 >> 32);
-            st[4] = static_cast<uint32_t>(rng.s2);
-            st[5] = static_cast<uint32_t>(rng.s2 >> 32);
-            st[6] = static_cast<uint32_t>(rng.s3);
-            st[7] = static_cast<uint32_t>(rng.s3 >> 32);
-            store_cursor(p.cursor, real, d.SP, sof[offset], st);
+            const uint32_t sl = offset + edge, sr = sl + 1;
+            const uint32_t left = m.sid[sl], right = m.sid[sr];
+            const float e1 = __fdiv_rn(static_cast<float>(m.E[sl]), n_f);
+            const float e2 = __fdiv_rn(static_cast<float>(m.E[sr]), n_f);
+            const float delta = __fmul_rn(__fmul_rn(n_f, __fsub_rn(e2, e1)), p.dbeta[edge]);
+            const uint32_t draw = static_cast<uint32_t>(rng.next() >> 40);
+            const bool accepted = delta >= p.ln_table[draw];
+            atomicAdd(&m.att[edge], 1u);
+            if (accepted) {
+                atomicAdd(&m.acc[edge], 1u);
+                // record_arrival(left, edge + 1), record_arrival(right, edge)
+                const uint32_t arr_sys[2] = {left, right};
+                const uint32_t arr_slot[2] = {edge + 1, edge};
+                for (int k = 0; k < 2; ++k) {
+                    const uint32_t sys = arr_sys[k], slt = arr_slot[k];
+                    if (slt == pt.hot_slot) {
+                        if (trip[sys] == 2) trips[sys] += 1;
+                        trip[sys] = 1;
+                    } else if (slt == pt.cold_slot && trip[sys] == 1) {
+                        trip[sys] = 2;
+                    }
+                }
+                m.sid[sl] = right;
+                m.sid[sr] = left;
+                const int32_t te = m.E[sl];
+                m.E[sl] = m.E[sr];
+                m.E[sr] = te;
+                const int32_t tm = m.M[sl];
+                m.M[sl] = m.M[sr];
+                m.M[sr] = tm;
+                atomicOr(&m.masks[round * d.W + (sl >> 5)], 1u << (sl & 31u));
+                m.flags[0] = 1;
+            }
         }
     }
     __syncthreads();
-    // Exchange bit columns (k, k+1) for every set mask bit k; round 0 then round 1.
-    bool any = false;
-    for (uint32_t w = 0; w < d.W; ++w) any = any || masks[0][w] || masks[1][w];
-    if (!any) return;
-    uint32_t *Sg = p.S + static_cast<size_t>(real) * d.N * d.W;
-    for (uint32_t i = tid; i < d.N; i += 256) {
-        uint32_t *row = Sg + static_cast<size_t>(i) * d.W;
-        for (int round = 0; round < 2; ++round) {
-            uint32_t carry_t = 0; // bit 31 of the previous word's t
-            for (uint32_t w = 0; w < d.W; ++w) {
-                const uint32_t v = row[w];
-                const uint32_t next = (w + 1 < d.W) ? row[w + 1] : 0u;
-                const uint32_t shr1 = (v >> 1) | (next << 31);
-                const uint32_t t = (v ^ shr1) & masks[round][w];
-                row[w] = v ^ t ^ ((t << 1) | carry_t);
-                carry_t = t >> 31;
+    for (uint32_t k = tid; k < d.n_edges; k += nthreads) {
+        if (m.att[k]) p.edge_att[static_cast<size_t>(real) * d.n_edges + k] += m.att[k];
+        if (m.acc[k]) p.edge_acc[static_cast<size_t>(real) * d.n_edges + k] += m.acc[k];
+    }
+    const bool any_swap = m.flags[0] != 0;
+    // cursors follow their systems: new cursor[slot] = old cursor[old slot of the system now there].
+    // All loads complete (registers) before any store, so the permutation needs no ordering.
+    uint32_t moved[2] = {0, 0};
+    const uint32_t n_items = d.n_sys * 8;
+    if (any_swap) {
+        for (uint32_t it = 0; it < 2; ++it) {
+            const uint32_t item = tid + it * nthreads;
+            if (item < n_items) {
+                const uint32_t slot = item >> 3, j = item & 7u;
+                const uint32_t src = m.sof0[m.sid[slot]];
+                moved[it] = p.cursor[(static_cast<size_t>(real) * 8 + j) * d.SP + src];
             }
         }
     }
+    __syncthreads();
+    if (any_swap) {
+        for (uint32_t it = 0; it < 2; ++it) {
+            const uint32_t item = tid + it * nthreads;
+            if (item < n_items) {
+                const uint32_t slot = item >> 3, j = item & 7u;
+                if (m.sid[slot] != m.sid0[slot])
+                    p.cursor[(static_cast<size_t>(real) * 8 + j) * d.SP + slot] = moved[it];
+            }
+        }
+        for (uint32_t k = tid; k < d.n_sys; k += nthreads) {
+            Eg[k] = m.E[k];
+            Mg[k] = m.M[k];
+            sidg[k] = m.sid[k];
+            sofg[m.sid[k]] = k;
+        }
+    }
+    __syncthreads();
+    // the ladder's generator state goes to wherever system r*n_temps now sits
+    if (tid < d.n_replicas) {
+        const uint32_t offset = tid * d.n_temps;
+        uint32_t final_slot = m.sof0[offset];
+        for (uint32_t k = offset; k < offset + d.n_temps; ++k)
+            if (m.sid[k] == offset) final_slot = k;
+        uint32_t st[8];
+        st[0] = static_cast<uint32_t>(rng.s0);
+        st[1] = static_cast<uint32_t>(rng.s0 >> 32);
+        st[2] = static_cast<uint32_t>(rng.s1);
+        st[3] = static_cast<uint32_t>(rng.s1 >> 32);
+        st[4] = static_cast<uint32_t>(rng.s2);
+        st[5] = static_cast<uint32_t>(rng.s2 >> 32);
+        st[6] = static_cast<uint32_t>(rng.s3);
+        st[7] = static_cast<uint32_t>(rng.s3 >> 32);
+        store_cursor(p.cursor, real, d.SP, final_slot, st);
+    }
+    if (!any_swap) return;
+    // exchange bit columns (k, k+1) for every set mask bit k; round 0 then round 1
+    if (!tile_loaded) {
+        for (size_t i = tid; i < tile_words; i += nthreads) m.tile[i] = Sg[i];
+        __syncthreads();
+    }
+    for (uint32_t i = tid; i < d.N; i += nthreads) {
+        for (int round = 0; round < 2; ++round) {
+            uint32_t carry_t = 0; // bit 31 of the previous word's t
+            uint32_t v = m.tile[i];
+            for (uint32_t w = 0; w < d.W; ++w) {
+                const uint32_t next = (w + 1 < d.W) ? m.tile[(w + 1) * d.N + i] : 0u;
+                const uint32_t shr1 = (v >> 1) | (next << 31);
+                const uint32_t t = (v ^ shr1) & m.masks[round * d.W + w];
+                m.tile[w * d.N + i] = v ^ t ^ ((t << 1) | carry_t);
+                carry_t = t >> 31;
+                v = next;
+            }
+        }
+    }
+    __syncthreads();
+    for (size_t i = tid; i < tile_words; i += nthreads) Sg[i] = m.tile[i];
 }
 
 // ---------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------
-size_t sweep_lds_bytes(const SimDims &d) { return (static_cast<size_t>(d.N) + 4 * 48) * 4; }
-static size_t overlap_lds_bytes(const SimDims &d) {
-    return (3 * static_cast<size_t>(d.N) + 4 * 48) * 4;
-}
+static constexpr size_t kLdsPerCu = 160 * 1024;
+static constexpr size_t kRngLds = 64 * 16 * 8 * 4;
 
-hipError_t configure_kernels(const SimDims &d) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(sweep_lds_bytes(d)));
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_overlap),
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               static_cast<int>(overlap_lds_bytes(d)));
+size_t sweep_lds_bytes(const SimDims &d) {
+    return ((static_cast<size_t>(d.N) + 1) / 2 * 2 + 2 * static_cast<size_t>(d.N) + 16 * 48) * 4;
+}
+size_t measure_lds_bytes(const SimDims &d) { return measure_lds_words(d) * 4; }
+
+hipError_t configure_kernels(const SimDims &) {
+    for (const void *fn : {reinterpret_cast<const void *>(k_rng),
+                           reinterpret_cast<const void *>(k_sweep<false>),
+                           reinterpret_cast<const void *>(k_sweep<true>),
+                           reinterpret_cast<const void *>(k_measure)}) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(kLdsPerCu));
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_rng(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
-    hipLaunchKernelGGL(k_rng, dim3(d.n_real * d.W * d.BP), dim3(64), 0, stream, d, p);
+    const uint32_t n_pairs_tw = (d.n_real * d.W + 1) / 2;
+    const uint32_t groups = (n_pairs_tw + 3) / 4;
+    hipLaunchKernelGGL(k_rng, dim3(groups * d.B), dim3(256), kRngLds, stream, d, p);
     return hipGetLastError();
 }
 
 hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,
                         hipStream_t stream) {
-    hipLaunchKernelGGL(k_sweep, dim3(d.n_real * d.W), dim3(256), sweep_lds_bytes(d), stream, d, p,
-                       with_energy ? 1 : 0, do_sweep ? 1 : 0);
+    hipLaunchKernelGGL(k_sweep<false>, dim3(d.n_real * d.W), dim3(256), sweep_lds_bytes(d), stream,
+                       d, p, with_energy ? 1 : 0, do_sweep ? 1 : 0,
+                       static_cast<unsigned long long *>(nullptr));
     return hipGetLastError();
 }
 
-hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
-    hipLaunchKernelGGL(k_overlap, dim3(d.n_real * d.W), dim3(256), overlap_lds_bytes(d), stream, d,
-                       p);
+// Diagnostic build of k_sweep: workgroup 0 records shader-clock stamps at phase boundaries.
+hipError_t launch_sweep_stamped(const SimDims &d, const DevPtrs &p, unsigned long long *stamps,
+                                hipStream_t stream) {
+    hipLaunchKernelGGL(k_sweep<true>, dim3(d.n_real * d.W), dim3(256), sweep_lds_bytes(d), stream,
+                       d, p, 1, 1, stamps);
     return hipGetLastError();
 }
 
-hipError_t launch_accumulate(const SimDims &d, const DevPtrs &p, bool with_overlap,
-                             hipStream_t stream) {
-    const uint32_t total = d.n_real * d.n_temps;
-    hipLaunchKernelGGL(k_accumulate, dim3((total + 63) / 64), dim3(64), 0, stream, d, p,
-                       with_overlap ? 1 : 0);
-    return hipGetLastError();
-}
-
-hipError_t launch_pt(const SimDims &d, const DevPtrs &p, const PtParams &pt, hipStream_t stream) {
-    hipLaunchKernelGGL(k_pt, dim3(d.n_real), dim3(256), 0, stream, d, p, pt);
+hipError_t launch_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_overlap,
+                          bool do_accum, bool accum_overlap, bool do_pt, hipStream_t stream) {
+    hipLaunchKernelGGL(k_measure, dim3(d.n_real), dim3(1024), measure_lds_bytes(d), stream, d, p, pt,
+                       do_overlap ? 1 : 0, do_accum ? 1 : 0, accum_overlap ? 1 : 0, do_pt ? 1 : 0);
     return hipGetLastError();
 }
 

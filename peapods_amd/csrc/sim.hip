@@ -14,6 +14,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -60,9 +61,8 @@ struct pa_sim {
     uint32_t hot_slot = 0, cold_slot = 0;
     uint32_t next_parity = 0;
     // non-const aliases of the static tables (filled once in create)
-    uint32_t *thr = nullptr, *mpar = nullptr, *sched = nullptr, *level_start = nullptr,
-             *jump = nullptr;
-    uint16_t *jmeta = nullptr;
+    uint32_t *thr = nullptr, *mpar = nullptr, *pass_start = nullptr, *jump = nullptr;
+    uint4 *rec = nullptr;
     int32_t *nz_bonds = nullptr;
     float *dbeta = nullptr;
     // bookkeeping of the last sample()
@@ -70,6 +70,17 @@ struct pa_sim {
     bool overlap_collected = false;
     std::atomic<bool> interrupt{false};
     std::string error;
+    // Realisations are independent, so the sweep pipeline runs as several interleaved groups of
+    // realisations on separate streams: the VALU-bound random-stream kernel of one group overlaps
+    // the latency-bound sweep / measurement / tempering kernels of another.
+    struct Group {
+        SimDims d;
+        DevPtrs p;
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+    };
+    std::vector<Group> groups;
+    hipEvent_t fork = nullptr;
 };
 
 namespace {
@@ -153,7 +164,7 @@ int seed_state(pa_sim *sim, uint64_t seed) {
                     Xoshiro rng = Xoshiro::from_seed_u64(child_seed(base, kSystemSeedDomain, sys));
                     const uint32_t word = sys >> 5, bit = 1u << (sys & 31u);
                     for (uint32_t site = 0; site < d.N; ++site) // gen::<f32>() < 0.5 -> -1
-                        if (rng.next_draw24() < (1u << 23)) tile[static_cast<size_t>(site) * d.W + word] |= bit;
+                        if (rng.next_draw24() < (1u << 23)) tile[static_cast<size_t>(word) * d.N + site] |= bit;
                     for (int w = 0; w < 4; ++w) {
                         cursor[(static_cast<size_t>(real) * 8 + 2 * w) * d.SP + sys] =
                             static_cast<uint32_t>(rng.s[w]);
@@ -201,6 +212,59 @@ int zero_accumulators(pa_sim *sim) {
     return PA_OK;
 }
 
+// DevPtrs of the sub-ensemble starting at realisation r0 (every per-realisation array advanced).
+DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
+    DevPtrs q = p;
+    const size_t tile_words = static_cast<size_t>(d.N) * d.W;
+    const size_t bins = static_cast<size_t>(d.n_temps) * (d.N + 1);
+    q.S += tile_words * r0;
+    q.planes += tile_words * r0;
+    q.cursor += static_cast<size_t>(8) * d.SP * r0;
+    q.system_ids += static_cast<size_t>(d.n_sys) * r0;
+    q.slot_of += static_cast<size_t>(d.n_sys) * r0;
+    q.mpar += static_cast<size_t>(d.MW) * r0;
+    q.rec += static_cast<size_t>(d.N) * r0;
+    q.Esum += static_cast<size_t>(d.n_sys) * r0;
+    q.Msum += static_cast<size_t>(d.n_sys) * r0;
+    q.nz_bonds += r0;
+    q.dot_spin += static_cast<size_t>(d.n_pairs) * d.n_temps * r0;
+    q.dot_link += static_cast<size_t>(d.n_pairs) * d.n_temps * r0;
+    q.mom += static_cast<size_t>(5) * d.n_temps * r0;
+    q.ovm += static_cast<size_t>(6) * d.n_temps * r0;
+    if (d.n_pairs) {
+        q.hist += bins * r0;
+        q.qlq += bins * r0;
+        q.ql2q += bins * r0;
+    }
+    q.edge_att += static_cast<size_t>(d.n_edges) * r0;
+    q.edge_acc += static_cast<size_t>(d.n_edges) * r0;
+    q.round_trips += static_cast<size_t>(d.n_sys) * r0;
+    q.trip_state += static_cast<size_t>(d.n_sys) * r0;
+    q.swap_masks += static_cast<size_t>(2) * d.W * r0;
+    return q;
+}
+
+int make_groups(pa_sim *sim) {
+    uint32_t n_groups = 2;
+    if (const char *env = std::getenv("PEAPODS_STREAMS")) {
+        const long v = std::strtol(env, nullptr, 10);
+        if (v >= 1 && v <= 16) n_groups = static_cast<uint32_t>(v);
+    }
+    n_groups = std::min<uint32_t>(n_groups, sim->d.n_real);
+    PA_HIP(sim, hipEventCreateWithFlags(&sim->fork, hipEventDisableTiming));
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const uint32_t r0 = sim->d.n_real * g / n_groups, r1 = sim->d.n_real * (g + 1) / n_groups;
+        pa_sim::Group grp;
+        grp.d = sim->d;
+        grp.d.n_real = r1 - r0;
+        grp.p = offset_ptrs(sim->p, sim->d, r0);
+        PA_HIP(sim, hipStreamCreateWithFlags(&grp.stream, hipStreamNonBlocking));
+        PA_HIP(sim, hipEventCreateWithFlags(&grp.done, hipEventDisableTiming));
+        sim->groups.push_back(grp);
+    }
+    return PA_OK;
+}
+
 std::string validate_text(const pa_sample_config *cfg, uint64_t n_replicas, int *code) {
     *code = PA_ERR_INVALID;
     // spin-sim/src/config.rs:180-247 (message texts are the reference's)
@@ -233,26 +297,38 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     const bool want_overlap = d.n_pairs > 0 && cfg->measure_overlap;
     sim->n_recorded = 0;
     sim->overlap_collected = want_overlap;
-    for (uint64_t sweep_id = 0; sweep_id < cfg->n_sweeps; ++sweep_id) {
+    // fork: every group stream starts after what is already queued on the main stream
+    PA_HIP(sim, hipEventRecord(sim->fork, sim->stream));
+    for (auto &g : sim->groups) PA_HIP(sim, hipStreamWaitEvent(g.stream, sim->fork, 0));
+    int status = PA_OK;
+    for (uint64_t sweep_id = 0; sweep_id < cfg->n_sweeps && status == PA_OK; ++sweep_id) {
         if ((sweep_id & 31u) == 0 && sim->interrupt.load(std::memory_order_relaxed)) {
-            (void)hipStreamSynchronize(sim->stream);
             sim->interrupt.store(false);
-            return fail(sim, PA_ERR_INTERRUPTED, "interrupted");
+            status = fail(sim, PA_ERR_INTERRUPTED, "interrupted");
+            break;
         }
         const bool record = sweep_id >= cfg->warmup_sweeps; // mod.rs:410
         const bool pt_this = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0; // :486-488
-        PA_HIP(sim, launch_rng(d, sim->p, sim->stream));                                // :412-432
-        PA_HIP(sim, launch_sweep(d, sim->p, record || pt_this, true, sim->stream));     // :492-509
-        if (record) {
-            if (want_overlap) PA_HIP(sim, launch_overlap(d, sim->p, sim->stream));      // :527-529
-            PA_HIP(sim, launch_accumulate(d, sim->p, want_overlap, sim->stream));       // :543-578
-            sim->n_recorded += 1;
+        for (auto &g : sim->groups) {
+            PA_HIP(sim, launch_rng(g.d, g.p, g.stream));                                // :412-432
+            PA_HIP(sim, launch_sweep(g.d, g.p, record || pt_this, true, g.stream));     // :492-509
+            if (record || pt_this) { // overlap :527-529, statistics :543-578, tempering :748-796
+                PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
+                PA_HIP(sim, launch_measure(g.d, g.p, pt, record && want_overlap, record,
+                                           want_overlap, pt_this, g.stream));
+            }
         }
-        if (pt_this) {                                                                  // :748-796
-            PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
-            PA_HIP(sim, launch_pt(d, sim->p, pt, sim->stream));
-            if (cfg->pt_schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
-        }
+        if (record) sim->n_recorded += 1;
+        if (pt_this && cfg->pt_schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
+    }
+    // join: the main stream continues after every group
+    for (auto &g : sim->groups) {
+        PA_HIP(sim, hipEventRecord(g.done, g.stream));
+        PA_HIP(sim, hipStreamWaitEvent(sim->stream, g.done, 0));
+    }
+    if (status != PA_OK) {
+        (void)hipStreamSynchronize(sim->stream);
+        return status;
     }
     return PA_OK;
 }
@@ -389,8 +465,9 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         sim->error = "more than 3 forward directions are not built on the HIP path yet";
         return bail(PA_ERR_UNSUPPORTED);
     }
-    if (lat.n_spins > 40000) {
-        sim->error = "lattices above 40000 sites are not built on the HIP path yet";
+    if (lat.n_spins > 12000 || desc->n_temps > 1024) {
+        sim->error = "lattices above 12000 sites (or more than 1024 temperatures) are not built "
+                     "on the HIP path yet";
         return bail(PA_ERR_UNSUPPORTED);
     }
     sim->n_replicas = desc->n_replicas;
@@ -410,7 +487,12 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     d.n_pairs = d.n_replicas / 2;
     d.n_real = static_cast<uint32_t>(desc->n_realizations);
     d.nn = lat.n_neighbors;
-    d.B = std::max<uint32_t>(1, (d.N + 128) / 256);
+    uint32_t target_block = 256; // sites per RNG block (tuning knob: PEAPODS_RNG_BLOCK)
+    if (const char *env = std::getenv("PEAPODS_RNG_BLOCK")) {
+        const long v = std::strtol(env, nullptr, 10);
+        if (v >= 16 && v <= 65536) target_block = static_cast<uint32_t>(v);
+    }
+    d.B = std::max<uint32_t>(1, (d.N + target_block / 2) / target_block);
     d.BS = (d.N + d.B - 1) / d.B;
     d.B = (d.N + d.BS - 1) / d.BS;
     d.BP = (d.B + 1) / 2;
@@ -445,29 +527,24 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
             }
     }
 
-    // ---- dependency levels -> schedule order
+    // ---- dependency levels -> schedule order, cut into passes of <= 256 sites
     std::vector<uint32_t> level;
-    d.n_levels = build_levels(lat, level);
+    const uint32_t n_levels = build_levels(lat, level);
     std::vector<uint32_t> order(d.N);
     for (uint32_t i = 0; i < d.N; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(),
                      [&](uint32_t a, uint32_t b) { return level[a] < level[b]; });
-    std::vector<uint32_t> level_start(d.n_levels + 1, 0);
+    std::vector<uint32_t> level_start(n_levels + 1, 0);
     for (uint32_t i = 0; i < d.N; ++i) level_start[level[i] + 1] += 1;
-    for (uint32_t l = 0; l < d.n_levels; ++l) level_start[l + 1] += level_start[l];
-    std::vector<uint32_t> sched(static_cast<size_t>(d.N) * 8, 0u);
-    for (uint32_t pos = 0; pos < d.N; ++pos) {
-        const uint32_t site = order[pos];
-        uint32_t *rec = &sched[static_cast<size_t>(pos) * 8];
-        rec[0] = site;
-        for (uint32_t k = 0; k < 3; ++k) {
-            rec[1 + 2 * k] = k < d.nn ? lat.fwd[site * d.nn + k] : site;
-            rec[2 + 2 * k] = k < d.nn ? lat.bwd[site * d.nn + k] : site;
-        }
-    }
+    for (uint32_t l = 0; l < n_levels; ++l) level_start[l + 1] += level_start[l];
+    std::vector<uint32_t> pass_start;
+    for (uint32_t l = 0; l < n_levels; ++l)
+        for (uint32_t b = level_start[l]; b < level_start[l + 1]; b += 256) pass_start.push_back(b);
+    pass_start.push_back(d.N);
+    d.n_passes = static_cast<uint32_t>(pass_start.size()) - 1;
 
-    // ---- per-realisation coupling metadata in schedule order
-    std::vector<uint16_t> jmeta(static_cast<size_t>(d.n_real) * d.N, 0);
+    // ---- per-realisation site records in schedule order (neighbours + coupling metadata)
+    std::vector<uint4> rec(static_cast<size_t>(d.n_real) * d.N);
     std::vector<uint32_t> mpar(static_cast<size_t>(d.n_real) * d.MW, 0u);
     std::vector<int32_t> nz_bonds(d.n_real, 0);
     d.has_odd = 0;
@@ -475,18 +552,24 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         const float *J = desc->couplings + n_coup * real;
         for (uint32_t pos = 0; pos < d.N; ++pos) {
             const uint32_t site = order[pos];
+            uint32_t nb[6];
             uint32_t neg = 0, nz = 0, m = 0;
-            for (uint32_t k = 0; k < d.nn; ++k) {
-                const float jf = J[site * d.nn + k];                  // bond site -> fwd
-                const float jb = J[lat.bwd[site * d.nn + k] * d.nn + k]; // owned by the bwd neighbour
+            for (uint32_t k = 0; k < 3; ++k) {
+                nb[2 * k] = k < d.nn ? lat.fwd[site * d.nn + k] : site;
+                nb[2 * k + 1] = k < d.nn ? lat.bwd[site * d.nn + k] : site;
+                if (k >= d.nn) continue;
+                const float jf = J[site * d.nn + k];             // bond site -> fwd, owned by site
+                const float jb = J[nb[2 * k + 1] * d.nn + k];    // bond bwd -> site, owned by bwd
                 if (jf != 0.0f) { nz |= 1u << (2 * k); m += 1; nz_bonds[real] += 1; }
                 if (jf < 0.0f) neg |= 1u << (2 * k);
                 if (jb != 0.0f) { nz |= 1u << (2 * k + 1); m += 1; }
                 if (jb < 0.0f) neg |= 1u << (2 * k + 1);
             }
             const uint32_t h = (m + 1) / 2;
-            jmeta[static_cast<size_t>(real) * d.N + pos] =
-                static_cast<uint16_t>(neg | (nz << 6) | (h << 12));
+            const uint32_t jm = neg | (nz << 6) | (h << 12);
+            rec[static_cast<size_t>(real) * d.N + pos] =
+                make_uint4(site | (nb[0] << 16), nb[1] | (nb[2] << 16), nb[3] | (nb[4] << 16),
+                           nb[5] | (jm << 16));
             if (m & 1u) {
                 mpar[static_cast<size_t>(real) * d.MW + (site >> 5)] |= 1u << (site & 31u);
                 d.has_odd = 1;
@@ -543,9 +626,8 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     ok(bufs.alloc(&p.slot_of, static_cast<size_t>(d.n_real) * d.n_sys));
     ok(bufs.alloc(&sim->thr, thr.size()));
     ok(bufs.alloc(&sim->mpar, mpar.size()));
-    ok(bufs.alloc(&sim->sched, sched.size()));
-    ok(bufs.alloc(&sim->jmeta, jmeta.size()));
-    ok(bufs.alloc(&sim->level_start, level_start.size()));
+    ok(bufs.alloc(&sim->rec, rec.size()));
+    ok(bufs.alloc(&sim->pass_start, pass_start.size()));
     ok(bufs.alloc(&sim->jump, jump.size()));
     ok(bufs.alloc(&p.Esum, static_cast<size_t>(d.n_real) * d.n_sys));
     ok(bufs.alloc(&p.Msum, static_cast<size_t>(d.n_real) * d.n_sys));
@@ -569,21 +651,21 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     }
     p.thr = sim->thr;
     p.mpar = sim->mpar;
-    p.sched = sim->sched;
-    p.jmeta = sim->jmeta;
-    p.level_start = sim->level_start;
+    p.rec = sim->rec;
+    p.pass_start = sim->pass_start;
     p.jump = sim->jump;
     p.nz_bonds = sim->nz_bonds;
     p.dbeta = sim->dbeta;
     if ((rc = upload(sim, sim->thr, thr)) || (rc = upload(sim, sim->mpar, mpar)) ||
-        (rc = upload(sim, sim->sched, sched)) || (rc = upload(sim, sim->jmeta, jmeta)) ||
-        (rc = upload(sim, sim->level_start, level_start)) || (rc = upload(sim, sim->jump, jump)) ||
+        (rc = upload(sim, sim->rec, rec)) || (rc = upload(sim, sim->pass_start, pass_start)) ||
+        (rc = upload(sim, sim->jump, jump)) ||
         (rc = upload(sim, sim->nz_bonds, nz_bonds)) || (rc = upload(sim, sim->dbeta, dbeta)))
         return bail(rc);
     if (configure_kernels(d) != hipSuccess) {
         sim->error = "kernel LDS configuration failed";
         return bail(PA_ERR_DEVICE);
     }
+    if ((rc = make_groups(sim))) return bail(rc);
     if ((rc = zero_accumulators(sim))) return bail(rc);
     if ((rc = seed_state(sim, desc->seed))) return bail(rc);
     *out = sim;
@@ -595,6 +677,14 @@ void pa_sim_destroy(pa_sim *sim) {
     if (sim->stream) {
         (void)hipSetDevice(sim->device);
         (void)hipStreamSynchronize(sim->stream);
+        for (auto &g : sim->groups) {
+            if (g.stream) {
+                (void)hipStreamSynchronize(g.stream);
+                (void)hipStreamDestroy(g.stream);
+            }
+            if (g.done) (void)hipEventDestroy(g.done);
+        }
+        if (sim->fork) (void)hipEventDestroy(sim->fork);
         sim->buffers.release();
         (void)hipStreamDestroy(sim->stream);
     }
@@ -631,7 +721,7 @@ int pa_sim_sample(pa_sim *sim, const pa_sample_config *cfg) {
 }
 
 int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_sweeps,
-                           double ms_out[5]) {
+                           double ms_out[3]) {
     int code;
     const std::string text = validate_text(cfg, sim->n_replicas, &code);
     if (code != PA_OK) return fail(sim, code, text);
@@ -642,40 +732,31 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
     const bool want_overlap = d.n_pairs > 0 && cfg->measure_overlap;
     sim->n_recorded = 0;
     sim->overlap_collected = want_overlap;
-    hipEvent_t ev[6];
+    hipEvent_t ev[4];
     for (auto &e : ev) PA_HIP(sim, hipEventCreate(&e));
-    double total[5] = {0, 0, 0, 0, 0};
-    uint64_t count[5] = {0, 0, 0, 0, 0};
+    double total[3] = {0, 0, 0};
+    uint64_t count[3] = {0, 0, 0};
     for (uint64_t sweep_id = 0; sweep_id < n_sweeps; ++sweep_id) {
         const bool record = sweep_id >= cfg->warmup_sweeps;
         const bool pt_this = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0;
-        bool ran[5] = {true, true, false, false, false};
         PA_HIP(sim, hipEventRecord(ev[0], sim->stream));
         PA_HIP(sim, launch_rng(d, sim->p, sim->stream));
         PA_HIP(sim, hipEventRecord(ev[1], sim->stream));
         PA_HIP(sim, launch_sweep(d, sim->p, record || pt_this, true, sim->stream));
         PA_HIP(sim, hipEventRecord(ev[2], sim->stream));
-        if (record && want_overlap) {
-            PA_HIP(sim, launch_overlap(d, sim->p, sim->stream));
-            ran[2] = true;
-        }
-        PA_HIP(sim, hipEventRecord(ev[3], sim->stream));
-        if (record) {
-            PA_HIP(sim, launch_accumulate(d, sim->p, want_overlap, sim->stream));
-            sim->n_recorded += 1;
-            ran[3] = true;
-        }
-        PA_HIP(sim, hipEventRecord(ev[4], sim->stream));
-        if (pt_this) {
+        const bool measured = record || pt_this;
+        if (measured) {
             PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
-            PA_HIP(sim, launch_pt(d, sim->p, pt, sim->stream));
-            if (cfg->pt_schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
-            ran[4] = true;
+            PA_HIP(sim, launch_measure(d, sim->p, pt, record && want_overlap, record, want_overlap,
+                                       pt_this, sim->stream));
+            if (pt_this && cfg->pt_schedule == PA_PT_FULL_LADDER)
+                sim->next_parity = 1 - sim->next_parity;
         }
-        PA_HIP(sim, hipEventRecord(ev[5], sim->stream));
-        PA_HIP(sim, hipEventSynchronize(ev[5]));
-        for (int k = 0; k < 5; ++k) {
-            if (!ran[k]) continue;
+        if (record) sim->n_recorded += 1;
+        PA_HIP(sim, hipEventRecord(ev[3], sim->stream));
+        PA_HIP(sim, hipEventSynchronize(ev[3]));
+        for (int k = 0; k < 3; ++k) {
+            if (k == 2 && !measured) continue;
             float ms = 0.f;
             PA_HIP(sim, hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
             total[k] += ms;
@@ -683,7 +764,20 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
         }
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
-    for (int k = 0; k < 5; ++k) ms_out[k] = count[k] ? total[k] / static_cast<double>(count[k]) : 0.0;
+    for (int k = 0; k < 3; ++k) ms_out[k] = count[k] ? total[k] / static_cast<double>(count[k]) : 0.0;
+    return PA_OK;
+}
+
+// Diagnostic only (not in the public header): shader-clock stamps of one k_sweep workgroup.
+int pa_debug_sweep_stamps(pa_sim *sim, unsigned long long out[6]) {
+    PA_HIP(sim, hipSetDevice(sim->device));
+    unsigned long long *dev = nullptr;
+    PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&dev), 6 * sizeof(unsigned long long)));
+    PA_HIP(sim, launch_rng(sim->d, sim->p, sim->stream));
+    PA_HIP(sim, launch_sweep_stamped(sim->d, sim->p, dev, sim->stream));
+    PA_HIP(sim, hipStreamSynchronize(sim->stream));
+    PA_HIP(sim, hipMemcpy(out, dev, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    (void)hipFree(dev);
     return PA_OK;
 }
 
@@ -709,7 +803,7 @@ int pa_sim_parallel_tempering(pa_sim *sim, int32_t schedule) {
     PA_HIP(sim, hipSetDevice(sim->device));
     PA_HIP(sim, launch_sweep(sim->d, sim->p, true, false, sim->stream));
     PtParams pt{schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
-    PA_HIP(sim, launch_pt(sim->d, sim->p, pt, sim->stream));
+    PA_HIP(sim, launch_measure(sim->d, sim->p, pt, false, false, false, true, sim->stream));
     if (schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
     return pa_sim_synchronize(sim);
 }
@@ -718,7 +812,8 @@ int pa_sim_overlap_dots(pa_sim *sim, int64_t *dot_spin, int64_t *dot_link) {
     const SimDims &d = sim->d;
     if (d.n_pairs == 0) return fail(sim, PA_ERR_INVALID, "overlap needs n_replicas >= 2");
     PA_HIP(sim, hipSetDevice(sim->device));
-    PA_HIP(sim, launch_overlap(d, sim->p, sim->stream));
+    PtParams no_pt{0, 0, 0, 0};
+    PA_HIP(sim, launch_measure(d, sim->p, no_pt, true, false, false, false, sim->stream));
     const size_t count = static_cast<size_t>(d.n_real) * d.n_pairs * d.n_temps;
     std::vector<int32_t> a, b;
     int rc;
@@ -751,7 +846,7 @@ int pa_sim_get_spins(pa_sim *sim, uint64_t realization, int8_t *out) {
         const uint32_t slot = slot_of[sys], word = slot >> 5, bit = slot & 31u;
         int8_t *dst = out + static_cast<size_t>(sys) * d.N;
         for (uint32_t site = 0; site < d.N; ++site)
-            dst[site] = ((S[static_cast<size_t>(site) * d.W + word] >> bit) & 1u) ? -1 : 1;
+            dst[site] = ((S[static_cast<size_t>(word) * d.N + site] >> bit) & 1u) ? -1 : 1;
     }
     return PA_OK;
 }

@@ -64,6 +64,20 @@ def build_ensemble(rank, n_per_gpu, world):
     return sim, couplings, temps, dynamics_seed
 
 
+def host_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota
+    (the GPU boxes expose every host CPU but grant a share of them)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    env = os.environ.get("PEAPODS_BENCH_THREADS")
+    return int(env) if env else cores
+
+
 def cpu_baseline(couplings, temps, dynamics_seed, schedule, seconds):
     """Times the oracle (the reference's algorithm restated in C: i8 spins, f32 couplings,
     typewriter order, xoshiro256**, integer table) on this box's host cores: one thread per
@@ -74,7 +88,7 @@ def cpu_baseline(couplings, temps, dynamics_seed, schedule, seconds):
         lib = ob.load(ob.build(native=True))
     except Exception:
         lib = ob.load()
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     n_real = min(cores, couplings.shape[0])
     sim = ob.OracleSimulation(list(SHAPE), couplings[:n_real], temps, N_REPLICAS, None,
                               dynamics_seed, lib=lib)
@@ -145,19 +159,10 @@ def main():
     # final observable exchange: per-realisation blocks, all-gathered over RCCL, aggregated in
     # realisation order (results.rs:165-282) so the result is independent of the GPU count
     t_gather = time.perf_counter()
-    blocks = sim.result_blocks()
-    if dist is not None:
-        import torch
+    from peapods_amd.distributed import aggregate_mean, all_gather_blocks
 
-        local = torch.from_numpy(blocks).cuda()
-        gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device="cuda")
-        dist.all_gather_into_tensor(gathered, local)
-        blocks = gathered.reshape(-1, local.shape[1]).cpu().numpy()
-    from peapods_amd import _native as nat
-
-    mean = np.empty(blocks.shape[1], dtype=np.float64)
-    blocks = np.ascontiguousarray(blocks)
-    nat.lib().pa_aggregate_mean(nat.ptr(blocks), blocks.shape[0], blocks.shape[1], nat.ptr(mean))
+    blocks = all_gather_blocks(sim.result_blocks(), dist, device="cuda" if dist is not None else None)
+    mean = aggregate_mean(blocks)
     gather_ms = (time.perf_counter() - t_gather) * 1e3
 
     kernels_ms = sim.profile_kernels(config(args.profile_sweeps), args.profile_sweeps)
@@ -166,6 +171,7 @@ def main():
         total_attempts = attempts_per_step * world * args.steps
         value = total_attempts / elapsed
         sweep_ms = kernels_ms["k_rng"] + kernels_ms["k_sweep"]
+        step_ms = sum(kernels_ms.values())
         alg_bytes = BYTES_PER_ATTEMPT * attempts_per_step
         achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
         traffic = None

@@ -114,6 +114,10 @@ def load(path=None):
             vp,
             [vp, C.c_int, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, u64],
         ),
+        "orc_sim_create_shard": (
+            vp,
+            [vp, C.c_int, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, u64, u64],
+        ),
         "orc_sim_destroy": (None, [vp]),
         "orc_sim_reset": (None, [vp, u64]),
         "orc_sim_sample": (C.c_int, [vp, P(OrcConfig)]),
@@ -222,7 +226,7 @@ class OracleSimulation:
     """Mirror of the reference's `IsingSimulation` pyclass (src/lib.rs:104-634)."""
 
     def __init__(self, lattice_shape, couplings, temperatures, n_replicas=None,
-                 neighbor_offsets=None, seed=None, lib=None):
+                 neighbor_offsets=None, seed=None, lib=None, first_realization=0):
         self.lib = lib or load()
         self.shape = [int(x) for x in lattice_shape]
         n_dims = len(self.shape)
@@ -248,9 +252,9 @@ class OracleSimulation:
             off_ptr, n_off = _ptr(off), off.shape[0]
         else:
             off_ptr, n_off = None, 0
-        self.handle = self.lib.orc_sim_create(
+        self.handle = self.lib.orc_sim_create_shard(
             _ptr(shape_arr), n_dims, off_ptr, n_off, _ptr(couplings), n_real, _ptr(temps),
-            self.n_temps, self.n_replicas, self.constructor_seed,
+            self.n_temps, self.n_replicas, self.constructor_seed, int(first_realization),
         )
         self.n_spins = int(self.lib.orc_sim_n_spins(self.handle))
         self.n_systems = self.n_replicas * self.n_temps
@@ -351,6 +355,17 @@ class OracleSimulation:
                 )
             per_real.append(res)
         return per_real, has_ov
+
+    def result_blocks(self):
+        """Per-realisation f64 blocks in the layout of pa_sim_get_result_blocks."""
+        per_real, has_ov = self.per_realization_results()
+        rows = []
+        for res in per_real:
+            parts = [res["moments"].reshape(-1)]
+            if has_ov:
+                parts.append(res["overlap"].reshape(-1))
+            rows.append(np.concatenate(parts))
+        return np.stack(rows)
 
     def sample(self, n_sweeps, sweep_mode, pt_interval=None, pt_schedule=None,
                overlap_cluster_update_interval=None, overlap_cluster_build_mode=None,

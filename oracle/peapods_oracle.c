@@ -537,6 +537,7 @@ struct orc_sim {
     orc_lattice *lattice;
     size_t n_replicas, n_temps, n_realizations;
     uint64_t constructor_seed;
+    uint64_t first_realization; /* global index of realisation 0 (disorder sharding) */
     realization *realizations;
     sweep_result *results;
     char error[256];
@@ -1023,7 +1024,18 @@ static void run_sweep_loop(const orc_lattice *lat, realization *real, size_t n_r
 orc_sim *orc_sim_create(const uint64_t *shape, int n_dims, const int64_t *offsets, size_t n_offsets,
                         const float *couplings, size_t n_realizations, const float *temperatures,
                         size_t n_temps, size_t n_replicas, uint64_t seed) {
+    return orc_sim_create_shard(shape, n_dims, offsets, n_offsets, couplings, n_realizations,
+                                temperatures, n_temps, n_replicas, seed, 0);
+}
+
+/* Same, for a shard of a larger disorder ensemble: realisation r of this object is global
+ * realisation first_realization + r and is seeded as such (src/lib.rs:30-32,160). */
+orc_sim *orc_sim_create_shard(const uint64_t *shape, int n_dims, const int64_t *offsets,
+                              size_t n_offsets, const float *couplings, size_t n_realizations,
+                              const float *temperatures, size_t n_temps, size_t n_replicas,
+                              uint64_t seed, uint64_t first_realization) {
     orc_sim *sim = (orc_sim *)calloc(1, sizeof(*sim));
+    sim->first_realization = first_realization;
     sim->lattice = (offsets && n_offsets > 0)
                        ? orc_lattice_with_offsets(shape, n_dims, offsets, n_offsets)
                        : orc_lattice_new(shape, n_dims);
@@ -1042,7 +1054,7 @@ orc_sim *orc_sim_create(const uint64_t *shape, int n_dims, const int64_t *offset
         realization_alloc(sim->lattice, &sim->realizations[r], couplings + r * chunk, temperatures,
                           n_replicas, n_temps);
         realization_reset(sim->lattice, &sim->realizations[r], n_replicas, n_temps,
-                          orc_realization_seed(seed, r));
+                          orc_realization_seed(seed, first_realization + r));
     }
     return sim;
 }
@@ -1063,7 +1075,7 @@ void orc_sim_destroy(orc_sim *sim) {
 void orc_sim_reset(orc_sim *sim, uint64_t seed) {
     for (size_t r = 0; r < sim->n_realizations; ++r)
         realization_reset(sim->lattice, &sim->realizations[r], sim->n_replicas, sim->n_temps,
-                          orc_realization_seed(seed, r));
+                          orc_realization_seed(seed, sim->first_realization + r));
 }
 
 typedef struct {

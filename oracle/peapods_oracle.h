@@ -152,6 +152,10 @@ typedef struct orc_sim orc_sim;
 orc_sim *orc_sim_create(const uint64_t *shape, int n_dims, const int64_t *offsets, size_t n_offsets,
                         const float *couplings, size_t n_realizations, const float *temperatures,
                         size_t n_temps, size_t n_replicas, uint64_t seed);
+orc_sim *orc_sim_create_shard(const uint64_t *shape, int n_dims, const int64_t *offsets,
+                              size_t n_offsets, const float *couplings, size_t n_realizations,
+                              const float *temperatures, size_t n_temps, size_t n_replicas,
+                              uint64_t seed, uint64_t first_realization);
 void orc_sim_destroy(orc_sim *sim);
 void orc_sim_reset(orc_sim *sim, uint64_t seed);
 /* 0 on success; error text via orc_sim_last_error. */

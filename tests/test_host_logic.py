@@ -1,0 +1,187 @@
+"""CPU-only checks of the product's host code through the C ABI: the library loads and exports
+every declared symbol, and the host-side building blocks (seed tree, xoshiro jump-ahead,
+acceptance table, sweep dependency levels, aggregation, option validation) agree with the
+oracle.  No compute call touches a GPU here."""
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from peapods_amd import _native as nat
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "peapods_amd.h")).read()
+    declared = set(re.findall(r"\b(pa_[a-z0-9_]+)\s*\(", header))
+    declared -= {"pa_sim_desc", "pa_sample_config"}
+    assert len(declared) >= 35
+    raw = C.CDLL(nat.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), f"{name} declared in the header but not exported"
+    assert declared == set(nat.SIGNATURES), "ctypes binding table out of sync with the header"
+    assert nat.lib().pa_version().startswith(b"peapods_amd")
+
+
+def test_create_fails_loudly_without_a_device():
+    if nat.lib().pa_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    from peapods_amd import Ising
+
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        Ising((4, 4), temperatures=np.array([1.0, 2.0]), seed=1)
+
+
+def test_seed_tree_matches_oracle(oracle):
+    lib, orc = nat.lib(), oracle.load()
+    for v in (0, 1, 42, 2**63 + 12345, 2**64 - 1):
+        assert lib.pa_splitmix64(v) == orc.orc_splitmix64(v)
+        for idx in (0, 1, 95, 1023):
+            assert lib.pa_realization_seed(v, idx) == orc.orc_realization_seed(v, idx)
+            assert lib.pa_child_seed(v, 0x53A917E14C2D8B6F, idx) == orc.orc_child_seed(
+                v, 0x53A917E14C2D8B6F, idx)
+
+
+def test_xoshiro_state_and_jump_equal_sequential_steps(oracle):
+    lib, orc = nat.lib(), oracle.load()
+    rng = oracle.make_rngs([987654321])[0]
+    start = np.array(list(rng.s), dtype=np.uint64)
+    got = np.zeros(4, dtype=np.uint64)
+    lib.pa_xoshiro_state(987654321, 0, ptr(got))
+    np.testing.assert_array_equal(got, start)
+    position = 0
+    for n in (1, 2, 63, 64, 247, 256, 4096 - 256, 4096, 100003):
+        while position < n:
+            orc.orc_rng_next_u64(C.byref(rng))
+            position += 1
+        want = np.array(list(rng.s), dtype=np.uint64)
+        lib.pa_xoshiro_jump(ptr(start), n, ptr(got))
+        np.testing.assert_array_equal(got, want, err_msg=f"jump by {n}")
+        lib.pa_xoshiro_state(987654321, n, ptr(got))
+        np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("nn", [1, 2, 3])
+def test_metropolis_table_matches_oracle(oracle, nn):
+    lib, orc = nat.lib(), oracle.load()
+    temps = np.array([0.1, 0.7, 0.8, 1.1, 1.4, 2.0, 5.0, 1e6], dtype=np.float32)
+    couplings = np.array([-1.0, 0.0, 1.0], dtype=np.float32)
+    out = np.zeros(len(temps) * (4 * nn + 1), dtype=np.uint32)
+    assert lib.pa_build_metropolis_table(ptr(couplings), 3, ptr(temps), len(temps), nn, ptr(out)) == 0
+    handle = orc.orc_lookup_new(ptr(couplings), 3, ptr(temps), len(temps), nn)
+    k = 0
+    for t in range(len(temps)):
+        for e in range(-2 * nn, 2 * nn + 1):
+            assert out[k] == orc.orc_lookup_get(handle, t, e)
+            k += 1
+    orc.orc_lookup_free(handle)
+    bad = np.array([0.5, 1.0], dtype=np.float32)
+    assert lib.pa_build_metropolis_table(ptr(bad), 2, ptr(temps), len(temps), nn, ptr(out)) == 2
+    zero_t = np.array([0.0], dtype=np.float32)
+    assert lib.pa_build_metropolis_table(ptr(couplings), 3, ptr(zero_t), 1, nn, ptr(out)) == 2
+
+
+@pytest.mark.parametrize("shape,offsets", [((16, 16, 16), None), ((5, 7), None), ((2, 3, 4), None),
+                                           ((6, 6), [[1, 0], [0, 1], [1, -1]]), ((9,), None)])
+def test_sweep_levels_respect_the_typewriter_order(oracle, shape, offsets):
+    lib = nat.lib()
+    lat = oracle.Lattice(list(shape), offsets=offsets)
+    shape_arr = np.asarray(shape, dtype=np.uint64)
+    level = np.zeros(lat.n_spins, dtype=np.uint32)
+    if offsets is None:
+        n_levels = lib.pa_build_sweep_levels(len(shape), ptr(shape_arr), 0, None, ptr(level))
+    else:
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        n_levels = lib.pa_build_sweep_levels(len(shape), ptr(shape_arr), len(offsets), ptr(off),
+                                             ptr(level))
+    assert n_levels == level.max() + 1
+    for i in range(lat.n_spins):
+        for d in range(lat.n_neighbors):
+            for j in (lat.neighbor_fwd(i, d), lat.neighbor_bwd(i, d)):
+                if j < i:
+                    assert level[j] < level[i]  # already updated when i runs
+                elif j > i:
+                    assert level[j] > level[i]  # still old when i runs
+    if offsets is None:  # hyperplanes: level = sum of coordinates
+        coords = np.indices(shape).reshape(len(shape), -1)
+        np.testing.assert_array_equal(level, coords.sum(axis=0))
+
+
+def test_aggregation_matches_oracle(oracle):
+    lib = nat.lib()
+    rng = np.random.default_rng(0)
+    per = rng.standard_normal((7, 33))
+    mean = np.empty(33)
+    lib.pa_aggregate_mean(ptr(per), 7, 33, ptr(mean))
+    acc = np.zeros(33)
+    for row in per:
+        acc = acc + row
+    np.testing.assert_array_equal(mean, acc / 7.0)
+    one = np.empty(33)
+    lib.pa_aggregate_mean(ptr(per), 1, 33, ptr(one))
+    np.testing.assert_array_equal(one, per[0])
+    hist = rng.integers(0, 1000, size=(5, 12)).astype(np.uint64)
+    out = np.empty(12, dtype=np.uint64)
+    lib.pa_aggregate_sum_u64(ptr(hist), 5, 12, ptr(out))
+    np.testing.assert_array_equal(out, hist.sum(axis=0))
+
+
+def test_option_validation_messages():
+    lib = nat.lib()
+
+    def check(n_replicas=2, **kw):
+        cfg = nat.PaSampleConfig()
+        cfg.n_sweeps, cfg.warmup_sweeps = 10, 2
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        err = C.create_string_buffer(256)
+        return lib.pa_validate_sample_config(C.byref(cfg), n_replicas, err, 256), err.value.decode()
+
+    assert check()[0] == 0
+    assert check(n_sweeps=0) == (1, "n_sweeps must be >= 1")
+    assert check(warmup_sweeps=11) == (1, "warmup_sweeps must be <= n_sweeps")
+    code, text = check(n_replicas=1, overlap_cluster_interval=1, n_overlap_cluster_modes=1)
+    assert code == 1 and text.startswith("overlap cluster requires n_replicas >= max group_size")
+    assert check(sweep_mode=1)[0] == 2  # gibbs: valid in the reference, not on the HIP path yet
+
+
+def test_python_surface_host_side():
+    from peapods_amd._core import _parse_overlap_modes
+    from peapods_amd.spin_models import generate_couplings, seed_material
+
+    seq_a, dyn_a = seed_material(41)
+    seq_b, dyn_b = seed_material(41)
+    assert dyn_a == dyn_b and dyn_a != seed_material(42)[1]
+    with pytest.raises(ValueError, match="non-negative integer"):
+        seed_material(-1)
+    full = generate_couplings("bimodal", (4, 4, 4), 3, 8, seq_a)
+    part = generate_couplings("bimodal", (4, 4, 4), 3, 8, seq_b, realizations=range(5, 8))
+    for a, b in zip(full[5:], part):
+        np.testing.assert_array_equal(a, b)
+    assert set(np.unique(full[0])) == {-1.0, 1.0} and full[0].dtype == np.float32
+    # sample 0 is stable when the disorder count grows (reference test :45-48)
+    np.testing.assert_array_equal(generate_couplings("gaussian", (4, 4), 2, 1, seed_material(7)[0])[0],
+                                  generate_couplings("gaussian", (4, 4), 2, 3, seed_material(7)[0])[0])
+    assert _parse_overlap_modes("houdayer+jorg") == [1, 2]
+    with pytest.raises(ValueError, match="unknown overlap_cluster_build_mode"):
+        _parse_overlap_modes("bogus")
+    with pytest.raises(ValueError, match="must be even"):
+        _parse_overlap_modes("houd3")
+
+
+def test_shard_ranges_cover_the_ensemble():
+    from peapods_amd.distributed import shard_range
+
+    for n_total, world in ((128, 1), (1024, 8), (10, 4), (3, 8)):
+        edges = [shard_range(n_total, r, world) for r in range(world)]
+        assert edges[0][0] == 0 and edges[-1][1] == n_total
+        for (a0, a1), (b0, b1) in zip(edges, edges[1:]):
+            assert a1 == b0 and a0 <= a1

@@ -38,6 +38,7 @@ struct SimDims {
     uint32_t MW;         // ceil(N / 32): words of the per-site parity bitmap
     uint32_t has_odd;    // 1 if any site has an odd number of non-zero bonds
     uint32_t n_edges;    // max(n_temps - 1, 1) (allocation stride of the PT edge counters)
+    uint32_t dense_nn;   // = nn when every bond of every realisation is non-zero, else 0
 };
 
 struct DevPtrs {
@@ -48,7 +49,8 @@ struct DevPtrs {
     uint32_t *slot_of;       // [n_real][n_sys]  system -> slot
     const uint32_t *thr;     // [2][3][n_temps]  thresholds: even set (dE=-2,-4,-6), odd set (-1,-3,-5)
     const uint32_t *mpar;    // [n_real][MW]     parity of the non-zero bond count per site
-    const uint4 *rec;        // [n_real][N] schedule order, 16-bit fields: site,f0 | b0,f1 | b1,f2 | b2,jmeta
+    const uint4 *rec;        // [n_real][N + 1] schedule order (+ dummy), 16-bit fields holding 4 * index:
+                             //   site,f0 | b0,f1 | b1,f2 | b2,jmeta
                              //   jmeta = neg[0..5] | nz[6..11] | h[12..13] for bonds f0,b0,f1,b1,f2,b2
     const uint32_t *pass_start; // [n_passes + 1]
     const uint32_t *jump;    // [B][64][16][8] nibble tables of T^(b*BS)
@@ -81,10 +83,13 @@ struct PtParams {
 hipError_t launch_rng(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,
                         hipStream_t stream);
+hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 hipError_t launch_sweep_stamped(const SimDims &d, const DevPtrs &p, unsigned long long *stamps,
                                 hipStream_t stream);
 hipError_t launch_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_overlap,
                           bool do_accum, bool accum_overlap, bool do_pt, hipStream_t stream);
+hipError_t launch_measure_stamped(const SimDims &d, const DevPtrs &p, const PtParams &pt,
+                                  unsigned long long *stamps, hipStream_t stream);
 size_t sweep_lds_bytes(const SimDims &d);
 size_t measure_lds_bytes(const SimDims &d);
 hipError_t configure_kernels(const SimDims &d);

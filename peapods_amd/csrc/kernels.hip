@@ -284,49 +284,54 @@ __device__ __forceinline__ void byte_count(uint32_t c[8], uint32_t x) {
     for (int j = 0; j < 8; ++j) c[j] += (x >> j) & 0x01010101u;
 }
 
-// Sum over the 16 lanes of a DPP row, result in every lane of the row (row_ror 8, 4, 2, 1).
-// DPP adds are plain VALU instructions: unlike __shfl_xor (ds_bpermute) they do not touch the
-// LDS pipe, which the 48-register reductions below would otherwise saturate.
-__device__ __forceinline__ uint32_t row_sum16(uint32_t v) {
+// Wave-wide sum by DPP only (plain VALU instructions; unlike __shfl_xor / ds_bpermute they do not
+// touch the LDS pipe, which the 48-register reductions below would otherwise saturate):
+// row_ror 8,4,2,1 leave every lane with its 16-lane row sum, row_bcast15 adds row r into row r+1
+// for rows 1 and 3, row_bcast31 adds lane 31 into rows 2-3: lane 63 ends with the wave total.
+__device__ __forceinline__ uint32_t wave_sum_lane63(uint32_t v) {
     v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x128, 0xF, 0xF, false));
     v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x124, 0xF, 0xF, false));
     v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x122, 0xF, 0xF, false));
     v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x121, 0xF, 0xF, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xA, 0xF, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xC, 0xF, false));
     return v;
 }
 
 // Reduce NSET sets of byte counters over the workgroup (blockDim.x / 64 waves).  Thread b < 32
-// receives in out[set] the total for bit b.  scratch: [n_waves * 4][NSET*16] dwords of LDS.
+// receives in out[set] the total for bit b.  scratch: [n_waves + 1][NSET*16] dwords of LDS.
 template <int NSET>
 __device__ __forceinline__ void block_bit_totals(const uint32_t (*c)[8], uint32_t *scratch,
                                                  uint32_t out[NSET]) {
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t n_rows = blockDim.x >> 4;
-    const uint32_t row = tid >> 4;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n_waves = blockDim.x >> 6;
 #pragma unroll
     for (int s = 0; s < NSET; ++s) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             // widen the four byte counters to 16 bits (two registers) before summing lanes
-            const uint32_t lo = row_sum16(c[s][j] & 0x00FF00FFu);        // bits j, j+16
-            const uint32_t hi = row_sum16((c[s][j] >> 8) & 0x00FF00FFu); // bits j+8, j+24
-            if ((lane & 15u) == 0) {
-                scratch[row * (NSET * 16) + s * 16 + j * 2 + 0] = lo;
-                scratch[row * (NSET * 16) + s * 16 + j * 2 + 1] = hi;
+            const uint32_t lo = wave_sum_lane63(c[s][j] & 0x00FF00FFu);        // bits j, j+16
+            const uint32_t hi = wave_sum_lane63((c[s][j] >> 8) & 0x00FF00FFu); // bits j+8, j+24
+            if (lane == 63) {
+                scratch[wave * (NSET * 16) + s * 16 + j * 2 + 0] = lo;
+                scratch[wave * (NSET * 16) + s * 16 + j * 2 + 1] = hi;
             }
         }
+    }
+    __syncthreads();
+    uint32_t *total = scratch + n_waves * (NSET * 16);
+    if (tid < NSET * 16) { // 16-bit fields cannot overflow: a total is at most the site count
+        uint32_t sum = 0;
+        for (uint32_t wv = 0; wv < n_waves; ++wv) sum += scratch[wv * (NSET * 16) + tid];
+        total[tid] = sum;
     }
     __syncthreads();
     if (tid < 32) {
         const uint32_t j = tid & 7u, byte = tid >> 3;
 #pragma unroll
         for (int s = 0; s < NSET; ++s) {
-            uint32_t total = 0;
-            for (uint32_t rw = 0; rw < n_rows; ++rw) {
-                const uint32_t v = scratch[rw * (NSET * 16) + s * 16 + j * 2 + (byte & 1u)];
-                total += (byte >> 1) ? (v >> 16) : (v & 0xFFFFu);
-            }
-            out[s] = total;
+            const uint32_t v = total[s * 16 + j * 2 + (byte & 1u)];
+            out[s] = (byte >> 1) ? (v >> 16) : (v & 0xFFFFu);
         }
     }
     __syncthreads();
@@ -335,13 +340,17 @@ __device__ __forceinline__ void block_bit_totals(const uint32_t (*c)[8], uint32_
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which
 // would stall every schedule pass on the global prefetch issued just before it.
 __device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// Schedule record of one site (uint4, 16-bit fields):
+// Schedule record of one site (uint4, 16-bit fields holding LDS byte offsets = 4 * site index):
 //   x = site | f0 << 16,  y = b0 | f1 << 16,  z = b1 | f2 << 16,  w = b2 | jmeta << 16
+// Each realisation has N + 1 records; record N is a dummy whose site and neighbours all point
+// at the spare LDS slot N, so idle lanes of a pass run the same code without a branch.
 struct SiteRec {
-    uint32_t site, nb[6], jm;
+    uint32_t site, nb[6], jm; // byte offsets into a u32[N + 1] LDS array
     __device__ __forceinline__ explicit SiteRec(const uint4 r) {
         site = r.x & 0xFFFFu;
         nb[0] = r.x >> 16;
@@ -354,35 +363,122 @@ struct SiteRec {
     }
 };
 
+__device__ __forceinline__ uint32_t lds_word(const uint32_t *base, uint32_t byte_off) {
+    return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
+// Accept mask when every one of the 2*NN bonds of every site is non-zero (+-J and ferromagnets):
+// m = 2 NN, h = NN, no non-zero masks, no per-site case split.
+template <int NN>
+__device__ __forceinline__ uint32_t accept_mask_dense(uint32_t s, const uint32_t nb[6], uint32_t jm,
+                                                      uint32_t l0, uint32_t l1) {
+    uint32_t u[6];
+#pragma unroll
+    for (int k = 0; k < 2 * NN; ++k)
+        u[k] = s ^ nb[k] ^ static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(jm), k, 1));
+    uint32_t U0, U1, U2;
+    if (NN == 3) {
+        const uint32_t s1 = u[0] ^ u[1] ^ u[2], c1 = maj3(u[0], u[1], u[2]);
+        const uint32_t s2 = u[3] ^ u[4] ^ u[5], c2 = maj3(u[3], u[4], u[5]);
+        const uint32_t c3 = s1 & s2;
+        U0 = s1 ^ s2;
+        U1 = c1 ^ c2 ^ c3;
+        U2 = maj3(c1, c2, c3);
+    } else if (NN == 2) {
+        const uint32_t s1 = u[0] ^ u[1] ^ u[2], c1 = maj3(u[0], u[1], u[2]);
+        const uint32_t c2 = s1 & u[3];
+        U0 = s1 ^ u[3];
+        U1 = c1 ^ c2;
+        U2 = c1 & c2;
+    } else {
+        U0 = u[0] ^ u[1];
+        U1 = u[0] & u[1];
+        U2 = 0;
+    }
+    const uint32_t t0 = U0 ^ l0, k0 = U0 & l0;
+    const uint32_t t1 = U1 ^ l1 ^ k0, k1 = maj3(U1, l1, k0);
+    const uint32_t hi = U2 | k1; // t2 | t3 = (U2 ^ k1) | (U2 & k1)
+    if (NN == 3) return (t0 & t1) | hi;
+    if (NN == 2) return t1 | hi;
+    return t0 | t1 | hi;
+}
+
+// Cooperative global -> LDS copy of n dwords: loads are issued in batches of 8 before the first
+// store, so a wave keeps 8 requests in flight instead of one round trip per iteration.
+__device__ __forceinline__ void copy_to_lds(uint32_t *dst, const uint32_t *__restrict__ src,
+                                            uint32_t n, uint32_t tid, uint32_t nthreads) {
+    // 16-byte path (both pointers 16-byte aligned, n a multiple of 4): 8 dwordx4 loads in flight
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0 && (n & 3u) == 0) {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+        uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+        const uint32_t n4 = n >> 2;
+        for (uint32_t base = 0; base < n4; base += 8 * nthreads) {
+            uint4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t i = base + k * nthreads + tid;
+                v[k] = i < n4 ? s4[i] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t i = base + k * nthreads + tid;
+                if (i < n4) d4[i] = v[k];
+            }
+        }
+        return;
+    }
+    for (uint32_t base = 0; base < n; base += 8 * nthreads) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t i = base + k * nthreads + tid;
+            v[k] = i < n ? src[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t i = base + k * nthreads + tid;
+            if (i < n) dst[i] = v[k];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // k_sweep: workgroup = (tile, word).  The word's N site values and the two
 // acceptance-level planes live in LDS; the schedule passes (dependency levels
-// cut into chunks of <= 256 sites) run in order with one barrier each, which
+// cut into chunks of <= 256 sites) run in order with one LDS barrier each, which
 // reproduces the reference's sequential site order (sweep.rs:58-61) bit for
 // bit.  The next pass's site record is prefetched while the current one runs.
+// MODE 1..3: every bond non-zero with MODE forward directions (dense path);
+// MODE 0: couplings may contain zeros (general path).
 // Epilogue: energy sum_{i,d} J s_i s_fwd and magnetisation sum_i s_i for the
 // word's 32 slots (energy.rs:92-109), by byte-sliced vertical counters.
 // ---------------------------------------------------------------------------
 #define PA_STAMP(k)                                                                                \
     if (STAMPS && blockIdx.x == 0 && threadIdx.x == 0) stamps[k] = clock64();
 
-template <bool STAMPS>
+template <bool STAMPS, int MODE>
 __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_energy,
                                                int do_sweep, unsigned long long *stamps) {
     extern __shared__ uint32_t lds[];
     PA_STAMP(0)
-    const uint32_t n_pad = (d.N + 1u) & ~1u;
-    uint32_t *sw = lds;                                        // [N] spins of this word
-    uint2 *pl = reinterpret_cast<uint2 *>(lds + n_pad);        // [N] acceptance-level planes
-    uint32_t *scratch = lds + n_pad + 2 * static_cast<size_t>(d.N); // [16 rows][48]
+    const uint32_t n1 = d.N + 1;                               // + the dummy slot
+    const uint32_t n_pad = (n1 + 1u) & ~1u;
+    uint32_t *sw = lds;                                        // [N + 1] spins of this word
+    uint32_t *pl = lds + n_pad;                                // [N + 1][2] acceptance-level planes
+    uint32_t *scratch = lds + n_pad + 2 * static_cast<size_t>(n1); // [16 rows][48]
     const uint32_t real = blockIdx.x / d.W, w = blockIdx.x % d.W;
     const uint32_t tid = threadIdx.x;
     uint32_t *Sg = p.S + (static_cast<size_t>(real) * d.W + w) * d.N; // this word's N sites
-    const uint4 *rec = p.rec + static_cast<size_t>(real) * d.N;
-    for (uint32_t i = tid; i < d.N; i += 256) sw[i] = Sg[i];
-    if (do_sweep) {
-        const uint2 *planes = p.planes + (static_cast<size_t>(real) * d.W + w) * d.N;
-        for (uint32_t i = tid; i < d.N; i += 256) pl[i] = planes[i];
+    const uint4 *rec = p.rec + static_cast<size_t>(real) * n1;
+    copy_to_lds(sw, Sg, d.N, tid, 256);
+    if (do_sweep)
+        copy_to_lds(pl, reinterpret_cast<const uint32_t *>(
+                            p.planes + (static_cast<size_t>(real) * d.W + w) * d.N),
+                    2 * d.N, tid, 256);
+    if (tid == 0) {
+        sw[d.N] = 0;
+        pl[2 * d.N] = 0;
+        pl[2 * d.N + 1] = 0;
     }
     const uint32_t live = d.n_sys - w * 32;
     const uint32_t valid_bits = live >= 32 ? 0xFFFFFFFFu : ((1u << live) - 1u);
@@ -390,30 +486,57 @@ __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_en
     PA_STAMP(1)
 
     if (do_sweep) {
-        uint32_t begin = p.pass_start[0];
-        uint32_t end = p.pass_start[1];
-        uint4 cur = make_uint4(0, 0, 0, 0);
-        if (begin + tid < end) cur = rec[begin + tid];
-        for (uint32_t pass = 0; pass < d.n_passes; ++pass) {
-            const bool active = begin + tid < end;
-            const uint32_t nbegin = end;
-            const uint32_t nend = pass + 1 < d.n_passes ? p.pass_start[pass + 2] : end;
-            uint4 nxt = make_uint4(0, 0, 0, 0);
-            if (nbegin + tid < nend) nxt = rec[nbegin + tid]; // prefetch
-            if (active) {
-                const SiteRec r(cur);
-                uint32_t nb[6];
+        // Site records stream from global memory three passes ahead of their use (four rotating
+        // register buffers, loop unrolled by four so no buffer is ever copied).
+        const int dbg = STAMPS ? (with_energy >> 8) : 0; // diagnostic build only
+        // pass_start[] lives in two VGPRs (lane l holds entries l and 64 + l); a pass boundary is
+        // then one v_readlane away instead of a scalar-cache round trip in front of every fetch.
+        const uint32_t ps_lo = p.pass_start[min(tid & 63u, d.n_passes)];
+        const uint32_t ps_hi = p.pass_start[min(64u + (tid & 63u), d.n_passes)];
+        auto boundary = [&](uint32_t k) -> uint32_t {
+            if (k < 64) return __builtin_amdgcn_readlane(ps_lo, k);
+            if (k < 128) return __builtin_amdgcn_readlane(ps_hi, k - 64);
+            return p.pass_start[k];
+        };
+        auto fetch = [&](uint32_t pass) -> uint4 {
+            if (pass >= d.n_passes) return make_uint4(0, 0, 0, 0);
+            if (STAMPS && (dbg & 2)) return make_uint4(tid * 4, tid * 4, tid * 4, tid * 4);
+            const uint32_t pos = boundary(pass) + tid;
+            return rec[pos < boundary(pass + 1) ? pos : d.N]; // dummy record when idle
+        };
+        auto run = [&](const uint4 raw) {
+            const SiteRec r(raw);
+            uint32_t nb[6];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) nb[k] = sw[r.nb[k]];
-                const uint32_t s = sw[r.site];
-                const uint2 lv = pl[r.site];
-                const uint32_t acc = accept_mask(s, nb, r.jm, lv.x, lv.y) & valid_bits;
-                sw[r.site] = s ^ acc;
-            }
-            lds_barrier();
-            cur = nxt;
-            begin = nbegin;
-            end = nend;
+            for (int k = 0; k < 6; ++k)
+                nb[k] = (MODE == 0 || k < 2 * MODE) ? lds_word(sw, r.nb[k]) : 0u;
+            const uint32_t s = lds_word(sw, r.site);
+            const uint2 lv =
+                *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(pl) + 2 * r.site);
+            uint32_t acc;
+            if (STAMPS && (dbg & 1))
+                acc = nb[0] ^ nb[1] ^ nb[2] ^ nb[3] ^ nb[4] ^ nb[5] ^ lv.x ^ lv.y;
+            else if (MODE == 0)
+                acc = accept_mask(s, nb, r.jm, lv.x, lv.y);
+            else
+                acc = accept_mask_dense<MODE == 0 ? 1 : MODE>(s, nb, r.jm, lv.x, lv.y);
+            *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(sw) + r.site) =
+                s ^ (acc & valid_bits);
+            if (!(STAMPS && (dbg & 4))) lds_barrier();
+        };
+        uint4 b0 = fetch(0), b1 = fetch(1), b2 = fetch(2), b3;
+        for (uint32_t pass = 0; pass < d.n_passes; pass += 4) {
+            b3 = fetch(pass + 3);
+            run(b0);
+            if (pass + 1 >= d.n_passes) break;
+            b0 = fetch(pass + 4);
+            run(b1);
+            if (pass + 2 >= d.n_passes) break;
+            b1 = fetch(pass + 5);
+            run(b2);
+            if (pass + 3 >= d.n_passes) break;
+            b2 = fetch(pass + 6);
+            run(b3);
         }
         PA_STAMP(2)
         for (uint32_t i = tid; i < d.N; i += 256) Sg[i] = sw[i];
@@ -426,18 +549,28 @@ __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_en
         for (int s = 0; s < 3; ++s)
 #pragma unroll
             for (int j = 0; j < 8; ++j) c[s][j] = 0;
-#pragma unroll 4
-        for (uint32_t pos = tid; pos < d.N; pos += 256) {
-            const SiteRec r(rec[pos]);
-            const uint32_t jm = r.jm;
-            const uint32_t s = sw[r.site];
-            const uint32_t f0 = sw[r.nb[0]], f1 = sw[r.nb[2]], f2 = sw[r.nb[4]];
-            const uint32_t u0 = (s ^ f0 ^ (0u - ((jm >> 0) & 1u))) & (0u - ((jm >> 6) & 1u));
-            const uint32_t u1 = (s ^ f1 ^ (0u - ((jm >> 2) & 1u))) & (0u - ((jm >> 8) & 1u));
-            const uint32_t u2 = (s ^ f2 ^ (0u - ((jm >> 4) & 1u))) & (0u - ((jm >> 10) & 1u));
-            byte_count(c[0], u0 ^ u1 ^ u2);      // weight 1
-            byte_count(c[1], maj3(u0, u1, u2));  // weight 2
-            byte_count(c[2], s);                 // spins equal to -1
+        for (uint32_t base = 0; base < d.N; base += 4 * 256) {
+            uint4 rr[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t pos = base + k * 256 + tid;
+                rr[k] = rec[pos < d.N ? pos : d.N];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (base + k * 256 + tid >= d.N) continue;
+                const SiteRec r(rr[k]);
+                const uint32_t jm = r.jm;
+                const uint32_t s = lds_word(sw, r.site);
+                const uint32_t f0 = lds_word(sw, r.nb[0]), f1 = lds_word(sw, r.nb[2]),
+                               f2 = lds_word(sw, r.nb[4]);
+                const uint32_t u0 = (s ^ f0 ^ (0u - ((jm >> 0) & 1u))) & (0u - ((jm >> 6) & 1u));
+                const uint32_t u1 = (s ^ f1 ^ (0u - ((jm >> 2) & 1u))) & (0u - ((jm >> 8) & 1u));
+                const uint32_t u2 = (s ^ f2 ^ (0u - ((jm >> 4) & 1u))) & (0u - ((jm >> 10) & 1u));
+                byte_count(c[0], u0 ^ u1 ^ u2);      // weight 1
+                byte_count(c[1], maj3(u0, u1, u2));  // weight 2
+                byte_count(c[2], s);                 // spins equal to -1
+            }
         }
         PA_STAMP(4)
         uint32_t tot[3];
@@ -451,6 +584,85 @@ __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_en
         }
     }
     PA_STAMP(5)
+}
+
+// ---------------------------------------------------------------------------
+// k_overlap: workgroup = (tile, word), 256 threads.  Replica 2p and 2p+1 at
+// temperature t sit n_temps bit positions apart, so Y = V ^ (V >> n_temps) lines
+// every pair up in the bits of the even replica.  V = S gives q_i; V = S ^ S(fwd_d)
+// gives the bond products, and q_i q_k = +1 <=> both replicas agree on the bond
+// (overlap.rs:259-282).  Per-bit counts by byte-sliced counters -> dot_spin, dot_link.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_overlap(SimDims d, DevPtrs p) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t n1 = d.N + 1;
+    uint32_t *A = lds;            // word w
+    uint32_t *B0 = lds + n1;      // word w + q
+    uint32_t *B1 = lds + 2 * n1;  // word w + q + 1
+    uint32_t *scratch = lds + 3 * static_cast<size_t>(n1);
+    const uint32_t real = blockIdx.x / d.W, w = blockIdx.x % d.W;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t q = d.n_temps >> 5, r = d.n_temps & 31u;
+    const uint32_t wa = w + q, wb = w + q + 1;
+    const uint32_t *Sg = p.S + static_cast<size_t>(real) * d.W * d.N;
+    const uint4 *rec = p.rec + static_cast<size_t>(real) * n1;
+    copy_to_lds(A, Sg + static_cast<size_t>(w) * d.N, d.N, tid, 256);
+    if (wa < d.W) copy_to_lds(B0, Sg + static_cast<size_t>(wa) * d.N, d.N, tid, 256);
+    if (wb < d.W) copy_to_lds(B1, Sg + static_cast<size_t>(wb) * d.N, d.N, tid, 256);
+    if (wa >= d.W)
+        for (uint32_t i = tid; i < d.N; i += 256) B0[i] = 0;
+    if (wb >= d.W)
+        for (uint32_t i = tid; i < d.N; i += 256) B1[i] = 0;
+    __syncthreads();
+    uint32_t c[3][8];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[s][j] = 0;
+    for (uint32_t base = 0; base < d.N; base += 4 * 256) {
+        uint4 rr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t pos = base + k * 256 + tid;
+            rr[k] = rec[pos < d.N ? pos : d.N];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (base + k * 256 + tid >= d.N) continue;
+            const SiteRec sr(rr[k]);
+            const uint32_t a = lds_word(A, sr.site);
+            const uint32_t b0 = lds_word(B0, sr.site), b1 = lds_word(B1, sr.site);
+            const uint32_t sh = r ? ((b0 >> r) | (b1 << (32 - r))) : b0;
+            const uint32_t y = a ^ sh; // 1 where the pair disagrees at this site
+            uint32_t z[3];
+#pragma unroll
+            for (int dir = 0; dir < 3; ++dir) {
+                z[dir] = 0;
+                if (dir < static_cast<int>(d.nn)) {
+                    const uint32_t nbr = sr.nb[2 * dir];
+                    const uint32_t fa = lds_word(A, nbr);
+                    const uint32_t f0 = lds_word(B0, nbr), f1 = lds_word(B1, nbr);
+                    const uint32_t fsh = r ? ((f0 >> r) | (f1 << (32 - r))) : f0;
+                    z[dir] = y ^ fa ^ fsh; // 1 where q_i * q_k = -1
+                }
+            }
+            byte_count(c[0], y);
+            byte_count(c[1], z[0] ^ z[1] ^ z[2]);
+            byte_count(c[2], maj3(z[0], z[1], z[2]));
+        }
+    }
+    uint32_t tot[3];
+    block_bit_totals<3>(c, scratch, tot);
+    if (tid < 32) {
+        const uint32_t k = w * 32 + tid;
+        const uint32_t rep = k / d.n_temps, t = k % d.n_temps;
+        if (k < d.n_sys && (rep & 1u) == 0 && rep + 1 < d.n_replicas) {
+            const size_t o = (static_cast<size_t>(real) * d.n_pairs + (rep >> 1)) * d.n_temps + t;
+            p.dot_spin[o] = static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(tot[0]);
+            p.dot_link[o] = static_cast<int32_t>(d.N * d.nn) -
+                            2 * static_cast<int32_t>(tot[1] + 2 * tot[2]);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -470,7 +682,7 @@ __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_en
 // ---------------------------------------------------------------------------
 struct MeasureLds {
     uint32_t *tile;    // [W][N]
-    uint32_t *scratch; // [64 rows][48]
+    uint32_t *scratch; // [17][48]
     int32_t *dot_spin; // [n_sys]
     int32_t *dot_link; // [n_sys]
     int32_t *E;        // [n_sys] by slot
@@ -485,18 +697,21 @@ struct MeasureLds {
 };
 
 __host__ __device__ inline size_t measure_lds_words(const SimDims &d) {
-    return static_cast<size_t>(d.N) * d.W + 64 * 48 + 7 * static_cast<size_t>(d.n_sys) +
+    return static_cast<size_t>(d.N) * d.W + 17 * 48 + 7 * static_cast<size_t>(d.n_sys) +
            2 * static_cast<size_t>(d.n_edges) + 2 * static_cast<size_t>(d.W) + 4;
 }
 
+template <bool STAMPS>
 __global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams pt, int do_overlap,
-                                                  int do_accum, int accum_overlap, int do_pt) {
+                                                  int do_accum, int accum_overlap, int do_pt,
+                                                  unsigned long long *stamps) {
     extern __shared__ uint32_t lds[];
+    PA_STAMP(0)
     MeasureLds m;
     {
         uint32_t *q = lds;
         m.tile = q; q += static_cast<size_t>(d.N) * d.W;
-        m.scratch = q; q += 64 * 48;
+        m.scratch = q; q += 17 * 48;
         m.dot_spin = reinterpret_cast<int32_t *>(q); q += d.n_sys;
         m.dot_link = reinterpret_cast<int32_t *>(q); q += d.n_sys;
         m.E = reinterpret_cast<int32_t *>(q); q += d.n_sys;
@@ -511,18 +726,14 @@ __global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams
     }
     const uint32_t real = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
     uint32_t *Sg = p.S + static_cast<size_t>(real) * d.N * d.W;
-    const uint4 *rec = p.rec + static_cast<size_t>(real) * d.N;
     const size_t tile_words = static_cast<size_t>(d.N) * d.W;
     int32_t *Eg = p.Esum + static_cast<size_t>(real) * d.n_sys;
     int32_t *Mg = p.Msum + static_cast<size_t>(real) * d.n_sys;
     uint32_t *sidg = p.system_ids + static_cast<size_t>(real) * d.n_sys;
     uint32_t *sofg = p.slot_of + static_cast<size_t>(real) * d.n_sys;
 
-    bool tile_loaded = false;
-    if (do_overlap) {
-        for (size_t i = tid; i < tile_words; i += nthreads) m.tile[i] = Sg[i];
-        tile_loaded = true;
-    }
+    const bool tile_loaded = false;
+    (void)do_overlap;
     for (uint32_t k = tid; k < d.n_sys; k += nthreads) {
         m.E[k] = Eg[k];
         m.M[k] = Mg[k];
@@ -538,62 +749,16 @@ __global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams
     if (tid < 2 * d.W) m.masks[tid] = 0;
     if (tid == 0) m.flags[0] = 0;
     __syncthreads();
+    PA_STAMP(1)
 
-    // ---- (1) overlap dots ---------------------------------------------------
-    if (do_overlap && d.n_pairs) {
-        const uint32_t q = d.n_temps >> 5, r = d.n_temps & 31u;
-        for (uint32_t w = 0; w < d.W; ++w) {
-            const uint32_t wa = w + q, wb = w + q + 1;
-            uint32_t c[3][8];
-#pragma unroll
-            for (int s = 0; s < 3; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) c[s][j] = 0;
-            for (uint32_t pos = tid; pos < d.N; pos += nthreads) {
-                const SiteRec sr(rec[pos]);
-                const uint32_t a = m.tile[w * d.N + sr.site];
-                const uint32_t b0 = wa < d.W ? m.tile[wa * d.N + sr.site] : 0u;
-                const uint32_t b1 = wb < d.W ? m.tile[wb * d.N + sr.site] : 0u;
-                const uint32_t sh = r ? ((b0 >> r) | (b1 << (32 - r))) : b0;
-                const uint32_t y = a ^ sh; // 1 where the pair disagrees at this site
-                uint32_t z[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    z[k] = 0;
-                    if (k < static_cast<int>(d.nn)) {
-                        const uint32_t nbr = sr.nb[2 * k];
-                        const uint32_t fa = m.tile[w * d.N + nbr];
-                        const uint32_t f0 = wa < d.W ? m.tile[wa * d.N + nbr] : 0u;
-                        const uint32_t f1 = wb < d.W ? m.tile[wb * d.N + nbr] : 0u;
-                        const uint32_t fsh = r ? ((f0 >> r) | (f1 << (32 - r))) : f0;
-                        z[k] = y ^ fa ^ fsh; // 1 where q_i * q_k = -1
-                    }
-                }
-                byte_count(c[0], y);
-                byte_count(c[1], z[0] ^ z[1] ^ z[2]);
-                byte_count(c[2], maj3(z[0], z[1], z[2]));
-            }
-            uint32_t tot[3];
-            block_bit_totals<3>(c, m.scratch, tot);
-            if (tid < 32) {
-                const uint32_t k = w * 32 + tid;
-                const uint32_t rep = k / d.n_temps, t = k % d.n_temps;
-                if (k < d.n_sys && (rep & 1u) == 0 && rep + 1 < d.n_replicas) {
-                    const uint32_t o = (rep >> 1) * d.n_temps + t;
-                    const int32_t ds = static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(tot[0]);
-                    const int32_t dl = static_cast<int32_t>(d.N * d.nn) -
-                                       2 * static_cast<int32_t>(tot[1] + 2 * tot[2]);
-                    m.dot_spin[o] = ds;
-                    m.dot_link[o] = dl;
-                    const size_t g = static_cast<size_t>(real) * d.n_pairs * d.n_temps + o;
-                    p.dot_spin[g] = ds;
-                    p.dot_link[g] = dl;
-                }
-            }
+    // ---- (1) overlap dots come from k_overlap (previous launch on this stream) --------
+    if (accum_overlap && d.n_pairs)
+        for (uint32_t k = tid; k < d.n_pairs * d.n_temps; k += nthreads) {
+            m.dot_spin[k] = p.dot_spin[static_cast<size_t>(real) * d.n_pairs * d.n_temps + k];
+            m.dot_link[k] = p.dot_link[static_cast<size_t>(real) * d.n_pairs * d.n_temps + k];
         }
-        __syncthreads();
-    }
-
+    __syncthreads();
+    PA_STAMP(2)
     // ---- (2) running statistics ---------------------------------------------
     if (do_accum && tid < d.n_temps) {
         const uint32_t t = tid;
@@ -649,6 +814,7 @@ __global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams
             for (int k = 0; k < 6; ++k) ovm[k * d.n_temps + t] = o[k];
         }
     }
+    PA_STAMP(3)
     if (!do_pt || d.n_temps < 2) return;
     __syncthreads();
 
@@ -727,6 +893,7 @@ __global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams
         }
     }
     __syncthreads();
+    PA_STAMP(4)
     for (uint32_t k = tid; k < d.n_edges; k += nthreads) {
         if (m.att[k]) p.edge_att[static_cast<size_t>(real) * d.n_edges + k] += m.att[k];
         if (m.acc[k]) p.edge_acc[static_cast<size_t>(real) * d.n_edges + k] += m.acc[k];
@@ -781,10 +948,11 @@ __global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams
         st[7] = static_cast<uint32_t>(rng.s3 >> 32);
         store_cursor(p.cursor, real, d.SP, final_slot, st);
     }
+    PA_STAMP(5)
     if (!any_swap) return;
     // exchange bit columns (k, k+1) for every set mask bit k; round 0 then round 1
     if (!tile_loaded) {
-        for (size_t i = tid; i < tile_words; i += nthreads) m.tile[i] = Sg[i];
+        copy_to_lds(m.tile, Sg, static_cast<uint32_t>(tile_words), tid, nthreads);
         __syncthreads();
     }
     for (uint32_t i = tid; i < d.N; i += nthreads) {
@@ -803,6 +971,7 @@ __global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams
     }
     __syncthreads();
     for (size_t i = tid; i < tile_words; i += nthreads) Sg[i] = m.tile[i];
+    PA_STAMP(6)
 }
 
 // ---------------------------------------------------------------------------
@@ -812,15 +981,25 @@ static constexpr size_t kLdsPerCu = 160 * 1024;
 static constexpr size_t kRngLds = 64 * 16 * 8 * 4;
 
 size_t sweep_lds_bytes(const SimDims &d) {
-    return ((static_cast<size_t>(d.N) + 1) / 2 * 2 + 2 * static_cast<size_t>(d.N) + 16 * 48) * 4;
+    const size_t n1 = static_cast<size_t>(d.N) + 1;
+    return ((n1 + 1) / 2 * 2 + 2 * n1 + 5 * 48) * 4;
 }
 size_t measure_lds_bytes(const SimDims &d) { return measure_lds_words(d) * 4; }
+static size_t overlap_lds_bytes(const SimDims &d) {
+    return (3 * (static_cast<size_t>(d.N) + 1) + 5 * 48) * 4;
+}
 
 hipError_t configure_kernels(const SimDims &) {
     for (const void *fn : {reinterpret_cast<const void *>(k_rng),
-                           reinterpret_cast<const void *>(k_sweep<false>),
-                           reinterpret_cast<const void *>(k_sweep<true>),
-                           reinterpret_cast<const void *>(k_measure)}) {
+                           reinterpret_cast<const void *>(k_sweep<false, 0>),
+                           reinterpret_cast<const void *>(k_sweep<false, 1>),
+                           reinterpret_cast<const void *>(k_sweep<false, 2>),
+                           reinterpret_cast<const void *>(k_sweep<false, 3>),
+                           reinterpret_cast<const void *>(k_sweep<true, 0>),
+                           reinterpret_cast<const void *>(k_sweep<true, 3>),
+                           reinterpret_cast<const void *>(k_overlap),
+                           reinterpret_cast<const void *>(k_measure<false>),
+                           reinterpret_cast<const void *>(k_measure<true>)}) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            static_cast<int>(kLdsPerCu));
         if (e != hipSuccess) return e;
@@ -837,24 +1016,52 @@ hipError_t launch_rng(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
 
 hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,
                         hipStream_t stream) {
-    hipLaunchKernelGGL(k_sweep<false>, dim3(d.n_real * d.W), dim3(256), sweep_lds_bytes(d), stream,
-                       d, p, with_energy ? 1 : 0, do_sweep ? 1 : 0,
-                       static_cast<unsigned long long *>(nullptr));
+    const dim3 grid(d.n_real * d.W), block(256);
+    static const size_t pad = [] {
+        const char *env = std::getenv("PEAPODS_SWEEP_LDS");
+        return env ? static_cast<size_t>(std::strtol(env, nullptr, 10)) : 0;
+    }();
+    const size_t lds = std::max(sweep_lds_bytes(d), pad);
+    unsigned long long *no_stamps = nullptr;
+    const int e = with_energy ? 1 : 0, s = do_sweep ? 1 : 0;
+    switch (d.dense_nn) {
+    case 1: hipLaunchKernelGGL((k_sweep<false, 1>), grid, block, lds, stream, d, p, e, s, no_stamps); break;
+    case 2: hipLaunchKernelGGL((k_sweep<false, 2>), grid, block, lds, stream, d, p, e, s, no_stamps); break;
+    case 3: hipLaunchKernelGGL((k_sweep<false, 3>), grid, block, lds, stream, d, p, e, s, no_stamps); break;
+    default: hipLaunchKernelGGL((k_sweep<false, 0>), grid, block, lds, stream, d, p, e, s, no_stamps); break;
+    }
     return hipGetLastError();
 }
 
 // Diagnostic build of k_sweep: workgroup 0 records shader-clock stamps at phase boundaries.
 hipError_t launch_sweep_stamped(const SimDims &d, const DevPtrs &p, unsigned long long *stamps,
                                 hipStream_t stream) {
-    hipLaunchKernelGGL(k_sweep<true>, dim3(d.n_real * d.W), dim3(256), sweep_lds_bytes(d), stream,
-                       d, p, 1, 1, stamps);
+    const dim3 grid(d.n_real * d.W), block(256);
+    if (d.dense_nn == 3)
+        hipLaunchKernelGGL((k_sweep<true, 3>), grid, block, sweep_lds_bytes(d), stream, d, p,
+                           1 | (std::getenv("PEAPODS_DBG") ? std::atoi(std::getenv("PEAPODS_DBG")) << 8 : 0), 1, stamps);
+    else
+        hipLaunchKernelGGL((k_sweep<true, 0>), grid, block, sweep_lds_bytes(d), stream, d, p, 1, 1, stamps);
+    return hipGetLastError();
+}
+
+hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
+    hipLaunchKernelGGL(k_overlap, dim3(d.n_real * d.W), dim3(256), overlap_lds_bytes(d), stream, d, p);
     return hipGetLastError();
 }
 
 hipError_t launch_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_overlap,
                           bool do_accum, bool accum_overlap, bool do_pt, hipStream_t stream) {
-    hipLaunchKernelGGL(k_measure, dim3(d.n_real), dim3(1024), measure_lds_bytes(d), stream, d, p, pt,
-                       do_overlap ? 1 : 0, do_accum ? 1 : 0, accum_overlap ? 1 : 0, do_pt ? 1 : 0);
+    hipLaunchKernelGGL(k_measure<false>, dim3(d.n_real), dim3(1024), measure_lds_bytes(d), stream, d,
+                       p, pt, do_overlap ? 1 : 0, do_accum ? 1 : 0, accum_overlap ? 1 : 0,
+                       do_pt ? 1 : 0, static_cast<unsigned long long *>(nullptr));
+    return hipGetLastError();
+}
+
+hipError_t launch_measure_stamped(const SimDims &d, const DevPtrs &p, const PtParams &pt,
+                                  unsigned long long *stamps, hipStream_t stream) {
+    hipLaunchKernelGGL(k_measure<true>, dim3(d.n_real), dim3(1024), measure_lds_bytes(d), stream, d,
+                       p, pt, 1, 1, 1, 1, stamps);
     return hipGetLastError();
 }
 

@@ -223,7 +223,7 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     q.system_ids += static_cast<size_t>(d.n_sys) * r0;
     q.slot_of += static_cast<size_t>(d.n_sys) * r0;
     q.mpar += static_cast<size_t>(d.MW) * r0;
-    q.rec += static_cast<size_t>(d.N) * r0;
+    q.rec += (static_cast<size_t>(d.N) + 1) * r0;
     q.Esum += static_cast<size_t>(d.n_sys) * r0;
     q.Msum += static_cast<size_t>(d.n_sys) * r0;
     q.nz_bonds += r0;
@@ -312,7 +312,8 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         for (auto &g : sim->groups) {
             PA_HIP(sim, launch_rng(g.d, g.p, g.stream));                                // :412-432
             PA_HIP(sim, launch_sweep(g.d, g.p, record || pt_this, true, g.stream));     // :492-509
-            if (record || pt_this) { // overlap :527-529, statistics :543-578, tempering :748-796
+            if (record && want_overlap) PA_HIP(sim, launch_overlap(g.d, g.p, g.stream)); // :527-529
+            if (record || pt_this) { // statistics :543-578, tempering :748-796
                 PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
                 PA_HIP(sim, launch_measure(g.d, g.p, pt, record && want_overlap, record,
                                            want_overlap, pt_this, g.stream));
@@ -544,7 +545,8 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     d.n_passes = static_cast<uint32_t>(pass_start.size()) - 1;
 
     // ---- per-realisation site records in schedule order (neighbours + coupling metadata)
-    std::vector<uint4> rec(static_cast<size_t>(d.n_real) * d.N);
+    std::vector<uint4> rec(static_cast<size_t>(d.n_real) * (d.N + 1));
+    bool all_nonzero = true;
     std::vector<uint32_t> mpar(static_cast<size_t>(d.n_real) * d.MW, 0u);
     std::vector<int32_t> nz_bonds(d.n_real, 0);
     d.has_odd = 0;
@@ -567,15 +569,20 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
             }
             const uint32_t h = (m + 1) / 2;
             const uint32_t jm = neg | (nz << 6) | (h << 12);
-            rec[static_cast<size_t>(real) * d.N + pos] =
-                make_uint4(site | (nb[0] << 16), nb[1] | (nb[2] << 16), nb[3] | (nb[4] << 16),
-                           nb[5] | (jm << 16));
+            if (m != 2 * d.nn) all_nonzero = false;
+            rec[static_cast<size_t>(real) * (d.N + 1) + pos] = // fields hold LDS byte offsets (4 * index)
+                make_uint4((site * 4) | (nb[0] * 4 << 16), (nb[1] * 4) | (nb[2] * 4 << 16),
+                           (nb[3] * 4) | (nb[4] * 4 << 16), (nb[5] * 4) | (jm << 16));
             if (m & 1u) {
                 mpar[static_cast<size_t>(real) * d.MW + (site >> 5)] |= 1u << (site & 31u);
                 d.has_odd = 1;
             }
         }
+        const uint32_t dummy = d.N * 4; // idle lanes of a pass work on the spare slot N
+        rec[static_cast<size_t>(real) * (d.N + 1) + d.N] =
+            make_uint4(dummy | (dummy << 16), dummy | (dummy << 16), dummy | (dummy << 16), dummy);
     }
+    d.dense_nn = all_nonzero ? d.nn : 0;
 
     // ---- jump tables T^(b*BS), b = 0..B-1
     std::vector<uint32_t> jump(static_cast<size_t>(d.B) * 64 * 16 * 8);
@@ -746,6 +753,7 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
         PA_HIP(sim, hipEventRecord(ev[2], sim->stream));
         const bool measured = record || pt_this;
         if (measured) {
+            if (record && want_overlap) PA_HIP(sim, launch_overlap(d, sim->p, sim->stream));
             PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
             PA_HIP(sim, launch_measure(d, sim->p, pt, record && want_overlap, record, want_overlap,
                                        pt_this, sim->stream));
@@ -781,6 +789,22 @@ int pa_debug_sweep_stamps(pa_sim *sim, unsigned long long out[6]) {
     return PA_OK;
 }
 
+int pa_debug_measure_stamps(pa_sim *sim, unsigned long long out[7]) {
+    PA_HIP(sim, hipSetDevice(sim->device));
+    unsigned long long *dev = nullptr;
+    PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&dev), 7 * sizeof(unsigned long long)));
+    PA_HIP(sim, hipMemset(dev, 0, 7 * sizeof(unsigned long long)));
+    PA_HIP(sim, launch_rng(sim->d, sim->p, sim->stream));
+    PA_HIP(sim, launch_sweep(sim->d, sim->p, true, true, sim->stream));
+    PA_HIP(sim, launch_overlap(sim->d, sim->p, sim->stream));
+    PtParams pt{0, sim->next_parity, sim->hot_slot, sim->cold_slot};
+    PA_HIP(sim, launch_measure_stamped(sim->d, sim->p, pt, dev, sim->stream));
+    PA_HIP(sim, hipStreamSynchronize(sim->stream));
+    PA_HIP(sim, hipMemcpy(out, dev, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    (void)hipFree(dev);
+    return PA_OK;
+}
+
 int pa_sim_metropolis_sweep(pa_sim *sim, uint64_t n_sweeps) {
     PA_HIP(sim, hipSetDevice(sim->device));
     for (uint64_t k = 0; k < n_sweeps; ++k) {
@@ -812,8 +836,7 @@ int pa_sim_overlap_dots(pa_sim *sim, int64_t *dot_spin, int64_t *dot_link) {
     const SimDims &d = sim->d;
     if (d.n_pairs == 0) return fail(sim, PA_ERR_INVALID, "overlap needs n_replicas >= 2");
     PA_HIP(sim, hipSetDevice(sim->device));
-    PtParams no_pt{0, 0, 0, 0};
-    PA_HIP(sim, launch_measure(d, sim->p, no_pt, true, false, false, false, sim->stream));
+    PA_HIP(sim, launch_overlap(d, sim->p, sim->stream));
     const size_t count = static_cast<size_t>(d.n_real) * d.n_pairs * d.n_temps;
     std::vector<int32_t> a, b;
     int rc;

@@ -38,6 +38,7 @@ struct SimDims {
     uint32_t MW;         // ceil(N / 32): words of the per-site parity bitmap
     uint32_t has_odd;    // 1 if any site has an odd number of non-zero bonds
     uint32_t n_edges;    // max(n_temps - 1, 1) (allocation stride of the PT edge counters)
+    uint32_t thr_preshifted; // 1 if every threshold is < 2^24, so thr[6..12) = thr[0..6) << 8 is exact
     uint32_t dense_nn;   // = nn when every bond of every realisation is non-zero, else 0
 };
 
@@ -47,7 +48,8 @@ struct DevPtrs {
     uint32_t *cursor;        // [n_real][8][SP]  xoshiro state of the system in each slot
     uint32_t *system_ids;    // [n_real][n_sys]  slot -> system
     uint32_t *slot_of;       // [n_real][n_sys]  system -> slot
-    const uint32_t *thr;     // [2][3][n_temps]  thresholds: even set (dE=-2,-4,-6), odd set (-1,-3,-5)
+    const uint32_t *thr;     // [2][2][3][n_temps] thresholds: even set (dE=-2,-4,-6), odd set (-1,-3,-5);
+                             //   second copy shifted left by 8 (valid when thr_preshifted)
     const uint32_t *mpar;    // [n_real][MW]     parity of the non-zero bond count per site
     const uint4 *rec;        // [n_real][N + 1] schedule order (+ dummy), 16-bit fields holding 4 * index:
                              //   site,f0 | b0,f1 | b1,f2 | b2,jmeta

@@ -86,7 +86,8 @@ struct Rng32 {
         st[0] = a0; st[1] = a1; st[2] = b0; st[3] = b1;
         st[4] = c0; st[5] = c1; st[6] = d0; st[7] = d1;
     }
-    __device__ __forceinline__ uint32_t next24() {
+    // Returns the high word of the 64-bit output; the reference's draw is its top 24 bits.
+    __device__ __forceinline__ uint32_t next_top() {
         // P = s1 * 5 = (s1 << 2) + s1
         const uint32_t q = b0 << 2;
         const uint32_t plo = q + b0;
@@ -98,18 +99,20 @@ struct Rng32 {
         const uint32_t e = rlo << 3;
         const uint32_t f = e + rlo;
         const uint32_t top = ((rhi << 3) + rhi) + (rlo >> 29) + (f < e ? 1u : 0u);
-        // state transition
+        // state transition; three-input XORs (v_bitop3_b32, truth table 0x96) fold the chained updates
         const uint32_t t0 = b0 << 17;
         const uint32_t t1 = __builtin_amdgcn_alignbit(b1, b0, 15);
-        c0 ^= a0; c1 ^= a1;
-        d0 ^= b0; d1 ^= b1;
-        b0 ^= c0; b1 ^= c1;
-        a0 ^= d0; a1 ^= d1;
-        c0 ^= t0; c1 ^= t1;
-        const uint32_t nd1 = __builtin_amdgcn_alignbit(d0, d1, 19); // rotl(s3, 45)
-        const uint32_t nd0 = __builtin_amdgcn_alignbit(d1, d0, 19);
-        d0 = nd0; d1 = nd1;
-        return top >> 8;
+        const uint32_t e0 = d0 ^ b0, e1 = d1 ^ b1;                      // s3 ^ s1
+        const uint32_t nb0 = __builtin_amdgcn_bitop3_b32(b0, c0, a0, 0x96); // s1 ^ (s2 ^ s0)
+        const uint32_t nb1 = __builtin_amdgcn_bitop3_b32(b1, c1, a1, 0x96);
+        const uint32_t nc0 = __builtin_amdgcn_bitop3_b32(c0, a0, t0, 0x96); // (s2 ^ s0) ^ (s1 << 17)
+        const uint32_t nc1 = __builtin_amdgcn_bitop3_b32(c1, a1, t1, 0x96);
+        a0 ^= e0; a1 ^= e1;                                             // s0 ^ (s3 ^ s1)
+        b0 = nb0; b1 = nb1;
+        c0 = nc0; c1 = nc1;
+        d0 = __builtin_amdgcn_alignbit(e1, e0, 19);                     // rotl(s3 ^ s1, 45)
+        d1 = __builtin_amdgcn_alignbit(e0, e1, 19);
+        return top; // the 24-bit draw is top >> 8
     }
 };
 
@@ -136,10 +139,12 @@ template <int LANE> __device__ __forceinline__ uint32_t park_in_lane(uint32_t ve
     return vec;
 }
 
-template <int JJ>
+// PRESHIFTED: the thresholds were shifted left by 8 on the host (all of them < 2^24), so the
+// high word is compared directly: (top >> 8) < c  <=>  top < (c << 8).
+template <int JJ, bool PRESHIFTED>
 __device__ __forceinline__ void rng_step(Rng32 &rng, uint32_t ca0, uint32_t ca1, uint32_t ca2,
                                          uint32_t &keep0, uint32_t &keep1) {
-    const uint32_t draw = rng.next24();
+    const uint32_t draw = PRESHIFTED ? rng.next_top() : rng.next_top() >> 8;
     // thresholds fall with |dE| (checked on the host): level bit1 = (draw < c1),
     // bit0 = (draw < c0) ^ (draw < c1) ^ (draw < c2)
     const unsigned long long l0 = __ballot(draw < ca0);
@@ -152,11 +157,11 @@ __device__ __forceinline__ void rng_step(Rng32 &rng, uint32_t ca0, uint32_t ca1,
     keep1 = park_in_lane<JJ + 32>(keep1, static_cast<uint32_t>(l1 >> 32));
 }
 
-template <int... JJ>
+template <bool PRESHIFTED, int... JJ>
 __device__ __forceinline__ void rng_chunk32(Rng32 &rng, uint32_t ca0, uint32_t ca1, uint32_t ca2,
                                             uint32_t &keep0, uint32_t &keep1,
                                             std::integer_sequence<int, JJ...>) {
-    (rng_step<JJ>(rng, ca0, ca1, ca2, keep0, keep1), ...);
+    (rng_step<JJ, PRESHIFTED>(rng, ca0, ca1, ca2, keep0, keep1), ...);
 }
 
 // ---------------------------------------------------------------------------
@@ -169,6 +174,7 @@ __device__ __forceinline__ void rng_chunk32(Rng32 &rng, uint32_t ca0, uint32_t c
 // words are parked in lane (site & 31) with v_writelane and stored 32 sites at
 // a time, fully coalesced.
 // ---------------------------------------------------------------------------
+template <bool PRESHIFTED>
 __global__ __launch_bounds__(256) void k_rng(SimDims d, DevPtrs p) {
     extern __shared__ uint32_t tab[]; // [64 * 16 * 8] (+ padding that caps workgroups per CU)
     const uint32_t block = blockIdx.x % d.B;
@@ -197,12 +203,13 @@ __global__ __launch_bounds__(256) void k_rng(SimDims d, DevPtrs p) {
     uint32_t ca0 = 0, ca1 = 0, ca2 = 0, cb0 = 0, cb1 = 0, cb2 = 0;
     if (active) {
         const uint32_t t = slot % d.n_temps;
-        ca0 = p.thr[0 * d.n_temps + t];
-        ca1 = p.thr[1 * d.n_temps + t];
-        ca2 = p.thr[2 * d.n_temps + t];
-        cb0 = p.thr[3 * d.n_temps + t];
-        cb1 = p.thr[4 * d.n_temps + t];
-        cb2 = p.thr[5 * d.n_temps + t];
+        const uint32_t *thr = PRESHIFTED ? p.thr + 6 * d.n_temps : p.thr; // second half: c << 8
+        ca0 = thr[0 * d.n_temps + t];
+        ca1 = thr[1 * d.n_temps + t];
+        ca2 = thr[2 * d.n_temps + t];
+        cb0 = thr[3 * d.n_temps + t];
+        cb1 = thr[4 * d.n_temps + t];
+        cb2 = thr[5 * d.n_temps + t];
     }
     const uint32_t begin = block * d.BS;
     const uint32_t len = min(d.BS, d.N - begin); // uniform over the workgroup
@@ -213,11 +220,12 @@ __global__ __launch_bounds__(256) void k_rng(SimDims d, DevPtrs p) {
         uint32_t keep0 = 0, keep1 = 0;
         const uint32_t chunk = min(32u, len - j0);
         if (chunk == 32 && !d.has_odd) {
-            rng_chunk32(rng, ca0, ca1, ca2, keep0, keep1, std::make_integer_sequence<int, 32>{});
+            rng_chunk32<PRESHIFTED>(rng, ca0, ca1, ca2, keep0, keep1,
+                                    std::make_integer_sequence<int, 32>{});
         } else {
             for (uint32_t jj = 0; jj < chunk; ++jj) {
                 const uint32_t site = begin + j0 + jj;
-                const uint32_t draw = rng.next24();
+                const uint32_t draw = PRESHIFTED ? rng.next_top() : rng.next_top() >> 8;
                 uint32_t c0 = ca0, c1 = ca1, c2 = ca2;
                 if (d.has_odd && ((mpar[site >> 5] >> (site & 31u)) & 1u)) {
                     c0 = cb0;
@@ -990,7 +998,8 @@ static size_t overlap_lds_bytes(const SimDims &d) {
 }
 
 hipError_t configure_kernels(const SimDims &) {
-    for (const void *fn : {reinterpret_cast<const void *>(k_rng),
+    for (const void *fn : {reinterpret_cast<const void *>(k_rng<false>),
+                           reinterpret_cast<const void *>(k_rng<true>),
                            reinterpret_cast<const void *>(k_sweep<false, 0>),
                            reinterpret_cast<const void *>(k_sweep<false, 1>),
                            reinterpret_cast<const void *>(k_sweep<false, 2>),
@@ -1010,7 +1019,10 @@ hipError_t configure_kernels(const SimDims &) {
 hipError_t launch_rng(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
     const uint32_t n_pairs_tw = (d.n_real * d.W + 1) / 2;
     const uint32_t groups = (n_pairs_tw + 3) / 4;
-    hipLaunchKernelGGL(k_rng, dim3(groups * d.B), dim3(256), kRngLds, stream, d, p);
+    if (d.thr_preshifted)
+        hipLaunchKernelGGL(k_rng<true>, dim3(groups * d.B), dim3(256), kRngLds, stream, d, p);
+    else
+        hipLaunchKernelGGL(k_rng<false>, dim3(groups * d.B), dim3(256), kRngLds, stream, d, p);
     return hipGetLastError();
 }
 

@@ -514,7 +514,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         return bail(PA_ERR_UNSUPPORTED);
     }
     const uint32_t width = 4 * d.nn + 1, off = 2 * d.nn;
-    std::vector<uint32_t> thr(6 * d.n_temps, 0u);
+    std::vector<uint32_t> thr(12 * d.n_temps, 0u);
     for (uint32_t t = 0; t < d.n_temps; ++t) {
         for (uint32_t j = 0; j < 3; ++j) {
             const uint32_t even_e = 2 * (j + 1), odd_e = 2 * j + 1; // |dE|
@@ -526,6 +526,12 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
                 sim->error = "acceptance table is not monotone in the energy change";
                 return bail(PA_ERR_UNSUPPORTED);
             }
+    }
+
+    d.thr_preshifted = 1;
+    for (uint32_t k = 0; k < 6 * d.n_temps; ++k) {
+        if (thr[k] >= (1u << 24)) d.thr_preshifted = 0;
+        thr[6 * d.n_temps + k] = thr[k] << 8;
     }
 
     // ---- dependency levels -> schedule order, cut into passes of <= 256 sites

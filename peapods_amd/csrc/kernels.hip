@@ -292,6 +292,47 @@ __device__ __forceinline__ void byte_count(uint32_t c[8], uint32_t x) {
     for (int j = 0; j < 8; ++j) c[j] += (x >> j) & 0x01010101u;
 }
 
+// Per-bit count of 16 words at once.  A carry-save adder tree (11 full + 4 half adders, two
+// v_bitop3 each) compresses the 16 one-bit inputs of every bit position into a 5-bit number held
+// in five planes; the planes are then spread into the byte-sliced counters.  150 instructions per
+// 16 words instead of 16 x 24 for word-by-word byte counting.
+__device__ __forceinline__ void full_add(uint32_t a, uint32_t b, uint32_t c, uint32_t &sum,
+                                         uint32_t &carry) {
+    sum = a ^ b ^ c;
+    carry = maj3(a, b, c);
+}
+
+__device__ __forceinline__ void count16(const uint32_t w[16], uint32_t c[8]) {
+    uint32_t s0, s1, s2, s3, s4, c0, c1, c2, c3, c4;
+    full_add(w[0], w[1], w[2], s0, c0);
+    full_add(w[3], w[4], w[5], s1, c1);
+    full_add(w[6], w[7], w[8], s2, c2);
+    full_add(w[9], w[10], w[11], s3, c3);
+    full_add(w[12], w[13], w[14], s4, c4);
+    uint32_t t0, t1, d0, d1;
+    full_add(s0, s1, s2, t0, d0);
+    full_add(s3, s4, w[15], t1, d1);
+    const uint32_t p0 = t0 ^ t1, d2 = t0 & t1;                  // weight 1
+    uint32_t u0, u1, u2, e0, e1, e2;
+    full_add(c0, c1, c2, u0, e0);
+    full_add(c3, c4, d0, u1, e1);
+    full_add(d1, d2, u0, u2, e2);
+    const uint32_t p1 = u1 ^ u2, e3 = u1 & u2;                  // weight 2
+    uint32_t v0, f0;
+    full_add(e0, e1, e2, v0, f0);
+    const uint32_t p2 = v0 ^ e3, f1 = v0 & e3;                  // weight 4
+    const uint32_t p3 = f0 ^ f1, p4 = f0 & f1;                  // weights 8, 16
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        uint32_t acc = c[j] + ((p0 >> j) & 0x01010101u);
+        acc += ((p1 >> j) & 0x01010101u) << 1;
+        acc += ((p2 >> j) & 0x01010101u) << 2;
+        acc += ((p3 >> j) & 0x01010101u) << 3;
+        acc += ((p4 >> j) & 0x01010101u) << 4;
+        c[j] = acc;
+    }
+}
+
 // Wave-wide sum by DPP only (plain VALU instructions; unlike __shfl_xor / ds_bpermute they do not
 // touch the LDS pipe, which the 48-register reductions below would otherwise saturate):
 // row_ror 8,4,2,1 leave every lane with its 16-lane row sum, row_bcast15 adds row r into row r+1
@@ -557,16 +598,17 @@ __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_en
         for (int s = 0; s < 3; ++s)
 #pragma unroll
             for (int j = 0; j < 8; ++j) c[s][j] = 0;
-        for (uint32_t base = 0; base < d.N; base += 4 * 256) {
-            uint4 rr[4];
+        for (uint32_t base = 0; base < d.N; base += 16 * 256) {
+            uint4 rr[16];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 16; ++k) { // 16 record loads in flight
                 const uint32_t pos = base + k * 256 + tid;
                 rr[k] = rec[pos < d.N ? pos : d.N];
             }
+            uint32_t qa[16], qb[16], qc[16];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (base + k * 256 + tid >= d.N) continue;
+            for (int k = 0; k < 16; ++k) {
+                const bool live_site = base + k * 256 + tid < d.N;
                 const SiteRec r(rr[k]);
                 const uint32_t jm = r.jm;
                 const uint32_t s = lds_word(sw, r.site);
@@ -575,10 +617,13 @@ __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_en
                 const uint32_t u0 = (s ^ f0 ^ (0u - ((jm >> 0) & 1u))) & (0u - ((jm >> 6) & 1u));
                 const uint32_t u1 = (s ^ f1 ^ (0u - ((jm >> 2) & 1u))) & (0u - ((jm >> 8) & 1u));
                 const uint32_t u2 = (s ^ f2 ^ (0u - ((jm >> 4) & 1u))) & (0u - ((jm >> 10) & 1u));
-                byte_count(c[0], u0 ^ u1 ^ u2);      // weight 1
-                byte_count(c[1], maj3(u0, u1, u2));  // weight 2
-                byte_count(c[2], s);                 // spins equal to -1
+                qa[k] = live_site ? (u0 ^ u1 ^ u2) : 0u;   // unsatisfied bonds, weight 1
+                qb[k] = live_site ? maj3(u0, u1, u2) : 0u; // weight 2
+                qc[k] = live_site ? s : 0u;                // spins equal to -1
             }
+            count16(qa, c[0]);
+            count16(qb, c[1]);
+            count16(qc, c[2]);
         }
         PA_STAMP(4)
         uint32_t tot[3];
@@ -627,16 +672,17 @@ __global__ __launch_bounds__(256) void k_overlap(SimDims d, DevPtrs p) {
     for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) c[s][j] = 0;
-    for (uint32_t base = 0; base < d.N; base += 4 * 256) {
-        uint4 rr[4];
+    for (uint32_t base = 0; base < d.N; base += 16 * 256) {
+        uint4 rr[16];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 16; ++k) {
             const uint32_t pos = base + k * 256 + tid;
             rr[k] = rec[pos < d.N ? pos : d.N];
         }
+        uint32_t qa[16], qb[16], qc[16];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (base + k * 256 + tid >= d.N) continue;
+        for (int k = 0; k < 16; ++k) {
+            const bool live_site = base + k * 256 + tid < d.N;
             const SiteRec sr(rr[k]);
             const uint32_t a = lds_word(A, sr.site);
             const uint32_t b0 = lds_word(B0, sr.site), b1 = lds_word(B1, sr.site);
@@ -654,10 +700,13 @@ __global__ __launch_bounds__(256) void k_overlap(SimDims d, DevPtrs p) {
                     z[dir] = y ^ fa ^ fsh; // 1 where q_i * q_k = -1
                 }
             }
-            byte_count(c[0], y);
-            byte_count(c[1], z[0] ^ z[1] ^ z[2]);
-            byte_count(c[2], maj3(z[0], z[1], z[2]));
+            qa[k] = live_site ? y : 0u;
+            qb[k] = live_site ? (z[0] ^ z[1] ^ z[2]) : 0u;
+            qc[k] = live_site ? maj3(z[0], z[1], z[2]) : 0u;
         }
+        count16(qa, c[0]);
+        count16(qb, c[1]);
+        count16(qc, c[2]);
     }
     uint32_t tot[3];
     block_bit_totals<3>(c, scratch, tot);

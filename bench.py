@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--disorder-per-gpu", type=int, default=N_DISORDER_PER_GPU)
     ap.add_argument("--pt-schedule", default="single_random_edge")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--profile-sweeps", type=int, default=64)
     return ap.parse_args()
 

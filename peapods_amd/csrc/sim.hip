@@ -245,7 +245,7 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
 }
 
 int make_groups(pa_sim *sim) {
-    uint32_t n_groups = 2;
+    uint32_t n_groups = 1; // more streams did not pay on MI355X / ROCm 7.2
     if (const char *env = std::getenv("PEAPODS_STREAMS")) {
         const long v = std::strtol(env, nullptr, 10);
         if (v >= 1 && v <= 16) n_groups = static_cast<uint32_t>(v);

@@ -1,0 +1,102 @@
+"""GPU checks at the BASELINE.json sizes (configs[2]: 16^3 +-J, 24 T x 4 replicas x 128 disorder).
+
+A slice of the full ensemble is compared bit for bit with the oracle; the whole ensemble is
+checked through size-independent properties: sharding invariance (a realisation gives the same
+trajectory alone as inside the 128-realisation handle), energy and overlap definitions recomputed
+from the downloaded spins, and parallel-tempering bookkeeping invariants.
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SHAPE = (16, 16, 16)
+N = 4096
+N_TEMPS, N_REP = 24, 4
+
+
+def ensemble(n_dis, first=0):
+    from peapods_amd import IsingSimulation
+    from peapods_amd.spin_models import generate_couplings, seed_material
+
+    seq, dyn = seed_material(42)
+    couplings = np.stack(generate_couplings("bimodal", SHAPE, 3, 128, seq,
+                                            realizations=range(first, first + n_dis)))
+    temps = np.linspace(0.8, 1.4, N_TEMPS).astype(np.float32)
+    sim = IsingSimulation(list(SHAPE), couplings, temps, N_REP, None, dyn, first_realization=first)
+    return sim, couplings, temps, dyn
+
+
+def test_full_lattice_slice_matches_oracle(oracle):
+    sim, couplings, temps, dyn = ensemble(2)
+    cpu = oracle.OracleSimulation(list(SHAPE), couplings, temps, N_REP, None, dyn)
+    kw = dict(pt_interval=1, pt_schedule="single_random_edge", warmup_ratio=0.25)
+    a = sim.sample(16, "metropolis", **kw)
+    b = cpu.sample(16, "metropolis", **kw)
+    for key in ("mags", "mags2", "mags4", "energies", "energies2", "overlap", "overlap2",
+                "overlap4", "link_overlap", "link_overlap2", "link_overlap4", "ql_at_q_sum"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    np.testing.assert_array_equal(a["per_sample_overlap_histogram"], b["per_sample_overlap_histogram"])
+    for r in range(2):
+        np.testing.assert_array_equal(sim.get_spins(r), cpu.get_spins(r))
+        np.testing.assert_array_equal(sim.get_system_ids(r), cpu.get_system_ids(r))
+        np.testing.assert_array_equal(sim.get_energies(r), cpu.get_energies(r))
+    pt_a, pt_b = a["per_disorder"]["parallel_tempering"], b["per_disorder"]["parallel_tempering"]
+    for key in pt_a:
+        np.testing.assert_array_equal(pt_a[key], pt_b[key])
+
+
+def test_full_ensemble_properties(oracle):
+    n_sweeps = 40
+    full, couplings, temps, dyn = ensemble(128)
+    result = full.sample(n_sweeps, "metropolis", pt_interval=1, warmup_ratio=0.0)
+
+    # (1) sharding invariance: realisations 5 and 127 alone == inside the full handle
+    for r in (5, 127):
+        alone, *_ = ensemble(1, first=r)
+        alone.sample(n_sweeps, "metropolis", pt_interval=1, warmup_ratio=0.0)
+        np.testing.assert_array_equal(alone.get_spins(0), full.get_spins(r))
+        np.testing.assert_array_equal(alone.get_system_ids(0), full.get_system_ids(r))
+        np.testing.assert_array_equal(alone.result_blocks()[0], full.result_blocks()[r])
+
+    # (2) energies / magnetisation recomputed from the downloaded spins (energy.rs:92-109)
+    lib = oracle.load()
+    lat = oracle.Lattice(list(SHAPE))
+    full.compute_energies()
+    for r in (0, 77):
+        spins = full.get_spins(r)
+        energies = np.zeros(N_TEMPS * N_REP, dtype=np.float32)
+        mags = np.zeros(N_TEMPS * N_REP, dtype=np.int64)
+        J = np.ascontiguousarray(couplings[r].reshape(-1))
+        lib.orc_compute_energies(lat.handle, spins.ctypes.data, J.ctypes.data, N_TEMPS * N_REP,
+                                 energies.ctypes.data, mags.ctypes.data, None)
+        np.testing.assert_array_equal(full.get_energies(r), energies)
+        np.testing.assert_array_equal(full.get_magnetization_sums(r), mags)
+
+    # (3) overlap dots recomputed with numpy from the downloaded spins (overlap.rs:259-282)
+    dot_spin, dot_link = full.overlap_dots()
+    r = 31
+    s = full.get_spins(r).reshape(N_TEMPS * N_REP, *SHAPE).astype(np.int64)
+    ids = full.get_system_ids(r).astype(int)
+    for p in range(N_REP // 2):
+        for t in (0, 11, 23):
+            q = s[ids[(2 * p) * N_TEMPS + t]] * s[ids[(2 * p + 1) * N_TEMPS + t]]
+            assert dot_spin[r, p, t] == q.sum()
+            assert dot_link[r, p, t] == sum((q * np.roll(q, -1, axis=d)).sum() for d in range(3))
+
+    # (4) parallel-tempering bookkeeping
+    pt = result["per_disorder"]["parallel_tempering"]
+    assert pt["edge_attempts"].shape == (128, N_TEMPS - 1)
+    assert np.all(pt["edge_attempts"].sum(axis=1) == n_sweeps * N_REP)  # one edge per ladder per sweep
+    assert np.all(pt["edge_acceptances"] <= pt["edge_attempts"])
+    for r in (0, 64, 127):
+        ids = full.get_system_ids(r).reshape(N_REP, N_TEMPS)
+        for rep in range(N_REP):  # swaps stay inside a replica ladder
+            assert sorted(ids[rep]) == list(range(rep * N_TEMPS, (rep + 1) * N_TEMPS))
+
+    # (5) histogram bookkeeping: every recorded sweep adds one count per pair and temperature
+    hist = result["per_sample_overlap_histogram"]
+    assert hist.shape == (128, N_TEMPS, N + 1)
+    assert np.all(hist.sum(axis=2) == n_sweeps * (N_REP // 2))
+    assert np.all(np.abs(result["overlap"]) <= 1.0) and np.all(result["energies"] > 0)

@@ -73,6 +73,7 @@ struct DevPtrs {
     const float *ln_table;   // [2^24] ln(k * 2^-24) as computed by the host libm
     const float *dbeta;      // [n_edges] 1/T[t] - 1/T[t+1] (f32)
     uint32_t *swap_masks;    // [n_real][2][W] scratch of the PT kernel
+    uint64_t *pair_rng;      // [n_real][n_temps * n_pairs][4] xoshiro state of the overlap-move generators
 };
 
 struct PtParams {
@@ -86,6 +87,8 @@ hipError_t launch_rng(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,
                         hipStream_t stream);
 hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream);
+hipError_t launch_houdayer(const SimDims &d, const DevPtrs &p, hipStream_t stream);
+size_t houdayer_lds_bytes(const SimDims &d);
 hipError_t launch_sweep_stamped(const SimDims &d, const DevPtrs &p, unsigned long long *stamps,
                                 hipStream_t stream);
 hipError_t launch_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_overlap,

@@ -1032,6 +1032,164 @@ __global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams
 }
 
 // ---------------------------------------------------------------------------
+// k_houdayer: Houdayer isoenergetic cluster move, group size 2, single-cluster
+// ("wolff") variant -- clusters/overlap.rs:35-56 (build_tasks) and :153-339.
+// Workgroup = one realisation, all temperatures and pairs at once:
+//   * per temperature the replicas are shuffled with pair generator t*n_pairs
+//     (reverse Fisher-Yates, rand's u32 gen_range) and grouped consecutively;
+//     group g then draws from pair generator t*n_pairs + g;
+//   * A = "active" mask per slot (the pair's spins differ, i.e. they sum to
+//     zero); both slots of a pair carry the same bit;
+//   * every pair draws its seed with up to 64 probes gen_range(0..N)
+//     (utils.rs:107-119), then all clusters grow together,
+//     F <- A & (F | F(neighbours)), until nothing changes.  The reference's DFS
+//     visits exactly the connected component of the seed in the graph "both
+//     ends active", whatever the visiting order, so the result is identical;
+//   * both replicas are flipped on their cluster: S ^= F.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t dev_gen_range_u32(DevRng &rng, uint32_t range) {
+    const uint32_t zone = (range << __clz(range)) - 1u;
+    for (;;) {
+        const uint32_t v = static_cast<uint32_t>(rng.next() >> 32);
+        const uint64_t m = static_cast<uint64_t>(v) * range;
+        if (static_cast<uint32_t>(m) <= zone) return static_cast<uint32_t>(m >> 32);
+    }
+}
+
+__device__ __forceinline__ uint64_t dev_gen_range_u64(DevRng &rng, uint64_t range) {
+    const uint64_t zone = (range << __clzll(range)) - 1ull;
+    for (;;) {
+        const uint64_t v = rng.next();
+        if (v * range <= zone) return __umul64hi(v, range);
+    }
+}
+
+__host__ __device__ inline size_t houdayer_lds_words(const SimDims &d) {
+    return 3 * static_cast<size_t>(d.N) * d.W + 2 * static_cast<size_t>(d.n_temps) * d.n_pairs +
+           d.n_sys + 4;
+}
+
+__global__ __launch_bounds__(1024) void k_houdayer(SimDims d, DevPtrs p) {
+    extern __shared__ uint32_t lds[];
+    const size_t tile_words = static_cast<size_t>(d.N) * d.W;
+    uint32_t *tile = lds;                      // [W][N] spins
+    uint32_t *A = lds + tile_words;            // [W][N] active mask
+    uint32_t *F = lds + 2 * tile_words;        // [W][N] cluster membership
+    uint32_t *pair_slots = lds + 3 * tile_words; // [n_temps * n_pairs][2]
+    uint32_t *partner = pair_slots + 2 * d.n_temps * d.n_pairs; // [n_sys]
+    uint32_t *changed = partner + d.n_sys;     // [1]
+    const uint32_t real = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
+    uint32_t *Sg = p.S + static_cast<size_t>(real) * tile_words;
+    const uint4 *rec = p.rec + static_cast<size_t>(real) * (d.N + 1);
+    const uint32_t n_lanes = d.n_temps * d.n_pairs;
+    uint64_t *prng = p.pair_rng + static_cast<size_t>(real) * n_lanes * 4;
+
+    copy_to_lds(tile, Sg, static_cast<uint32_t>(tile_words), tid, nthreads);
+    for (size_t i = tid; i < tile_words; i += nthreads) F[i] = 0;
+    for (uint32_t k = tid; k < d.n_sys; k += nthreads) partner[k] = k; // unpaired: never active
+    __syncthreads();
+
+    // ---- pairing: lane (t, 0) shuffles the replicas at temperature t (overlap.rs:44-49).
+    // The shuffle moves positions, so shuffling replica indices equals shuffling the systems.
+    DevRng rng;
+    rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
+    if (tid < n_lanes) {
+        const uint32_t t = tid / d.n_pairs, g = tid % d.n_pairs;
+        const uint64_t *st = prng + static_cast<size_t>(tid) * 4;
+        rng.s0 = st[0];
+        rng.s1 = st[1];
+        rng.s2 = st[2];
+        rng.s3 = st[3];
+        if (g == 0) {
+            uint32_t order[32]; // n_replicas <= 32 (checked on the host)
+            for (uint32_t k = 0; k < d.n_replicas; ++k) order[k] = k;
+            for (uint32_t i = d.n_replicas - 1; i >= 1; --i) {
+                const uint32_t j = dev_gen_range_u32(rng, i + 1);
+                const uint32_t tmp = order[i];
+                order[i] = order[j];
+                order[j] = tmp;
+            }
+            for (uint32_t gg = 0; gg < d.n_pairs; ++gg) {
+                const uint32_t sa = order[2 * gg] * d.n_temps + t;
+                const uint32_t sb = order[2 * gg + 1] * d.n_temps + t;
+                pair_slots[2 * (t * d.n_pairs + gg) + 0] = sa;
+                pair_slots[2 * (t * d.n_pairs + gg) + 1] = sb;
+                partner[sa] = sb;
+                partner[sb] = sa;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- active mask: bit k of A = spin(k) != spin(partner(k))
+    for (uint32_t i = tid; i < d.N; i += nthreads) {
+        for (uint32_t w = 0; w < d.W; ++w) {
+            uint32_t a = 0;
+            const uint32_t v = tile[w * d.N + i];
+            const uint32_t top = min(32u, d.n_sys - w * 32);
+            for (uint32_t b = 0; b < top; ++b) {
+                const uint32_t q = partner[w * 32 + b];
+                const uint32_t pv = (tile[(q >> 5) * d.N + i] >> (q & 31u)) & 1u;
+                a |= (((v >> b) & 1u) ^ pv) << b;
+            }
+            A[w * d.N + i] = a;
+        }
+    }
+    __syncthreads();
+
+    // ---- seeds (utils.rs:107-119): up to 64 probes; no active probe -> this pair does nothing
+    if (tid < n_lanes) {
+        const uint32_t sa = pair_slots[2 * tid], sb = pair_slots[2 * tid + 1];
+        for (int probe = 0; probe < 64; ++probe) {
+            const uint32_t i = static_cast<uint32_t>(dev_gen_range_u64(rng, d.N));
+            if ((A[(sa >> 5) * d.N + i] >> (sa & 31u)) & 1u) {
+                atomicOr(&F[(sa >> 5) * d.N + i], 1u << (sa & 31u));
+                atomicOr(&F[(sb >> 5) * d.N + i], 1u << (sb & 31u));
+                break;
+            }
+        }
+        uint64_t *st = prng + static_cast<size_t>(tid) * 4;
+        st[0] = rng.s0;
+        st[1] = rng.s1;
+        st[2] = rng.s2;
+        st[3] = rng.s3;
+    }
+    if (tid == 0) changed[0] = 0;
+    __syncthreads();
+
+    // ---- grow every cluster to its connected component inside the active graph
+    for (uint32_t iter = 0; iter <= d.N; ++iter) {
+        bool grew = false;
+        for (uint32_t pos = tid; pos < d.N; pos += nthreads) {
+            const SiteRec r(rec[pos]);
+            for (uint32_t w = 0; w < d.W; ++w) {
+                const uint32_t *Fw = F + w * d.N;
+                const uint32_t f = lds_word(Fw, r.site);
+                uint32_t g = f;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) g |= lds_word(Fw, r.nb[k]);
+                g &= lds_word(A + w * d.N, r.site);
+                g |= f;
+                if (g != f) {
+                    F[w * d.N + (r.site >> 2)] = g;
+                    grew = true;
+                }
+            }
+        }
+        if (grew) changed[0] = 1;
+        __syncthreads();
+        const bool again = changed[0] != 0;
+        __syncthreads();
+        if (!again) break;
+        if (tid == 0) changed[0] = 0;
+        __syncthreads();
+    }
+
+    // ---- flip both replicas of every pair on its cluster
+    for (size_t i = tid; i < tile_words; i += nthreads) Sg[i] = tile[i] ^ F[i];
+}
+
+// ---------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------
 static constexpr size_t kLdsPerCu = 160 * 1024;
@@ -1056,6 +1214,7 @@ hipError_t configure_kernels(const SimDims &) {
                            reinterpret_cast<const void *>(k_sweep<true, 0>),
                            reinterpret_cast<const void *>(k_sweep<true, 3>),
                            reinterpret_cast<const void *>(k_overlap),
+                           reinterpret_cast<const void *>(k_houdayer),
                            reinterpret_cast<const void *>(k_measure<false>),
                            reinterpret_cast<const void *>(k_measure<true>)}) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1110,6 +1269,12 @@ hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream
     hipLaunchKernelGGL(k_overlap, dim3(d.n_real * d.W), dim3(256), overlap_lds_bytes(d), stream, d, p);
     return hipGetLastError();
 }
+
+hipError_t launch_houdayer(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
+    hipLaunchKernelGGL(k_houdayer, dim3(d.n_real), dim3(1024), houdayer_lds_words(d) * 4, stream, d, p);
+    return hipGetLastError();
+}
+size_t houdayer_lds_bytes(const SimDims &d) { return houdayer_lds_words(d) * 4; }
 
 hipError_t launch_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_overlap,
                           bool do_accum, bool accum_overlap, bool do_pt, hipStream_t stream) {

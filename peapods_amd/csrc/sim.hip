@@ -176,6 +176,17 @@ int seed_state(pa_sim *sim, uint64_t seed) {
         });
     for (auto &t : workers) t.join();
 
+    // pair generators of the overlap-cluster moves (realization.rs:186-194)
+    const uint32_t n_pair_rngs = d.n_temps * d.n_pairs;
+    std::vector<uint64_t> pair_rng(static_cast<size_t>(d.n_real) * n_pair_rngs * 4);
+    for (uint32_t real = 0; real < d.n_real; ++real) {
+        const uint64_t base = realization_seed(seed, sim->first_realization + real);
+        for (uint32_t i = 0; i < n_pair_rngs; ++i) {
+            const Xoshiro rng = Xoshiro::from_seed_u64(child_seed(base, kPairSeedDomain, i));
+            std::memcpy(&pair_rng[(static_cast<size_t>(real) * n_pair_rngs + i) * 4], rng.s, 32);
+        }
+    }
+
     std::vector<uint32_t> ids(static_cast<size_t>(d.n_real) * d.n_sys);
     for (size_t i = 0; i < ids.size(); ++i) ids[i] = static_cast<uint32_t>(i % d.n_sys);
     std::vector<uint8_t> trip(static_cast<size_t>(d.n_real) * d.n_sys, 0);
@@ -189,6 +200,7 @@ int seed_state(pa_sim *sim, uint64_t seed) {
     if ((rc = upload(sim, sim->p.system_ids, ids))) return rc;
     if ((rc = upload(sim, sim->p.slot_of, ids))) return rc;
     if ((rc = upload(sim, sim->p.trip_state, trip))) return rc;
+    if ((rc = upload(sim, sim->p.pair_rng, pair_rng))) return rc;
     PA_HIP(sim, hipMemsetAsync(sim->p.edge_att, 0, sizeof(uint64_t) * d.n_real * d.n_edges, sim->stream));
     PA_HIP(sim, hipMemsetAsync(sim->p.edge_acc, 0, sizeof(uint64_t) * d.n_real * d.n_edges, sim->stream));
     PA_HIP(sim, hipMemsetAsync(sim->p.round_trips, 0, sizeof(uint64_t) * d.n_real * d.n_sys, sim->stream));
@@ -241,6 +253,7 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     q.round_trips += static_cast<size_t>(d.n_sys) * r0;
     q.trip_state += static_cast<size_t>(d.n_sys) * r0;
     q.swap_masks += static_cast<size_t>(2) * d.W * r0;
+    q.pair_rng += static_cast<size_t>(4) * d.n_temps * d.n_pairs * r0;
     return q;
 }
 
@@ -284,8 +297,14 @@ std::string validate_text(const pa_sample_config *cfg, uint64_t n_replicas, int 
     *code = PA_ERR_UNSUPPORTED;
     if (cfg->sweep_mode == PA_SWEEP_GIBBS)
         return "sweep_mode='gibbs' is not built on the HIP path yet";
-    if (cfg->overlap_cluster_interval > 0)
-        return "overlap cluster moves are not built on the HIP path yet";
+    if (cfg->overlap_cluster_interval > 0) {
+        for (int k = 0; k < cfg->n_overlap_cluster_modes && k < 4; ++k)
+            if (cfg->overlap_cluster_modes[k] != PA_OC_HOUDAYER)
+                return "only the 'houdayer' overlap-cluster move is built on the HIP path yet";
+        if (cfg->overlap_cluster_mode != PA_CLUSTER_WOLFF)
+            return "overlap_cluster_mode='sw' is not built on the HIP path yet";
+        if (n_replicas > 32) return "overlap cluster moves support at most 32 replicas";
+    }
     *code = PA_OK;
     return "";
 }
@@ -313,10 +332,23 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             PA_HIP(sim, launch_rng(g.d, g.p, g.stream));                                // :412-432
             PA_HIP(sim, launch_sweep(g.d, g.p, record || pt_this, true, g.stream));     // :492-509
             if (record && want_overlap) PA_HIP(sim, launch_overlap(g.d, g.p, g.stream)); // :527-529
-            if (record || pt_this) { // statistics :543-578, tempering :748-796
-                PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
-                PA_HIP(sim, launch_measure(g.d, g.p, pt, record && want_overlap, record,
-                                           want_overlap, pt_this, g.stream));
+            const bool oc_this = cfg->overlap_cluster_interval > 0 &&
+                                 sweep_id % cfg->overlap_cluster_interval == 0; // :598-599
+            PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
+            if (!oc_this) {
+                if (record || pt_this) // statistics :543-578, tempering :748-796
+                    PA_HIP(sim, launch_measure(g.d, g.p, pt, false, record, want_overlap, pt_this,
+                                               g.stream));
+            } else {
+                if (record)
+                    PA_HIP(sim, launch_measure(g.d, g.p, pt, false, true, want_overlap, false, g.stream));
+                if (g.d.N * g.d.W * 12 + 4096 > 160 * 1024)
+                    return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the overlap-cluster kernel");
+                PA_HIP(sim, launch_houdayer(g.d, g.p, g.stream)); // :660-680
+                if (pt_this) { // energies are recomputed after a mutating move (:749-756)
+                    PA_HIP(sim, launch_sweep(g.d, g.p, true, false, g.stream));
+                    PA_HIP(sim, launch_measure(g.d, g.p, pt, false, false, false, true, g.stream));
+                }
             }
         }
         if (record) sim->n_recorded += 1;
@@ -658,6 +690,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     ok(bufs.alloc(&p.trip_state, static_cast<size_t>(d.n_real) * d.n_sys));
     ok(bufs.alloc(&sim->dbeta, dbeta.size()));
     ok(bufs.alloc(&p.swap_masks, static_cast<size_t>(d.n_real) * 2 * d.W));
+    ok(bufs.alloc(&p.pair_rng, static_cast<size_t>(d.n_real) * d.n_temps * d.n_pairs * 4));
     if (e != hipSuccess) {
         sim->error = std::string("hipMalloc: ") + hipGetErrorString(e);
         return bail(PA_ERR_DEVICE);

@@ -211,3 +211,40 @@ def test_ising_surface_seed_determinism_and_keys():
     again = first.sample(1, pt_interval=1, pt_schedule="full_ladder", warmup_ratio=0)
     assert np.all(again["per_disorder"]["parallel_tempering"]["edge_attempts"] == 2)
     assert many.sample(4)["mags"].shape == (32,)
+
+
+@pytest.mark.parametrize("shape,n_temps,n_rep,n_dis,interval", [((4, 4), 3, 2, 1, 1), ((6, 6, 6), 5, 4, 2, 1),
+                                                                ((12, 12, 12), 6, 4, 2, 2),
+                                                                ((8, 8), 4, 3, 2, 1)])
+def test_houdayer_overlap_cluster_move_matches_oracle(oracle, shape, n_temps, n_rep, n_dis, interval):
+    # BASELINE configs[4]: +-J glass with the Houdayer move (default 'wolff' inner mode)
+    couplings = bimodal(shape, len(shape), n_dis, 21)
+    temps = np.linspace(0.7, 1.6, n_temps)
+    gpu, cpu = make_pair(oracle, shape, couplings, temps, n_rep, 7)
+    kwargs = dict(pt_interval=1, overlap_cluster_update_interval=interval,
+                  overlap_cluster_build_mode="houdayer", overlap_cluster_mode="wolff",
+                  warmup_ratio=0.25)
+    a = gpu.sample(12, "metropolis", **kwargs)
+    b = cpu.sample(12, "metropolis", **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+    # without tempering, and continuing the same chains
+    kwargs.pop("pt_interval")
+    a = gpu.sample(5, "metropolis", **kwargs)
+    b = cpu.sample(5, "metropolis", **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu, check_energy=False)
+
+
+def test_unbuilt_overlap_modes_are_refused_not_emulated():
+    from peapods_amd import IsingSimulation
+
+    couplings = bimodal((4, 4), 2, 1, 2)
+    sim = IsingSimulation([4, 4], couplings, np.array([1.0, 2.0], np.float32), 2, None, 1)
+    before = sim.get_spins().copy()
+    with pytest.raises(NotImplementedError):
+        sim.sample(2, "metropolis", overlap_cluster_update_interval=1,
+                   overlap_cluster_build_mode="jorg")
+    with pytest.raises(NotImplementedError):
+        sim.sample(2, "gibbs")
+    np.testing.assert_array_equal(sim.get_spins(), before)

@@ -73,6 +73,10 @@ struct DevPtrs {
     const float *ln_table;   // [2^24] ln(k * 2^-24) as computed by the host libm
     const float *dbeta;      // [n_edges] 1/T[t] - 1/T[t+1] (f32)
     uint32_t *swap_masks;    // [n_real][2][W] scratch of the PT kernel
+    const uint16_t *nbr_site; // [N][6] neighbours by site: f0, b0, f1, b1, f2, b2 (self when unused)
+    const uint16_t *jsite;    // [n_real][N] by site: neg[0..5] | nz[6..11] for bonds f0,b0,f1,b1,f2,b2
+    const float *jorg_p;      // [n_temps] 1 - exp(-4 / T) by the host libm (Joerg bond probability)
+    uint16_t *dfs_stack;      // [n_real][n_temps * n_pairs][N] scratch of k_jorg
     uint64_t *pair_rng;      // [n_real][n_temps * n_pairs][4] xoshiro state of the overlap-move generators
 };
 
@@ -89,6 +93,8 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
 hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 hipError_t launch_houdayer(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 size_t houdayer_lds_bytes(const SimDims &d);
+hipError_t launch_jorg(const SimDims &d, const DevPtrs &p, hipStream_t stream);
+size_t jorg_lds_bytes(const SimDims &d);
 hipError_t launch_sweep_stamped(const SimDims &d, const DevPtrs &p, unsigned long long *stamps,
                                 hipStream_t stream);
 hipError_t launch_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_overlap,

@@ -1190,6 +1190,128 @@ __global__ __launch_bounds__(1024) void k_houdayer(SimDims d, DevPtrs p) {
 }
 
 // ---------------------------------------------------------------------------
+// k_jorg: Joerg stochastic overlap-cluster move, single-cluster ("wolff") variant --
+// clusters/overlap.rs:348-553 with dfs_cluster (utils.rs:125-149).  Bonds are
+// activated with p = 1 - exp(-4 J s_i s_j / T) by draws of the pair's generator
+// *in the order the depth-first search meets them*, so the search itself has to
+// be replayed exactly: one lane per pair runs the reference's stack-based DFS
+// (forward neighbour then backward neighbour per direction, LIFO stack), 48
+// pairs per wave side by side.  The tile sits in LDS; the stacks are global
+// scratch.  p depends only on the temperature for unit couplings and is
+// computed by the host's expf (jorg_p), so host and device agree bit for bit.
+// ---------------------------------------------------------------------------
+__host__ __device__ inline size_t jorg_lds_words(const SimDims &d) {
+    const size_t n_lanes = static_cast<size_t>(d.n_temps) * d.n_pairs;
+    return static_cast<size_t>(d.N) * d.W + n_lanes * d.MW + 2 * n_lanes + d.n_sys + 4;
+}
+
+__global__ __launch_bounds__(1024) void k_jorg(SimDims d, DevPtrs p) {
+    extern __shared__ uint32_t lds[];
+    const size_t tile_words = static_cast<size_t>(d.N) * d.W;
+    const uint32_t n_lanes = d.n_temps * d.n_pairs;
+    uint32_t *tile = lds;                                   // [W][N] spins
+    uint32_t *member = lds + tile_words;                    // [n_lanes][MW] cluster bitmaps
+    uint32_t *pair_slots = member + static_cast<size_t>(n_lanes) * d.MW; // [n_lanes][2]
+    const uint32_t real = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
+    uint32_t *Sg = p.S + static_cast<size_t>(real) * tile_words;
+    const uint16_t *jsite = p.jsite + static_cast<size_t>(real) * d.N;
+    uint64_t *prng = p.pair_rng + static_cast<size_t>(real) * n_lanes * 4;
+    uint16_t *stack = p.dfs_stack + (static_cast<size_t>(real) * n_lanes + tid) * d.N;
+
+    copy_to_lds(tile, Sg, static_cast<uint32_t>(tile_words), tid, nthreads);
+    for (size_t i = tid; i < static_cast<size_t>(n_lanes) * d.MW; i += nthreads) member[i] = 0;
+    __syncthreads();
+
+    DevRng rng;
+    rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
+    if (tid < n_lanes) {
+        const uint32_t t = tid / d.n_pairs, g = tid % d.n_pairs;
+        const uint64_t *st = prng + static_cast<size_t>(tid) * 4;
+        rng.s0 = st[0];
+        rng.s1 = st[1];
+        rng.s2 = st[2];
+        rng.s3 = st[3];
+        if (g == 0) { // shuffle the replicas at temperature t (overlap.rs:44-49)
+            uint32_t order[32];
+            for (uint32_t k = 0; k < d.n_replicas; ++k) order[k] = k;
+            for (uint32_t i = d.n_replicas - 1; i >= 1; --i) {
+                const uint32_t j = dev_gen_range_u32(rng, i + 1);
+                const uint32_t tmp = order[i];
+                order[i] = order[j];
+                order[j] = tmp;
+            }
+            for (uint32_t gg = 0; gg < d.n_pairs; ++gg) {
+                pair_slots[2 * (t * d.n_pairs + gg) + 0] = order[2 * gg] * d.n_temps + t;
+                pair_slots[2 * (t * d.n_pairs + gg) + 1] = order[2 * gg + 1] * d.n_temps + t;
+            }
+        }
+    }
+    __syncthreads();
+
+    if (tid < n_lanes) {
+        const uint32_t t = tid / d.n_pairs;
+        const uint32_t sa = pair_slots[2 * tid], sb = pair_slots[2 * tid + 1];
+        const uint32_t *wa = tile + (sa >> 5) * d.N, *wb = tile + (sb >> 5) * d.N;
+        const uint32_t ba = sa & 31u, bb = sb & 31u;
+        const float bond_p = p.jorg_p[t];
+        uint32_t *mine = member + static_cast<size_t>(tid) * d.MW;
+        auto spin_a = [&](uint32_t i) { return (wa[i] >> ba) & 1u; };
+        auto active = [&](uint32_t i) { return (((wa[i] >> ba) ^ (wb[i] >> bb)) & 1u) != 0; };
+        int64_t seed = -1;
+        for (int probe = 0; probe < 64; ++probe) { // utils.rs:107-119
+            const uint32_t i = static_cast<uint32_t>(dev_gen_range_u64(rng, d.N));
+            if (active(i)) {
+                seed = i;
+                break;
+            }
+        }
+        if (seed >= 0) {
+            uint32_t top = 0;
+            mine[seed >> 5] |= 1u << (seed & 31);
+            stack[top++] = static_cast<uint16_t>(seed);
+            while (top > 0) {
+                const uint32_t site = stack[--top];
+                const uint32_t jm = jsite[site];
+                for (uint32_t dir = 0; dir < 2 * d.nn; ++dir) { // f0, b0, f1, b1, ...
+                    const uint32_t nb = p.nbr_site[site * 6 + dir];
+                    if ((mine[nb >> 5] >> (nb & 31u)) & 1u) continue;
+                    if (!active(nb)) continue;
+                    // inter = s_a(site) * s_a(nb) * J(bond) must be > 0
+                    if (!((jm >> (6 + dir)) & 1u)) continue;
+                    if ((spin_a(site) ^ spin_a(nb) ^ ((jm >> dir) & 1u)) != 0) continue;
+                    const uint32_t draw = static_cast<uint32_t>(rng.next() >> 40);
+                    const float u = __fmul_rn(static_cast<float>(draw), 1.0f / 16777216.0f);
+                    if (u < bond_p) {
+                        mine[nb >> 5] |= 1u << (nb & 31u);
+                        stack[top++] = static_cast<uint16_t>(nb);
+                    }
+                }
+            }
+        }
+        uint64_t *st = prng + static_cast<size_t>(tid) * 4;
+        st[0] = rng.s0;
+        st[1] = rng.s1;
+        st[2] = rng.s2;
+        st[3] = rng.s3;
+    }
+    __syncthreads();
+    // flip both replicas of every pair on its cluster (pairs own disjoint bits of the tile)
+    for (uint32_t item = tid; item < n_lanes * d.MW; item += nthreads) {
+        const uint32_t lane = item / d.MW, mw = item % d.MW;
+        uint32_t bits = member[item];
+        const uint32_t sa = pair_slots[2 * lane], sb = pair_slots[2 * lane + 1];
+        while (bits) {
+            const uint32_t site = mw * 32 + (__ffs(bits) - 1);
+            bits &= bits - 1;
+            atomicXor(&tile[(sa >> 5) * d.N + site], 1u << (sa & 31u));
+            atomicXor(&tile[(sb >> 5) * d.N + site], 1u << (sb & 31u));
+        }
+    }
+    __syncthreads();
+    for (size_t i = tid; i < tile_words; i += nthreads) Sg[i] = tile[i];
+}
+
+// ---------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------
 static constexpr size_t kLdsPerCu = 160 * 1024;
@@ -1215,6 +1337,7 @@ hipError_t configure_kernels(const SimDims &) {
                            reinterpret_cast<const void *>(k_sweep<true, 3>),
                            reinterpret_cast<const void *>(k_overlap),
                            reinterpret_cast<const void *>(k_houdayer),
+                           reinterpret_cast<const void *>(k_jorg),
                            reinterpret_cast<const void *>(k_measure<false>),
                            reinterpret_cast<const void *>(k_measure<true>)}) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1275,6 +1398,12 @@ hipError_t launch_houdayer(const SimDims &d, const DevPtrs &p, hipStream_t strea
     return hipGetLastError();
 }
 size_t houdayer_lds_bytes(const SimDims &d) { return houdayer_lds_words(d) * 4; }
+
+hipError_t launch_jorg(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
+    hipLaunchKernelGGL(k_jorg, dim3(d.n_real), dim3(1024), jorg_lds_words(d) * 4, stream, d, p);
+    return hipGetLastError();
+}
+size_t jorg_lds_bytes(const SimDims &d) { return jorg_lds_words(d) * 4; }
 
 hipError_t launch_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_overlap,
                           bool do_accum, bool accum_overlap, bool do_pt, hipStream_t stream) {

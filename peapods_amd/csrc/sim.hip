@@ -63,6 +63,8 @@ struct pa_sim {
     // non-const aliases of the static tables (filled once in create)
     uint32_t *thr = nullptr, *mpar = nullptr, *pass_start = nullptr, *jump = nullptr;
     uint4 *rec = nullptr;
+    uint16_t *nbr_site = nullptr, *jsite = nullptr;
+    float *jorg_p = nullptr;
     int32_t *nz_bonds = nullptr;
     float *dbeta = nullptr;
     // bookkeeping of the last sample()
@@ -254,6 +256,8 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     q.trip_state += static_cast<size_t>(d.n_sys) * r0;
     q.swap_masks += static_cast<size_t>(2) * d.W * r0;
     q.pair_rng += static_cast<size_t>(4) * d.n_temps * d.n_pairs * r0;
+    q.jsite += static_cast<size_t>(d.N) * r0;
+    q.dfs_stack += static_cast<size_t>(d.n_temps) * d.n_pairs * d.N * r0;
     return q;
 }
 
@@ -299,8 +303,8 @@ std::string validate_text(const pa_sample_config *cfg, uint64_t n_replicas, int 
         return "sweep_mode='gibbs' is not built on the HIP path yet";
     if (cfg->overlap_cluster_interval > 0) {
         for (int k = 0; k < cfg->n_overlap_cluster_modes && k < 4; ++k)
-            if (cfg->overlap_cluster_modes[k] != PA_OC_HOUDAYER)
-                return "only the 'houdayer' overlap-cluster move is built on the HIP path yet";
+            if (cfg->overlap_cluster_modes[k] != PA_OC_HOUDAYER && cfg->overlap_cluster_modes[k] != PA_OC_JORG)
+                return "only the 'houdayer' and 'jorg' overlap-cluster moves are built on the HIP path yet";
         if (cfg->overlap_cluster_mode != PA_CLUSTER_WOLFF)
             return "overlap_cluster_mode='sw' is not built on the HIP path yet";
         if (n_replicas > 32) return "overlap cluster moves support at most 32 replicas";
@@ -320,6 +324,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     PA_HIP(sim, hipEventRecord(sim->fork, sim->stream));
     for (auto &g : sim->groups) PA_HIP(sim, hipStreamWaitEvent(g.stream, sim->fork, 0));
     int status = PA_OK;
+    uint64_t overlap_call_count = 0; // mod.rs:300
     for (uint64_t sweep_id = 0; sweep_id < cfg->n_sweeps && status == PA_OK; ++sweep_id) {
         if ((sweep_id & 31u) == 0 && sim->interrupt.load(std::memory_order_relaxed)) {
             sim->interrupt.store(false);
@@ -344,7 +349,12 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                     PA_HIP(sim, launch_measure(g.d, g.p, pt, false, true, want_overlap, false, g.stream));
                 if (g.d.N * g.d.W * 12 + 4096 > 160 * 1024)
                     return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the overlap-cluster kernel");
-                PA_HIP(sim, launch_houdayer(g.d, g.p, g.stream)); // :660-680
+                const int oc_mode = cfg->overlap_cluster_modes[overlap_call_count %
+                                                               static_cast<uint64_t>(cfg->n_overlap_cluster_modes)];
+                if (oc_mode == PA_OC_JORG)
+                    PA_HIP(sim, launch_jorg(g.d, g.p, g.stream)); // :601-602,660-680
+                else
+                    PA_HIP(sim, launch_houdayer(g.d, g.p, g.stream));
                 if (pt_this) { // energies are recomputed after a mutating move (:749-756)
                     PA_HIP(sim, launch_sweep(g.d, g.p, true, false, g.stream));
                     PA_HIP(sim, launch_measure(g.d, g.p, pt, false, false, false, true, g.stream));
@@ -352,6 +362,8 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             }
         }
         if (record) sim->n_recorded += 1;
+        if (cfg->overlap_cluster_interval > 0 && sweep_id % cfg->overlap_cluster_interval == 0)
+            overlap_call_count += 1; // :744
         if (pt_this && cfg->pt_schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
     }
     // join: the main stream continues after every group
@@ -584,6 +596,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
 
     // ---- per-realisation site records in schedule order (neighbours + coupling metadata)
     std::vector<uint4> rec(static_cast<size_t>(d.n_real) * (d.N + 1));
+    std::vector<uint16_t> nbr_site(static_cast<size_t>(d.N) * 6), jsite(static_cast<size_t>(d.n_real) * d.N);
     bool all_nonzero = true;
     std::vector<uint32_t> mpar(static_cast<size_t>(d.n_real) * d.MW, 0u);
     std::vector<int32_t> nz_bonds(d.n_real, 0);
@@ -608,6 +621,8 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
             const uint32_t h = (m + 1) / 2;
             const uint32_t jm = neg | (nz << 6) | (h << 12);
             if (m != 2 * d.nn) all_nonzero = false;
+            jsite[static_cast<size_t>(real) * d.N + site] = static_cast<uint16_t>(neg | (nz << 6));
+            for (int k = 0; k < 6; ++k) nbr_site[static_cast<size_t>(site) * 6 + k] = static_cast<uint16_t>(nb[k]);
             rec[static_cast<size_t>(real) * (d.N + 1) + pos] = // fields hold LDS byte offsets (4 * index)
                 make_uint4((site * 4) | (nb[0] * 4 << 16), (nb[1] * 4) | (nb[2] * 4 << 16),
                            (nb[3] * 4) | (nb[4] * 4 << 16), (nb[5] * 4) | (jm << 16));
@@ -632,6 +647,10 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
             if (b + 1 < d.B) acc = step.compose(acc);
         }
     }
+
+    // ---- Joerg bond probability per temperature for a satisfied unit bond (clusters/overlap.rs:435)
+    std::vector<float> jorg_p(d.n_temps);
+    for (uint32_t t = 0; t < d.n_temps; ++t) jorg_p[t] = 1.0f - expf(-4.0f * 1.0f / sim->temps[t]);
 
     // ---- PT constants
     std::vector<float> dbeta(d.n_edges, 0.0f);
@@ -691,6 +710,10 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     ok(bufs.alloc(&sim->dbeta, dbeta.size()));
     ok(bufs.alloc(&p.swap_masks, static_cast<size_t>(d.n_real) * 2 * d.W));
     ok(bufs.alloc(&p.pair_rng, static_cast<size_t>(d.n_real) * d.n_temps * d.n_pairs * 4));
+    ok(bufs.alloc(&sim->nbr_site, nbr_site.size()));
+    ok(bufs.alloc(&sim->jsite, jsite.size()));
+    ok(bufs.alloc(&sim->jorg_p, jorg_p.size()));
+    ok(bufs.alloc(&p.dfs_stack, static_cast<size_t>(d.n_real) * d.n_temps * d.n_pairs * d.N));
     if (e != hipSuccess) {
         sim->error = std::string("hipMalloc: ") + hipGetErrorString(e);
         return bail(PA_ERR_DEVICE);
@@ -702,9 +725,13 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     p.jump = sim->jump;
     p.nz_bonds = sim->nz_bonds;
     p.dbeta = sim->dbeta;
+    p.nbr_site = sim->nbr_site;
+    p.jsite = sim->jsite;
+    p.jorg_p = sim->jorg_p;
     if ((rc = upload(sim, sim->thr, thr)) || (rc = upload(sim, sim->mpar, mpar)) ||
         (rc = upload(sim, sim->rec, rec)) || (rc = upload(sim, sim->pass_start, pass_start)) ||
-        (rc = upload(sim, sim->jump, jump)) ||
+        (rc = upload(sim, sim->jump, jump)) || (rc = upload(sim, sim->nbr_site, nbr_site)) ||
+        (rc = upload(sim, sim->jsite, jsite)) || (rc = upload(sim, sim->jorg_p, jorg_p)) ||
         (rc = upload(sim, sim->nz_bonds, nz_bonds)) || (rc = upload(sim, sim->dbeta, dbeta)))
         return bail(rc);
     if (configure_kernels(d) != hipSuccess) {

@@ -236,6 +236,22 @@ def test_houdayer_overlap_cluster_move_matches_oracle(oracle, shape, n_temps, n_
     assert_state_equal(gpu, cpu, check_energy=False)
 
 
+@pytest.mark.parametrize("mode", ["jorg", "houdayer+jorg"])
+@pytest.mark.parametrize("shape,n_temps,n_rep,n_dis", [((4, 4), 3, 2, 1), ((6, 6, 6), 5, 4, 2),
+                                                       ((12, 12, 12), 6, 4, 2), ((2, 4, 6), 3, 2, 1)])
+def test_jorg_overlap_cluster_move_matches_oracle(oracle, mode, shape, n_temps, n_rep, n_dis):
+    # Joerg's stochastic bonds consume the pair generator in depth-first order; the GPU replays it
+    couplings = bimodal(shape, len(shape), n_dis, 33)
+    temps = np.linspace(0.7, 1.6, n_temps)
+    gpu, cpu = make_pair(oracle, shape, couplings, temps, n_rep, 9)
+    kwargs = dict(pt_interval=2, overlap_cluster_update_interval=1, overlap_cluster_build_mode=mode,
+                  overlap_cluster_mode="wolff", warmup_ratio=0.25)
+    a = gpu.sample(10, "metropolis", **kwargs)
+    b = cpu.sample(10, "metropolis", **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu, check_energy=False)
+
+
 def test_unbuilt_overlap_modes_are_refused_not_emulated():
     from peapods_amd import IsingSimulation
 
@@ -244,7 +260,9 @@ def test_unbuilt_overlap_modes_are_refused_not_emulated():
     before = sim.get_spins().copy()
     with pytest.raises(NotImplementedError):
         sim.sample(2, "metropolis", overlap_cluster_update_interval=1,
-                   overlap_cluster_build_mode="jorg")
+                   overlap_cluster_build_mode="cmr")
+    with pytest.raises(NotImplementedError):
+        sim.sample(2, "metropolis", overlap_cluster_update_interval=1, overlap_cluster_mode="sw")
     with pytest.raises(NotImplementedError):
         sim.sample(2, "gibbs")
     np.testing.assert_array_equal(sim.get_spins(), before)

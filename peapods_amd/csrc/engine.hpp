@@ -39,6 +39,7 @@ struct SimDims {
     uint32_t has_odd;    // 1 if any site has an odd number of non-zero bonds
     uint32_t n_edges;    // max(n_temps - 1, 1) (allocation stride of the PT edge counters)
     uint32_t thr_preshifted; // 1 if every threshold is < 2^24, so thr[6..12) = thr[0..6) << 8 is exact
+    uint32_t big;        // 1: lattice too large for the LDS kernels (spins stay in global memory)
     uint32_t dense_nn;   // = nn when every bond of every realisation is non-zero, else 0
 };
 
@@ -51,7 +52,8 @@ struct DevPtrs {
     const uint32_t *thr;     // [2][2][3][n_temps] thresholds: even set (dE=-2,-4,-6), odd set (-1,-3,-5);
                              //   second copy shifted left by 8 (valid when thr_preshifted)
     const uint32_t *mpar;    // [n_real][MW]     parity of the non-zero bond count per site
-    const uint4 *rec;        // [n_real][N + 1] schedule order (+ dummy), 16-bit fields holding 4 * index:
+    const uint4 *rec;        // [n_real][N + 1] schedule order (+ dummy), 16-bit fields holding 4 * index
+                             //   (large lattices: two uint4 per site = site, f0,b0,f1,b1,f2,b2, jmeta):
                              //   site,f0 | b0,f1 | b1,f2 | b2,jmeta
                              //   jmeta = neg[0..5] | nz[6..11] | h[12..13] for bonds f0,b0,f1,b1,f2,b2
     const uint32_t *pass_start; // [n_passes + 1]
@@ -73,6 +75,7 @@ struct DevPtrs {
     const float *ln_table;   // [2^24] ln(k * 2^-24) as computed by the host libm
     const float *dbeta;      // [n_edges] 1/T[t] - 1/T[t+1] (f32)
     uint32_t *swap_masks;    // [n_real][2][W] scratch of the PT kernel
+    uint32_t *big_counts;     // [n_real][n_sys][4] u32 scratch counters of the large-lattice kernels
     const uint16_t *nbr_site; // [N][6] neighbours by site: f0, b0, f1, b1, f2, b2 (self when unused)
     const uint16_t *jsite;    // [n_real][N] by site: neg[0..5] | nz[6..11] for bonds f0,b0,f1,b1,f2,b2
     const float *jorg_p;      // [n_temps] 1 - exp(-4 / T) by the host libm (Joerg bond probability)

@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256) void k_rng(SimDims d, DevPtrs p) {
     uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (active) load_cursor(p.cursor, real, d.SP, slot, st);
     __syncthreads();
+    if (__builtin_amdgcn_readfirstlane((group * 4 + wave) * 2) >= n_tw) return; // idle wave
     if (block > 0) jump_state_lds(st, tab);
     Rng32 rng;
     rng.load(st);
@@ -754,7 +755,8 @@ struct MeasureLds {
 };
 
 __host__ __device__ inline size_t measure_lds_words(const SimDims &d) {
-    return static_cast<size_t>(d.N) * d.W + 17 * 48 + 7 * static_cast<size_t>(d.n_sys) +
+    // the tile is only needed to exchange bit columns after a tempering swap (not built for big)
+    return (d.big ? 0 : static_cast<size_t>(d.N) * d.W) + 17 * 48 + 7 * static_cast<size_t>(d.n_sys) +
            2 * static_cast<size_t>(d.n_edges) + 2 * static_cast<size_t>(d.W) + 4;
 }
 
@@ -767,7 +769,7 @@ __global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams
     MeasureLds m;
     {
         uint32_t *q = lds;
-        m.tile = q; q += static_cast<size_t>(d.N) * d.W;
+        m.tile = q; q += d.big ? 0 : static_cast<size_t>(d.N) * d.W;
         m.scratch = q; q += 17 * 48;
         m.dot_spin = reinterpret_cast<int32_t *>(q); q += d.n_sys;
         m.dot_link = reinterpret_cast<int32_t *>(q); q += d.n_sys;
@@ -1312,6 +1314,172 @@ __global__ __launch_bounds__(1024) void k_jorg(SimDims d, DevPtrs p) {
 }
 
 // ---------------------------------------------------------------------------
+// Large lattices (a word's N sites do not fit the LDS, e.g. 64^3): the same
+// algorithm with the spins left in global memory (L2-resident: 1 MB per word at
+// 64^3).  k_sweep_big keeps one workgroup per (realisation, word) so that a
+// workgroup barrier still orders the dependency levels; spin loads and stores
+// are agent-scope relaxed atomics (served by L2, never a stale L1 line).
+// Energy / magnetisation and the overlap dots are chunked over many workgroups
+// and combined with integer atomics (exact, order-independent).
+// Site records are 8 dwords here: site, f0, b0, f1, b1, f2, b2, jmeta.
+// ---------------------------------------------------------------------------
+struct BigRec {
+    uint32_t site, nb[6], jm;
+    __device__ __forceinline__ BigRec(const uint4 a, const uint4 b) {
+        site = a.x; nb[0] = a.y; nb[1] = a.z; nb[2] = a.w;
+        nb[3] = b.x; nb[4] = b.y; nb[5] = b.z; jm = b.w;
+    }
+};
+
+__device__ __forceinline__ uint32_t coherent_load(const uint32_t *ptr) {
+    return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void coherent_store(uint32_t *ptr, uint32_t v) {
+    __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(1024) void k_sweep_big(SimDims d, DevPtrs p) {
+    const uint32_t real = blockIdx.x / d.W, w = blockIdx.x % d.W;
+    const uint32_t tid = threadIdx.x;
+    uint32_t *Sg = p.S + (static_cast<size_t>(real) * d.W + w) * d.N;
+    const uint2 *planes = p.planes + (static_cast<size_t>(real) * d.W + w) * d.N;
+    const uint4 *rec = p.rec + static_cast<size_t>(real) * (d.N + 1) * 2;
+    const uint32_t live = d.n_sys - w * 32;
+    const uint32_t valid_bits = live >= 32 ? 0xFFFFFFFFu : ((1u << live) - 1u);
+    for (uint32_t pass = 0; pass < d.n_passes; ++pass) {
+        const uint32_t pos = p.pass_start[pass] + tid;
+        if (pos < p.pass_start[pass + 1]) {
+            const BigRec r(rec[2 * pos], rec[2 * pos + 1]);
+            uint32_t nb[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) nb[k] = coherent_load(Sg + r.nb[k]);
+            const uint32_t s = coherent_load(Sg + r.site);
+            const uint2 lv = planes[r.site];
+            const uint32_t acc = accept_mask(s, nb, r.jm, lv.x, lv.y) & valid_bits;
+            coherent_store(Sg + r.site, s ^ acc);
+        }
+        __syncthreads(); // drains the stores (vmcnt 0) before the next level reads them
+    }
+}
+
+// chunk = 4096 schedule positions per workgroup; counts go to cnt[real][n_sys][3] (u32 atomics)
+__global__ __launch_bounds__(256) void k_energy_big(SimDims d, DevPtrs p, uint32_t n_chunks) {
+    __shared__ uint32_t scratch[5 * 48];
+    const uint32_t chunk = blockIdx.x % n_chunks;
+    const uint32_t w = (blockIdx.x / n_chunks) % d.W, real = blockIdx.x / (n_chunks * d.W);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t *Sg = p.S + (static_cast<size_t>(real) * d.W + w) * d.N;
+    const uint4 *rec = p.rec + static_cast<size_t>(real) * (d.N + 1) * 2;
+    uint32_t c[3][8];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[s][j] = 0;
+    uint32_t qa[16], qb[16], qc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t pos = chunk * 4096 + k * 256 + tid;
+        qa[k] = qb[k] = qc[k] = 0;
+        if (pos < d.N) {
+            const BigRec r(rec[2 * pos], rec[2 * pos + 1]);
+            const uint32_t jm = r.jm;
+            const uint32_t s = Sg[r.site];
+            const uint32_t f0 = Sg[r.nb[0]], f1 = Sg[r.nb[2]], f2 = Sg[r.nb[4]];
+            const uint32_t u0 = (s ^ f0 ^ (0u - ((jm >> 0) & 1u))) & (0u - ((jm >> 6) & 1u));
+            const uint32_t u1 = (s ^ f1 ^ (0u - ((jm >> 2) & 1u))) & (0u - ((jm >> 8) & 1u));
+            const uint32_t u2 = (s ^ f2 ^ (0u - ((jm >> 4) & 1u))) & (0u - ((jm >> 10) & 1u));
+            qa[k] = u0 ^ u1 ^ u2;
+            qb[k] = maj3(u0, u1, u2);
+            qc[k] = s;
+        }
+    }
+    count16(qa, c[0]);
+    count16(qb, c[1]);
+    count16(qc, c[2]);
+    uint32_t tot[3];
+    block_bit_totals<3>(c, scratch, tot);
+    if (tid < 32 && w * 32 + tid < d.n_sys) {
+        uint32_t *cnt = p.big_counts + (static_cast<size_t>(real) * d.n_sys + w * 32 + tid) * 4;
+        atomicAdd(&cnt[0], tot[0] + 2 * tot[1]); // unsatisfied forward bonds
+        atomicAdd(&cnt[1], tot[2]);              // spins equal to -1
+    }
+}
+
+__global__ __launch_bounds__(256) void k_overlap_big(SimDims d, DevPtrs p, uint32_t n_chunks) {
+    __shared__ uint32_t scratch[5 * 48];
+    const uint32_t chunk = blockIdx.x % n_chunks;
+    const uint32_t w = (blockIdx.x / n_chunks) % d.W, real = blockIdx.x / (n_chunks * d.W);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t q = d.n_temps >> 5, r = d.n_temps & 31u;
+    const uint32_t wa = w + q, wb = w + q + 1;
+    const uint32_t *S0 = p.S + static_cast<size_t>(real) * d.W * d.N;
+    const uint32_t *A = S0 + static_cast<size_t>(w) * d.N;
+    const uint32_t *B0 = wa < d.W ? S0 + static_cast<size_t>(wa) * d.N : nullptr;
+    const uint32_t *B1 = wb < d.W ? S0 + static_cast<size_t>(wb) * d.N : nullptr;
+    const uint4 *rec = p.rec + static_cast<size_t>(real) * (d.N + 1) * 2;
+    auto shifted = [&](uint32_t site) {
+        const uint32_t b0 = B0 ? B0[site] : 0u, b1 = B1 ? B1[site] : 0u;
+        return r ? ((b0 >> r) | (b1 << (32 - r))) : b0;
+    };
+    uint32_t c[3][8];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[s][j] = 0;
+    uint32_t qa[16], qb[16], qc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t pos = chunk * 4096 + k * 256 + tid;
+        qa[k] = qb[k] = qc[k] = 0;
+        if (pos < d.N) {
+            const BigRec sr(rec[2 * pos], rec[2 * pos + 1]);
+            const uint32_t y = A[sr.site] ^ shifted(sr.site);
+            uint32_t z[3] = {0, 0, 0};
+            for (uint32_t dir = 0; dir < d.nn; ++dir) {
+                const uint32_t nbr = sr.nb[2 * dir];
+                z[dir] = y ^ A[nbr] ^ shifted(nbr);
+            }
+            qa[k] = y;
+            qb[k] = z[0] ^ z[1] ^ z[2];
+            qc[k] = maj3(z[0], z[1], z[2]);
+        }
+    }
+    count16(qa, c[0]);
+    count16(qb, c[1]);
+    count16(qc, c[2]);
+    uint32_t tot[3];
+    block_bit_totals<3>(c, scratch, tot);
+    if (tid < 32 && w * 32 + tid < d.n_sys) {
+        uint32_t *cnt = p.big_counts + (static_cast<size_t>(real) * d.n_sys + w * 32 + tid) * 4;
+        atomicAdd(&cnt[2], tot[0]);              // sites where the pair disagrees
+        atomicAdd(&cnt[3], tot[1] + 2 * tot[2]); // bonds with q_i q_k = -1
+    }
+}
+
+// counts -> Esum / Msum (mode 0) or dot_spin / dot_link (mode 1); one thread per slot
+__global__ void k_big_finalize(SimDims d, DevPtrs p, int mode) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= d.n_real * d.n_sys) return;
+    const uint32_t real = idx / d.n_sys, k = idx % d.n_sys;
+    uint32_t *cnt = p.big_counts + static_cast<size_t>(idx) * 4;
+    if (mode == 0) {
+        p.Esum[idx] = p.nz_bonds[real] - 2 * static_cast<int32_t>(cnt[0]);
+        p.Msum[idx] = static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(cnt[1]);
+        cnt[0] = 0;
+        cnt[1] = 0;
+    } else {
+        const uint32_t rep = k / d.n_temps, t = k % d.n_temps;
+        if ((rep & 1u) == 0 && rep + 1 < d.n_replicas) {
+            const size_t o = (static_cast<size_t>(real) * d.n_pairs + (rep >> 1)) * d.n_temps + t;
+            p.dot_spin[o] = static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(cnt[2]);
+            p.dot_link[o] = static_cast<int32_t>(d.N * d.nn) - 2 * static_cast<int32_t>(cnt[3]);
+        }
+        cnt[2] = 0;
+        cnt[3] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------
 static constexpr size_t kLdsPerCu = 160 * 1024;
@@ -1359,6 +1527,18 @@ hipError_t launch_rng(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
 
 hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,
                         hipStream_t stream) {
+    if (d.big) {
+        if (do_sweep)
+            hipLaunchKernelGGL(k_sweep_big, dim3(d.n_real * d.W), dim3(1024), 0, stream, d, p);
+        if (with_energy) {
+            const uint32_t n_chunks = (d.N + 4095) / 4096;
+            hipLaunchKernelGGL(k_energy_big, dim3(d.n_real * d.W * n_chunks), dim3(256), 0, stream, d,
+                               p, n_chunks);
+            hipLaunchKernelGGL(k_big_finalize, dim3((d.n_real * d.n_sys + 255) / 256), dim3(256), 0,
+                               stream, d, p, 0);
+        }
+        return hipGetLastError();
+    }
     const dim3 grid(d.n_real * d.W), block(256);
     static const size_t pad = [] {
         const char *env = std::getenv("PEAPODS_SWEEP_LDS");
@@ -1389,6 +1569,14 @@ hipError_t launch_sweep_stamped(const SimDims &d, const DevPtrs &p, unsigned lon
 }
 
 hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
+    if (d.big) {
+        const uint32_t n_chunks = (d.N + 4095) / 4096;
+        hipLaunchKernelGGL(k_overlap_big, dim3(d.n_real * d.W * n_chunks), dim3(256), 0, stream, d, p,
+                           n_chunks);
+        hipLaunchKernelGGL(k_big_finalize, dim3((d.n_real * d.n_sys + 255) / 256), dim3(256), 0,
+                           stream, d, p, 1);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_overlap, dim3(d.n_real * d.W), dim3(256), overlap_lds_bytes(d), stream, d, p);
     return hipGetLastError();
 }

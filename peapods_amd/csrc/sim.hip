@@ -237,7 +237,8 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     q.system_ids += static_cast<size_t>(d.n_sys) * r0;
     q.slot_of += static_cast<size_t>(d.n_sys) * r0;
     q.mpar += static_cast<size_t>(d.MW) * r0;
-    q.rec += (static_cast<size_t>(d.N) + 1) * r0;
+    q.rec += (static_cast<size_t>(d.N) + 1) * (d.big ? 2 : 1) * r0;
+    q.big_counts += static_cast<size_t>(4) * d.n_sys * r0;
     q.Esum += static_cast<size_t>(d.n_sys) * r0;
     q.Msum += static_cast<size_t>(d.n_sys) * r0;
     q.nz_bonds += r0;
@@ -315,6 +316,12 @@ std::string validate_text(const pa_sample_config *cfg, uint64_t n_replicas, int 
 
 int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     const SimDims &d = sim->d;
+    if (d.big && (cfg->pt_interval > 0 || cfg->overlap_cluster_interval > 0))
+        return fail(sim, PA_ERR_UNSUPPORTED,
+                    "parallel tempering and overlap-cluster moves are not built for lattices above "
+                    "12000 sites yet");
+    if (cfg->overlap_cluster_interval > 0 && d.n_temps * d.n_pairs > 1024)
+        return fail(sim, PA_ERR_UNSUPPORTED, "overlap-cluster moves support at most 1024 pairs per realisation");
     int rc = zero_accumulators(sim);
     if (rc) return rc;
     const bool want_overlap = d.n_pairs > 0 && cfg->measure_overlap;
@@ -510,8 +517,8 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         sim->error = "more than 3 forward directions are not built on the HIP path yet";
         return bail(PA_ERR_UNSUPPORTED);
     }
-    if (lat.n_spins > 12000 || desc->n_temps > 1024) {
-        sim->error = "lattices above 12000 sites (or more than 1024 temperatures) are not built "
+    if (lat.n_spins > (1u << 22) || desc->n_temps > 1024) {
+        sim->error = "lattices above 4194304 sites (or more than 1024 temperatures) are not built "
                      "on the HIP path yet";
         return bail(PA_ERR_UNSUPPORTED);
     }
@@ -542,6 +549,8 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     d.B = (d.N + d.BS - 1) / d.BS;
     d.BP = (d.B + 1) / 2;
     d.MW = (d.N + 31) / 32;
+    // the LDS kernels hold a word's N sites (sweep) / the W-word tile (tempering swaps) on chip
+    d.big = (d.N > 12000 || static_cast<size_t>(d.N) * d.W * 4 > 150000) ? 1 : 0;
     d.n_edges = std::max<uint32_t>(1, d.n_temps - 1);
     if (d.W > 64) {
         sim->error = "more than 2048 systems per realisation are not built on the HIP path yet";
@@ -590,12 +599,14 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     for (uint32_t l = 0; l < n_levels; ++l) level_start[l + 1] += level_start[l];
     std::vector<uint32_t> pass_start;
     for (uint32_t l = 0; l < n_levels; ++l)
-        for (uint32_t b = level_start[l]; b < level_start[l + 1]; b += 256) pass_start.push_back(b);
+        for (uint32_t b = level_start[l]; b < level_start[l + 1]; b += (d.big ? 1024 : 256))
+            pass_start.push_back(b);
     pass_start.push_back(d.N);
     d.n_passes = static_cast<uint32_t>(pass_start.size()) - 1;
 
     // ---- per-realisation site records in schedule order (neighbours + coupling metadata)
-    std::vector<uint4> rec(static_cast<size_t>(d.n_real) * (d.N + 1));
+    const size_t rec_stride = (static_cast<size_t>(d.N) + 1) * (d.big ? 2 : 1); // uint4 per realisation
+    std::vector<uint4> rec(static_cast<size_t>(d.n_real) * rec_stride);
     std::vector<uint16_t> nbr_site(static_cast<size_t>(d.N) * 6), jsite(static_cast<size_t>(d.n_real) * d.N);
     bool all_nonzero = true;
     std::vector<uint32_t> mpar(static_cast<size_t>(d.n_real) * d.MW, 0u);
@@ -622,8 +633,13 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
             const uint32_t jm = neg | (nz << 6) | (h << 12);
             if (m != 2 * d.nn) all_nonzero = false;
             jsite[static_cast<size_t>(real) * d.N + site] = static_cast<uint16_t>(neg | (nz << 6));
+            if (d.big) { // full-width indices, two uint4 per site
+                rec[static_cast<size_t>(real) * rec_stride + 2 * pos] = make_uint4(site, nb[0], nb[1], nb[2]);
+                rec[static_cast<size_t>(real) * rec_stride + 2 * pos + 1] = make_uint4(nb[3], nb[4], nb[5], jm);
+                continue;
+            }
             for (int k = 0; k < 6; ++k) nbr_site[static_cast<size_t>(site) * 6 + k] = static_cast<uint16_t>(nb[k]);
-            rec[static_cast<size_t>(real) * (d.N + 1) + pos] = // fields hold LDS byte offsets (4 * index)
+            rec[static_cast<size_t>(real) * rec_stride + pos] = // fields hold LDS byte offsets (4 * index)
                 make_uint4((site * 4) | (nb[0] * 4 << 16), (nb[1] * 4) | (nb[2] * 4 << 16),
                            (nb[3] * 4) | (nb[4] * 4 << 16), (nb[5] * 4) | (jm << 16));
             if (m & 1u) {
@@ -632,8 +648,9 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
             }
         }
         const uint32_t dummy = d.N * 4; // idle lanes of a pass work on the spare slot N
-        rec[static_cast<size_t>(real) * (d.N + 1) + d.N] =
-            make_uint4(dummy | (dummy << 16), dummy | (dummy << 16), dummy | (dummy << 16), dummy);
+        if (!d.big)
+            rec[static_cast<size_t>(real) * rec_stride + d.N] =
+                make_uint4(dummy | (dummy << 16), dummy | (dummy << 16), dummy | (dummy << 16), dummy);
     }
     d.dense_nn = all_nonzero ? d.nn : 0;
 
@@ -713,7 +730,8 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     ok(bufs.alloc(&sim->nbr_site, nbr_site.size()));
     ok(bufs.alloc(&sim->jsite, jsite.size()));
     ok(bufs.alloc(&sim->jorg_p, jorg_p.size()));
-    ok(bufs.alloc(&p.dfs_stack, static_cast<size_t>(d.n_real) * d.n_temps * d.n_pairs * d.N));
+    ok(bufs.alloc(&p.dfs_stack, d.big ? 1 : static_cast<size_t>(d.n_real) * d.n_temps * d.n_pairs * d.N));
+    ok(bufs.alloc(&p.big_counts, static_cast<size_t>(d.n_real) * d.n_sys * 4));
     if (e != hipSuccess) {
         sim->error = std::string("hipMalloc: ") + hipGetErrorString(e);
         return bail(PA_ERR_DEVICE);
@@ -734,6 +752,10 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         (rc = upload(sim, sim->jsite, jsite)) || (rc = upload(sim, sim->jorg_p, jorg_p)) ||
         (rc = upload(sim, sim->nz_bonds, nz_bonds)) || (rc = upload(sim, sim->dbeta, dbeta)))
         return bail(rc);
+    if (hipMemsetAsync(p.big_counts, 0, sizeof(uint32_t) * d.n_real * d.n_sys * 4, sim->stream) != hipSuccess) {
+        sim->error = "hipMemsetAsync failed";
+        return bail(PA_ERR_DEVICE);
+    }
     if (configure_kernels(d) != hipSuccess) {
         sim->error = "kernel LDS configuration failed";
         return bail(PA_ERR_DEVICE);
@@ -887,6 +909,8 @@ int pa_sim_compute_energies(pa_sim *sim) {
 }
 
 int pa_sim_parallel_tempering(pa_sim *sim, int32_t schedule) {
+    if (sim->d.big)
+        return fail(sim, PA_ERR_UNSUPPORTED, "parallel tempering is not built for lattices above 12000 sites yet");
     if (schedule != PA_PT_SINGLE_RANDOM_EDGE && schedule != PA_PT_FULL_LADDER)
         return fail(sim, PA_ERR_INVALID,
                     "unknown pt_schedule, expected 'single_random_edge' or 'full_ladder'");

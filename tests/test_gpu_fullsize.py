@@ -100,3 +100,37 @@ def test_full_ensemble_properties(oracle):
     assert hist.shape == (128, N_TEMPS, N + 1)
     assert np.all(hist.sum(axis=2) == n_sweeps * (N_REP // 2))
     assert np.all(np.abs(result["overlap"]) <= 1.0) and np.all(result["energies"] > 0)
+
+
+@pytest.mark.parametrize("shape,kind,n_temps,n_rep,n_dis,n_sweeps", [
+    ((24, 24, 24), "bimodal", 3, 2, 2, 6),   # smallest lattice on the large-lattice path
+    ((128, 128), "ferro", 5, 2, 1, 4),        # 2D, 255 dependency levels
+    ((64, 64, 64), "ferro", 32, 2, 1, 3),     # BASELINE configs[1]: 64^3 ferromagnet, 32 T x 2 replicas
+])
+def test_large_lattice_path_matches_oracle(oracle, shape, kind, n_temps, n_rep, n_dis, n_sweeps):
+    from peapods_amd import IsingSimulation
+
+    nn = len(shape)
+    if kind == "ferro":
+        couplings = np.ones((n_dis,) + shape + (nn,), np.float32) if n_dis > 1 else np.ones(shape + (nn,), np.float32)
+        temps = np.linspace(4.111, 4.911, n_temps) if nn == 3 else np.linspace(1.969, 2.569, n_temps)
+    else:
+        rng = np.random.default_rng(4)
+        couplings = (2 * rng.integers(0, 2, size=(n_dis,) + shape + (nn,)) - 1).astype(np.float32)
+        temps = np.linspace(0.8, 1.4, n_temps)
+    temps = temps.astype(np.float32)
+    gpu = IsingSimulation(list(shape), couplings, temps, n_rep, None, 5)
+    cpu = oracle.OracleSimulation(list(shape), couplings, temps, n_rep, None, 5)
+    a = gpu.sample(n_sweeps, "metropolis", warmup_ratio=0.25)
+    b = cpu.sample(n_sweeps, "metropolis", warmup_ratio=0.25, n_threads=8)
+    for key in b:
+        if key == "overlap_histogram":
+            for x, y in zip(a[key], b[key]):
+                np.testing.assert_array_equal(x, y)
+        else:
+            np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    for r in range(n_dis):
+        np.testing.assert_array_equal(gpu.get_spins(r), cpu.get_spins(r))
+        np.testing.assert_array_equal(gpu.get_energies(r), cpu.get_energies(r))
+    with pytest.raises(NotImplementedError):
+        gpu.sample(2, "metropolis", pt_interval=1)

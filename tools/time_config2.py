@@ -1,0 +1,15 @@
+"""Timing of BASELINE configs[1]: 64^3 ferromagnet, 32 temperatures x 2 replicas."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from peapods_amd import IsingSimulation
+shape = (64, 64, 64)
+t0 = time.perf_counter()
+sim = IsingSimulation(list(shape), np.ones(shape + (3,), np.float32), np.linspace(4.111, 4.911, 32).astype(np.float32), 2, None, 42)
+print("create %.2f s" % (time.perf_counter() - t0))
+cfg = sim.make_config(50, "metropolis", warmup_ratio=0.0)
+sim.run(cfg)
+t0 = time.perf_counter(); sim.run(cfg); dt = time.perf_counter() - t0
+flips = 64**3 * 64 * 50
+print("64^3 x 64 systems: %.1f us/sweep, %.2f Gflips/s" % (dt / 50 * 1e6, flips / dt / 1e9))
+print(sim.profile_kernels(sim.make_config(10, "metropolis", warmup_ratio=0.0), 10))

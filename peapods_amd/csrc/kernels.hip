@@ -76,6 +76,14 @@ __device__ __forceinline__ void jump_state(uint32_t st[8], const uint32_t *__res
 // 64-bit multiply); only the top 24 bits of the output are formed, which is
 // all the reference uses (next_u32 >> 8 of next_u64 >> 32, sweep.rs:181).
 // ---------------------------------------------------------------------------
+// (x << SH) + y in one instruction.  hipcc canonicalises (x << 2) + x to a multiplication and
+// lowers it to three v_mad_u64_u32, so the instruction is named explicitly.
+template <int SH> __device__ __forceinline__ uint64_t lshl_add_u64(uint64_t x, uint64_t y) {
+    uint64_t r;
+    asm("v_lshl_add_u64 %0, %1, %2, %3" : "=v"(r) : "v"(x), "n"(SH), "v"(y));
+    return r;
+}
+
 struct Rng32 {
     uint32_t a0, a1, b0, b1, c0, c1, d0, d1; // s0 = a1:a0, s1 = b1:b0, s2 = c1:c0, s3 = d1:d0
     __device__ __forceinline__ void load(const uint32_t st[8]) {
@@ -88,17 +96,15 @@ struct Rng32 {
     }
     // Returns the high word of the 64-bit output; the reference's draw is its top 24 bits.
     __device__ __forceinline__ uint32_t next_top() {
-        // P = s1 * 5 = (s1 << 2) + s1
-        const uint32_t q = b0 << 2;
-        const uint32_t plo = q + b0;
-        const uint32_t phi = ((b1 << 2) + b1) + (b0 >> 30) + (plo < q ? 1u : 0u);
-        // R = rotl(P, 7)
-        const uint32_t rhi = __builtin_amdgcn_alignbit(phi, plo, 25);
+        // output = rotl(s1 * 5, 7) * 9, both multiplications as one 64-bit shift-add each
+        // (v_lshl_add_u64); only the high word of the result is needed
+        const uint64_t s1 = (static_cast<uint64_t>(b1) << 32) | b0;
+        const uint64_t pp = lshl_add_u64<2>(s1, s1);
+        const uint32_t plo = static_cast<uint32_t>(pp), phi = static_cast<uint32_t>(pp >> 32);
+        const uint32_t rhi = __builtin_amdgcn_alignbit(phi, plo, 25); // R = rotl(P, 7)
         const uint32_t rlo = __builtin_amdgcn_alignbit(plo, phi, 25);
-        // high word of R * 9 = rhi * 9 + mulhi(rlo, 9)
-        const uint32_t e = rlo << 3;
-        const uint32_t f = e + rlo;
-        const uint32_t top = ((rhi << 3) + rhi) + (rlo >> 29) + (f < e ? 1u : 0u);
+        const uint64_t rr = (static_cast<uint64_t>(rhi) << 32) | rlo;
+        const uint32_t top = static_cast<uint32_t>(lshl_add_u64<3>(rr, rr) >> 32);
         // state transition; three-input XORs (v_bitop3_b32, truth table 0x96) fold the chained updates
         const uint32_t t0 = b0 << 17;
         const uint32_t t1 = __builtin_amdgcn_alignbit(b1, b0, 15);

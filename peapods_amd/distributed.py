@@ -24,7 +24,7 @@ def all_gather_blocks(blocks, dist=None, device=None):
     """All-gathers [n_local][block_len] f64 blocks into [n_total][block_len] in rank order.
     Ranks may own different numbers of realisations."""
     blocks = np.ascontiguousarray(blocks, dtype=np.float64)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return blocks
     import torch
 

@@ -44,7 +44,8 @@ struct SimDims {
 };
 
 struct DevPtrs {
-    uint32_t *S;             // [n_real][W][N]
+    uint32_t *S;             // [n_real][W][N] current spins
+    uint32_t *S_next;        // [n_real][W][N] k_sweep writes here (double buffer; = S on the large path)
     uint2 *planes;           // [n_real][W][N]  .x/.y = bit 0/1 of the acceptance level
     uint32_t *cursor;        // [n_real][8][SP]  xoshiro state of the system in each slot
     uint32_t *system_ids;    // [n_real][n_sys]  slot -> system
@@ -74,7 +75,9 @@ struct DevPtrs {
     uint8_t *trip_state;     // [n_real][n_sys] by system
     const float *ln_table;   // [2^24] ln(k * 2^-24) as computed by the host libm
     const float *dbeta;      // [n_edges] 1/T[t] - 1/T[t+1] (f32)
-    uint32_t *swap_masks;    // [n_real][2][W] scratch of the PT kernel
+    uint32_t *swap_masks;    // [n_real][2][W] accepted tempering swaps of the last event (deferred exchange)
+    uint32_t *swap_epoch;    // [n_real] bumped by every event that accepted a swap
+    uint32_t *applied_epoch; // [n_real][W] epoch whose swaps are already in S
     uint32_t *big_counts;     // [n_real][n_sys][4] u32 scratch counters of the large-lattice kernels
     const uint16_t *nbr_site; // [N][6] neighbours by site: f0, b0, f1, b1, f2, b2 (self when unused)
     const uint16_t *jsite;    // [n_real][N] by site: neg[0..5] | nz[6..11] for bonds f0,b0,f1,b1,f2,b2
@@ -94,6 +97,7 @@ hipError_t launch_rng(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,
                         hipStream_t stream);
 hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream);
+hipError_t launch_apply_swaps(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 hipError_t launch_houdayer(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 size_t houdayer_lds_bytes(const SimDims &d);
 hipError_t launch_jorg(const SimDims &d, const DevPtrs &p, hipStream_t stream);

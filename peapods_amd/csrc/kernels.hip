@@ -498,6 +498,99 @@ __device__ __forceinline__ void copy_to_lds(uint32_t *dst, const uint32_t *__res
     }
 }
 
+// Two arrays in one go for a 256-thread workgroup: all loads of both copies are issued before the
+// first LDS store when everything is 16-byte aligned and fits 16 vector loads per thread.
+__device__ __forceinline__ void copy2_to_lds(uint32_t *dst_a, const uint32_t *__restrict__ src_a,
+                                             uint32_t n_a, uint32_t *dst_b,
+                                             const uint32_t *__restrict__ src_b, uint32_t n_b,
+                                             uint32_t tid) {
+    const bool aligned = ((reinterpret_cast<uintptr_t>(src_a) | reinterpret_cast<uintptr_t>(dst_a) |
+                           reinterpret_cast<uintptr_t>(src_b) | reinterpret_cast<uintptr_t>(dst_b)) & 15u) == 0 &&
+                         ((n_a | n_b) & 3u) == 0;
+    const uint32_t qa = n_a >> 2, qb = n_b >> 2; // uint4 counts
+    if (aligned && qa <= 4 * 256 && qb <= 12 * 256) {
+        const uint4 *a4 = reinterpret_cast<const uint4 *>(src_a), *b4 = reinterpret_cast<const uint4 *>(src_b);
+        uint4 va[4], vb[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = k * 256 + tid;
+            va[k] = i < qa ? a4[i] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const uint32_t i = k * 256 + tid;
+            vb[k] = i < qb ? b4[i] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = k * 256 + tid;
+            if (i < qa) reinterpret_cast<uint4 *>(dst_a)[i] = va[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const uint32_t i = k * 256 + tid;
+            if (i < qb) reinterpret_cast<uint4 *>(dst_b)[i] = vb[k];
+        }
+        return;
+    }
+    copy_to_lds(dst_a, src_a, n_a, tid, 256);
+    copy_to_lds(dst_b, src_b, n_b, tid, 256);
+}
+
+// ---------------------------------------------------------------------------
+// Deferred tempering swaps.  An accepted swap of slots (k, k+1) exchanges two adjacent bit
+// columns of the tile.  masks[round][w] has bit k%32 set for every accepted pair whose lower slot
+// is k = 32 w + bit; round 0 pairs are applied before round 1 pairs (full ladder: the two
+// parities; single edge: round 0 only).  A pair may straddle two words (bits 31 | 0).
+// ---------------------------------------------------------------------------
+// One round on a window of three consecutive words; returns the new middle word.  (prev, next)
+// are the old neighbouring words; only their bits next to the middle word matter.
+__device__ __forceinline__ uint32_t swap_round_mid(uint32_t prev, uint32_t v, uint32_t next,
+                                                   uint32_t m_prev, uint32_t m_cur) {
+    const uint32_t t = (v ^ ((v >> 1) | (next << 31))) & m_cur;      // pairs whose lower bit is in v
+    const uint32_t t_prev31 = ((prev >> 31) ^ (v & 1u)) & (m_prev >> 31); // pair (31 of prev, 0 of v)
+    return v ^ t ^ ((t << 1) | t_prev31);
+}
+
+// Both rounds for the middle word of a window (prev, v, next); masks are [round][word-1..word+1].
+__device__ __forceinline__ uint32_t apply_swaps_window(uint32_t prev, uint32_t v, uint32_t next,
+                                                       const uint32_t mp[2], const uint32_t mc[2],
+                                                       const uint32_t mn[2]) {
+    // round 0 on all three words (the outer two only need to be right next to the middle word,
+    // which they are: their far neighbours cannot reach bit 31 of prev / bit 0 of next in one round
+    // except through pairs that are themselves inside the window)
+    const uint32_t v0 = swap_round_mid(prev, v, next, mp[0], mc[0]);
+    const uint32_t p0 = swap_round_mid(0u, prev, v, 0u, mp[0]);
+    const uint32_t n0 = swap_round_mid(v, next, 0u, mc[0], mn[0] & 0x7FFFFFFFu);
+    return swap_round_mid(p0, v0, n0, mp[1], mc[1]);
+}
+
+// Materialise pending swaps in place (any lattice size): one thread per site handles all W words.
+__global__ void k_apply_swaps(SimDims d, DevPtrs p) {
+    const uint32_t real = blockIdx.y;
+    const uint32_t site = blockIdx.x * blockDim.x + threadIdx.x;
+    if (site >= d.N) return;
+    if (p.swap_epoch[real] == p.applied_epoch[static_cast<size_t>(real) * d.W]) return;
+    uint32_t *Sg = p.S + static_cast<size_t>(real) * d.W * d.N;
+    const uint32_t *masks = p.swap_masks + static_cast<size_t>(real) * 2 * d.W;
+    for (int round = 0; round < 2; ++round) {
+        uint32_t carry_t = 0; // bit 31 of the previous word's t
+        uint32_t v = Sg[site];
+        for (uint32_t w = 0; w < d.W; ++w) {
+            const uint32_t next = (w + 1 < d.W) ? Sg[static_cast<size_t>(w + 1) * d.N + site] : 0u;
+            const uint32_t t = (v ^ ((v >> 1) | (next << 31))) & masks[round * d.W + w];
+            Sg[static_cast<size_t>(w) * d.N + site] = v ^ t ^ ((t << 1) | carry_t);
+            carry_t = t >> 31;
+            v = next;
+        }
+    }
+}
+
+__global__ void k_mark_applied(SimDims d, DevPtrs p) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < d.n_real * d.W) p.applied_epoch[idx] = p.swap_epoch[idx / d.W];
+}
+
 // ---------------------------------------------------------------------------
 // k_sweep: workgroup = (tile, word).  The word's N site values and the two
 // acceptance-level planes live in LDS; the schedule passes (dependency levels
@@ -524,13 +617,42 @@ __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_en
     uint32_t *scratch = lds + n_pad + 2 * static_cast<size_t>(n1); // [16 rows][48]
     const uint32_t real = blockIdx.x / d.W, w = blockIdx.x % d.W;
     const uint32_t tid = threadIdx.x;
-    uint32_t *Sg = p.S + (static_cast<size_t>(real) * d.W + w) * d.N; // this word's N sites
+    const uint32_t *Sin = p.S + (static_cast<size_t>(real) * d.W + w) * d.N;  // this word's N sites
+    uint32_t *Sout = p.S_next + (static_cast<size_t>(real) * d.W + w) * d.N; // double buffer
     const uint4 *rec = p.rec + static_cast<size_t>(real) * n1;
-    copy_to_lds(sw, Sg, d.N, tid, 256);
-    if (do_sweep)
-        copy_to_lds(pl, reinterpret_cast<const uint32_t *>(
-                            p.planes + (static_cast<size_t>(real) * d.W + w) * d.N),
-                    2 * d.N, tid, 256);
+    // the few words that describe pending tempering swaps are requested first, so that their
+    // latency hides behind the bulk copy below
+    const uint32_t epoch = p.swap_epoch[real];
+    const uint32_t applied = p.applied_epoch[static_cast<size_t>(real) * d.W + w];
+    uint32_t mp[2], mc[2], mn[2];
+    {
+        const uint32_t *masks = p.swap_masks + static_cast<size_t>(real) * 2 * d.W;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            mp[r] = w > 0 ? masks[r * d.W + w - 1] : 0u;
+            mc[r] = masks[r * d.W + w];
+            mn[r] = w + 1 < d.W ? masks[r * d.W + w + 1] : 0u;
+        }
+    }
+    // spins and acceptance planes are requested together (one memory round trip, not two)
+    const uint32_t *planes_in = reinterpret_cast<const uint32_t *>(
+        p.planes + (static_cast<size_t>(real) * d.W + w) * d.N);
+    copy2_to_lds(sw, Sin, d.N, pl, planes_in, do_sweep ? 2 * d.N : 0, tid);
+    if (do_sweep && epoch != applied) {
+        // tempering swaps accepted after the previous sweep: exchange the bit columns now
+        const bool window = (((mp[0] | mp[1] | mc[0] | mc[1]) >> 31) != 0); // a pair straddles words
+        __syncthreads();
+        for (uint32_t i = tid; i < d.N; i += 256) {
+            const uint32_t v = sw[i];
+            uint32_t prev = 0, next = 0;
+            if (window) { // old neighbouring words (the input buffer is not written in this launch)
+                if (w > 0) prev = Sin[static_cast<ptrdiff_t>(i) - static_cast<ptrdiff_t>(d.N)];
+                if (w + 1 < d.W) next = Sin[static_cast<size_t>(i) + d.N];
+            }
+            sw[i] = apply_swaps_window(prev, v, next, mp, mc, mn);
+        }
+        if (tid == 0) p.applied_epoch[static_cast<size_t>(real) * d.W + w] = epoch;
+    }
     if (tid == 0) {
         sw[d.N] = 0;
         pl[2 * d.N] = 0;
@@ -544,7 +666,7 @@ __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_en
     if (do_sweep) {
         // Site records stream from global memory three passes ahead of their use (four rotating
         // register buffers, loop unrolled by four so no buffer is ever copied).
-        const int dbg = STAMPS ? (with_energy >> 8) : 0; // diagnostic build only
+        const int dbg = STAMPS ? (with_energy >> 8) : 0; // diagnostic build only (PEAPODS_DBG)
         // pass_start[] lives in two VGPRs (lane l holds entries l and 64 + l); a pass boundary is
         // then one v_readlane away instead of a scalar-cache round trip in front of every fetch.
         const uint32_t ps_lo = p.pass_start[min(tid & 63u, d.n_passes)];
@@ -556,7 +678,7 @@ __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_en
         };
         auto fetch = [&](uint32_t pass) -> uint4 {
             if (pass >= d.n_passes) return make_uint4(0, 0, 0, 0);
-            if (STAMPS && (dbg & 2)) return make_uint4(tid * 4, tid * 4, tid * 4, tid * 4);
+            if (dbg & 2) return make_uint4(tid * 4, tid * 4, tid * 4, tid * 4);
             const uint32_t pos = boundary(pass) + tid;
             return rec[pos < boundary(pass + 1) ? pos : d.N]; // dummy record when idle
         };
@@ -570,7 +692,7 @@ __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_en
             const uint2 lv =
                 *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(pl) + 2 * r.site);
             uint32_t acc;
-            if (STAMPS && (dbg & 1))
+            if (dbg & 1)
                 acc = nb[0] ^ nb[1] ^ nb[2] ^ nb[3] ^ nb[4] ^ nb[5] ^ lv.x ^ lv.y;
             else if (MODE == 0)
                 acc = accept_mask(s, nb, r.jm, lv.x, lv.y);
@@ -578,28 +700,43 @@ __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_en
                 acc = accept_mask_dense<MODE == 0 ? 1 : MODE>(s, nb, r.jm, lv.x, lv.y);
             *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(sw) + r.site) =
                 s ^ (acc & valid_bits);
-            if (!(STAMPS && (dbg & 4))) lds_barrier();
+            if (!(dbg & 4)) lds_barrier();
         };
-        uint4 b0 = fetch(0), b1 = fetch(1), b2 = fetch(2), b3;
-        for (uint32_t pass = 0; pass < d.n_passes; pass += 4) {
-            b3 = fetch(pass + 3);
+        // eight rotating buffers: a record is requested seven passes (about 3 us) before its use
+        uint4 b0 = fetch(0), b1 = fetch(1), b2 = fetch(2), b3 = fetch(3), b4 = fetch(4),
+              b5 = fetch(5), b6 = fetch(6), b7;
+        const uint32_t n_run = (dbg & 8) ? 0u : d.n_passes;
+        for (uint32_t pass = 0; pass < n_run; pass += 8) {
+            b7 = fetch(pass + 7);
             run(b0);
-            if (pass + 1 >= d.n_passes) break;
-            b0 = fetch(pass + 4);
+            if (pass + 1 >= n_run) break;
+            b0 = fetch(pass + 8);
             run(b1);
-            if (pass + 2 >= d.n_passes) break;
-            b1 = fetch(pass + 5);
+            if (pass + 2 >= n_run) break;
+            b1 = fetch(pass + 9);
             run(b2);
-            if (pass + 3 >= d.n_passes) break;
-            b2 = fetch(pass + 6);
+            if (pass + 3 >= n_run) break;
+            b2 = fetch(pass + 10);
             run(b3);
+            if (pass + 4 >= n_run) break;
+            b3 = fetch(pass + 11);
+            run(b4);
+            if (pass + 5 >= n_run) break;
+            b4 = fetch(pass + 12);
+            run(b5);
+            if (pass + 6 >= n_run) break;
+            b5 = fetch(pass + 13);
+            run(b6);
+            if (pass + 7 >= n_run) break;
+            b6 = fetch(pass + 14);
+            run(b7);
         }
         PA_STAMP(2)
-        for (uint32_t i = tid; i < d.N; i += 256) Sg[i] = sw[i];
+        for (uint32_t i = tid; i < d.N; i += 256) Sout[i] = sw[i];
     }
     PA_STAMP(3)
 
-    if (with_energy) {
+    if (with_energy & 1) {
         uint32_t c[3][8];
 #pragma unroll
         for (int s = 0; s < 3; ++s)
@@ -745,7 +882,6 @@ __global__ __launch_bounds__(256) void k_overlap(SimDims d, DevPtrs p) {
 //      columns of the tile, and the slot cursors are permuted accordingly.
 // ---------------------------------------------------------------------------
 struct MeasureLds {
-    uint32_t *tile;    // [W][N]
     uint32_t *scratch; // [17][48]
     int32_t *dot_spin; // [n_sys]
     int32_t *dot_link; // [n_sys]
@@ -761,8 +897,7 @@ struct MeasureLds {
 };
 
 __host__ __device__ inline size_t measure_lds_words(const SimDims &d) {
-    // the tile is only needed to exchange bit columns after a tempering swap (not built for big)
-    return (d.big ? 0 : static_cast<size_t>(d.N) * d.W) + 17 * 48 + 7 * static_cast<size_t>(d.n_sys) +
+    return 17 * 48 + 7 * static_cast<size_t>(d.n_sys) +
            2 * static_cast<size_t>(d.n_edges) + 2 * static_cast<size_t>(d.W) + 4;
 }
 
@@ -775,7 +910,6 @@ __global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams
     MeasureLds m;
     {
         uint32_t *q = lds;
-        m.tile = q; q += d.big ? 0 : static_cast<size_t>(d.N) * d.W;
         m.scratch = q; q += 17 * 48;
         m.dot_spin = reinterpret_cast<int32_t *>(q); q += d.n_sys;
         m.dot_link = reinterpret_cast<int32_t *>(q); q += d.n_sys;
@@ -790,14 +924,11 @@ __global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams
         m.flags = q;
     }
     const uint32_t real = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
-    uint32_t *Sg = p.S + static_cast<size_t>(real) * d.N * d.W;
-    const size_t tile_words = static_cast<size_t>(d.N) * d.W;
     int32_t *Eg = p.Esum + static_cast<size_t>(real) * d.n_sys;
     int32_t *Mg = p.Msum + static_cast<size_t>(real) * d.n_sys;
     uint32_t *sidg = p.system_ids + static_cast<size_t>(real) * d.n_sys;
     uint32_t *sofg = p.slot_of + static_cast<size_t>(real) * d.n_sys;
 
-    const bool tile_loaded = false;
     (void)do_overlap;
     for (uint32_t k = tid; k < d.n_sys; k += nthreads) {
         m.E[k] = Eg[k];
@@ -1014,28 +1145,11 @@ __global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams
         store_cursor(p.cursor, real, d.SP, final_slot, st);
     }
     PA_STAMP(5)
-    if (!any_swap) return;
-    // exchange bit columns (k, k+1) for every set mask bit k; round 0 then round 1
-    if (!tile_loaded) {
-        copy_to_lds(m.tile, Sg, static_cast<uint32_t>(tile_words), tid, nthreads);
-        __syncthreads();
-    }
-    for (uint32_t i = tid; i < d.N; i += nthreads) {
-        for (int round = 0; round < 2; ++round) {
-            uint32_t carry_t = 0; // bit 31 of the previous word's t
-            uint32_t v = m.tile[i];
-            for (uint32_t w = 0; w < d.W; ++w) {
-                const uint32_t next = (w + 1 < d.W) ? m.tile[(w + 1) * d.N + i] : 0u;
-                const uint32_t shr1 = (v >> 1) | (next << 31);
-                const uint32_t t = (v ^ shr1) & m.masks[round * d.W + w];
-                m.tile[w * d.N + i] = v ^ t ^ ((t << 1) | carry_t);
-                carry_t = t >> 31;
-                v = next;
-            }
-        }
-    }
-    __syncthreads();
-    for (size_t i = tid; i < tile_words; i += nthreads) Sg[i] = m.tile[i];
+    // The accepted swaps exchange adjacent bit columns (k, k+1) of the tile, round 0 then round 1.
+    // The exchange itself is deferred: the masks are published and the next k_sweep applies them
+    // while it loads its word (k_apply_swaps materialises them for every other reader).
+    if (tid < 2 * d.W) p.swap_masks[static_cast<size_t>(real) * 2 * d.W + tid] = m.masks[tid];
+    if (tid == 0 && any_swap) p.swap_epoch[real] += 1;
     PA_STAMP(6)
 }
 
@@ -1571,6 +1685,12 @@ hipError_t launch_sweep_stamped(const SimDims &d, const DevPtrs &p, unsigned lon
                            1 | (std::getenv("PEAPODS_DBG") ? std::atoi(std::getenv("PEAPODS_DBG")) << 8 : 0), 1, stamps);
     else
         hipLaunchKernelGGL((k_sweep<true, 0>), grid, block, sweep_lds_bytes(d), stream, d, p, 1, 1, stamps);
+    return hipGetLastError();
+}
+
+hipError_t launch_apply_swaps(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
+    hipLaunchKernelGGL(k_apply_swaps, dim3((d.N + 255) / 256, d.n_real), dim3(256), 0, stream, d, p);
+    hipLaunchKernelGGL(k_mark_applied, dim3((d.n_real * d.W + 255) / 256), dim3(256), 0, stream, d, p);
     return hipGetLastError();
 }
 

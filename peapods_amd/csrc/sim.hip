@@ -70,6 +70,7 @@ struct pa_sim {
     // bookkeeping of the last sample()
     uint64_t n_recorded = 0;
     bool overlap_collected = false;
+    bool swaps_pending = false; // a tempering event ran after the last sweep (deferred bit-column swaps)
     std::atomic<bool> interrupt{false};
     std::string error;
     // Realisations are independent, so the sweep pipeline runs as several interleaved groups of
@@ -206,6 +207,10 @@ int seed_state(pa_sim *sim, uint64_t seed) {
     PA_HIP(sim, hipMemsetAsync(sim->p.edge_att, 0, sizeof(uint64_t) * d.n_real * d.n_edges, sim->stream));
     PA_HIP(sim, hipMemsetAsync(sim->p.edge_acc, 0, sizeof(uint64_t) * d.n_real * d.n_edges, sim->stream));
     PA_HIP(sim, hipMemsetAsync(sim->p.round_trips, 0, sizeof(uint64_t) * d.n_real * d.n_sys, sim->stream));
+    PA_HIP(sim, hipMemsetAsync(sim->p.swap_epoch, 0, sizeof(uint32_t) * d.n_real, sim->stream));
+    PA_HIP(sim, hipMemsetAsync(sim->p.applied_epoch, 0, sizeof(uint32_t) * d.n_real * d.W, sim->stream));
+    PA_HIP(sim, hipMemsetAsync(sim->p.swap_masks, 0, sizeof(uint32_t) * d.n_real * 2 * d.W, sim->stream));
+    sim->swaps_pending = false;
     sim->next_parity = 0;
     // Realization::new computes the initial energies (realization.rs:196-197)
     PA_HIP(sim, launch_sweep(sim->d, sim->p, true, false, sim->stream));
@@ -232,6 +237,9 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     const size_t tile_words = static_cast<size_t>(d.N) * d.W;
     const size_t bins = static_cast<size_t>(d.n_temps) * (d.N + 1);
     q.S += tile_words * r0;
+    q.S_next += tile_words * r0;
+    q.swap_epoch += r0;
+    q.applied_epoch += static_cast<size_t>(d.W) * r0;
     q.planes += tile_words * r0;
     q.cursor += static_cast<size_t>(8) * d.SP * r0;
     q.system_ids += static_cast<size_t>(d.n_sys) * r0;
@@ -263,7 +271,7 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
 }
 
 int make_groups(pa_sim *sim) {
-    uint32_t n_groups = 1; // more streams did not pay on MI355X / ROCm 7.2
+    uint32_t n_groups = 2; // two interleaved groups overlap a little (5 %); three or more collapse
     if (const char *env = std::getenv("PEAPODS_STREAMS")) {
         const long v = std::strtol(env, nullptr, 10);
         if (v >= 1 && v <= 16) n_groups = static_cast<uint32_t>(v);
@@ -280,6 +288,32 @@ int make_groups(pa_sim *sim) {
         PA_HIP(sim, hipEventCreateWithFlags(&grp.done, hipEventDisableTiming));
         sim->groups.push_back(grp);
     }
+    return PA_OK;
+}
+
+// k_sweep reads S and writes S_next: exchange the roles everywhere after every sweep launch.
+void toggle_spin_buffers(pa_sim *sim) {
+    if (sim->d.big) return;
+    std::swap(sim->p.S, sim->p.S_next);
+    for (auto &g : sim->groups) std::swap(g.p.S, g.p.S_next);
+}
+
+// Sweep of one group (and whatever has to precede it): on the large path pending tempering swaps
+// are materialised first; the LDS kernel applies them itself while loading.
+hipError_t enqueue_sweep(pa_sim *sim, const SimDims &d, const DevPtrs &p, bool with_energy,
+                         hipStream_t stream) {
+    if (d.big && sim->swaps_pending) {
+        hipError_t e = launch_apply_swaps(d, p, stream);
+        if (e != hipSuccess) return e;
+    }
+    return launch_sweep(d, p, with_energy, true, stream);
+}
+
+// Make S consistent for every reader other than k_sweep (getters, standalone phases, end of run).
+int flush_swaps(pa_sim *sim) {
+    if (!sim->swaps_pending) return PA_OK;
+    PA_HIP(sim, launch_apply_swaps(sim->d, sim->p, sim->stream));
+    sim->swaps_pending = false;
     return PA_OK;
 }
 
@@ -316,10 +350,9 @@ std::string validate_text(const pa_sample_config *cfg, uint64_t n_replicas, int 
 
 int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     const SimDims &d = sim->d;
-    if (d.big && (cfg->pt_interval > 0 || cfg->overlap_cluster_interval > 0))
+    if (d.big && cfg->overlap_cluster_interval > 0)
         return fail(sim, PA_ERR_UNSUPPORTED,
-                    "parallel tempering and overlap-cluster moves are not built for lattices above "
-                    "12000 sites yet");
+                    "overlap-cluster moves are not built for lattices above 12000 sites yet");
     if (cfg->overlap_cluster_interval > 0 && d.n_temps * d.n_pairs > 1024)
         return fail(sim, PA_ERR_UNSUPPORTED, "overlap-cluster moves support at most 1024 pairs per realisation");
     int rc = zero_accumulators(sim);
@@ -342,7 +375,11 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         const bool pt_this = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0; // :486-488
         for (auto &g : sim->groups) {
             PA_HIP(sim, launch_rng(g.d, g.p, g.stream));                                // :412-432
-            PA_HIP(sim, launch_sweep(g.d, g.p, record || pt_this, true, g.stream));     // :492-509
+            PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, record || pt_this, g.stream));     // :492-509
+        }
+        sim->swaps_pending = false;
+        toggle_spin_buffers(sim);
+        for (auto &g : sim->groups) {
             if (record && want_overlap) PA_HIP(sim, launch_overlap(g.d, g.p, g.stream)); // :527-529
             const bool oc_this = cfg->overlap_cluster_interval > 0 &&
                                  sweep_id % cfg->overlap_cluster_interval == 0; // :598-599
@@ -368,6 +405,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                 }
             }
         }
+        if (pt_this) sim->swaps_pending = true;
         if (record) sim->n_recorded += 1;
         if (cfg->overlap_cluster_interval > 0 && sweep_id % cfg->overlap_cluster_interval == 0)
             overlap_call_count += 1; // :744
@@ -382,7 +420,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         (void)hipStreamSynchronize(sim->stream);
         return status;
     }
-    return PA_OK;
+    return flush_swaps(sim); // the last tempering event's bit-column swaps become visible in S
 }
 
 } // namespace
@@ -701,6 +739,12 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         if (e == hipSuccess) e = r;
     };
     ok(bufs.alloc(&p.S, tile_words * d.n_real));
+    if (d.big)
+        p.S_next = p.S; // the large path sweeps in place
+    else
+        ok(bufs.alloc(&p.S_next, tile_words * d.n_real));
+    ok(bufs.alloc(&p.swap_epoch, static_cast<size_t>(d.n_real)));
+    ok(bufs.alloc(&p.applied_epoch, static_cast<size_t>(d.n_real) * d.W));
     ok(bufs.alloc(&p.planes, tile_words * d.n_real));
     ok(bufs.alloc(&p.cursor, static_cast<size_t>(d.n_real) * 8 * d.SP));
     ok(bufs.alloc(&p.system_ids, static_cast<size_t>(d.n_real) * d.n_sys));
@@ -837,7 +881,9 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
         PA_HIP(sim, hipEventRecord(ev[0], sim->stream));
         PA_HIP(sim, launch_rng(d, sim->p, sim->stream));
         PA_HIP(sim, hipEventRecord(ev[1], sim->stream));
-        PA_HIP(sim, launch_sweep(d, sim->p, record || pt_this, true, sim->stream));
+        PA_HIP(sim, enqueue_sweep(sim, d, sim->p, record || pt_this, sim->stream));
+        sim->swaps_pending = false;
+        toggle_spin_buffers(sim);
         PA_HIP(sim, hipEventRecord(ev[2], sim->stream));
         const bool measured = record || pt_this;
         if (measured) {
@@ -847,6 +893,7 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
                                        pt_this, sim->stream));
             if (pt_this && cfg->pt_schedule == PA_PT_FULL_LADDER)
                 sim->next_parity = 1 - sim->next_parity;
+            if (pt_this) sim->swaps_pending = true;
         }
         if (record) sim->n_recorded += 1;
         PA_HIP(sim, hipEventRecord(ev[3], sim->stream));
@@ -861,6 +908,9 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
     for (int k = 0; k < 3; ++k) ms_out[k] = count[k] ? total[k] / static_cast<double>(count[k]) : 0.0;
+    int rc_flush = flush_swaps(sim);
+    if (rc_flush) return rc_flush;
+    PA_HIP(sim, hipStreamSynchronize(sim->stream));
     return PA_OK;
 }
 
@@ -871,6 +921,7 @@ int pa_debug_sweep_stamps(pa_sim *sim, unsigned long long out[6]) {
     PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&dev), 6 * sizeof(unsigned long long)));
     PA_HIP(sim, launch_rng(sim->d, sim->p, sim->stream));
     PA_HIP(sim, launch_sweep_stamped(sim->d, sim->p, dev, sim->stream));
+    toggle_spin_buffers(sim);
     PA_HIP(sim, hipStreamSynchronize(sim->stream));
     PA_HIP(sim, hipMemcpy(out, dev, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     (void)hipFree(dev);
@@ -884,9 +935,12 @@ int pa_debug_measure_stamps(pa_sim *sim, unsigned long long out[7]) {
     PA_HIP(sim, hipMemset(dev, 0, 7 * sizeof(unsigned long long)));
     PA_HIP(sim, launch_rng(sim->d, sim->p, sim->stream));
     PA_HIP(sim, launch_sweep(sim->d, sim->p, true, true, sim->stream));
+    toggle_spin_buffers(sim);
     PA_HIP(sim, launch_overlap(sim->d, sim->p, sim->stream));
     PtParams pt{0, sim->next_parity, sim->hot_slot, sim->cold_slot};
     PA_HIP(sim, launch_measure_stamped(sim->d, sim->p, pt, dev, sim->stream));
+    sim->swaps_pending = true;
+    if (int rc = flush_swaps(sim)) return rc;
     PA_HIP(sim, hipStreamSynchronize(sim->stream));
     PA_HIP(sim, hipMemcpy(out, dev, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     (void)hipFree(dev);
@@ -897,28 +951,33 @@ int pa_sim_metropolis_sweep(pa_sim *sim, uint64_t n_sweeps) {
     PA_HIP(sim, hipSetDevice(sim->device));
     for (uint64_t k = 0; k < n_sweeps; ++k) {
         PA_HIP(sim, launch_rng(sim->d, sim->p, sim->stream));
-        PA_HIP(sim, launch_sweep(sim->d, sim->p, false, true, sim->stream));
+        PA_HIP(sim, enqueue_sweep(sim, sim->d, sim->p, false, sim->stream));
+        sim->swaps_pending = false;
+        toggle_spin_buffers(sim);
     }
     return pa_sim_synchronize(sim);
 }
 
 int pa_sim_compute_energies(pa_sim *sim) {
     PA_HIP(sim, hipSetDevice(sim->device));
+    if (int rc = flush_swaps(sim)) return rc;
     PA_HIP(sim, launch_sweep(sim->d, sim->p, true, false, sim->stream));
     return pa_sim_synchronize(sim);
 }
 
 int pa_sim_parallel_tempering(pa_sim *sim, int32_t schedule) {
-    if (sim->d.big)
-        return fail(sim, PA_ERR_UNSUPPORTED, "parallel tempering is not built for lattices above 12000 sites yet");
+
     if (schedule != PA_PT_SINGLE_RANDOM_EDGE && schedule != PA_PT_FULL_LADDER)
         return fail(sim, PA_ERR_INVALID,
                     "unknown pt_schedule, expected 'single_random_edge' or 'full_ladder'");
     PA_HIP(sim, hipSetDevice(sim->device));
+    if (int rc = flush_swaps(sim)) return rc;
     PA_HIP(sim, launch_sweep(sim->d, sim->p, true, false, sim->stream));
     PtParams pt{schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
     PA_HIP(sim, launch_measure(sim->d, sim->p, pt, false, false, false, true, sim->stream));
     if (schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
+    sim->swaps_pending = true;
+    if (int rc = flush_swaps(sim)) return rc;
     return pa_sim_synchronize(sim);
 }
 
@@ -926,6 +985,7 @@ int pa_sim_overlap_dots(pa_sim *sim, int64_t *dot_spin, int64_t *dot_link) {
     const SimDims &d = sim->d;
     if (d.n_pairs == 0) return fail(sim, PA_ERR_INVALID, "overlap needs n_replicas >= 2");
     PA_HIP(sim, hipSetDevice(sim->device));
+    if (int rc = flush_swaps(sim)) return rc;
     PA_HIP(sim, launch_overlap(d, sim->p, sim->stream));
     const size_t count = static_cast<size_t>(d.n_real) * d.n_pairs * d.n_temps;
     std::vector<int32_t> a, b;
@@ -949,6 +1009,7 @@ uint64_t pa_sim_n_systems(const pa_sim *sim) { return sim->d.n_sys; }
 int pa_sim_get_spins(pa_sim *sim, uint64_t realization, int8_t *out) {
     PA_CHECK_REAL(sim, realization);
     PA_HIP(sim, hipSetDevice(sim->device));
+    if (int rc = flush_swaps(sim)) return rc;
     const SimDims &d = sim->d;
     std::vector<uint32_t> S, slot_of;
     int rc;

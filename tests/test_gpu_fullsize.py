@@ -132,5 +132,13 @@ def test_large_lattice_path_matches_oracle(oracle, shape, kind, n_temps, n_rep, 
     for r in range(n_dis):
         np.testing.assert_array_equal(gpu.get_spins(r), cpu.get_spins(r))
         np.testing.assert_array_equal(gpu.get_energies(r), cpu.get_energies(r))
-    with pytest.raises(NotImplementedError):
-        gpu.sample(2, "metropolis", pt_interval=1)
+    # tempering on the large path too (swaps are applied to the global-memory tile)
+    kw = dict(pt_interval=1, pt_schedule="full_ladder", warmup_ratio=0.0)
+    a = gpu.sample(3, "metropolis", **kw)
+    b = cpu.sample(3, "metropolis", n_threads=8, **kw)
+    np.testing.assert_array_equal(a["energies"], b["energies"])
+    np.testing.assert_array_equal(a["per_disorder"]["parallel_tempering"]["edge_acceptances"],
+                                  b["per_disorder"]["parallel_tempering"]["edge_acceptances"])
+    for r in range(n_dis):
+        np.testing.assert_array_equal(gpu.get_spins(r), cpu.get_spins(r))
+        np.testing.assert_array_equal(gpu.get_system_ids(r), cpu.get_system_ids(r))

@@ -33,7 +33,6 @@ struct SimDims {
     uint32_t nn;         // forward directions z' (<= 3)
     uint32_t B;          // RNG blocks per sweep
     uint32_t BS;         // sites per RNG block
-    uint32_t BP;         // ceil(B / 2): block pairs (one wave handles two blocks x 32 slots)
     uint32_t n_passes;   // schedule passes: dependency levels cut into chunks of <= 256 sites
     uint32_t MW;         // ceil(N / 32): words of the per-site parity bitmap
     uint32_t has_odd;    // 1 if any site has an odd number of non-zero bonds

@@ -3,8 +3,10 @@
 //   k_rng        reference-exact random stream -> acceptance-level bit planes
 //   k_sweep      level-ordered Metropolis sweep on 32 slots per word (+ energy / magnetisation)
 //   k_overlap    replica-overlap and link-overlap dot products
-//   k_accumulate running f64 statistics, P(q) histograms
-//   k_pt         parallel-tempering swaps (bit-column exchange)
+//   k_measure    running f64 statistics, P(q) histograms, parallel tempering
+//   k_houdayer / k_jorg   overlap-cluster moves
+//   k_*_big      the same algorithm for lattices that do not fit the LDS
+//   k_apply_swaps         materialises deferred tempering swaps
 //
 // Decisions are integer throughout (24-bit draw < table threshold); floating
 // point appears only where the reference has it (one f32 division per
@@ -48,27 +50,6 @@ __device__ __forceinline__ void store_cursor(uint32_t *cursor, uint32_t real, ui
                                              uint32_t slot, const uint32_t st[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) cursor[(static_cast<size_t>(real) * 8 + j) * SP + slot] = st[j];
-}
-
-// state <- M * state with M given as nibble tables [64][16][8].
-__device__ __forceinline__ void jump_state(uint32_t st[8], const uint32_t *__restrict__ tab) {
-    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int p = 0; p < 64; ++p) {
-        const uint32_t nib = (st[p >> 3] >> ((p & 7) * 4)) & 15u;
-        const uint4 *e = reinterpret_cast<const uint4 *>(tab + (p * 16 + nib) * 8);
-        const uint4 a = e[0], b = e[1];
-        acc[0] ^= a.x;
-        acc[1] ^= a.y;
-        acc[2] ^= a.z;
-        acc[3] ^= a.w;
-        acc[4] ^= b.x;
-        acc[5] ^= b.y;
-        acc[6] ^= b.z;
-        acc[7] ^= b.w;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) st[j] = acc[j];
 }
 
 // ---------------------------------------------------------------------------

@@ -585,7 +585,6 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     d.B = std::max<uint32_t>(1, (d.N + target_block / 2) / target_block);
     d.BS = (d.N + d.B - 1) / d.B;
     d.B = (d.N + d.BS - 1) / d.BS;
-    d.BP = (d.B + 1) / 2;
     d.MW = (d.N + 31) / 32;
     // the LDS kernels hold a word's N sites (sweep) / the W-word tile (tempering swaps) on chip
     d.big = (d.N > 12000 || static_cast<size_t>(d.N) * d.W * 4 > 150000) ? 1 : 0;

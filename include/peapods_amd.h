@@ -12,6 +12,7 @@
  *        <- PyO3 class IsingSimulation {new, reset, sample, get_spins}, src/lib.rs:104-634
  *           (which wraps spin_sim::{Lattice, Realization, run_sweep_parallel}, src/lib.rs:9-10)
  *   pa_sim_metropolis_sweep      <- mcmc::sweep::metropolis_sweep,          ss/mcmc/sweep.rs:220-229
+ *   pa_sim_gibbs_sweep           <- mcmc::sweep::gibbs_sweep,               ss/mcmc/sweep.rs:262-284
  *   pa_sim_compute_energies      <- spins::energy::compute_energies_and_magnetizations_into,
  *                                                                          ss/spins/energy.rs:59-65
  *   pa_sim_parallel_tempering    <- mcmc::tempering::parallel_tempering(_full_ladder) as driven by
@@ -124,6 +125,7 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
 
 /* ---- phase-level entry points (inner boundary; state stays on the device) -- */
 int pa_sim_metropolis_sweep(pa_sim *sim, uint64_t n_sweeps);
+int pa_sim_gibbs_sweep(pa_sim *sim, uint64_t n_sweeps);
 int pa_sim_compute_energies(pa_sim *sim);
 int pa_sim_parallel_tempering(pa_sim *sim, int32_t schedule);
 /* dot_spin/dot_link: [n_realizations][n_pairs][n_temps] i64, pairs (2p, 2p+1) at slot t */
@@ -177,6 +179,11 @@ void pa_xoshiro_jump(const uint64_t in[4], uint64_t n_steps, uint64_t out[4]);
 int pa_build_metropolis_table(const float *couplings, uint64_t n_couplings,
                               const float *temperatures, uint64_t n_temperatures,
                               uint64_t n_neighbors, uint32_t *out);
+/* Gibbs (heat-bath) counterpart for unit couplings: out[t * (4z'+1) + (e + 2z')] = number of 24-bit
+ * draws k with e >= (T/2) ln(u / (1 - u)), u = k * 2^-24 (ss/mcmc/sweep.rs:262-284 on the grid of
+ * gen::<f32>()).  PA_ERR_UNSUPPORTED outside the table's domain. */
+int pa_build_gibbs_table(const float *couplings, uint64_t n_couplings, const float *temperatures,
+                         uint64_t n_temperatures, uint64_t n_neighbors, uint32_t *out);
 /* Dependency levels of the typewriter sweep: level[i] for every site; returns the level count.
  * Sites of one level are mutually independent; executing levels in order reproduces the
  * reference's sequential site order exactly. */

@@ -220,6 +220,9 @@ class IsingSimulation:
     def metropolis_sweep(self, n_sweeps=1):
         self._check(self._lib.pa_sim_metropolis_sweep(self._handle, int(n_sweeps)))
 
+    def gibbs_sweep(self, n_sweeps=1):
+        self._check(self._lib.pa_sim_gibbs_sweep(self._handle, int(n_sweeps)))
+
     def compute_energies(self):
         self._check(self._lib.pa_sim_compute_energies(self._handle))
 

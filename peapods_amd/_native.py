@@ -60,6 +60,7 @@ SIGNATURES = {
     "pa_sim_request_interrupt": (None, [_vp]),
     "pa_sim_profile_kernels": (C.c_int, [_vp, C.POINTER(PaSampleConfig), _u64, _vp]),
     "pa_sim_metropolis_sweep": (C.c_int, [_vp, _u64]),
+    "pa_sim_gibbs_sweep": (C.c_int, [_vp, _u64]),
     "pa_sim_compute_energies": (C.c_int, [_vp]),
     "pa_sim_parallel_tempering": (C.c_int, [_vp, _i32]),
     "pa_sim_overlap_dots": (C.c_int, [_vp, _vp, _vp]),
@@ -83,6 +84,7 @@ SIGNATURES = {
     "pa_xoshiro_state": (None, [_u64, _u64, _vp]),
     "pa_xoshiro_jump": (None, [_vp, _u64, _vp]),
     "pa_build_metropolis_table": (C.c_int, [_vp, _u64, _vp, _u64, _u64, _vp]),
+    "pa_build_gibbs_table": (C.c_int, [_vp, _u64, _vp, _u64, _u64, _vp]),
     "pa_build_sweep_levels": (_u64, [_u32, _vp, _u32, _vp, _vp]),
     "pa_aggregate_mean": (None, [_vp, _u64, _u64, _vp]),
     "pa_aggregate_sum_u64": (None, [_vp, _u64, _u64, _vp]),

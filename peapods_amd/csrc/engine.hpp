@@ -46,11 +46,14 @@ struct DevPtrs {
     uint32_t *S;             // [n_real][W][N] current spins
     uint32_t *S_next;        // [n_real][W][N] k_sweep writes here (double buffer; = S on the large path)
     uint2 *planes;           // [n_real][W][N]  .x/.y = bit 0/1 of the acceptance level
+    uint32_t *planes_hi;     // [n_real][W][N]  bit 2 of the acceptance level (Gibbs sweeps; allocated on first use)
     uint32_t *cursor;        // [n_real][8][SP]  xoshiro state of the system in each slot
     uint32_t *system_ids;    // [n_real][n_sys]  slot -> system
     uint32_t *slot_of;       // [n_real][n_sys]  system -> slot
     const uint32_t *thr;     // [2][2][3][n_temps] thresholds: even set (dE=-2,-4,-6), odd set (-1,-3,-5);
                              //   second copy shifted left by 8 (valid when thr_preshifted)
+    const uint32_t *thr_gibbs; // [2][7][n_temps] Gibbs thresholds, falling: even set dE = 2z', 2z'-2, ..;
+                             //   odd set dE = 2z'-1, 2z'-3, ..; unused entries 0
     const uint32_t *mpar;    // [n_real][MW]     parity of the non-zero bond count per site
     const uint4 *rec;        // [n_real][N + 1] schedule order (+ dummy), 16-bit fields holding 4 * index
                              //   (large lattices: two uint4 per site = site, f0,b0,f1,b1,f2,b2, jmeta):
@@ -92,9 +95,9 @@ struct PtParams {
 };
 
 // All launchers enqueue on `stream` and return the hipGetLastError() of the launch.
-hipError_t launch_rng(const SimDims &d, const DevPtrs &p, hipStream_t stream);
+hipError_t launch_rng(const SimDims &d, const DevPtrs &p, bool gibbs, hipStream_t stream);
 hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,
-                        hipStream_t stream);
+                        bool gibbs, hipStream_t stream);
 hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 hipError_t launch_apply_swaps(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 hipError_t launch_houdayer(const SimDims &d, const DevPtrs &p, hipStream_t stream);
@@ -107,7 +110,7 @@ hipError_t launch_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt
                           bool do_accum, bool accum_overlap, bool do_pt, hipStream_t stream);
 hipError_t launch_measure_stamped(const SimDims &d, const DevPtrs &p, const PtParams &pt,
                                   unsigned long long *stamps, hipStream_t stream);
-size_t sweep_lds_bytes(const SimDims &d);
+size_t sweep_lds_bytes(const SimDims &d, bool gibbs);
 size_t measure_lds_bytes(const SimDims &d);
 hipError_t configure_kernels(const SimDims &d);
 

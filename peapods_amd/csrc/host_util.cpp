@@ -1,7 +1,9 @@
 #include "host_util.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <thread>
 
 namespace pa {
 
@@ -199,6 +201,72 @@ bool build_metropolis_table(const float *couplings, uint64_t n_couplings, const 
     for (uint64_t t = 0; t < n_temps; ++t)
         for (int32_t e = -offset; e <= offset; ++e)
             out[t * width + static_cast<uint64_t>(e + offset)] = accepted_count(temps[t], e);
+    return true;
+}
+
+namespace {
+
+template <typename F> std::vector<float> fill_uniform_table(F fn) {
+    std::vector<float> table(1u << 24);
+    const unsigned n_threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> workers;
+    for (unsigned k = 0; k < n_threads; ++k)
+        workers.emplace_back([&, k] {
+            const uint32_t lo = static_cast<uint32_t>((1ull << 24) * k / n_threads);
+            const uint32_t hi = static_cast<uint32_t>((1ull << 24) * (k + 1) / n_threads);
+            for (uint32_t v = lo; v < hi; ++v) table[v] = fn(static_cast<float>(v) / 16777216.0f);
+        });
+    for (auto &t : workers) t.join();
+    return table;
+}
+
+} // namespace
+
+const std::vector<float> &uniform_log_table() {
+    static const std::vector<float> table = fill_uniform_table([](float u) { return logf(u); });
+    return table;
+}
+
+const std::vector<float> &uniform_logit_table(bool *monotone) {
+    static const std::vector<float> table =
+        fill_uniform_table([](float u) { return logf(u / (1.0f - u)); });
+    static const bool rising = [] {
+        for (size_t k = 1; k < table.size(); ++k)
+            if (table[k] < table[k - 1]) return false;
+        return true;
+    }();
+    if (monotone) *monotone = rising;
+    return table;
+}
+
+bool build_gibbs_table(const float *couplings, uint64_t n_couplings, const float *temps,
+                       uint64_t n_temps, uint64_t n_neighbors, std::vector<uint32_t> &out) {
+    for (uint64_t i = 0; i < n_couplings; ++i) {
+        const float c = couplings[i];
+        if (!(c == -1.0f || c == 0.0f || c == 1.0f)) return false;
+    }
+    for (uint64_t t = 0; t < n_temps; ++t)
+        if (!(std::isfinite(temps[t]) && temps[t] / 2.0f > 0.0f)) return false;
+    bool monotone = false;
+    const std::vector<float> &logit = uniform_logit_table(&monotone);
+    if (!monotone) return false;
+    const int32_t offset = static_cast<int32_t>(2 * n_neighbors);
+    const uint64_t width = 4 * n_neighbors + 1;
+    out.resize(n_temps * width);
+    for (uint64_t t = 0; t < n_temps; ++t) {
+        const float half_t = temps[t] / 2.0f;
+        for (int32_t e = -offset; e <= offset; ++e) {
+            uint32_t lo = 0, hi = 1u << 24;
+            while (lo < hi) {
+                const uint32_t mid = lo + (hi - lo) / 2;
+                if (static_cast<float>(e) >= half_t * logit[mid])
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            out[t * width + static_cast<uint64_t>(e + offset)] = lo;
+        }
+    }
     return true;
 }
 

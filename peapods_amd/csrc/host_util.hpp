@@ -69,6 +69,20 @@ bool build_metropolis_table(const float *couplings, uint64_t n_couplings, const 
                             uint64_t n_temps, uint64_t n_neighbors, std::vector<uint32_t> &out);
 uint32_t accepted_count(float temperature, int32_t energy_change);
 
+// ln(u) and ln(u / (1 - u)) for every 24-bit uniform u = k * 2^-24, computed once per process
+// with the host libm (the reference's f32::ln; sweep.rs:256,279-282, tempering.rs:89).
+// *monotone tells whether the table never decreases with k (then "e >= (T/2) * table[k]" is a
+// prefix of the draws and a threshold describes it exactly).
+const std::vector<float> &uniform_log_table();
+const std::vector<float> &uniform_logit_table(bool *monotone);
+
+// Gibbs counterpart of the table for unit couplings: out[t * (4z'+1) + (e + 2z')] = number of
+// draws k with e >= (T/2) ln(u / (1 - u)) (sweep.rs:262-284 evaluated on the 2^24 grid).
+// Returns false when the couplings / temperatures are outside the table's domain or the
+// predicate is not a prefix of the draws.
+bool build_gibbs_table(const float *couplings, uint64_t n_couplings, const float *temps,
+                       uint64_t n_temps, uint64_t n_neighbors, std::vector<uint32_t> &out);
+
 // level[i] = 1 + max(level[j]) over neighbours j < i (0 if none).  Returns level count.
 uint32_t build_levels(const LatticeTables &lat, std::vector<uint32_t> &level);
 

@@ -151,6 +151,42 @@ __device__ __forceinline__ void rng_chunk32(Rng32 &rng, uint32_t ca0, uint32_t c
     (rng_step<JJ, PRESHIFTED>(rng, ca0, ca1, ca2, keep0, keep1), ...);
 }
 
+// Gibbs: seven thresholds c[0] >= ... >= c[6] (dE = e_max, e_max - 2, ...; checked on the host),
+// so the comparisons are nested and the level L = #{j : draw < c[j]} in 0..7 has the bits
+//   bit2 = b3,  bit1 = b1 ^ b3 ^ b5,  bit0 = b0 ^ ... ^ b6      (b_j = draw < c[j]).
+__device__ __forceinline__ void gibbs_level_ballots(uint32_t draw, const uint32_t c[7],
+                                                    unsigned long long &m0, unsigned long long &m1,
+                                                    unsigned long long &m2) {
+    const unsigned long long b0 = __ballot(draw < c[0]), b1 = __ballot(draw < c[1]);
+    const unsigned long long b2 = __ballot(draw < c[2]), b3 = __ballot(draw < c[3]);
+    const unsigned long long b4 = __ballot(draw < c[4]), b5 = __ballot(draw < c[5]);
+    const unsigned long long b6 = __ballot(draw < c[6]);
+    m2 = b3;
+    m1 = b1 ^ b3 ^ b5;
+    m0 = b0 ^ b1 ^ b2 ^ b3 ^ b4 ^ b5 ^ b6;
+}
+
+template <int JJ>
+__device__ __forceinline__ void rng_step_gibbs(Rng32 &rng, const uint32_t c[7], uint32_t &keep0,
+                                               uint32_t &keep1, uint32_t &keep2) {
+    const uint32_t draw = rng.next_top() >> 8;
+    unsigned long long m0, m1, m2;
+    gibbs_level_ballots(draw, c, m0, m1, m2);
+    keep0 = park_in_lane<JJ>(keep0, static_cast<uint32_t>(m0));
+    keep0 = park_in_lane<JJ + 32>(keep0, static_cast<uint32_t>(m0 >> 32));
+    keep1 = park_in_lane<JJ>(keep1, static_cast<uint32_t>(m1));
+    keep1 = park_in_lane<JJ + 32>(keep1, static_cast<uint32_t>(m1 >> 32));
+    keep2 = park_in_lane<JJ>(keep2, static_cast<uint32_t>(m2));
+    keep2 = park_in_lane<JJ + 32>(keep2, static_cast<uint32_t>(m2 >> 32));
+}
+
+template <int... JJ>
+__device__ __forceinline__ void rng_chunk32_gibbs(Rng32 &rng, const uint32_t c[7], uint32_t &keep0,
+                                                  uint32_t &keep1, uint32_t &keep2,
+                                                  std::integer_sequence<int, JJ...>) {
+    (rng_step_gibbs<JJ>(rng, c, keep0, keep1, keep2), ...);
+}
+
 // ---------------------------------------------------------------------------
 // k_rng: workgroup = 4 waves that share ONE site block b (so one jump table,
 // staged in LDS); each wave serves two tile words: lanes 0-31 the 32 slots of
@@ -161,7 +197,9 @@ __device__ __forceinline__ void rng_chunk32(Rng32 &rng, uint32_t ca0, uint32_t c
 // words are parked in lane (site & 31) with v_writelane and stored 32 sites at
 // a time, fully coalesced.
 // ---------------------------------------------------------------------------
-template <bool PRESHIFTED>
+// GIBBS: seven thresholds per parity class and a third level plane (planes_hi); thresholds are
+// compared unshifted (a Gibbs threshold can be 2^24 = "every draw").
+template <bool PRESHIFTED, bool GIBBS>
 __global__ __launch_bounds__(256) void k_rng(SimDims d, DevPtrs p) {
     extern __shared__ uint32_t tab[]; // [64 * 16 * 8] (+ padding that caps workgroups per CU)
     const uint32_t block = blockIdx.x % d.B;
@@ -188,6 +226,56 @@ __global__ __launch_bounds__(256) void k_rng(SimDims d, DevPtrs p) {
     Rng32 rng;
     rng.load(st);
 
+    const uint32_t begin = block * d.BS;
+    const uint32_t len = min(d.BS, d.N - begin); // uniform over the workgroup
+    uint2 *planes = p.planes + static_cast<size_t>(tw_ok ? tw : 0) * d.N;
+    const uint32_t *mpar = p.mpar + static_cast<size_t>(real) * d.MW;
+
+    if (GIBBS) {
+        uint32_t ce[7] = {0, 0, 0, 0, 0, 0, 0}, co[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (active) {
+            const uint32_t t = slot % d.n_temps;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                ce[j] = p.thr_gibbs[(0 + j) * d.n_temps + t];
+                co[j] = p.thr_gibbs[(7 + j) * d.n_temps + t];
+            }
+        }
+        uint32_t *planes_hi = p.planes_hi + static_cast<size_t>(tw_ok ? tw : 0) * d.N;
+        for (uint32_t j0 = 0; j0 < len; j0 += 32) {
+            uint32_t keep0 = 0, keep1 = 0, keep2 = 0;
+            const uint32_t chunk = min(32u, len - j0);
+            if (chunk == 32 && !d.has_odd) {
+                rng_chunk32_gibbs(rng, ce, keep0, keep1, keep2, std::make_integer_sequence<int, 32>{});
+            } else {
+                for (uint32_t jj = 0; jj < chunk; ++jj) {
+                    const uint32_t site = begin + j0 + jj;
+                    const uint32_t draw = rng.next_top() >> 8;
+                    const bool odd = d.has_odd && ((mpar[site >> 5] >> (site & 31u)) & 1u);
+                    uint32_t c[7];
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) c[j] = odd ? co[j] : ce[j];
+                    unsigned long long m0, m1, m2;
+                    gibbs_level_ballots(draw, c, m0, m1, m2);
+                    if (bit == jj) {
+                        keep0 = half ? static_cast<uint32_t>(m0 >> 32) : static_cast<uint32_t>(m0);
+                        keep1 = half ? static_cast<uint32_t>(m1 >> 32) : static_cast<uint32_t>(m1);
+                        keep2 = half ? static_cast<uint32_t>(m2 >> 32) : static_cast<uint32_t>(m2);
+                    }
+                }
+            }
+            if (tw_ok && bit < chunk) {
+                planes[begin + j0 + bit] = make_uint2(keep0, keep1);
+                planes_hi[begin + j0 + bit] = keep2;
+            }
+        }
+        if (active && block == d.B - 1) {
+            rng.store(st);
+            store_cursor(p.cursor, real, d.SP, slot, st);
+        }
+        return;
+    }
+
     uint32_t ca0 = 0, ca1 = 0, ca2 = 0, cb0 = 0, cb1 = 0, cb2 = 0;
     if (active) {
         const uint32_t t = slot % d.n_temps;
@@ -199,10 +287,6 @@ __global__ __launch_bounds__(256) void k_rng(SimDims d, DevPtrs p) {
         cb1 = thr[4 * d.n_temps + t];
         cb2 = thr[5 * d.n_temps + t];
     }
-    const uint32_t begin = block * d.BS;
-    const uint32_t len = min(d.BS, d.N - begin); // uniform over the workgroup
-    uint2 *planes = p.planes + static_cast<size_t>(tw_ok ? tw : 0) * d.N;
-    const uint32_t *mpar = p.mpar + static_cast<size_t>(real) * d.MW;
 
     for (uint32_t j0 = 0; j0 < len; j0 += 32) {
         uint32_t keep0 = 0, keep1 = 0;
@@ -272,6 +356,38 @@ __device__ __forceinline__ uint32_t accept_mask(uint32_t s, const uint32_t nb[6]
     const uint32_t ge1 = t0 | t1 | hi, ge2 = t1 | hi, ge3 = (t0 & t1) | hi;
     const uint32_t h = (jm >> 12) & 3u;
     return h == 0 ? 0xFFFFFFFFu : (h == 1 ? ge1 : (h == 2 ? ge2 : ge3));
+}
+
+// Gibbs accept mask (heat-bath rule on the 2^24 grid, sweep.rs:262-284): L = number of the
+// parity class's thresholds the draw is below (3 planes), counted from dE = e_max = 2 z' (even m)
+// or 2 z' - 1 (odd m) downwards, so the accepted energy changes are the top L values and
+//   flip  <=>  2U - m >= e_max - 2 (L - 1)  <=>  U + L >= z' + 1 + floor(m / 2) =: h.
+// The comparison is the carry out of the 4-bit addition (U + L) + (16 - h).
+__device__ __forceinline__ uint32_t accept_mask_gibbs(uint32_t s, const uint32_t nb[6], uint32_t jm,
+                                                      uint32_t nn, uint32_t l0, uint32_t l1,
+                                                      uint32_t l2) {
+    uint32_t u[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const uint32_t neg = 0u - ((jm >> k) & 1u);
+        const uint32_t nz = 0u - ((jm >> (6 + k)) & 1u);
+        u[k] = (s ^ nb[k] ^ neg) & nz;
+    }
+    const uint32_t s1 = u[0] ^ u[1] ^ u[2], c1 = maj3(u[0], u[1], u[2]);
+    const uint32_t s2 = u[3] ^ u[4] ^ u[5], c2 = maj3(u[3], u[4], u[5]);
+    const uint32_t U0 = s1 ^ s2, c3 = s1 & s2;
+    const uint32_t U1 = c1 ^ c2 ^ c3, U2 = maj3(c1, c2, c3);
+    const uint32_t t0 = U0 ^ l0, k0 = U0 & l0;
+    const uint32_t t1 = U1 ^ l1 ^ k0, k1 = maj3(U1, l1, k0);
+    const uint32_t t2 = U2 ^ l2 ^ k1, t3 = maj3(U2, l2, k1);
+    const uint32_t m = __popc((jm >> 6) & 63u);
+    const uint32_t K = 16u - (nn + 1u + (m >> 1)); // 16 - h, h in 2..7
+    const uint32_t K0 = 0u - (K & 1u), K1 = 0u - ((K >> 1) & 1u), K2 = 0u - ((K >> 2) & 1u),
+                   K3 = 0u - ((K >> 3) & 1u);
+    const uint32_t a0 = t0 & K0;
+    const uint32_t a1 = maj3(t1, K1, a0);
+    const uint32_t a2 = maj3(t2, K2, a1);
+    return maj3(t3, K3, a2);
 }
 
 // Byte-sliced vertical counters: c[j] holds four byte counters for bits j, j+8, j+16, j+24.
@@ -586,7 +702,8 @@ __global__ void k_mark_applied(SimDims d, DevPtrs p) {
 #define PA_STAMP(k)                                                                                \
     if (STAMPS && blockIdx.x == 0 && threadIdx.x == 0) stamps[k] = clock64();
 
-template <bool STAMPS, int MODE>
+// GIBBS: heat-bath rule; a third level plane (planes_hi) sits behind the two Metropolis ones.
+template <bool STAMPS, int MODE, bool GIBBS = false>
 __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_energy,
                                                int do_sweep, unsigned long long *stamps) {
     extern __shared__ uint32_t lds[];
@@ -595,7 +712,8 @@ __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_en
     const uint32_t n_pad = (n1 + 1u) & ~1u;
     uint32_t *sw = lds;                                        // [N + 1] spins of this word
     uint32_t *pl = lds + n_pad;                                // [N + 1][2] acceptance-level planes
-    uint32_t *scratch = lds + n_pad + 2 * static_cast<size_t>(n1); // [16 rows][48]
+    uint32_t *pl2 = lds + n_pad + 2 * static_cast<size_t>(n1); // [N + 1] third plane (Gibbs only)
+    uint32_t *scratch = lds + n_pad + (GIBBS ? 3 : 2) * static_cast<size_t>(n1); // [16 rows][48]
     const uint32_t real = blockIdx.x / d.W, w = blockIdx.x % d.W;
     const uint32_t tid = threadIdx.x;
     const uint32_t *Sin = p.S + (static_cast<size_t>(real) * d.W + w) * d.N;  // this word's N sites
@@ -619,6 +737,8 @@ __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_en
     const uint32_t *planes_in = reinterpret_cast<const uint32_t *>(
         p.planes + (static_cast<size_t>(real) * d.W + w) * d.N);
     copy2_to_lds(sw, Sin, d.N, pl, planes_in, do_sweep ? 2 * d.N : 0, tid);
+    if (GIBBS && do_sweep)
+        copy_to_lds(pl2, p.planes_hi + (static_cast<size_t>(real) * d.W + w) * d.N, d.N, tid, 256);
     if (do_sweep && epoch != applied) {
         // tempering swaps accepted after the previous sweep: exchange the bit columns now
         const bool window = (((mp[0] | mp[1] | mc[0] | mc[1]) >> 31) != 0); // a pair straddles words
@@ -638,6 +758,7 @@ __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_en
         sw[d.N] = 0;
         pl[2 * d.N] = 0;
         pl[2 * d.N + 1] = 0;
+        if (GIBBS) pl2[d.N] = 0;
     }
     const uint32_t live = d.n_sys - w * 32;
     const uint32_t valid_bits = live >= 32 ? 0xFFFFFFFFu : ((1u << live) - 1u);
@@ -673,7 +794,9 @@ __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_en
             const uint2 lv =
                 *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(pl) + 2 * r.site);
             uint32_t acc;
-            if (dbg & 1)
+            if (GIBBS)
+                acc = accept_mask_gibbs(s, nb, r.jm, d.nn, lv.x, lv.y, lds_word(pl2, r.site));
+            else if (dbg & 1)
                 acc = nb[0] ^ nb[1] ^ nb[2] ^ nb[3] ^ nb[4] ^ nb[5] ^ lv.x ^ lv.y;
             else if (MODE == 0)
                 acc = accept_mask(s, nb, r.jm, lv.x, lv.y);
@@ -1439,11 +1562,12 @@ __device__ __forceinline__ void coherent_store(uint32_t *ptr, uint32_t v) {
     __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(1024) void k_sweep_big(SimDims d, DevPtrs p) {
+__global__ __launch_bounds__(1024) void k_sweep_big(SimDims d, DevPtrs p, int gibbs) {
     const uint32_t real = blockIdx.x / d.W, w = blockIdx.x % d.W;
     const uint32_t tid = threadIdx.x;
     uint32_t *Sg = p.S + (static_cast<size_t>(real) * d.W + w) * d.N;
     const uint2 *planes = p.planes + (static_cast<size_t>(real) * d.W + w) * d.N;
+    const uint32_t *planes_hi = p.planes_hi + (static_cast<size_t>(real) * d.W + w) * d.N;
     const uint4 *rec = p.rec + static_cast<size_t>(real) * (d.N + 1) * 2;
     const uint32_t live = d.n_sys - w * 32;
     const uint32_t valid_bits = live >= 32 ? 0xFFFFFFFFu : ((1u << live) - 1u);
@@ -1456,7 +1580,8 @@ __global__ __launch_bounds__(1024) void k_sweep_big(SimDims d, DevPtrs p) {
             for (int k = 0; k < 6; ++k) nb[k] = coherent_load(Sg + r.nb[k]);
             const uint32_t s = coherent_load(Sg + r.site);
             const uint2 lv = planes[r.site];
-            const uint32_t acc = accept_mask(s, nb, r.jm, lv.x, lv.y) & valid_bits;
+            const uint32_t acc = (gibbs ? accept_mask_gibbs(s, nb, r.jm, d.nn, lv.x, lv.y, planes_hi[r.site])
+                                        : accept_mask(s, nb, r.jm, lv.x, lv.y)) & valid_bits;
             coherent_store(Sg + r.site, s ^ acc);
         }
         __syncthreads(); // drains the stores (vmcnt 0) before the next level reads them
@@ -1586,9 +1711,9 @@ __global__ void k_big_finalize(SimDims d, DevPtrs p, int mode) {
 static constexpr size_t kLdsPerCu = 160 * 1024;
 static constexpr size_t kRngLds = 64 * 16 * 8 * 4;
 
-size_t sweep_lds_bytes(const SimDims &d) {
+size_t sweep_lds_bytes(const SimDims &d, bool gibbs) {
     const size_t n1 = static_cast<size_t>(d.N) + 1;
-    return ((n1 + 1) / 2 * 2 + 2 * n1 + 5 * 48) * 4;
+    return ((n1 + 1) / 2 * 2 + (gibbs ? 3 : 2) * n1 + 5 * 48) * 4;
 }
 size_t measure_lds_bytes(const SimDims &d) { return measure_lds_words(d) * 4; }
 static size_t overlap_lds_bytes(const SimDims &d) {
@@ -1596,8 +1721,10 @@ static size_t overlap_lds_bytes(const SimDims &d) {
 }
 
 hipError_t configure_kernels(const SimDims &) {
-    for (const void *fn : {reinterpret_cast<const void *>(k_rng<false>),
-                           reinterpret_cast<const void *>(k_rng<true>),
+    for (const void *fn : {reinterpret_cast<const void *>(k_rng<false, false>),
+                           reinterpret_cast<const void *>(k_rng<true, false>),
+                           reinterpret_cast<const void *>(k_rng<false, true>),
+                           reinterpret_cast<const void *>(k_sweep<false, 0, true>),
                            reinterpret_cast<const void *>(k_sweep<false, 0>),
                            reinterpret_cast<const void *>(k_sweep<false, 1>),
                            reinterpret_cast<const void *>(k_sweep<false, 2>),
@@ -1616,21 +1743,24 @@ hipError_t configure_kernels(const SimDims &) {
     return hipSuccess;
 }
 
-hipError_t launch_rng(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
+hipError_t launch_rng(const SimDims &d, const DevPtrs &p, bool gibbs, hipStream_t stream) {
     const uint32_t n_pairs_tw = (d.n_real * d.W + 1) / 2;
     const uint32_t groups = (n_pairs_tw + 3) / 4;
-    if (d.thr_preshifted)
-        hipLaunchKernelGGL(k_rng<true>, dim3(groups * d.B), dim3(256), kRngLds, stream, d, p);
+    if (gibbs)
+        hipLaunchKernelGGL((k_rng<false, true>), dim3(groups * d.B), dim3(256), kRngLds, stream, d, p);
+    else if (d.thr_preshifted)
+        hipLaunchKernelGGL((k_rng<true, false>), dim3(groups * d.B), dim3(256), kRngLds, stream, d, p);
     else
-        hipLaunchKernelGGL(k_rng<false>, dim3(groups * d.B), dim3(256), kRngLds, stream, d, p);
+        hipLaunchKernelGGL((k_rng<false, false>), dim3(groups * d.B), dim3(256), kRngLds, stream, d, p);
     return hipGetLastError();
 }
 
 hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,
-                        hipStream_t stream) {
+                        bool gibbs, hipStream_t stream) {
     if (d.big) {
         if (do_sweep)
-            hipLaunchKernelGGL(k_sweep_big, dim3(d.n_real * d.W), dim3(1024), 0, stream, d, p);
+            hipLaunchKernelGGL(k_sweep_big, dim3(d.n_real * d.W), dim3(1024), 0, stream, d, p,
+                               gibbs ? 1 : 0);
         if (with_energy) {
             const uint32_t n_chunks = (d.N + 4095) / 4096;
             hipLaunchKernelGGL(k_energy_big, dim3(d.n_real * d.W * n_chunks), dim3(256), 0, stream, d,
@@ -1645,9 +1775,13 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
         const char *env = std::getenv("PEAPODS_SWEEP_LDS");
         return env ? static_cast<size_t>(std::strtol(env, nullptr, 10)) : 0;
     }();
-    const size_t lds = std::max(sweep_lds_bytes(d), pad);
+    const size_t lds = std::max(sweep_lds_bytes(d, gibbs && do_sweep), pad);
     unsigned long long *no_stamps = nullptr;
     const int e = with_energy ? 1 : 0, s = do_sweep ? 1 : 0;
+    if (gibbs && do_sweep) {
+        hipLaunchKernelGGL((k_sweep<false, 0, true>), grid, block, lds, stream, d, p, e, s, no_stamps);
+        return hipGetLastError();
+    }
     switch (d.dense_nn) {
     case 1: hipLaunchKernelGGL((k_sweep<false, 1>), grid, block, lds, stream, d, p, e, s, no_stamps); break;
     case 2: hipLaunchKernelGGL((k_sweep<false, 2>), grid, block, lds, stream, d, p, e, s, no_stamps); break;
@@ -1662,10 +1796,10 @@ hipError_t launch_sweep_stamped(const SimDims &d, const DevPtrs &p, unsigned lon
                                 hipStream_t stream) {
     const dim3 grid(d.n_real * d.W), block(256);
     if (d.dense_nn == 3)
-        hipLaunchKernelGGL((k_sweep<true, 3>), grid, block, sweep_lds_bytes(d), stream, d, p,
+        hipLaunchKernelGGL((k_sweep<true, 3>), grid, block, sweep_lds_bytes(d, false), stream, d, p,
                            1 | (std::getenv("PEAPODS_DBG") ? std::atoi(std::getenv("PEAPODS_DBG")) << 8 : 0), 1, stamps);
     else
-        hipLaunchKernelGGL((k_sweep<true, 0>), grid, block, sweep_lds_bytes(d), stream, d, p, 1, 1, stamps);
+        hipLaunchKernelGGL((k_sweep<true, 0>), grid, block, sweep_lds_bytes(d, false), stream, d, p, 1, 1, stamps);
     return hipGetLastError();
 }
 

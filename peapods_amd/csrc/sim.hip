@@ -65,6 +65,7 @@ struct pa_sim {
     uint4 *rec = nullptr;
     uint16_t *nbr_site = nullptr, *jsite = nullptr;
     float *jorg_p = nullptr;
+    uint32_t *thr_gibbs = nullptr; // built by the first Gibbs sample (ensure_gibbs)
     int32_t *nz_bonds = nullptr;
     float *dbeta = nullptr;
     // bookkeeping of the last sample()
@@ -112,17 +113,7 @@ int ensure_ln_table(pa_sim *sim) {
     std::lock_guard<std::mutex> lock(g_ln_mutex);
     auto it = g_ln_tables.find(sim->device);
     if (it == g_ln_tables.end()) {
-        std::vector<float> table(1u << 24);
-        const unsigned n_threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
-        std::vector<std::thread> workers;
-        for (unsigned k = 0; k < n_threads; ++k)
-            workers.emplace_back([&, k] {
-                const uint32_t lo = static_cast<uint32_t>((1ull << 24) * k / n_threads);
-                const uint32_t hi = static_cast<uint32_t>((1ull << 24) * (k + 1) / n_threads);
-                for (uint32_t v = lo; v < hi; ++v)
-                    table[v] = logf(static_cast<float>(v) * (1.0f / 16777216.0f));
-            });
-        for (auto &t : workers) t.join();
+        const std::vector<float> &table = uniform_log_table();
         float *dev = nullptr;
         PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&dev), sizeof(float) << 24));
         PA_HIP(sim, hipMemcpy(dev, table.data(), sizeof(float) << 24, hipMemcpyHostToDevice));
@@ -213,7 +204,7 @@ int seed_state(pa_sim *sim, uint64_t seed) {
     sim->swaps_pending = false;
     sim->next_parity = 0;
     // Realization::new computes the initial energies (realization.rs:196-197)
-    PA_HIP(sim, launch_sweep(sim->d, sim->p, true, false, sim->stream));
+    PA_HIP(sim, launch_sweep(sim->d, sim->p, true, false, false, sim->stream));
     PA_HIP(sim, hipStreamSynchronize(sim->stream));
     return PA_OK;
 }
@@ -301,12 +292,48 @@ void toggle_spin_buffers(pa_sim *sim) {
 // Sweep of one group (and whatever has to precede it): on the large path pending tempering swaps
 // are materialised first; the LDS kernel applies them itself while loading.
 hipError_t enqueue_sweep(pa_sim *sim, const SimDims &d, const DevPtrs &p, bool with_energy,
-                         hipStream_t stream) {
+                         bool gibbs, hipStream_t stream) {
     if (d.big && sim->swaps_pending) {
         hipError_t e = launch_apply_swaps(d, p, stream);
         if (e != hipSuccess) return e;
     }
-    return launch_sweep(d, p, with_energy, true, stream);
+    return launch_sweep(d, p, with_energy, true, gibbs, stream);
+}
+
+// Gibbs sweeps need seven thresholds per temperature and parity class and a third level plane;
+// both are built by the first call that asks for them (sweep.rs:262-284).
+int ensure_gibbs(pa_sim *sim) {
+    if (sim->thr_gibbs) return PA_OK;
+    const SimDims &d = sim->d;
+    if (!d.big && sweep_lds_bytes(d, true) > 160 * 1024)
+        return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the on-chip Gibbs sweep");
+    std::vector<uint32_t> table;
+    const float unit = 1.0f;
+    if (!build_gibbs_table(&unit, 1, sim->temps.data(), d.n_temps, d.nn, table))
+        return fail(sim, PA_ERR_UNSUPPORTED,
+                    "the host libm's ln(u / (1 - u)) is not monotone on the 2^24 grid");
+    const uint32_t width = 4 * d.nn + 1, off = 2 * d.nn;
+    for (uint32_t t = 0; t < d.n_temps; ++t)
+        for (uint32_t e = 1; e < width; ++e)
+            if (table[t * width + e] < table[t * width + e - 1])
+                return fail(sim, PA_ERR_UNSUPPORTED, "Gibbs acceptance table is not monotone in the energy change");
+    std::vector<uint32_t> thr(14 * d.n_temps, 0u);
+    for (uint32_t t = 0; t < d.n_temps; ++t)
+        for (uint32_t j = 0; j < 7; ++j) {
+            if (2 * j <= 2 * off) thr[(0 + j) * d.n_temps + t] = table[t * width + 2 * off - 2 * j];         // dE = 2z' - 2j
+            if (2 * j + 1 <= 2 * off - 1) thr[(7 + j) * d.n_temps + t] = table[t * width + 2 * off - 1 - 2 * j]; // 2z' - 1 - 2j
+        }
+    PA_HIP(sim, sim->buffers.alloc(&sim->thr_gibbs, thr.size()));
+    PA_HIP(sim, sim->buffers.alloc(&sim->p.planes_hi, static_cast<size_t>(d.N) * d.W * d.n_real));
+    if (int rc = upload(sim, sim->thr_gibbs, thr)) return rc;
+    sim->p.thr_gibbs = sim->thr_gibbs;
+    uint32_t r0 = 0;
+    for (auto &g : sim->groups) {
+        g.p.thr_gibbs = sim->thr_gibbs;
+        g.p.planes_hi = sim->p.planes_hi + static_cast<size_t>(d.N) * d.W * r0;
+        r0 += g.d.n_real;
+    }
+    return PA_OK;
 }
 
 // Make S consistent for every reader other than k_sweep (getters, standalone phases, end of run).
@@ -334,8 +361,6 @@ std::string validate_text(const pa_sample_config *cfg, uint64_t n_replicas, int 
                    std::to_string(n_replicas) + " < 2)";
     }
     *code = PA_ERR_UNSUPPORTED;
-    if (cfg->sweep_mode == PA_SWEEP_GIBBS)
-        return "sweep_mode='gibbs' is not built on the HIP path yet";
     if (cfg->overlap_cluster_interval > 0) {
         for (int k = 0; k < cfg->n_overlap_cluster_modes && k < 4; ++k)
             if (cfg->overlap_cluster_modes[k] != PA_OC_HOUDAYER && cfg->overlap_cluster_modes[k] != PA_OC_JORG)
@@ -355,8 +380,10 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                     "overlap-cluster moves are not built for lattices above 12000 sites yet");
     if (cfg->overlap_cluster_interval > 0 && d.n_temps * d.n_pairs > 1024)
         return fail(sim, PA_ERR_UNSUPPORTED, "overlap-cluster moves support at most 1024 pairs per realisation");
-    int rc = zero_accumulators(sim);
+    const bool gibbs = cfg->sweep_mode == PA_SWEEP_GIBBS;
+    int rc = gibbs ? ensure_gibbs(sim) : PA_OK;
     if (rc) return rc;
+    if ((rc = zero_accumulators(sim))) return rc;
     const bool want_overlap = d.n_pairs > 0 && cfg->measure_overlap;
     sim->n_recorded = 0;
     sim->overlap_collected = want_overlap;
@@ -374,8 +401,8 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         const bool record = sweep_id >= cfg->warmup_sweeps; // mod.rs:410
         const bool pt_this = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0; // :486-488
         for (auto &g : sim->groups) {
-            PA_HIP(sim, launch_rng(g.d, g.p, g.stream));                                // :412-432
-            PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, record || pt_this, g.stream));     // :492-509
+            PA_HIP(sim, launch_rng(g.d, g.p, gibbs, g.stream));                         // :412-432
+            PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, record || pt_this, gibbs, g.stream)); // :492-509
         }
         sim->swaps_pending = false;
         toggle_spin_buffers(sim);
@@ -400,7 +427,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                 else
                     PA_HIP(sim, launch_houdayer(g.d, g.p, g.stream));
                 if (pt_this) { // energies are recomputed after a mutating move (:749-756)
-                    PA_HIP(sim, launch_sweep(g.d, g.p, true, false, g.stream));
+                    PA_HIP(sim, launch_sweep(g.d, g.p, true, false, false, g.stream));
                     PA_HIP(sim, launch_measure(g.d, g.p, pt, false, false, false, true, g.stream));
                 }
             }
@@ -472,6 +499,15 @@ int pa_build_metropolis_table(const float *couplings, uint64_t n_couplings,
     std::vector<uint32_t> table;
     if (!build_metropolis_table(couplings, n_couplings, temperatures, n_temperatures, n_neighbors,
                                 table))
+        return PA_ERR_UNSUPPORTED;
+    std::memcpy(out, table.data(), table.size() * sizeof(uint32_t));
+    return PA_OK;
+}
+
+int pa_build_gibbs_table(const float *couplings, uint64_t n_couplings, const float *temperatures,
+                         uint64_t n_temperatures, uint64_t n_neighbors, uint32_t *out) {
+    std::vector<uint32_t> table;
+    if (!build_gibbs_table(couplings, n_couplings, temperatures, n_temperatures, n_neighbors, table))
         return PA_ERR_UNSUPPORTED;
     std::memcpy(out, table.data(), table.size() * sizeof(uint32_t));
     return PA_OK;
@@ -865,8 +901,10 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
     if (code != PA_OK) return fail(sim, code, text);
     PA_HIP(sim, hipSetDevice(sim->device));
     const SimDims &d = sim->d;
-    int rc = zero_accumulators(sim);
+    const bool gibbs = cfg->sweep_mode == PA_SWEEP_GIBBS;
+    int rc = gibbs ? ensure_gibbs(sim) : PA_OK;
     if (rc) return rc;
+    if ((rc = zero_accumulators(sim))) return rc;
     const bool want_overlap = d.n_pairs > 0 && cfg->measure_overlap;
     sim->n_recorded = 0;
     sim->overlap_collected = want_overlap;
@@ -878,9 +916,9 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
         const bool record = sweep_id >= cfg->warmup_sweeps;
         const bool pt_this = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0;
         PA_HIP(sim, hipEventRecord(ev[0], sim->stream));
-        PA_HIP(sim, launch_rng(d, sim->p, sim->stream));
+        PA_HIP(sim, launch_rng(d, sim->p, gibbs, sim->stream));
         PA_HIP(sim, hipEventRecord(ev[1], sim->stream));
-        PA_HIP(sim, enqueue_sweep(sim, d, sim->p, record || pt_this, sim->stream));
+        PA_HIP(sim, enqueue_sweep(sim, d, sim->p, record || pt_this, gibbs, sim->stream));
         sim->swaps_pending = false;
         toggle_spin_buffers(sim);
         PA_HIP(sim, hipEventRecord(ev[2], sim->stream));
@@ -918,7 +956,7 @@ int pa_debug_sweep_stamps(pa_sim *sim, unsigned long long out[6]) {
     PA_HIP(sim, hipSetDevice(sim->device));
     unsigned long long *dev = nullptr;
     PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&dev), 6 * sizeof(unsigned long long)));
-    PA_HIP(sim, launch_rng(sim->d, sim->p, sim->stream));
+    PA_HIP(sim, launch_rng(sim->d, sim->p, false, sim->stream));
     PA_HIP(sim, launch_sweep_stamped(sim->d, sim->p, dev, sim->stream));
     toggle_spin_buffers(sim);
     PA_HIP(sim, hipStreamSynchronize(sim->stream));
@@ -932,8 +970,8 @@ int pa_debug_measure_stamps(pa_sim *sim, unsigned long long out[7]) {
     unsigned long long *dev = nullptr;
     PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&dev), 7 * sizeof(unsigned long long)));
     PA_HIP(sim, hipMemset(dev, 0, 7 * sizeof(unsigned long long)));
-    PA_HIP(sim, launch_rng(sim->d, sim->p, sim->stream));
-    PA_HIP(sim, launch_sweep(sim->d, sim->p, true, true, sim->stream));
+    PA_HIP(sim, launch_rng(sim->d, sim->p, false, sim->stream));
+    PA_HIP(sim, launch_sweep(sim->d, sim->p, true, true, false, sim->stream));
     toggle_spin_buffers(sim);
     PA_HIP(sim, launch_overlap(sim->d, sim->p, sim->stream));
     PtParams pt{0, sim->next_parity, sim->hot_slot, sim->cold_slot};
@@ -946,21 +984,26 @@ int pa_debug_measure_stamps(pa_sim *sim, unsigned long long out[7]) {
     return PA_OK;
 }
 
-int pa_sim_metropolis_sweep(pa_sim *sim, uint64_t n_sweeps) {
+static int sweep_only(pa_sim *sim, uint64_t n_sweeps, bool gibbs) {
     PA_HIP(sim, hipSetDevice(sim->device));
+    if (gibbs)
+        if (int rc = ensure_gibbs(sim)) return rc;
     for (uint64_t k = 0; k < n_sweeps; ++k) {
-        PA_HIP(sim, launch_rng(sim->d, sim->p, sim->stream));
-        PA_HIP(sim, enqueue_sweep(sim, sim->d, sim->p, false, sim->stream));
+        PA_HIP(sim, launch_rng(sim->d, sim->p, gibbs, sim->stream));
+        PA_HIP(sim, enqueue_sweep(sim, sim->d, sim->p, false, gibbs, sim->stream));
         sim->swaps_pending = false;
         toggle_spin_buffers(sim);
     }
     return pa_sim_synchronize(sim);
 }
 
+int pa_sim_metropolis_sweep(pa_sim *sim, uint64_t n_sweeps) { return sweep_only(sim, n_sweeps, false); }
+int pa_sim_gibbs_sweep(pa_sim *sim, uint64_t n_sweeps) { return sweep_only(sim, n_sweeps, true); }
+
 int pa_sim_compute_energies(pa_sim *sim) {
     PA_HIP(sim, hipSetDevice(sim->device));
     if (int rc = flush_swaps(sim)) return rc;
-    PA_HIP(sim, launch_sweep(sim->d, sim->p, true, false, sim->stream));
+    PA_HIP(sim, launch_sweep(sim->d, sim->p, true, false, false, sim->stream));
     return pa_sim_synchronize(sim);
 }
 
@@ -971,7 +1014,7 @@ int pa_sim_parallel_tempering(pa_sim *sim, int32_t schedule) {
                     "unknown pt_schedule, expected 'single_random_edge' or 'full_ladder'");
     PA_HIP(sim, hipSetDevice(sim->device));
     if (int rc = flush_swaps(sim)) return rc;
-    PA_HIP(sim, launch_sweep(sim->d, sim->p, true, false, sim->stream));
+    PA_HIP(sim, launch_sweep(sim->d, sim->p, true, false, false, sim->stream));
     PtParams pt{schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
     PA_HIP(sim, launch_measure(sim->d, sim->p, pt, false, false, false, true, sim->stream));
     if (schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;

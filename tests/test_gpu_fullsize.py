@@ -142,3 +142,9 @@ def test_large_lattice_path_matches_oracle(oracle, shape, kind, n_temps, n_rep, 
     for r in range(n_dis):
         np.testing.assert_array_equal(gpu.get_spins(r), cpu.get_spins(r))
         np.testing.assert_array_equal(gpu.get_system_ids(r), cpu.get_system_ids(r))
+    # heat-bath sweeps on the large path (third acceptance plane read from global memory)
+    a = gpu.sample(2, "gibbs", **kw)
+    b = cpu.sample(2, "gibbs", n_threads=8, **kw)
+    np.testing.assert_array_equal(a["energies"], b["energies"])
+    for r in range(n_dis):
+        np.testing.assert_array_equal(gpu.get_spins(r), cpu.get_spins(r))

@@ -74,6 +74,38 @@ def test_initial_state_and_sweep_trajectory(oracle, shape, n_temps, n_rep, n_dis
     assert_state_equal(gpu, cpu, check_energy=False)
 
 
+@pytest.mark.parametrize("shape,n_temps,n_rep,n_dis,offsets", CASES)
+def test_gibbs_sweep_trajectory(oracle, shape, n_temps, n_rep, n_dis, offsets):
+    # heat-bath rule (sweep.rs:262-284): same stream, one draw per site, e >= (T/2) ln(u/(1-u))
+    nn = len(offsets) if offsets else len(shape)
+    couplings = bimodal(shape, nn, n_dis, 6)
+    temps = np.linspace(0.6, 3.0, n_temps)
+    gpu, cpu = make_pair(oracle, shape, couplings, temps, n_rep, 4321, offsets)
+    gpu.gibbs_sweep(7)
+    cpu.sample(7, "gibbs", warmup_ratio=1.0)
+    assert_state_equal(gpu, cpu, check_energy=False)
+
+
+def test_gibbs_with_zero_couplings_and_tempering(oracle):
+    shape = (6, 6, 6)
+    rng = np.random.default_rng(8)
+    couplings = rng.integers(-1, 2, size=(2,) + shape + (3,)).astype(np.float32)  # diluted +-J
+    gpu, cpu = make_pair(oracle, shape, couplings, np.linspace(0.5, 2.5, 7), 4, 17)
+    kwargs = dict(pt_interval=1, pt_schedule="full_ladder", warmup_ratio=0.25)
+    a = gpu.sample(20, "gibbs", **kwargs)
+    b = cpu.sample(20, "gibbs", **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+    # alternating rules on one handle keeps a single random stream per system
+    a = gpu.sample(5, "metropolis", **kwargs)
+    b = cpu.sample(5, "metropolis", **kwargs)
+    assert_results_equal(a, b)
+    a = gpu.sample(5, "gibbs", **kwargs)
+    b = cpu.sample(5, "gibbs", **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+
+
 def test_unit_lookup_case_with_zero_couplings(oracle):
     # the reference's own table test pattern (sweep.rs:382-442): couplings cycle -1, 0, +1
     shape = (8, 8)
@@ -263,6 +295,4 @@ def test_unbuilt_overlap_modes_are_refused_not_emulated():
                    overlap_cluster_build_mode="cmr")
     with pytest.raises(NotImplementedError):
         sim.sample(2, "metropolis", overlap_cluster_update_interval=1, overlap_cluster_mode="sw")
-    with pytest.raises(NotImplementedError):
-        sim.sample(2, "gibbs")
     np.testing.assert_array_equal(sim.get_spins(), before)

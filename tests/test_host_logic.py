@@ -89,6 +89,45 @@ def test_metropolis_table_matches_oracle(oracle, nn):
     assert lib.pa_build_metropolis_table(ptr(couplings), 3, ptr(zero_t), 1, nn, ptr(out)) == 2
 
 
+@pytest.mark.parametrize("nn", [1, 2, 3])
+def test_gibbs_table_is_the_heat_bath_rule_on_the_draw_grid(nn):
+    """threshold[t][e] must split the 2^24 draws exactly where the reference's per-draw test
+    e >= (T/2) ln(u/(1-u)) (sweep.rs:279-282, f32, platform logf) changes from true to false."""
+    import ctypes.util
+
+    lib = nat.lib()
+    libm = C.CDLL(ctypes.util.find_library("m"))
+    libm.logf.restype = C.c_float
+    libm.logf.argtypes = [C.c_float]
+    temps = np.array([0.1, 0.5, 0.8, 1.4, 2.269, 5.0, 50.0], dtype=np.float32)
+    couplings = np.array([-1.0, 0.0, 1.0], dtype=np.float32)
+    width = 4 * nn + 1
+    out = np.zeros(len(temps) * width, dtype=np.uint32)
+    assert lib.pa_build_gibbs_table(ptr(couplings), 3, ptr(temps), len(temps), nn, ptr(out)) == 0
+
+    def accepts(t, e, k):
+        u = np.float32(k) / np.float32(16777216.0)
+        with np.errstate(divide="ignore"):
+            ratio = np.float32(u / np.float32(np.float32(1.0) - u))
+        logit = np.float32(libm.logf(C.c_float(float(ratio)))) if ratio > 0 else np.float32(-np.inf)
+        return np.float32(e) >= np.float32(np.float32(t / np.float32(2.0)) * logit)
+
+    rng = np.random.default_rng(5)
+    for ti, t in enumerate(temps):
+        for e in range(-2 * nn, 2 * nn + 1):
+            thr = int(out[ti * width + e + 2 * nn])
+            assert 1 <= thr <= 1 << 24  # u = 0 always flips
+            probes = {0, thr - 1, (1 << 24) - 1} | set(int(x) for x in rng.integers(0, 1 << 24, 6))
+            if thr < 1 << 24:
+                probes.add(thr)
+            for k in probes:
+                assert bool(accepts(t, e, k)) == (k < thr), (t, e, k, thr)
+        row = out[ti * width:(ti + 1) * width]
+        assert np.all(np.diff(row.astype(np.int64)) >= 0)  # favourable moves are accepted more often
+    bad = np.array([0.5, 1.0], dtype=np.float32)
+    assert lib.pa_build_gibbs_table(ptr(bad), 2, ptr(temps), len(temps), nn, ptr(out)) == 2
+
+
 @pytest.mark.parametrize("shape,offsets", [((16, 16, 16), None), ((5, 7), None), ((2, 3, 4), None),
                                            ((6, 6), [[1, 0], [0, 1], [1, -1]]), ((9,), None)])
 def test_sweep_levels_respect_the_typewriter_order(oracle, shape, offsets):
@@ -150,7 +189,8 @@ def test_option_validation_messages():
     assert check(warmup_sweeps=11) == (1, "warmup_sweeps must be <= n_sweeps")
     code, text = check(n_replicas=1, overlap_cluster_interval=1, n_overlap_cluster_modes=1)
     assert code == 1 and text.startswith("overlap cluster requires n_replicas >= max group_size")
-    assert check(sweep_mode=1)[0] == 2  # gibbs: valid in the reference, not on the HIP path yet
+    assert check(sweep_mode=1)[0] == 0  # gibbs
+    assert check(sweep_mode=2) == (1, "unknown sweep_mode, expected 'metropolis' or 'gibbs'")
 
 
 def test_python_surface_host_side():

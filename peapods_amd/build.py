@@ -14,8 +14,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpeapods_amd.so")
-SOURCES = ["host_util.cpp", "kernels.hip", "sim.hip"]
-HEADERS = ["engine.hpp", "host_util.hpp", os.path.join("..", "..", "include", "peapods_amd.h")]
+SOURCES = ["host_util.cpp", "kernels.hip", "kernels_general.hip", "sim.hip"]
+HEADERS = ["engine.hpp", "host_util.hpp", "device_util.hpp", os.path.join("..", "..", "include", "peapods_amd.h")]
 FLAGS = [
     "--offload-arch=gfx950",
     "-O3",

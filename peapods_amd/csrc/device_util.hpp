@@ -1,0 +1,198 @@
+// Device-side helpers shared by the kernel translation units (kernels.hip: unit-coupling
+// bit-sliced path; kernels_general.hip: f32-coupling path).
+#pragma once
+
+#include "engine.hpp"
+
+#include <cstdint>
+#include <hip/hip_runtime.h>
+
+namespace pa {
+
+// ---------------------------------------------------------------------------
+// xoshiro256** on the device.  State is kept as four u64; hipcc lowers the
+// 64-bit shifts/rotates to v_alignbit / v_lshl_add pairs.
+// ---------------------------------------------------------------------------
+struct DevRng {
+    uint64_t s0, s1, s2, s3;
+    __device__ __forceinline__ uint64_t next() {
+        const uint64_t m5 = s1 * 5;
+        const uint64_t result = ((m5 << 7) | (m5 >> 57)) * 9;
+        const uint64_t t = s1 << 17;
+        s2 ^= s0;
+        s3 ^= s1;
+        s1 ^= s2;
+        s0 ^= s3;
+        s2 ^= t;
+        s3 = (s3 << 45) | (s3 >> 19);
+        return result;
+    }
+};
+
+__device__ __forceinline__ void load_cursor(const uint32_t *cursor, uint32_t real, uint32_t SP,
+                                            uint32_t slot, uint32_t st[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) st[j] = cursor[(static_cast<size_t>(real) * 8 + j) * SP + slot];
+}
+
+__device__ __forceinline__ void store_cursor(uint32_t *cursor, uint32_t real, uint32_t SP,
+                                             uint32_t slot, const uint32_t st[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cursor[(static_cast<size_t>(real) * 8 + j) * SP + slot] = st[j];
+}
+
+// ---------------------------------------------------------------------------
+// xoshiro256** in 32-bit halves: every operation is a full-rate VALU op (no
+// 64-bit multiply); only the top 24 bits of the output are formed, which is
+// all the reference uses (next_u32 >> 8 of next_u64 >> 32, sweep.rs:181).
+// ---------------------------------------------------------------------------
+// (x << SH) + y in one instruction.  hipcc canonicalises (x << 2) + x to a multiplication and
+// lowers it to three v_mad_u64_u32, so the instruction is named explicitly.
+template <int SH> __device__ __forceinline__ uint64_t lshl_add_u64(uint64_t x, uint64_t y) {
+    uint64_t r;
+    asm("v_lshl_add_u64 %0, %1, %2, %3" : "=v"(r) : "v"(x), "n"(SH), "v"(y));
+    return r;
+}
+
+struct Rng32 {
+    uint32_t a0, a1, b0, b1, c0, c1, d0, d1; // s0 = a1:a0, s1 = b1:b0, s2 = c1:c0, s3 = d1:d0
+    __device__ __forceinline__ void load(const uint32_t st[8]) {
+        a0 = st[0]; a1 = st[1]; b0 = st[2]; b1 = st[3];
+        c0 = st[4]; c1 = st[5]; d0 = st[6]; d1 = st[7];
+    }
+    __device__ __forceinline__ void store(uint32_t st[8]) const {
+        st[0] = a0; st[1] = a1; st[2] = b0; st[3] = b1;
+        st[4] = c0; st[5] = c1; st[6] = d0; st[7] = d1;
+    }
+    // Returns the high word of the 64-bit output; the reference's draw is its top 24 bits.
+    __device__ __forceinline__ uint32_t next_top() {
+        // output = rotl(s1 * 5, 7) * 9, both multiplications as one 64-bit shift-add each
+        // (v_lshl_add_u64); only the high word of the result is needed
+        const uint64_t s1 = (static_cast<uint64_t>(b1) << 32) | b0;
+        const uint64_t pp = lshl_add_u64<2>(s1, s1);
+        const uint32_t plo = static_cast<uint32_t>(pp), phi = static_cast<uint32_t>(pp >> 32);
+        const uint32_t rhi = __builtin_amdgcn_alignbit(phi, plo, 25); // R = rotl(P, 7)
+        const uint32_t rlo = __builtin_amdgcn_alignbit(plo, phi, 25);
+        const uint64_t rr = (static_cast<uint64_t>(rhi) << 32) | rlo;
+        const uint32_t top = static_cast<uint32_t>(lshl_add_u64<3>(rr, rr) >> 32);
+        // state transition; three-input XORs (v_bitop3_b32, truth table 0x96) fold the chained updates
+        const uint32_t t0 = b0 << 17;
+        const uint32_t t1 = __builtin_amdgcn_alignbit(b1, b0, 15);
+        const uint32_t e0 = d0 ^ b0, e1 = d1 ^ b1;                      // s3 ^ s1
+        const uint32_t nb0 = __builtin_amdgcn_bitop3_b32(b0, c0, a0, 0x96); // s1 ^ (s2 ^ s0)
+        const uint32_t nb1 = __builtin_amdgcn_bitop3_b32(b1, c1, a1, 0x96);
+        const uint32_t nc0 = __builtin_amdgcn_bitop3_b32(c0, a0, t0, 0x96); // (s2 ^ s0) ^ (s1 << 17)
+        const uint32_t nc1 = __builtin_amdgcn_bitop3_b32(c1, a1, t1, 0x96);
+        a0 ^= e0; a1 ^= e1;                                             // s0 ^ (s3 ^ s1)
+        b0 = nb0; b1 = nb1;
+        c0 = nc0; c1 = nc1;
+        d0 = __builtin_amdgcn_alignbit(e1, e0, 19);                     // rotl(s3 ^ s1, 45)
+        d1 = __builtin_amdgcn_alignbit(e0, e1, 19);
+        return top; // the 24-bit draw is top >> 8
+    }
+};
+
+// state <- M * state with M as nibble tables [64][16][8] in LDS.
+__device__ __forceinline__ void jump_state_lds(uint32_t st[8], const uint32_t *tab) {
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int p = 0; p < 64; ++p) {
+        const uint32_t nib = (st[p >> 3] >> ((p & 7) * 4)) & 15u;
+        const uint4 *e = reinterpret_cast<const uint4 *>(tab + (p * 16 + nib) * 8);
+        const uint4 a = e[0], b = e[1];
+        acc[0] ^= a.x; acc[1] ^= a.y; acc[2] ^= a.z; acc[3] ^= a.w;
+        acc[4] ^= b.x; acc[5] ^= b.y; acc[6] ^= b.z; acc[7] ^= b.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) st[j] = acc[j];
+}
+
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which
+// would stall every schedule pass on the global prefetch issued just before it.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// Schedule record of one site (uint4, 16-bit fields holding LDS byte offsets = 4 * site index):
+//   x = site | f0 << 16,  y = b0 | f1 << 16,  z = b1 | f2 << 16,  w = b2 | jmeta << 16
+// Each realisation has N + 1 records; record N is a dummy whose site and neighbours all point
+// at the spare LDS slot N, so idle lanes of a pass run the same code without a branch.
+struct SiteRec {
+    uint32_t site, nb[6], jm; // byte offsets into a u32[N + 1] LDS array
+    __device__ __forceinline__ explicit SiteRec(const uint4 r) {
+        site = r.x & 0xFFFFu;
+        nb[0] = r.x >> 16;
+        nb[1] = r.y & 0xFFFFu;
+        nb[2] = r.y >> 16;
+        nb[3] = r.z & 0xFFFFu;
+        nb[4] = r.z >> 16;
+        nb[5] = r.w & 0xFFFFu;
+        jm = r.w >> 16;
+    }
+};
+
+__device__ __forceinline__ uint32_t lds_word(const uint32_t *base, uint32_t byte_off) {
+    return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
+
+// Cooperative global -> LDS copy of n dwords: loads are issued in batches of 8 before the first
+// store, so a wave keeps 8 requests in flight instead of one round trip per iteration.
+__device__ __forceinline__ void copy_to_lds(uint32_t *dst, const uint32_t *__restrict__ src,
+                                            uint32_t n, uint32_t tid, uint32_t nthreads) {
+    // 16-byte path (both pointers 16-byte aligned, n a multiple of 4): 8 dwordx4 loads in flight
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0 && (n & 3u) == 0) {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+        uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+        const uint32_t n4 = n >> 2;
+        for (uint32_t base = 0; base < n4; base += 8 * nthreads) {
+            uint4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t i = base + k * nthreads + tid;
+                v[k] = i < n4 ? s4[i] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t i = base + k * nthreads + tid;
+                if (i < n4) d4[i] = v[k];
+            }
+        }
+        return;
+    }
+    for (uint32_t base = 0; base < n; base += 8 * nthreads) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t i = base + k * nthreads + tid;
+            v[k] = i < n ? src[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t i = base + k * nthreads + tid;
+            if (i < n) dst[i] = v[k];
+        }
+    }
+}
+
+
+struct BigRec {
+    uint32_t site, nb[6], jm;
+    __device__ __forceinline__ BigRec(const uint4 a, const uint4 b) {
+        site = a.x; nb[0] = a.y; nb[1] = a.z; nb[2] = a.w;
+        nb[3] = b.x; nb[4] = b.y; nb[5] = b.z; jm = b.w;
+    }
+};
+
+__device__ __forceinline__ uint32_t coherent_load(const uint32_t *ptr) {
+    return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void coherent_store(uint32_t *ptr, uint32_t v) {
+    __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+
+} // namespace pa

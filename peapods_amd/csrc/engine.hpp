@@ -40,6 +40,8 @@ struct SimDims {
     uint32_t thr_preshifted; // 1 if every threshold is < 2^24, so thr[6..12) = thr[0..6) << 8 is exact
     uint32_t big;        // 1: lattice too large for the LDS kernels (spins stay in global memory)
     uint32_t dense_nn;   // = nn when every bond of every realisation is non-zero, else 0
+    uint32_t general;    // 1: arbitrary f32 couplings / temperatures -> the reference's logarithmic rule
+                         //    (kernels_general.hip); Esum then holds raw f32 bits of the energy sum
 };
 
 struct DevPtrs {
@@ -86,6 +88,11 @@ struct DevPtrs {
     const float *jorg_p;      // [n_temps] 1 - exp(-4 / T) by the host libm (Joerg bond probability)
     uint16_t *dfs_stack;      // [n_real][n_temps * n_pairs][N] scratch of k_jorg
     uint64_t *pair_rng;      // [n_real][n_temps * n_pairs][4] xoshiro state of the overlap-move generators
+    // general-coupling path only
+    const float *Jf;         // [n_real][N][nn] forward couplings as given
+    const float *temps;      // [n_temps]
+    float *thr_f;            // [n_real][W][N][32] thresholds (T/2) ln(..) of the current sweep
+    uint32_t *xw;            // [n_real][W][N][4] bond sign words S_i ^ S_fwd(i,d)
 };
 
 struct PtParams {
@@ -111,6 +118,13 @@ hipError_t launch_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt
 hipError_t launch_measure_stamped(const SimDims &d, const DevPtrs &p, const PtParams &pt,
                                   unsigned long long *stamps, hipStream_t stream);
 size_t sweep_lds_bytes(const SimDims &d, bool gibbs);
+// kernels_general.hip
+hipError_t launch_rng_f(const SimDims &d, const DevPtrs &p, bool gibbs, hipStream_t stream);
+hipError_t launch_sweep_f(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,
+                          hipStream_t stream);
+hipError_t launch_log_selftest(float *out_ln, float *out_logit, hipStream_t stream);
+hipError_t configure_general_kernels();
+size_t sweep_f_lds_bytes(const SimDims &d);
 size_t measure_lds_bytes(const SimDims &d);
 hipError_t configure_kernels(const SimDims &d);
 

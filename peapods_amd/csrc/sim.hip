@@ -66,6 +66,7 @@ struct pa_sim {
     uint16_t *nbr_site = nullptr, *jsite = nullptr;
     float *jorg_p = nullptr;
     uint32_t *thr_gibbs = nullptr; // built by the first Gibbs sample (ensure_gibbs)
+    float *Jf = nullptr, *temps_dev = nullptr; // general-coupling path
     int32_t *nz_bonds = nullptr;
     float *dbeta = nullptr;
     // bookkeeping of the last sample()
@@ -120,6 +121,38 @@ int ensure_ln_table(pa_sim *sim) {
         it = g_ln_tables.emplace(sim->device, dev).first;
     }
     sim->p.ln_table = it->second;
+    return PA_OK;
+}
+
+// General-coupling sweeps evaluate ln on the device (kernels_general.hip restates glibc's logf).
+// Before the first such sweep on a device, every one of the 2^24 possible draws is pushed through
+// it and compared with the host libm, for both ln(u) and ln(u / (1 - u)).
+std::map<int, bool> g_log_verified;
+
+int ensure_device_log(pa_sim *sim) {
+    std::lock_guard<std::mutex> lock(g_ln_mutex);
+    auto it = g_log_verified.find(sim->device);
+    if (it == g_log_verified.end()) {
+        const size_t n = size_t(1) << 24;
+        float *dev_ln = nullptr, *dev_logit = nullptr;
+        PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&dev_ln), n * sizeof(float)));
+        PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&dev_logit), n * sizeof(float)));
+        std::vector<float> got_ln(n), got_logit(n);
+        hipError_t e = launch_log_selftest(dev_ln, dev_logit, sim->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(got_ln.data(), dev_ln, n * sizeof(float), hipMemcpyDeviceToHost, sim->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(got_logit.data(), dev_logit, n * sizeof(float), hipMemcpyDeviceToHost, sim->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(sim->stream);
+        (void)hipFree(dev_ln);
+        (void)hipFree(dev_logit);
+        if (e != hipSuccess) return fail(sim, PA_ERR_DEVICE, std::string("logarithm self-test: ") + hipGetErrorString(e));
+        const bool same = std::memcmp(got_ln.data(), uniform_log_table().data(), n * sizeof(float)) == 0 &&
+                          std::memcmp(got_logit.data(), uniform_logit_table(nullptr).data(), n * sizeof(float)) == 0;
+        it = g_log_verified.emplace(sim->device, same).first;
+    }
+    if (!it->second)
+        return fail(sim, PA_ERR_UNSUPPORTED,
+                    "the device logarithm does not reproduce this host's logf on the 2^24 draw grid; "
+                    "general-coupling sweeps would not match the reference");
     return PA_OK;
 }
 
@@ -231,7 +264,13 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     q.S_next += tile_words * r0;
     q.swap_epoch += r0;
     q.applied_epoch += static_cast<size_t>(d.W) * r0;
-    q.planes += tile_words * r0;
+    if (d.general) {
+        q.Jf += static_cast<size_t>(d.N) * d.nn * r0;
+        q.thr_f += tile_words * 32 * r0;
+        q.xw += tile_words * 4 * r0;
+    } else {
+        q.planes += tile_words * r0;
+    }
     q.cursor += static_cast<size_t>(8) * d.SP * r0;
     q.system_ids += static_cast<size_t>(d.n_sys) * r0;
     q.slot_of += static_cast<size_t>(d.n_sys) * r0;
@@ -284,7 +323,7 @@ int make_groups(pa_sim *sim) {
 
 // k_sweep reads S and writes S_next: exchange the roles everywhere after every sweep launch.
 void toggle_spin_buffers(pa_sim *sim) {
-    if (sim->d.big) return;
+    if (sim->d.big || sim->d.general) return; // those paths sweep in place
     std::swap(sim->p.S, sim->p.S_next);
     for (auto &g : sim->groups) std::swap(g.p.S, g.p.S_next);
 }
@@ -293,7 +332,7 @@ void toggle_spin_buffers(pa_sim *sim) {
 // are materialised first; the LDS kernel applies them itself while loading.
 hipError_t enqueue_sweep(pa_sim *sim, const SimDims &d, const DevPtrs &p, bool with_energy,
                          bool gibbs, hipStream_t stream) {
-    if (d.big && sim->swaps_pending) {
+    if ((d.big || d.general) && sim->swaps_pending) {
         hipError_t e = launch_apply_swaps(d, p, stream);
         if (e != hipSuccess) return e;
     }
@@ -303,7 +342,7 @@ hipError_t enqueue_sweep(pa_sim *sim, const SimDims &d, const DevPtrs &p, bool w
 // Gibbs sweeps need seven thresholds per temperature and parity class and a third level plane;
 // both are built by the first call that asks for them (sweep.rs:262-284).
 int ensure_gibbs(pa_sim *sim) {
-    if (sim->thr_gibbs) return PA_OK;
+    if (sim->thr_gibbs || sim->d.general) return PA_OK; // the general path evaluates the rule per draw
     const SimDims &d = sim->d;
     if (!d.big && sweep_lds_bytes(d, true) > 160 * 1024)
         return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the on-chip Gibbs sweep");
@@ -378,6 +417,12 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     if (d.big && cfg->overlap_cluster_interval > 0)
         return fail(sim, PA_ERR_UNSUPPORTED,
                     "overlap-cluster moves are not built for lattices above 12000 sites yet");
+    if (d.general && cfg->overlap_cluster_interval > 0)
+        for (int k = 0; k < cfg->n_overlap_cluster_modes && k < 4; ++k)
+            if (cfg->overlap_cluster_modes[k] == PA_OC_JORG)
+                return fail(sim, PA_ERR_UNSUPPORTED,
+                            "the 'jorg' move needs expf of arbitrary couplings, which is not built on "
+                            "the HIP path yet (unit couplings only)");
     if (cfg->overlap_cluster_interval > 0 && d.n_temps * d.n_pairs > 1024)
         return fail(sim, PA_ERR_UNSUPPORTED, "overlap-cluster moves support at most 1024 pairs per realisation");
     const bool gibbs = cfg->sweep_mode == PA_SWEEP_GIBBS;
@@ -622,26 +667,24 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     d.BS = (d.N + d.B - 1) / d.B;
     d.B = (d.N + d.BS - 1) / d.BS;
     d.MW = (d.N + 31) / 32;
+    // ---- acceptance rule: integer table (unit couplings, sweep.rs:109-139) or the logarithm
+    const size_t n_coup = static_cast<size_t>(d.N) * d.nn;
+    std::vector<uint32_t> table;
+    d.general = build_metropolis_table(desc->couplings, n_coup * d.n_real, sim->temps.data(),
+                                       d.n_temps, d.nn, table) ? 0 : 1;
     // the LDS kernels hold a word's N sites (sweep) / the W-word tile (tempering swaps) on chip
     d.big = (d.N > 12000 || static_cast<size_t>(d.N) * d.W * 4 > 150000) ? 1 : 0;
+    if (d.general && sweep_f_lds_bytes(d) > 160 * 1024) d.big = 1;
     d.n_edges = std::max<uint32_t>(1, d.n_temps - 1);
     if (d.W > 64) {
         sim->error = "more than 2048 systems per realisation are not built on the HIP path yet";
         return bail(PA_ERR_UNSUPPORTED);
     }
 
-    // ---- acceptance thresholds (sweep.rs:109-139); all realisations must take the table path
-    const size_t n_coup = static_cast<size_t>(d.N) * d.nn;
-    std::vector<uint32_t> table;
-    if (!build_metropolis_table(desc->couplings, n_coup * d.n_real, sim->temps.data(), d.n_temps,
-                                d.nn, table)) {
-        sim->error = "couplings outside {-1,0,+1} or non-positive temperatures need the "
-                     "reference's logarithmic path, which is not built on the HIP path yet";
-        return bail(PA_ERR_UNSUPPORTED);
-    }
+    // ---- acceptance thresholds of the table path
     const uint32_t width = 4 * d.nn + 1, off = 2 * d.nn;
     std::vector<uint32_t> thr(12 * d.n_temps, 0u);
-    for (uint32_t t = 0; t < d.n_temps; ++t) {
+    for (uint32_t t = 0; t < d.n_temps && !d.general; ++t) {
         for (uint32_t j = 0; j < 3; ++j) {
             const uint32_t even_e = 2 * (j + 1), odd_e = 2 * j + 1; // |dE|
             if (even_e <= off) thr[(0 + j) * d.n_temps + t] = table[t * width + off - even_e];
@@ -654,7 +697,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
             }
     }
 
-    d.thr_preshifted = 1;
+    d.thr_preshifted = d.general ? 0 : 1;
     for (uint32_t k = 0; k < 6 * d.n_temps; ++k) {
         if (thr[k] >= (1u << 24)) d.thr_preshifted = 0;
         thr[6 * d.n_temps + k] = thr[k] << 8;
@@ -763,6 +806,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     }
     int rc = ensure_ln_table(sim);
     if (rc) return bail(rc);
+    if (d.general && (rc = ensure_device_log(sim))) return bail(rc);
 
     DevPtrs &p = sim->p;
     DeviceBuffers &bufs = sim->buffers;
@@ -774,13 +818,19 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         if (e == hipSuccess) e = r;
     };
     ok(bufs.alloc(&p.S, tile_words * d.n_real));
-    if (d.big)
-        p.S_next = p.S; // the large path sweeps in place
+    if (d.big || d.general)
+        p.S_next = p.S; // these paths sweep in place
     else
         ok(bufs.alloc(&p.S_next, tile_words * d.n_real));
     ok(bufs.alloc(&p.swap_epoch, static_cast<size_t>(d.n_real)));
     ok(bufs.alloc(&p.applied_epoch, static_cast<size_t>(d.n_real) * d.W));
-    ok(bufs.alloc(&p.planes, tile_words * d.n_real));
+    ok(bufs.alloc(&p.planes, d.general ? 1 : tile_words * d.n_real));
+    if (d.general) {
+        ok(bufs.alloc(&sim->Jf, n_coup * d.n_real));
+        ok(bufs.alloc(&sim->temps_dev, static_cast<size_t>(d.n_temps)));
+        ok(bufs.alloc(&p.thr_f, tile_words * d.n_real * 32));
+        ok(bufs.alloc(&p.xw, tile_words * d.n_real * 4));
+    }
     ok(bufs.alloc(&p.cursor, static_cast<size_t>(d.n_real) * 8 * d.SP));
     ok(bufs.alloc(&p.system_ids, static_cast<size_t>(d.n_real) * d.n_sys));
     ok(bufs.alloc(&p.slot_of, static_cast<size_t>(d.n_real) * d.n_sys));
@@ -825,6 +875,16 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     p.nbr_site = sim->nbr_site;
     p.jsite = sim->jsite;
     p.jorg_p = sim->jorg_p;
+    p.Jf = sim->Jf;
+    p.temps = sim->temps_dev;
+    if (d.general) {
+        const std::vector<float> J(desc->couplings, desc->couplings + n_coup * d.n_real);
+        if ((rc = upload(sim, sim->Jf, J)) || (rc = upload(sim, sim->temps_dev, sim->temps))) return bail(rc);
+        if (configure_general_kernels() != hipSuccess) {
+            sim->error = "kernel LDS configuration failed";
+            return bail(PA_ERR_DEVICE);
+        }
+    }
     if ((rc = upload(sim, sim->thr, thr)) || (rc = upload(sim, sim->mpar, mpar)) ||
         (rc = upload(sim, sim->rec, rec)) || (rc = upload(sim, sim->pass_start, pass_start)) ||
         (rc = upload(sim, sim->jump, jump)) || (rc = upload(sim, sim->nbr_site, nbr_site)) ||
@@ -1086,8 +1146,12 @@ int pa_sim_get_energies(pa_sim *sim, uint64_t realization, float *out) {
     int rc;
     if ((rc = download(sim, E, sim->p.Esum + d.n_sys * realization, d.n_sys))) return rc;
     if ((rc = download(sim, slot_of, sim->p.slot_of + d.n_sys * realization, d.n_sys))) return rc;
-    for (uint32_t sys = 0; sys < d.n_sys; ++sys) // energy.rs:108: total / n_spins as f32
-        out[sys] = static_cast<float>(E[slot_of[sys]]) / static_cast<float>(d.N);
+    for (uint32_t sys = 0; sys < d.n_sys; ++sys) { // energy.rs:108: total / n_spins as f32
+        const int32_t raw = E[slot_of[sys]];
+        float total = static_cast<float>(raw);
+        if (d.general) std::memcpy(&total, &raw, sizeof(float)); // raw bits of the f32 sum
+        out[sys] = total / static_cast<float>(d.N);
+    }
     return PA_OK;
 }
 

@@ -148,3 +148,25 @@ def test_large_lattice_path_matches_oracle(oracle, shape, kind, n_temps, n_rep, 
     np.testing.assert_array_equal(a["energies"], b["energies"])
     for r in range(n_dis):
         np.testing.assert_array_equal(gpu.get_spins(r), cpu.get_spins(r))
+
+
+def test_general_couplings_on_the_large_lattice_path(oracle):
+    """24^3 Gaussian couplings: the spins + couplings of a word no longer fit the LDS, so the
+    general sweep runs from global memory (k_sweep_f<BIG>)."""
+    from peapods_amd import IsingSimulation
+
+    shape = (24, 24, 24)
+    rng = np.random.default_rng(12)
+    couplings = rng.standard_normal(size=shape + (3,)).astype(np.float32)
+    temps = np.linspace(0.7, 1.6, 8).astype(np.float32)
+    gpu = IsingSimulation(list(shape), couplings, temps, 2, None, 9)
+    cpu = oracle.OracleSimulation(list(shape), couplings, temps, 2, None, 9)
+    kw = dict(pt_interval=1, pt_schedule="full_ladder", warmup_ratio=0.5)
+    for mode, n in (("metropolis", 4), ("gibbs", 2)):
+        a = gpu.sample(n, mode, **kw)
+        b = cpu.sample(n, mode, n_threads=8, **kw)
+        for key in ("mags", "energies", "energies2", "overlap", "link_overlap"):
+            np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+        np.testing.assert_array_equal(gpu.get_spins(0), cpu.get_spins(0))
+        np.testing.assert_array_equal(gpu.get_system_ids(0), cpu.get_system_ids(0))
+        np.testing.assert_array_equal(gpu.get_energies(0), cpu.get_energies(0))

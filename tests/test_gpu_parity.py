@@ -106,6 +106,69 @@ def test_gibbs_with_zero_couplings_and_tempering(oracle):
     assert_state_equal(gpu, cpu)
 
 
+def gaussian(shape, nn, n_dis, seed):
+    rng = np.random.default_rng(seed)
+    full = (n_dis,) + tuple(shape) + (nn,) if n_dis > 1 else tuple(shape) + (nn,)
+    return rng.standard_normal(size=full).astype(np.float32)
+
+
+@pytest.mark.parametrize("mode", ["metropolis", "gibbs"])
+@pytest.mark.parametrize("shape,n_temps,n_rep,n_dis,offsets", CASES)
+def test_general_couplings_sweep_trajectory(oracle, mode, shape, n_temps, n_rep, n_dis, offsets):
+    """Gaussian couplings take the reference's logarithmic rule (sweep.rs:35-48,247-284): f32 local
+    field in the reference's order, (T/2) ln(u) from the platform logf."""
+    nn = len(offsets) if offsets else len(shape)
+    couplings = gaussian(shape, nn, n_dis, 9)
+    temps = np.linspace(0.4, 2.5, n_temps)
+    gpu, cpu = make_pair(oracle, shape, couplings, temps, n_rep, 777, offsets)
+    assert_state_equal(gpu, cpu)  # initial energies: sequential f32 sums (energy.rs:92-109)
+    if mode == "gibbs":
+        gpu.gibbs_sweep(6)
+    else:
+        gpu.metropolis_sweep(6)
+    cpu.sample(6, mode, warmup_ratio=1.0)
+    assert_state_equal(gpu, cpu, check_energy=False)
+
+
+@pytest.mark.parametrize("schedule", ["single_random_edge", "full_ladder"])
+def test_general_couplings_sample_matches_oracle(oracle, schedule):
+    shape = (6, 6, 6)
+    couplings = gaussian(shape, 3, 3, 21)
+    gpu, cpu = make_pair(oracle, shape, couplings, np.linspace(0.5, 1.8, 12), 4, 5)
+    kwargs = dict(pt_interval=1, pt_schedule=schedule, warmup_ratio=0.25)
+    a = gpu.sample(20, "metropolis", **kwargs)
+    b = cpu.sample(20, "metropolis", **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+    a = gpu.sample(7, "gibbs", pt_interval=2, pt_schedule=schedule, warmup_ratio=0.0)
+    b = cpu.sample(7, "gibbs", pt_interval=2, pt_schedule=schedule, warmup_ratio=0.0)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+    # Houdayer needs no couplings beyond the energies recomputed after the move
+    kwargs = dict(pt_interval=1, pt_schedule=schedule, warmup_ratio=0.0,
+                  overlap_cluster_update_interval=2, overlap_cluster_build_mode="houdayer")
+    a = gpu.sample(6, "metropolis", **kwargs)
+    b = cpu.sample(6, "metropolis", **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+    with pytest.raises(NotImplementedError):
+        gpu.sample(2, "metropolis", overlap_cluster_update_interval=1,
+                   overlap_cluster_build_mode="jorg")
+
+
+def test_unit_couplings_outside_the_table_domain_take_the_logarithmic_rule(oracle):
+    # T = 0 and T < 0 make the reference decline the table (sweep.rs:112-116)
+    shape = (6, 6)
+    couplings = bimodal(shape, 2, 1, 3)
+    gpu, cpu = make_pair(oracle, shape, couplings, [0.0, -1.0, 1.5], 2, 8)
+    gpu.metropolis_sweep(5)
+    cpu.sample(5, "metropolis", warmup_ratio=1.0)
+    assert_state_equal(gpu, cpu, check_energy=False)
+    gpu.gibbs_sweep(5)
+    cpu.sample(5, "gibbs", warmup_ratio=1.0)
+    assert_state_equal(gpu, cpu, check_energy=False)
+
+
 def test_unit_lookup_case_with_zero_couplings(oracle):
     # the reference's own table test pattern (sweep.rs:382-442): couplings cycle -1, 0, +1
     shape = (8, 8)

@@ -42,7 +42,9 @@ __device__ const double kLogfLogC[16] = {
     -0x1.252f438e10c1ep-5, 0x0p+0,                0x1.aa5aa5df25984p-5,  0x1.c5e53aa362eb4p-4,
     0x1.526e57720db08p-3,  0x1.bc2860d22477p-3,   0x1.1058bc8a07ee1p-2,  0x1.4043057b6ee09p-2};
 
-__device__ __forceinline__ float dev_logf(float x) {
+// tab: [16][2] doubles (1/c, ln c); the kernels stage it in LDS (a per-lane index into constant
+// memory would be a global gather in front of every draw).
+__device__ __forceinline__ float dev_logf(float x, const double2 *tab) {
     uint32_t ix = __float_as_uint(x);
     if (ix == 0x3f800000u) return 0.0f;
     if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
@@ -56,7 +58,8 @@ __device__ __forceinline__ float dev_logf(float x) {
     const uint32_t i = (tmp >> 19) & 15u;
     const int32_t k = static_cast<int32_t>(tmp) >> 23;
     const uint32_t iz = ix - (tmp & (0x1ffu << 23));
-    const double invc = kLogfInvC[i], logc = kLogfLogC[i];
+    const double2 entry = tab[i];
+    const double invc = entry.x, logc = entry.y;
     const double z = static_cast<double>(__uint_as_float(iz));
     const double r = __dsub_rn(__dmul_rn(z, invc), 1.0);
     const double y0 = __dadd_rn(logc, __dmul_rn(static_cast<double>(k), 0x1.62e42fefa39efp-1));
@@ -67,6 +70,10 @@ __device__ __forceinline__ float dev_logf(float x) {
     return static_cast<float>(y);
 }
 
+__device__ __forceinline__ void stage_logf_table(double2 *tab, uint32_t tid) {
+    if (tid < 16) tab[tid] = make_double2(kLogfInvC[tid], kLogfLogC[tid]);
+}
+
 __device__ __forceinline__ float uniform_of_draw(uint32_t draw24) {
     return __fmul_rn(static_cast<float>(draw24), 0x1p-24f); // exact: gen::<f32>()
 }
@@ -75,11 +82,14 @@ __device__ __forceinline__ float logit_arg(float u) { return __fdiv_rn(u, __fsub
 // out_ln[k] = ln(k 2^-24), out_logit[k] = ln(u / (1 - u)): compared with the host libm by the
 // engine before the first general-coupling sweep.
 __global__ void k_log_selftest(float *out_ln, float *out_logit) {
+    __shared__ double2 tab[16];
+    stage_logf_table(tab, threadIdx.x);
+    __syncthreads();
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= (1u << 24)) return;
     const float u = uniform_of_draw(k);
-    out_ln[k] = dev_logf(u);
-    out_logit[k] = dev_logf(logit_arg(u));
+    out_ln[k] = dev_logf(u, tab);
+    out_logit[k] = dev_logf(logit_arg(u), tab);
 }
 
 // s * j for a spin stored as bit `bit` of `word` (1 <=> -1): an exact sign flip.
@@ -94,7 +104,8 @@ __device__ __forceinline__ float signed_by_spin(float j, uint32_t word, uint32_t
 // ---------------------------------------------------------------------------
 template <bool GIBBS>
 __global__ __launch_bounds__(256) void k_rng_f(SimDims d, DevPtrs p) {
-    extern __shared__ uint32_t tab[]; // [64 * 16 * 8]
+    extern __shared__ uint32_t tab[]; // [64 * 16 * 8] jump table, then the logf table
+    double2 *log_tab = reinterpret_cast<double2 *>(tab + 64 * 16 * 8);
     const uint32_t block = blockIdx.x % d.B;
     const uint32_t group = blockIdx.x / d.B;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -106,6 +117,7 @@ __global__ __launch_bounds__(256) void k_rng_f(SimDims d, DevPtrs p) {
     const uint32_t slot = w * 32 + bit;
     const bool active = tw_ok && slot < d.n_sys;
 
+    stage_logf_table(log_tab, tid);
     if (block > 0) {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.jump + static_cast<size_t>(block) * (64 * 16 * 8));
         uint4 *dst = reinterpret_cast<uint4 *>(tab);
@@ -125,7 +137,7 @@ __global__ __launch_bounds__(256) void k_rng_f(SimDims d, DevPtrs p) {
     float *out = p.thr_f + (static_cast<size_t>(tw_ok ? tw : 0) * d.N + begin) * 32 + bit;
     for (uint32_t j = 0; j < len; ++j) {
         const float u = uniform_of_draw(rng.next_top() >> 8);
-        const float l = dev_logf(GIBBS ? logit_arg(u) : u);
+        const float l = dev_logf(GIBBS ? logit_arg(u) : u, log_tab);
         if (active) out[static_cast<size_t>(j) * 32] = __fmul_rn(half_t, l);
     }
     if (active && block == d.B - 1) {
@@ -135,80 +147,153 @@ __global__ __launch_bounds__(256) void k_rng_f(SimDims d, DevPtrs p) {
 }
 
 // ---------------------------------------------------------------------------
-// k_sweep_f: workgroup = (realisation, tile word).  A work item is (site of the current
-// dependency level, slot); the 32 lanes of a half wave share a site, so its record, couplings
-// and neighbour words are broadcast reads and the half wave's ballot is the site's flip word.
-// !BIG: the word's spins and the realisation's couplings are staged in LDS.
+// k_sweep_f: workgroup = (realisation, tile word), 512 threads.  A work item is (site of the
+// current dependency level, group of 4 slots): the record decode, the neighbour words and the
+// couplings are fetched once per item and serve four systems; the item's four decisions are
+// XORed into the site's word with one LDS (or L2) atomic.  Records and thresholds of the next
+// round are requested before the current round is computed.
+// !BIG: the word's spins and the realisation's couplings ([site] -> float4 of forward bonds)
+//       are staged in LDS.
 //  BIG: both stay in global memory (spins through agent-scope atomics, as in k_sweep_big).
 // ---------------------------------------------------------------------------
-template <bool BIG>
-__global__ __launch_bounds__(BIG ? 1024 : 256) void k_sweep_f(SimDims d, DevPtrs p) {
+constexpr uint32_t kSweepFThreads = 512;
+
+template <bool BIG, int NN>
+__global__ __launch_bounds__(kSweepFThreads) void k_sweep_f(SimDims d, DevPtrs p) {
     extern __shared__ uint32_t lds[];
     const uint32_t real = blockIdx.x / d.W, w = blockIdx.x % d.W;
-    const uint32_t tid = threadIdx.x, n_threads = blockDim.x;
+    const uint32_t tid = threadIdx.x;
     const uint32_t tw = real * d.W + w;
     uint32_t *Sg = p.S + static_cast<size_t>(tw) * d.N;
-    const float *Jg = p.Jf + static_cast<size_t>(real) * d.N * d.nn;
-    const float *thr = p.thr_f + static_cast<size_t>(tw) * d.N * 32;
+    const float *Jg = p.Jf + static_cast<size_t>(real) * d.N * NN;
+    const float4 *thr = reinterpret_cast<const float4 *>(p.thr_f + static_cast<size_t>(tw) * d.N * 32);
     const uint32_t n_pad = (d.N + 3u) & ~3u;
-    uint32_t *sw = lds;                                   // [N]
-    float *Jl = reinterpret_cast<float *>(lds + n_pad);   // [N * nn]
+    uint32_t *sw = lds;                                      // [N]
+    float4 *J4 = reinterpret_cast<float4 *>(lds + n_pad);    // [N] forward couplings of each site
     if (!BIG) {
-        copy_to_lds(sw, Sg, d.N, tid, n_threads);
-        copy_to_lds(reinterpret_cast<uint32_t *>(Jl), reinterpret_cast<const uint32_t *>(Jg),
-                    d.N * d.nn, tid, n_threads);
+        copy_to_lds(sw, Sg, d.N, tid, kSweepFThreads);
+        for (uint32_t i = tid; i < d.N; i += kSweepFThreads) {
+            float4 j = make_float4(0.f, 0.f, 0.f, 0.f);
+            j.x = Jg[i * NN + 0];
+            if (NN > 1) j.y = Jg[i * NN + 1];
+            if (NN > 2) j.z = Jg[i * NN + 2];
+            J4[i] = j;
+        }
         __syncthreads();
     }
-    const float *J = BIG ? Jg : Jl;
     const uint32_t live = d.n_sys - w * 32;
     const uint32_t valid_bits = live >= 32 ? 0xFFFFFFFFu : ((1u << live) - 1u);
-    const uint32_t bit = tid & 31u, half = (tid >> 5) & 1u;
+    const uint32_t g = tid & 7u, shift = g * 4;              // this lane's four slots: bits shift..shift+3
+    const uint32_t valid4 = (valid_bits >> shift) & 15u;
     const uint4 *rec = p.rec + static_cast<size_t>(real) * (d.N + 1) * (BIG ? 2 : 1);
-    auto spin_word = [&](uint32_t site) -> uint32_t { return BIG ? coherent_load(Sg + site) : sw[site]; };
+
+    struct Item {
+        uint4 r0, r1;  // record (r1: BIG only)
+        float4 t;      // thresholds of the four slots
+    };
+    auto fetch = [&](uint32_t pos, bool live_item) -> Item {
+        Item it;
+        it.r0 = it.r1 = make_uint4(0, 0, 0, 0);
+        it.t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!live_item) return it;
+        uint32_t site;
+        if (BIG) {
+            it.r0 = rec[2 * pos];
+            it.r1 = rec[2 * pos + 1];
+            site = it.r0.x;
+        } else {
+            it.r0 = rec[pos];
+            site = (it.r0.x & 0xFFFFu) >> 2;
+        }
+        it.t = thr[static_cast<size_t>(site) * 8 + g];
+        return it;
+    };
+    // s * J for the lane's four slots of neighbour word `word`, added to h[0..3]
+    auto add_bond = [&](float h[4], uint32_t word, float j) {
+        const uint32_t x = word >> shift;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            h[k] = __fadd_rn(h[k], __uint_as_float(__builtin_amdgcn_bitop3_b32(
+                                       x << (31 - k), 0x80000000u, __float_as_uint(j), 0x6A)));
+    };
+    auto run = [&](const Item &it) {
+        uint32_t site, nb[6];
+        if (BIG) {
+            const BigRec r(it.r0, it.r1);
+            site = r.site;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) nb[k] = r.nb[k];
+        } else {
+            const SiteRec r(it.r0); // LDS byte offsets = 4 * index
+            site = r.site >> 2;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) nb[k] = r.nb[k] >> 2;
+        }
+        const uint32_t s = BIG ? coherent_load(Sg + site) : sw[site];
+        float jf[3] = {0.f, 0.f, 0.f}, jb[3] = {0.f, 0.f, 0.f};
+        uint32_t wf[3] = {0, 0, 0}, wb[3] = {0, 0, 0};
+        if (BIG) {
+#pragma unroll
+            for (int dd = 0; dd < NN; ++dd) {
+                jf[dd] = Jg[static_cast<size_t>(site) * NN + dd];
+                jb[dd] = Jg[static_cast<size_t>(nb[2 * dd + 1]) * NN + dd];
+                wf[dd] = coherent_load(Sg + nb[2 * dd]);
+                wb[dd] = coherent_load(Sg + nb[2 * dd + 1]);
+            }
+        } else {
+            const float4 own = J4[site];
+            jf[0] = own.x; jf[1] = own.y; jf[2] = own.z;
+#pragma unroll
+            for (int dd = 0; dd < NN; ++dd) {
+                const float *jrow = reinterpret_cast<const float *>(&J4[nb[2 * dd + 1]]);
+                jb[dd] = jrow[dd];
+                wf[dd] = sw[nb[2 * dd]];
+                wb[dd] = sw[nb[2 * dd + 1]];
+            }
+        }
+        float h[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dd = 0; dd < NN; ++dd) { // sweep.rs:11-17: forward then backward bond of each direction
+            add_bond(h, wf[dd], jf[dd]);
+            add_bond(h, wb[dd], jb[dd]);
+        }
+        // eng_change = -s_i * h (sweep.rs:43-44): s_i = +1 (bit clear) negates h
+        const uint32_t xs = (~s) >> shift;
+        const float tk[4] = {it.t.x, it.t.y, it.t.z, it.t.w};
+        uint32_t mask = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float e = __uint_as_float(__builtin_amdgcn_bitop3_b32(xs << (31 - k), 0x80000000u,
+                                                                        __float_as_uint(h[k]), 0x6A));
+            mask |= (e >= tk[k]) ? (1u << k) : 0u;
+        }
+        mask &= valid4;
+        if (mask) {
+            if (BIG)
+                __hip_atomic_fetch_xor(Sg + site, mask << shift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                atomicXor(&sw[site], mask << shift);
+        }
+    };
 
     for (uint32_t pass = 0; pass < d.n_passes; ++pass) {
         const uint32_t begin = p.pass_start[pass], end = p.pass_start[pass + 1];
-        const uint32_t n_items = (end - begin) * 32;
-        for (uint32_t item = tid; item < n_items; item += n_threads) {
-            const uint32_t pos = begin + (item >> 5);
-            uint32_t site, nb[6];
-            if (BIG) {
-                const BigRec r(rec[2 * pos], rec[2 * pos + 1]);
-                site = r.site;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) nb[k] = r.nb[k];
-            } else {
-                const SiteRec r(rec[pos]); // LDS byte offsets = 4 * index
-                site = r.site >> 2;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) nb[k] = r.nb[k] >> 2;
-            }
-            const uint32_t s = spin_word(site);
-            float h = 0.0f;
-            for (uint32_t dd = 0; dd < d.nn; ++dd) { // sweep.rs:11-17
-                const uint32_t jf = nb[2 * dd], jb = nb[2 * dd + 1];
-                h = __fadd_rn(h, signed_by_spin(J[site * d.nn + dd], spin_word(jf), bit));
-                h = __fadd_rn(h, signed_by_spin(J[jb * d.nn + dd], spin_word(jb), bit));
-            }
-            // eng_change = -s_i * h (sweep.rs:43-44): s_i = +1 (bit clear) negates h
-            const float e = signed_by_spin(h, ~s, bit);
-            const bool flip = e >= thr[static_cast<size_t>(site) * 32 + bit];
-            const unsigned long long votes = __ballot(flip);
-            const uint32_t mask = (half ? static_cast<uint32_t>(votes >> 32) : static_cast<uint32_t>(votes)) & valid_bits;
-            if (bit == 0 && mask) {
-                if (BIG)
-                    coherent_store(Sg + site, s ^ mask);
-                else
-                    sw[site] = s ^ mask;
-            }
+        const uint32_t n_items = (end - begin) * 8;
+        Item cur = fetch(begin + (tid >> 3), tid < n_items);
+        for (uint32_t item = tid; item < n_items; item += kSweepFThreads) {
+            const uint32_t next_item = item + kSweepFThreads;
+            const Item nxt = fetch(begin + (next_item >> 3), next_item < n_items);
+            run(cur);
+            cur = nxt;
         }
         __syncthreads();
     }
     if (!BIG)
-        for (uint32_t i = tid; i < d.N; i += n_threads) Sg[i] = sw[i];
+        for (uint32_t i = tid; i < d.N; i += kSweepFThreads) Sg[i] = sw[i];
 }
 
-// xw[tile word][site][4] = S_i ^ S_fwd(i, d) for d < nn (bit set <=> s_i s_j = -1).
+// xw[tile word][site] = (S_i ^ S_fwd(i,0), S_i ^ S_fwd(i,1), S_i ^ S_fwd(i,2), S_i):
+// bond sign words (bit set <=> s_i s_j = -1) and the spin word itself, for k_energy_f.
 __global__ __launch_bounds__(256) void k_bonds_f(SimDims d, DevPtrs p) {
     const uint32_t tw = blockIdx.y, real = tw / d.W;
     const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
@@ -224,47 +309,177 @@ __global__ __launch_bounds__(256) void k_bonds_f(SimDims d, DevPtrs p) {
         site = r.site >> 2; f[0] = r.nb[0] >> 2; f[1] = r.nb[2] >> 2; f[2] = r.nb[4] >> 2;
     }
     const uint32_t s = Sg[site];
-    uint4 out = make_uint4(0, 0, 0, 0);
+    uint4 out = make_uint4(0, 0, 0, s);
     out.x = s ^ Sg[f[0]];
     if (d.nn > 1) out.y = s ^ Sg[f[1]];
     if (d.nn > 2) out.z = s ^ Sg[f[2]];
     reinterpret_cast<uint4 *>(p.xw)[static_cast<size_t>(tw) * d.N + site] = out;
 }
 
-// One wave per tile word, lane = slot: the reference's sequential f32 sum over (site, direction)
-// in typewriter order (energy.rs:92-107) and the magnetisation count.  Addresses are wave-uniform
-// (scalar loads); only the additions depend on each other.
-__global__ __launch_bounds__(64) void k_energy_f(SimDims d, DevPtrs p) {
-    const uint32_t tw = blockIdx.x, real = tw / d.W, w = tw % d.W;
-    const uint32_t bit = threadIdx.x & 31u;
-    const uint4 *__restrict__ xw = reinterpret_cast<const uint4 *>(p.xw) + static_cast<size_t>(tw) * d.N;
-    const float *__restrict__ J = p.Jf + static_cast<size_t>(real) * d.N * d.nn;
-    const uint32_t *__restrict__ Sg = p.S + static_cast<size_t>(tw) * d.N;
+// ---------------------------------------------------------------------------
+// k_energy_f: the reference's energy is a strictly sequential f32 sum over (site, direction)
+// in typewriter order (energy.rs:92-107), so each system is one dependent chain of N z'
+// additions (about 8 cycles each on a lone wave: ~40 us at 16^3 whatever else happens).
+// Workgroup = (realisation, pair of tile words), 8 waves.  Wave 0 CONSUMES: lane = one of the
+// pair's 64 slots, nothing but LDS reads and the additions.  Waves 1-7 PRODUCE the signed terms
+// +-J of the next chunk of 64 sites into LDS (sign = the bond word's bit of the lane's slot):
+// one pass of a producer wave serves 4 consecutive sites of both words (12 terms = three
+// 16-byte LDS writes per lane).  The producers' inputs (bond words, couplings) are loaded from
+// global memory two chunks ahead and staged through LDS; one barrier per chunk.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kEnergyChunk = 64;     // sites per chunk
+constexpr uint32_t kEnergyThreads = 512;  // 1 consumer + 7 producer waves
+constexpr uint32_t kProducers = kEnergyThreads / 64 - 1;
+
+template <int NN> struct EnergyLds {
+    static constexpr uint32_t kTerms = kEnergyChunk * NN;   // terms per chunk and word
+    static constexpr uint32_t kQuads = kTerms / 4;
+    float4 terms[2][2][kQuads][32];   // [buffer][word of the pair][term / 4][slot] -> 4 terms
+    uint4 rawx[2][2][kEnergyChunk];   // [buffer][word][site] bond words + spin word
+    float4 rawj[2][kEnergyChunk];     // [buffer][site] forward couplings
+    uint32_t neg_total[64];
+};
+
+template <int NN>
+__global__ __launch_bounds__(kEnergyThreads) void k_energy_f(SimDims d, DevPtrs p) {
+    using Lds = EnergyLds<NN>;
+    constexpr uint32_t kTerms = Lds::kTerms, kQuads = Lds::kQuads;
+    extern __shared__ uint32_t lds_raw[];
+    Lds &L = *reinterpret_cast<Lds *>(lds_raw);
+    const uint32_t n_pairs_w = (d.W + 1) / 2;
+    const uint32_t real = blockIdx.x / n_pairs_w, w0 = (blockIdx.x % n_pairs_w) * 2;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, bit = lane & 31u, half = lane >> 5;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool word_ok = w0 + half < d.W; // the pair's second word may not exist
+    const uint32_t tw0 = real * d.W + w0;
+    const uint4 *__restrict__ xw = reinterpret_cast<const uint4 *>(p.xw);
+    const float *__restrict__ J = p.Jf + static_cast<size_t>(real) * d.N * NN;
+    const uint32_t n_chunks = (d.N + kEnergyChunk - 1) / kEnergyChunk;
+    if (tid < 64) L.neg_total[tid] = 0;
+
+    // raw inputs of one chunk: producer thread pt < 128 holds a (word, site) uint4,
+    // 128 <= pt < 128 + 64 NN one coupling
+    const uint32_t pt = tid - 64; // producer thread index (meaningless for wave 0)
+    uint4 reg_x = make_uint4(0, 0, 0, 0);
+    float reg_j = 0.0f;
+    auto load_raw = [&](uint32_t chunk) {
+        if (chunk >= n_chunks) return;
+        const uint32_t base = chunk * kEnergyChunk;
+        if (pt < 2 * kEnergyChunk) {
+            const uint32_t wsel = pt / kEnergyChunk, k = pt % kEnergyChunk;
+            reg_x = (base + k < d.N && w0 + wsel < d.W)
+                        ? xw[static_cast<size_t>(tw0 + wsel) * d.N + base + k]
+                        : make_uint4(0, 0, 0, 0);
+        } else if (pt < 2 * kEnergyChunk + kTerms) {
+            const size_t e = static_cast<size_t>(base) * NN + (pt - 2 * kEnergyChunk);
+            reg_j = e < static_cast<size_t>(d.N) * NN ? J[e] : 0.0f;
+        }
+    };
+    auto stash_raw = [&](uint32_t chunk) {
+        if (chunk >= n_chunks) return;
+        if (pt < 2 * kEnergyChunk) {
+            L.rawx[chunk & 1u][pt / kEnergyChunk][pt % kEnergyChunk] = reg_x;
+        } else if (pt < 2 * kEnergyChunk + kTerms) {
+            const uint32_t e = pt - 2 * kEnergyChunk;
+            reinterpret_cast<float *>(L.rawj[chunk & 1u])[(e / NN) * 4 + e % NN] = reg_j;
+        }
+    };
+
     float total = 0.0f;
     uint32_t neg = 0;
-    if (d.nn == 3) {
-#pragma unroll 4
-        for (uint32_t i = 0; i < d.N; ++i) {
-            const uint4 x = xw[i];
-            total = __fadd_rn(total, signed_by_spin(J[i * 3 + 0], x.x, bit));
-            total = __fadd_rn(total, signed_by_spin(J[i * 3 + 1], x.y, bit));
-            total = __fadd_rn(total, signed_by_spin(J[i * 3 + 2], x.z, bit));
-            neg += (Sg[i] >> bit) & 1u;
+    const uint32_t sh = 31u - bit;
+    auto signed_term = [&](uint32_t xword, float jv) {
+        return __uint_as_float(__builtin_amdgcn_bitop3_b32(xword << sh, 0x80000000u, __float_as_uint(jv), 0x6A));
+    };
+    // producer pass g: sites 4g .. 4g+3 of the chunk, lanes 0-31 for the pair's first word and
+    // lanes 32-63 for its second; the 4 NN terms are NN consecutive quads of the lane's column
+    auto produce = [&](uint32_t chunk) {
+        if (chunk >= n_chunks) return;
+        const uint32_t buf = chunk & 1u;
+        for (uint32_t g = wave - 1; g < kEnergyChunk / 4; g += kProducers) {
+            float t[4 * NN];
+#pragma unroll
+            for (uint32_t s4 = 0; s4 < 4; ++s4) {
+                const uint4 x = L.rawx[buf][half][4 * g + s4];
+                const float4 j = L.rawj[buf][4 * g + s4];
+                t[s4 * NN + 0] = signed_term(x.x, j.x);
+                if (NN > 1) t[s4 * NN + 1] = signed_term(x.y, j.y);
+                if (NN > 2) t[s4 * NN + 2] = signed_term(x.z, j.z);
+                neg += (x.w >> bit) & 1u;
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < NN; ++q)
+                L.terms[buf][half][g * NN + q][bit] = make_float4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
         }
-    } else {
-        for (uint32_t i = 0; i < d.N; ++i) {
-            const uint4 x = xw[i];
-            const uint32_t xs[3] = {x.x, x.y, x.z};
-            for (uint32_t dd = 0; dd < d.nn; ++dd)
-                total = __fadd_rn(total, signed_by_spin(J[i * d.nn + dd], xs[dd], bit));
-            neg += (Sg[i] >> bit) & 1u;
+    };
+    auto add4 = [&](const float4 v) {
+        total = __fadd_rn(total, v.x);
+        total = __fadd_rn(total, v.y);
+        total = __fadd_rn(total, v.z);
+        total = __fadd_rn(total, v.w);
+    };
+    auto consume = [&](uint32_t chunk) {
+        const uint32_t n_terms = min(kEnergyChunk, d.N - chunk * kEnergyChunk) * NN;
+        const float4(*buf)[32] = L.terms[chunk & 1u][half];
+        if (n_terms == kTerms) {
+            // full chunk: LDS reads run one batch of 8 quads ahead of the additions
+            constexpr uint32_t kB = 8;
+            static_assert(kQuads % kB == 0, "chunk terms must split into read batches");
+            float4 cur[kB], nxt[kB];
+#pragma unroll
+            for (uint32_t m = 0; m < kB; ++m) cur[m] = buf[m][bit];
+#pragma unroll
+            for (uint32_t b = 0; b < kQuads / kB; ++b) {
+                if (b + 1 < kQuads / kB) {
+#pragma unroll
+                    for (uint32_t m = 0; m < kB; ++m) nxt[m] = buf[(b + 1) * kB + m][bit];
+                }
+#pragma unroll
+                for (uint32_t m = 0; m < kB; ++m) add4(cur[m]);
+#pragma unroll
+                for (uint32_t m = 0; m < kB; ++m) cur[m] = nxt[m];
+            }
+            return;
         }
+        uint32_t q = 0;
+        for (; q < n_terms / 4; ++q) add4(buf[q][bit]);
+        const uint32_t rest = n_terms & 3u;
+        if (rest) {
+            const float4 v = buf[q][bit];
+            total = __fadd_rn(total, v.x);
+            if (rest > 1) total = __fadd_rn(total, v.y);
+            if (rest > 2) total = __fadd_rn(total, v.z);
+        }
+    };
+
+    // prologue: raw(0), raw(1) in LDS, raw(2) in flight, terms(0) produced
+    if (wave > 0) {
+        load_raw(0);
+        stash_raw(0);
+        load_raw(1);
+        stash_raw(1);
+        load_raw(2);
     }
-    const uint32_t slot = w * 32 + bit;
-    if (threadIdx.x < 32 && slot < d.n_sys) {
+    __syncthreads();
+    if (wave > 0) produce(0);
+    __syncthreads();
+    for (uint32_t chunk = 0; chunk < n_chunks; ++chunk) {
+        if (wave == 0) {
+            consume(chunk);
+        } else {
+            produce(chunk + 1);     // from raw(chunk + 1), staged before the last barrier
+            stash_raw(chunk + 2);   // overwrites raw(chunk), which produce(chunk) finished with
+            load_raw(chunk + 3);
+        }
+        __syncthreads();
+    }
+    if (wave > 0) atomicAdd(&L.neg_total[lane], neg);
+    __syncthreads();
+    const uint32_t slot = (w0 + half) * 32 + bit;
+    if (tid < 64 && word_ok && slot < d.n_sys) {
         p.Esum[static_cast<size_t>(real) * d.n_sys + slot] = __float_as_int(total); // raw f32 bits
         p.Msum[static_cast<size_t>(real) * d.n_sys + slot] =
-            static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(neg);
+            static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(L.neg_total[lane]);
     }
 }
 
@@ -272,12 +487,30 @@ __global__ __launch_bounds__(64) void k_energy_f(SimDims d, DevPtrs p) {
 // Launchers
 // ---------------------------------------------------------------------------
 size_t sweep_f_lds_bytes(const SimDims &d) {
-    return ((static_cast<size_t>(d.N) + 3) / 4 * 4 + static_cast<size_t>(d.N) * d.nn) * 4;
+    return ((static_cast<size_t>(d.N) + 3) / 4 * 4 + static_cast<size_t>(d.N) * 4) * 4;
 }
 
 hipError_t configure_general_kernels() {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_f<false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (const void *fn : {reinterpret_cast<const void *>(k_sweep_f<false, 1>),
+                           reinterpret_cast<const void *>(k_sweep_f<false, 2>),
+                           reinterpret_cast<const void *>(k_sweep_f<false, 3>),
+                           reinterpret_cast<const void *>(k_energy_f<1>),
+                           reinterpret_cast<const void *>(k_energy_f<2>),
+                           reinterpret_cast<const void *>(k_energy_f<3>)}) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+template <bool BIG>
+static void launch_sweep_f_nn(const SimDims &d, const DevPtrs &p, size_t lds, hipStream_t stream) {
+    const dim3 grid(d.n_real * d.W), block(kSweepFThreads);
+    switch (d.nn) {
+    case 1: hipLaunchKernelGGL((k_sweep_f<BIG, 1>), grid, block, lds, stream, d, p); break;
+    case 2: hipLaunchKernelGGL((k_sweep_f<BIG, 2>), grid, block, lds, stream, d, p); break;
+    default: hipLaunchKernelGGL((k_sweep_f<BIG, 3>), grid, block, lds, stream, d, p); break;
+    }
 }
 
 hipError_t launch_log_selftest(float *out_ln, float *out_logit, hipStream_t stream) {
@@ -288,7 +521,7 @@ hipError_t launch_log_selftest(float *out_ln, float *out_logit, hipStream_t stre
 hipError_t launch_rng_f(const SimDims &d, const DevPtrs &p, bool gibbs, hipStream_t stream) {
     const uint32_t n_pairs_tw = (d.n_real * d.W + 1) / 2;
     const uint32_t groups = (n_pairs_tw + 3) / 4;
-    const size_t lds = 64 * 16 * 8 * 4;
+    const size_t lds = 64 * 16 * 8 * 4 + 16 * sizeof(double2);
     if (gibbs)
         hipLaunchKernelGGL(k_rng_f<true>, dim3(groups * d.B), dim3(256), lds, stream, d, p);
     else
@@ -300,14 +533,18 @@ hipError_t launch_sweep_f(const SimDims &d, const DevPtrs &p, bool with_energy, 
                           hipStream_t stream) {
     if (do_sweep) {
         if (d.big)
-            hipLaunchKernelGGL(k_sweep_f<true>, dim3(d.n_real * d.W), dim3(1024), 0, stream, d, p);
+            launch_sweep_f_nn<true>(d, p, 0, stream);
         else
-            hipLaunchKernelGGL(k_sweep_f<false>, dim3(d.n_real * d.W), dim3(256), sweep_f_lds_bytes(d),
-                               stream, d, p);
+            launch_sweep_f_nn<false>(d, p, sweep_f_lds_bytes(d), stream);
     }
     if (with_energy) {
         hipLaunchKernelGGL(k_bonds_f, dim3((d.N + 255) / 256, d.n_real * d.W), dim3(256), 0, stream, d, p);
-        hipLaunchKernelGGL(k_energy_f, dim3(d.n_real * d.W), dim3(64), 0, stream, d, p);
+        const dim3 grid(d.n_real * ((d.W + 1) / 2)), block(kEnergyThreads);
+        switch (d.nn) {
+        case 1: hipLaunchKernelGGL(k_energy_f<1>, grid, block, sizeof(EnergyLds<1>), stream, d, p); break;
+        case 2: hipLaunchKernelGGL(k_energy_f<2>, grid, block, sizeof(EnergyLds<2>), stream, d, p); break;
+        default: hipLaunchKernelGGL(k_energy_f<3>, grid, block, sizeof(EnergyLds<3>), stream, d, p); break;
+        }
     }
     return hipGetLastError();
 }

@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpeapods_amd.so")
-SOURCES = ["host_util.cpp", "kernels.hip", "kernels_general.hip", "sim.hip"]
+SOURCES = ["host_util.cpp", "kernels.hip", "kernels_general.hip", "kernels_cluster.hip", "sim.hip"]
 HEADERS = ["engine.hpp", "host_util.hpp", "device_util.hpp", os.path.join("..", "..", "include", "peapods_amd.h")]
 FLAGS = [
     "--offload-arch=gfx950",

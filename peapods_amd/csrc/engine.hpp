@@ -88,6 +88,10 @@ struct DevPtrs {
     const float *jorg_p;      // [n_temps] 1 - exp(-4 / T) by the host libm (Joerg bond probability)
     uint16_t *dfs_stack;      // [n_real][n_temps * n_pairs][N] scratch of k_jorg
     uint64_t *pair_rng;      // [n_real][n_temps * n_pairs][4] xoshiro state of the overlap-move generators
+    // "sw" inner variant of the overlap-cluster moves (kernels_cluster.hip; built on first use)
+    uint32_t *pair_slots;    // [n_real][n_temps * n_pairs][2] slots of every group of two
+    const uint32_t *jump256; // [n_jump256][64][16][8] nibble tables of T^(256 b)
+    const uint32_t *jorg_thr;// [n_temps] ceil((1 - exp(-4/T)) 2^24): draw < thr <=> gen::<f32>() < p
     // general-coupling path only
     const float *Jf;         // [n_real][N][nn] forward couplings as given
     const float *temps;      // [n_temps]
@@ -118,6 +122,10 @@ hipError_t launch_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt
 hipError_t launch_measure_stamped(const SimDims &d, const DevPtrs &p, const PtParams &pt,
                                   unsigned long long *stamps, hipStream_t stream);
 size_t sweep_lds_bytes(const SimDims &d, bool gibbs);
+// kernels_cluster.hip
+hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, bool jorg, hipStream_t stream);
+size_t cluster_sw_lds_bytes(const SimDims &d);
+hipError_t configure_cluster_kernels();
 // kernels_general.hip
 hipError_t launch_rng_f(const SimDims &d, const DevPtrs &p, bool gibbs, hipStream_t stream);
 hipError_t launch_sweep_f(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,

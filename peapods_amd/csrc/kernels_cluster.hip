@@ -1,0 +1,371 @@
+// Overlap-cluster moves, Swendsen-Wang ("sw") inner variant (gfx950).
+//
+// Reference: clusters/overlap.rs houdayer_step (:153-339) and jorg_step (:348-553) with
+// cluster_mode = sw, i.e. the union-find path: activate_bonds (clusters/utils.rs:225-241) visits
+// every forward bond (site, dim) in order and asks should_bond, which consumes one draw of the
+// pair's generator for every ELIGIBLE bond of the Joerg move (none for Houdayer); after
+// uf_flatten_counts the sites are scanned in order and every cluster of more than one site
+// receives a coin gen::<f32>() < 0.5 the first time one of its sites is met; clusters with
+// coin 1 are flipped in both replicas.
+//
+// None of this depends on the order of the unions: the draw a bond sees is fixed by the number
+// of eligible bonds before it in (site, dim) order, cluster membership is the connected
+// components of the accepted bonds, and a cluster's coin is fixed by the rank of its smallest
+// site among the multi-site clusters.  So the move runs as a parallel algorithm per pair:
+//   eligibility bitmaps (ballots) -> prefix sums -> the pair's xoshiro stream generated in
+//   blocks of 256 draws by jump-ahead -> accepted bonds -> connected components by min-label
+//   hooking + pointer jumping in LDS -> cluster ranks -> coin draws -> flips (atomic XOR on the
+//   two bit columns of the pair).
+//
+//   k_pairing      per realisation: the per-temperature shuffles of build_tasks (:35-56)
+//   k_cluster_sw   workgroup = (realisation, temperature, pair)
+#include "engine.hpp"
+
+#include <cstdlib>
+
+#include "device_util.hpp"
+
+namespace pa {
+
+__device__ __forceinline__ uint32_t gen_range_u32(DevRng &rng, uint32_t range) {
+    // rand 0.8.5 UniformInt<u32>::sample_single: widening multiply, zone rejection
+    const uint32_t zone = (range << __clz(range)) - 1u;
+    for (;;) {
+        const uint32_t v = static_cast<uint32_t>(rng.next() >> 32);
+        const uint64_t m = static_cast<uint64_t>(v) * range;
+        if (static_cast<uint32_t>(m) <= zone) return static_cast<uint32_t>(m >> 32);
+    }
+}
+
+// One thread per temperature: shuffle the replicas with pair generator t * n_pairs (reverse
+// Fisher-Yates, SliceRandom::shuffle) and write the slots of every group of two.
+__global__ void k_pairing(SimDims d, DevPtrs p) {
+    const uint32_t real = blockIdx.x, t = threadIdx.x;
+    if (t >= d.n_temps) return;
+    const uint32_t n_lanes = d.n_temps * d.n_pairs;
+    uint64_t *st = p.pair_rng + (static_cast<size_t>(real) * n_lanes + static_cast<size_t>(t) * d.n_pairs) * 4;
+    DevRng rng;
+    rng.s0 = st[0]; rng.s1 = st[1]; rng.s2 = st[2]; rng.s3 = st[3];
+    uint32_t order[32]; // n_replicas <= 32 (checked on the host)
+    for (uint32_t k = 0; k < d.n_replicas; ++k) order[k] = k;
+    for (uint32_t i = d.n_replicas - 1; i >= 1; --i) {
+        const uint32_t j = gen_range_u32(rng, i + 1);
+        const uint32_t tmp = order[i];
+        order[i] = order[j];
+        order[j] = tmp;
+    }
+    uint32_t *slots = p.pair_slots + (static_cast<size_t>(real) * n_lanes + static_cast<size_t>(t) * d.n_pairs) * 2;
+    for (uint32_t g = 0; g < d.n_pairs; ++g) {
+        slots[2 * g + 0] = order[2 * g] * d.n_temps + t;
+        slots[2 * g + 1] = order[2 * g + 1] * d.n_temps + t;
+    }
+    st[0] = rng.s0; st[1] = rng.s1; st[2] = rng.s2; st[3] = rng.s3;
+}
+
+constexpr uint32_t kSwThreads = 256;
+
+// Exclusive prefix sum of v over the workgroup's threads (tid order); returns the exclusive
+// prefix, *total receives the sum.  scratch: [kSwThreads / 64 + 1] dwords of LDS.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *scratch, uint32_t *total) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off);
+        if (lane >= static_cast<uint32_t>(off)) incl += up;
+    }
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, sum = 0;
+    for (uint32_t k = 0; k < kSwThreads / 64; ++k) {
+        if (k < wave) base += scratch[k];
+        sum += scratch[k];
+    }
+    __syncthreads();
+    *total = sum;
+    return base + incl - v;
+}
+
+struct SwLds {
+    uint32_t *label;   // [N] component label (smallest site after convergence)
+    uint32_t *aux;     // [N] multi-site flag of roots
+    uint32_t *act;     // [MW] active sites (the pair's spins differ)
+    uint32_t *spa;     // [MW] spin of the pair's first system (1 <=> -1)
+    uint32_t *bond;    // [3][MW] eligible, later accepted, forward bonds per direction
+    uint32_t *wbase;   // [MW + 1] exclusive prefix (eligible bonds / multi-site roots) per 32-site word
+    uint32_t *roots;   // [MW] multi-site roots
+    uint32_t *bits;    // [n_bit_words] accept bits by draw position, later coin bits
+    uint32_t *scratch; // [8]
+    uint32_t *misc;    // [4] changed flag
+};
+
+__host__ __device__ inline size_t cluster_sw_bit_words(const SimDims &d) {
+    return (static_cast<size_t>(d.N) * d.nn + 255) / 256 * 8 + 16;
+}
+__host__ __device__ inline size_t cluster_sw_lds_words(const SimDims &d) {
+    return 2 * static_cast<size_t>(d.N) + 7 * static_cast<size_t>(d.MW) + 1 + cluster_sw_bit_words(d) + 12;
+}
+
+// Position-dependent helpers on the 32-site word bitmaps: number of set (site, dim) entries
+// strictly before (i, dd) in (site, dim) order, within site i's word.
+template <bool JORG>
+__global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p) {
+    extern __shared__ uint32_t lds[];
+    SwLds L;
+    {
+        uint32_t *q = lds;
+        L.label = q; q += d.N;
+        L.aux = q; q += d.N;
+        L.act = q; q += d.MW;
+        L.spa = q; q += d.MW;
+        L.bond = q; q += 3 * d.MW;
+        L.wbase = q; q += d.MW + 1;
+        L.roots = q; q += d.MW;
+        L.bits = q; q += cluster_sw_bit_words(d);
+        L.scratch = q; q += 8;
+        L.misc = q;
+    }
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t n_lanes = d.n_temps * d.n_pairs;
+    const uint32_t real = blockIdx.x / n_lanes, task = blockIdx.x % n_lanes;
+    const uint32_t t = task / d.n_pairs;
+    const uint32_t sa = p.pair_slots[(static_cast<size_t>(real) * n_lanes + task) * 2 + 0];
+    const uint32_t sb = p.pair_slots[(static_cast<size_t>(real) * n_lanes + task) * 2 + 1];
+    uint32_t *Sa = p.S + (static_cast<size_t>(real) * d.W + (sa >> 5)) * d.N;
+    uint32_t *Sb = p.S + (static_cast<size_t>(real) * d.W + (sb >> 5)) * d.N;
+    const uint32_t ba = sa & 31u, bb = sb & 31u;
+    const uint16_t *jsite = p.jsite + static_cast<size_t>(real) * d.N;
+    uint64_t *rng_state = p.pair_rng + (static_cast<size_t>(real) * n_lanes + task) * 4;
+    const uint32_t n_rounds = (d.N + kSwThreads - 1) / kSwThreads; // site i = r * 256 + tid
+    // write the ballot of a predicate over sites r*256 + tid into a bitmap (two words per wave)
+    auto put_ballot = [&](uint32_t *bitmap, uint32_t r, bool pred) {
+        const unsigned long long votes = __ballot(pred);
+        const uint32_t word = (r * kSwThreads + (tid & ~63u)) >> 5;
+        if (lane == 0 && word < d.MW) bitmap[word] = static_cast<uint32_t>(votes);
+        if (lane == 32 && word + 1 < d.MW) bitmap[word + 1] = static_cast<uint32_t>(votes >> 32);
+    };
+    auto get_bit = [&](const uint32_t *bitmap, uint32_t i) -> uint32_t { return (bitmap[i >> 5] >> (i & 31u)) & 1u; };
+
+    // ---- A: active sites and the first system's spins
+    for (uint32_t r = 0; r < n_rounds; ++r) {
+        const uint32_t i = r * kSwThreads + tid;
+        uint32_t a = 0, b = 0;
+        if (i < d.N) {
+            a = (Sa[i] >> ba) & 1u;
+            b = (Sb[i] >> bb) & 1u;
+        }
+        put_ballot(L.act, r, (a ^ b) != 0);
+        put_ballot(L.spa, r, a != 0);
+    }
+    __syncthreads();
+
+    // ---- B: eligible forward bonds.  Houdayer: both ends active (overlap.rs:228-231).
+    // Joerg: both ends active and s_a(i) s_a(j) J > 0 (:417-429).
+    for (uint32_t r = 0; r < n_rounds; ++r) {
+        const uint32_t i = r * kSwThreads + tid;
+        bool e[3] = {false, false, false};
+        if (i < d.N && get_bit(L.act, i)) {
+            const uint32_t jm = JORG ? jsite[i] : 0u;
+            for (uint32_t dd = 0; dd < d.nn; ++dd) {
+                const uint32_t j = p.nbr_site[i * 6 + 2 * dd];
+                bool ok = get_bit(L.act, j) != 0;
+                if (JORG && ok) {
+                    const bool nz = (jm >> (6 + 2 * dd)) & 1u;
+                    const uint32_t unsat = get_bit(L.spa, i) ^ get_bit(L.spa, j) ^ ((jm >> (2 * dd)) & 1u);
+                    ok = nz && unsat == 0;
+                }
+                e[dd] = ok;
+            }
+        }
+        for (uint32_t dd = 0; dd < 3; ++dd) put_ballot(L.bond + dd * d.MW, r, e[dd]);
+    }
+    __syncthreads();
+
+    // number of set entries before (i, dd) in (site, dim) order, from the per-word prefix wbase
+    auto entries_before = [&](uint32_t i, uint32_t dd) -> uint32_t {
+        const uint32_t m = i >> 5, k = i & 31u, below = (1u << k) - 1u;
+        uint32_t n = L.wbase[m];
+        for (uint32_t x = 0; x < d.nn; ++x) {
+            const uint32_t wv = L.bond[x * d.MW + m];
+            n += __popc(wv & below) + ((x < dd) ? ((wv >> k) & 1u) : 0u);
+        }
+        return n;
+    };
+    // exclusive scan of a per-word count into wbase[0..MW]; returns the total
+    auto scan_words = [&](auto count_of_word) -> uint32_t {
+        uint32_t total = 0, carry = 0;
+        for (uint32_t m0 = 0; m0 < d.MW; m0 += kSwThreads) {
+            const uint32_t m = m0 + tid;
+            const uint32_t c = m < d.MW ? count_of_word(m) : 0u;
+            uint32_t part = 0;
+            const uint32_t ex = block_exclusive_scan(c, L.scratch, &part);
+            if (m < d.MW) L.wbase[m] = carry + ex;
+            carry += part;
+        }
+        total = carry;
+        if (tid == 0) L.wbase[d.MW] = total;
+        __syncthreads();
+        return total;
+    };
+
+    // the pair's generator, advanced by `offset` draws through the stride-256 jump tables:
+    // returns the state at draw 256 * block
+    uint32_t base_state[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        base_state[2 * k] = static_cast<uint32_t>(rng_state[k]);
+        base_state[2 * k + 1] = static_cast<uint32_t>(rng_state[k] >> 32);
+    }
+    auto stream_at_block = [&](uint32_t block) -> Rng32 {
+        uint32_t st[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) st[k] = base_state[k];
+        if (block > 0) jump_state_lds(st, p.jump256 + static_cast<size_t>(block) * (64 * 16 * 8));
+        Rng32 rng;
+        rng.load(st);
+        return rng;
+    };
+
+    // ---- C, D (Joerg only): draw positions of the eligible bonds, accept bits of the stream
+    uint32_t n_eligible = 0;
+    if (JORG) {
+        n_eligible = scan_words([&](uint32_t m) {
+            uint32_t c = 0;
+            for (uint32_t x = 0; x < d.nn; ++x) c += __popc(L.bond[x * d.MW + m]);
+            return c;
+        });
+        const uint32_t n_blocks = (n_eligible + 255) / 256;
+        const uint32_t threshold = p.jorg_thr[t]; // draw < ceil(p 2^24)  <=>  gen::<f32>() < p
+        for (uint32_t blk = tid; blk < n_blocks; blk += kSwThreads) {
+            Rng32 rng = stream_at_block(blk);
+            for (uint32_t wd = 0; wd < 8; ++wd) {
+                uint32_t acc = 0;
+                for (uint32_t k = 0; k < 32; ++k) acc |= ((rng.next_top() >> 8) < threshold ? 1u : 0u) << k;
+                L.bits[blk * 8 + wd] = acc;
+            }
+        }
+        __syncthreads();
+        // ---- E: accepted bonds
+        for (uint32_t r = 0; r < n_rounds; ++r) {
+            const uint32_t i = r * kSwThreads + tid;
+            bool e[3] = {false, false, false};
+            if (i < d.N)
+                for (uint32_t dd = 0; dd < d.nn; ++dd)
+                    if (get_bit(L.bond + dd * d.MW, i)) {
+                        const uint32_t pos = entries_before(i, dd);
+                        e[dd] = (L.bits[pos >> 5] >> (pos & 31u)) & 1u;
+                    }
+            __syncthreads(); // every thread has read its bond words before any is replaced
+            for (uint32_t dd = 0; dd < 3; ++dd) put_ballot(L.bond + dd * d.MW, r, e[dd]);
+            __syncthreads();
+        }
+    }
+
+    // ---- F: connected components.  Roots are hooked under the smaller root, so a component's
+    // final root is its smallest site -- the order in which the reference meets the clusters.
+    for (uint32_t i = tid; i < d.N; i += kSwThreads) L.label[i] = i;
+    if (tid == 0) L.misc[0] = 0;
+    __syncthreads();
+    auto find_root = [&](uint32_t x) -> uint32_t {
+        for (;;) {
+            const uint32_t up = L.label[x];
+            if (up == x) return x;
+            x = up;
+        }
+    };
+    for (uint32_t iter = 0; iter <= d.N; ++iter) {
+        bool hooked = false;
+        for (uint32_t i = tid; i < d.N; i += kSwThreads)
+            for (uint32_t dd = 0; dd < d.nn; ++dd)
+                if (get_bit(L.bond + dd * d.MW, i)) {
+                    const uint32_t j = p.nbr_site[i * 6 + 2 * dd];
+                    const uint32_t ra = find_root(i), rb = find_root(j);
+                    if (ra != rb) {
+                        atomicMin(&L.label[max(ra, rb)], min(ra, rb));
+                        hooked = true;
+                    }
+                }
+        if (hooked) L.misc[0] = 1;
+        __syncthreads();
+        for (uint32_t i = tid; i < d.N; i += kSwThreads) { // pointer jumping
+            uint32_t x = L.label[i];
+            while (L.label[x] != x) x = L.label[x];
+            L.label[i] = x;
+        }
+        const bool again = L.misc[0] != 0;
+        __syncthreads();
+        if (!again) break;
+        if (tid == 0) L.misc[0] = 0;
+        __syncthreads();
+    }
+
+    // ---- G: clusters of more than one site, ranked by their smallest site (overlap.rs:312-318)
+    for (uint32_t i = tid; i < d.N; i += kSwThreads) L.aux[i] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < d.N; i += kSwThreads)
+        if (L.label[i] != i) L.aux[L.label[i]] = 1;
+    __syncthreads();
+    for (uint32_t r = 0; r < n_rounds; ++r) {
+        const uint32_t i = r * kSwThreads + tid;
+        put_ballot(L.roots, r, i < d.N && L.label[i] == i && L.aux[i] != 0);
+    }
+    __syncthreads();
+    const uint32_t n_clusters = scan_words([&](uint32_t m) { return static_cast<uint32_t>(__popc(L.roots[m])); });
+
+    // ---- H: coin draws continue the stream after the bond draws; the generator ends
+    // n_eligible + n_clusters draws after where it started
+    const uint32_t first_block = n_eligible / 256, end_pos = n_eligible + n_clusters;
+    const uint32_t last_block = end_pos / 256;
+    for (uint32_t blk = first_block + tid; blk <= last_block; blk += kSwThreads) {
+        Rng32 rng = stream_at_block(blk);
+        for (uint32_t wd = 0; wd < 8; ++wd) {
+            uint32_t acc = 0;
+            for (uint32_t k = 0; k < 32; ++k) {
+                if (blk == last_block && blk * 256 + wd * 32 + k == end_pos) {
+                    uint32_t st[8];
+                    rng.store(st);
+                    for (int q = 0; q < 4; ++q)
+                        rng_state[q] = (static_cast<uint64_t>(st[2 * q + 1]) << 32) | st[2 * q];
+                }
+                acc |= ((rng.next_top() >> 8) < (1u << 23) ? 1u : 0u) << k; // gen::<f32>() < 0.5
+            }
+            L.bits[(blk - first_block) * 8 + wd] = acc;
+        }
+    }
+    __syncthreads();
+
+    // ---- I: flip both replicas on the clusters whose coin is 1
+    for (uint32_t i = tid; i < d.N; i += kSwThreads) {
+        const uint32_t root = L.label[i];
+        if (!L.aux[root]) continue;
+        const uint32_t rank = L.wbase[root >> 5] + __popc(L.roots[root >> 5] & ((1u << (root & 31u)) - 1u));
+        const uint32_t pos = n_eligible + rank - first_block * 256;
+        if ((L.bits[pos >> 5] >> (pos & 31u)) & 1u) {
+            atomicXor(&Sa[i], 1u << ba);
+            atomicXor(&Sb[i], 1u << bb);
+        }
+    }
+}
+
+size_t cluster_sw_lds_bytes(const SimDims &d) { return cluster_sw_lds_words(d) * 4; }
+
+hipError_t configure_cluster_kernels() {
+    for (const void *fn : {reinterpret_cast<const void *>(k_cluster_sw<false>),
+                           reinterpret_cast<const void *>(k_cluster_sw<true>)}) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, bool jorg, hipStream_t stream) {
+    hipLaunchKernelGGL(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
+    const dim3 grid(d.n_real * d.n_temps * d.n_pairs), block(kSwThreads);
+    if (jorg)
+        hipLaunchKernelGGL(k_cluster_sw<true>, grid, block, cluster_sw_lds_bytes(d), stream, d, p);
+    else
+        hipLaunchKernelGGL(k_cluster_sw<false>, grid, block, cluster_sw_lds_bytes(d), stream, d, p);
+    return hipGetLastError();
+}
+
+} // namespace pa

@@ -67,6 +67,7 @@ struct pa_sim {
     float *jorg_p = nullptr;
     uint32_t *thr_gibbs = nullptr; // built by the first Gibbs sample (ensure_gibbs)
     float *Jf = nullptr, *temps_dev = nullptr; // general-coupling path
+    uint32_t *jump256 = nullptr, *jorg_thr = nullptr; // "sw" overlap-cluster variant (ensure_cluster_sw)
     int32_t *nz_bonds = nullptr;
     float *dbeta = nullptr;
     // bookkeeping of the last sample()
@@ -383,6 +384,49 @@ int flush_swaps(pa_sim *sim) {
     return PA_OK;
 }
 
+// The "sw" inner variant of the overlap moves draws the pair generators' streams in blocks of 256
+// by jump-ahead: tables T^(256 b) for every block a move can reach, integer bond thresholds and the
+// pairing scratch are built by the first call that asks for them.
+int ensure_cluster_sw(pa_sim *sim) {
+    if (sim->jump256) return PA_OK;
+    const SimDims &d = sim->d;
+    if (d.big || cluster_sw_lds_bytes(d) > 160 * 1024)
+        return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the overlap-cluster kernel");
+    const uint32_t n_tab = (d.N * d.nn + d.N) / 256 + 2;
+    std::vector<uint32_t> jump(static_cast<size_t>(n_tab) * 64 * 16 * 8);
+    {
+        JumpMatrix step = JumpMatrix::steps(256);
+        JumpMatrix acc = JumpMatrix::identity();
+        for (uint32_t b = 0; b < n_tab; ++b) {
+            acc.nibble_table(&jump[static_cast<size_t>(b) * 64 * 16 * 8]);
+            if (b + 1 < n_tab) acc = step.compose(acc);
+        }
+    }
+    std::vector<uint32_t> thr(d.n_temps);
+    for (uint32_t t = 0; t < d.n_temps; ++t) { // gen::<f32>() < p on the 2^24 grid (overlap.rs:430)
+        const float bond_p = 1.0f - expf(-4.0f * 1.0f / sim->temps[t]);
+        const double scaled = std::ceil(static_cast<double>(bond_p) * 16777216.0);
+        thr[t] = scaled <= 0.0 ? 0u : (scaled >= 16777216.0 ? (1u << 24) : static_cast<uint32_t>(scaled));
+    }
+    const size_t n_lanes = static_cast<size_t>(d.n_temps) * d.n_pairs;
+    PA_HIP(sim, sim->buffers.alloc(&sim->jump256, jump.size()));
+    PA_HIP(sim, sim->buffers.alloc(&sim->jorg_thr, thr.size()));
+    PA_HIP(sim, sim->buffers.alloc(&sim->p.pair_slots, n_lanes * 2 * d.n_real));
+    int rc;
+    if ((rc = upload(sim, sim->jump256, jump)) || (rc = upload(sim, sim->jorg_thr, thr))) return rc;
+    if (configure_cluster_kernels() != hipSuccess) return fail(sim, PA_ERR_DEVICE, "kernel LDS configuration failed");
+    sim->p.jump256 = sim->jump256;
+    sim->p.jorg_thr = sim->jorg_thr;
+    uint32_t r0 = 0;
+    for (auto &g : sim->groups) {
+        g.p.jump256 = sim->jump256;
+        g.p.jorg_thr = sim->jorg_thr;
+        g.p.pair_slots = sim->p.pair_slots + n_lanes * 2 * r0;
+        r0 += g.d.n_real;
+    }
+    return PA_OK;
+}
+
 std::string validate_text(const pa_sample_config *cfg, uint64_t n_replicas, int *code) {
     *code = PA_ERR_INVALID;
     // spin-sim/src/config.rs:180-247 (message texts are the reference's)
@@ -404,8 +448,10 @@ std::string validate_text(const pa_sample_config *cfg, uint64_t n_replicas, int 
         for (int k = 0; k < cfg->n_overlap_cluster_modes && k < 4; ++k)
             if (cfg->overlap_cluster_modes[k] != PA_OC_HOUDAYER && cfg->overlap_cluster_modes[k] != PA_OC_JORG)
                 return "only the 'houdayer' and 'jorg' overlap-cluster moves are built on the HIP path yet";
-        if (cfg->overlap_cluster_mode != PA_CLUSTER_WOLFF)
-            return "overlap_cluster_mode='sw' is not built on the HIP path yet";
+        if (cfg->overlap_cluster_mode != PA_CLUSTER_WOLFF && cfg->overlap_cluster_mode != PA_CLUSTER_SW) {
+            *code = PA_ERR_INVALID;
+            return "unknown overlap_cluster_mode, expected 'wolff' or 'sw'";
+        }
         if (n_replicas > 32) return "overlap cluster moves support at most 32 replicas";
     }
     *code = PA_OK;
@@ -428,6 +474,8 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     const bool gibbs = cfg->sweep_mode == PA_SWEEP_GIBBS;
     int rc = gibbs ? ensure_gibbs(sim) : PA_OK;
     if (rc) return rc;
+    const bool oc_sw = cfg->overlap_cluster_interval > 0 && cfg->overlap_cluster_mode == PA_CLUSTER_SW;
+    if (oc_sw && (rc = ensure_cluster_sw(sim))) return rc;
     if ((rc = zero_accumulators(sim))) return rc;
     const bool want_overlap = d.n_pairs > 0 && cfg->measure_overlap;
     sim->n_recorded = 0;
@@ -467,7 +515,9 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                     return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the overlap-cluster kernel");
                 const int oc_mode = cfg->overlap_cluster_modes[overlap_call_count %
                                                                static_cast<uint64_t>(cfg->n_overlap_cluster_modes)];
-                if (oc_mode == PA_OC_JORG)
+                if (oc_sw)
+                    PA_HIP(sim, launch_cluster_sw(g.d, g.p, oc_mode == PA_OC_JORG, g.stream));
+                else if (oc_mode == PA_OC_JORG)
                     PA_HIP(sim, launch_jorg(g.d, g.p, g.stream)); // :601-602,660-680
                 else
                     PA_HIP(sim, launch_houdayer(g.d, g.p, g.stream));

@@ -347,6 +347,44 @@ def test_jorg_overlap_cluster_move_matches_oracle(oracle, mode, shape, n_temps, 
     assert_state_equal(gpu, cpu, check_energy=False)
 
 
+@pytest.mark.parametrize("mode", ["houdayer", "jorg", "houdayer+jorg"])
+@pytest.mark.parametrize("shape,n_temps,n_rep,n_dis", [((4, 4), 3, 2, 1), ((6, 6, 6), 5, 4, 2),
+                                                       ((12, 12, 12), 6, 4, 2), ((2, 4, 6), 3, 2, 1),
+                                                       ((5, 7), 4, 6, 1)])
+def test_sw_variant_of_the_overlap_moves_matches_oracle(oracle, mode, shape, n_temps, n_rep, n_dis):
+    """cluster_mode='sw' (overlap.rs:228-318,417-520): union-find over every forward bond in
+    (site, dim) order, one draw per eligible Joerg bond, one coin per multi-site cluster in the
+    order of its smallest site.  The GPU builds the same partition with parallel components."""
+    couplings = bimodal(shape, len(shape), n_dis, 35)
+    temps = np.linspace(0.7, 1.9, n_temps)
+    gpu, cpu = make_pair(oracle, shape, couplings, temps, n_rep, 19)
+    kwargs = dict(pt_interval=2, overlap_cluster_update_interval=1, overlap_cluster_build_mode=mode,
+                  overlap_cluster_mode="sw", warmup_ratio=0.25)
+    a = gpu.sample(10, "metropolis", **kwargs)
+    b = cpu.sample(10, "metropolis", **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu, check_energy=False)
+    # wolff and sw calls share the pair generators
+    kwargs["overlap_cluster_mode"] = "wolff"
+    a = gpu.sample(4, "metropolis", **kwargs)
+    b = cpu.sample(4, "metropolis", **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu, check_energy=False)
+
+
+def test_sw_variant_with_diluted_couplings(oracle):
+    shape = (8, 8, 8)
+    rng = np.random.default_rng(3)
+    couplings = rng.integers(-1, 2, size=shape + (3,)).astype(np.float32)
+    gpu, cpu = make_pair(oracle, shape, couplings, np.linspace(0.6, 2.2, 6), 4, 23)
+    kwargs = dict(pt_interval=1, overlap_cluster_update_interval=2, overlap_cluster_build_mode="jorg",
+                  overlap_cluster_mode="sw", warmup_ratio=0.0)
+    a = gpu.sample(12, "metropolis", **kwargs)
+    b = cpu.sample(12, "metropolis", **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+
+
 def test_unbuilt_overlap_modes_are_refused_not_emulated():
     from peapods_amd import IsingSimulation
 
@@ -356,6 +394,4 @@ def test_unbuilt_overlap_modes_are_refused_not_emulated():
     with pytest.raises(NotImplementedError):
         sim.sample(2, "metropolis", overlap_cluster_update_interval=1,
                    overlap_cluster_build_mode="cmr")
-    with pytest.raises(NotImplementedError):
-        sim.sample(2, "metropolis", overlap_cluster_update_interval=1, overlap_cluster_mode="sw")
     np.testing.assert_array_equal(sim.get_spins(), before)

@@ -17,6 +17,7 @@
  *                                                                          ss/spins/energy.rs:59-65
  *   pa_sim_parallel_tempering    <- mcmc::tempering::parallel_tempering(_full_ladder) as driven by
  *                                   ss/simulation/mod.rs:748-796 (one event for every replica ladder)
+ *   (sample with cluster_interval) <- clusters::fk_update, ss/clusters/fk.rs:27-200 (update action)
  *   pa_sim_overlap_dots          <- the integer part of OverlapAccum::collect, ss/statistics/overlap.rs:259-282
  *   pa_sim_get_result_*          <- SweepResult / OverlapStats fields, ss/statistics/results.rs:56-77,
  *                                   ss/statistics/overlap.rs:8-39 (per realisation, before aggregation)
@@ -95,6 +96,9 @@ typedef struct {
     int32_t overlap_cluster_mode; /* PA_CLUSTER_* */
     int32_t measure_overlap;      /* 1 = collect overlap statistics on recorded sweeps (reference
                                      behaviour whenever n_replicas >= 2); 0 only for timing runs */
+    uint64_t cluster_interval;    /* FK cluster update of every system each k sweeps
+                                     (cluster_update_interval, ss/clusters/fk.rs); 0 = none */
+    int32_t cluster_mode;         /* PA_CLUSTER_*: Swendsen-Wang or Wolff */
 } pa_sample_config;
 
 /* ---- lifecycle ----------------------------------------------------------- */

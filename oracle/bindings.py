@@ -38,6 +38,8 @@ class OrcConfig(C.Structure):
         ("n_overlap_cluster_modes", C.c_int32),
         ("overlap_cluster_mode", C.c_int32),
         ("n_threads", C.c_int32),
+        ("cluster_interval", C.c_uint64),
+        ("cluster_mode", C.c_int32),
     ]
 
 
@@ -299,7 +301,8 @@ class OracleSimulation:
     # -- sampling ---------------------------------------------------------
     def make_config(self, n_sweeps, sweep_mode, pt_interval=None, pt_schedule=None,
                     overlap_cluster_update_interval=None, overlap_cluster_build_mode=None,
-                    overlap_cluster_mode=None, warmup_ratio=None, n_threads=1):
+                    overlap_cluster_mode=None, warmup_ratio=None, n_threads=1,
+                    cluster_update_interval=None, cluster_mode=None):
         warmup = 0.25 if warmup_ratio is None else warmup_ratio
         cfg = OrcConfig()
         cfg.n_sweeps = int(n_sweeps)
@@ -329,6 +332,11 @@ class OracleSimulation:
             cfg.n_overlap_cluster_modes = len(modes)
             cfg.overlap_cluster_mode = CLUSTER_MODES[overlap_cluster_mode or "wolff"]
         cfg.n_threads = int(n_threads)
+        if cluster_update_interval is not None:
+            if cluster_update_interval < 1:
+                raise ValueError("cluster_update interval must be >= 1")
+            cfg.cluster_interval = int(cluster_update_interval)
+            cfg.cluster_mode = CLUSTER_MODES[cluster_mode or "sw"]  # src/lib.rs:233
         return cfg
 
     def run(self, cfg):
@@ -369,10 +377,12 @@ class OracleSimulation:
 
     def sample(self, n_sweeps, sweep_mode, pt_interval=None, pt_schedule=None,
                overlap_cluster_update_interval=None, overlap_cluster_build_mode=None,
-               overlap_cluster_mode=None, warmup_ratio=None, n_threads=1, **ignored):
+               overlap_cluster_mode=None, warmup_ratio=None, n_threads=1,
+               cluster_update_interval=None, cluster_mode=None):
         cfg = self.make_config(n_sweeps, sweep_mode, pt_interval, pt_schedule,
                                overlap_cluster_update_interval, overlap_cluster_build_mode,
-                               overlap_cluster_mode, warmup_ratio, n_threads)
+                               overlap_cluster_mode, warmup_ratio, n_threads,
+                               cluster_update_interval, cluster_mode)
         self.run(cfg)
         per_real, has_ov = self.per_realization_results()
         out = aggregate_results(per_real, self.n_temps, has_ov, self.n_realizations > 1)

@@ -823,6 +823,74 @@ static void overlap_update(const orc_lattice *lat, realization *real, size_t n_r
 }
 
 /* ========================================================================== */
+/* Fortuin-Kasteleyn cluster update of every system (ss/clusters/fk.rs:27-200) */
+/* ========================================================================== */
+
+/* Update action without CSD collection: Wolff takes the DFS fast path (:42-86), SW the
+ * union-find path (:102-196).  Slot k carries temperature temperatures[k] and system
+ * system_ids[k]; the system's own generator is used (par_over_replicas / rngs[system_id]). */
+static void fk_update(const orc_lattice *lat, realization *real, size_t n_systems, int wolff) {
+    size_t n = lat->n_spins, nn = lat->n_neighbors;
+    uint8_t *in_cluster = (uint8_t *)malloc(n + 1);
+    size_t *stack = (size_t *)malloc(sizeof(size_t) * (n + 1));
+    uint32_t *parent = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
+    uint8_t *rank = (uint8_t *)malloc(n + 1);
+    for (size_t slot = 0; slot < n_systems; ++slot) {
+        size_t system = (size_t)real->system_ids[slot];
+        int8_t *spin = real->spins + system * n;
+        orc_rng *rng = &real->rngs[system];
+        float temp = real->temperatures[slot];
+        if (wolff) {
+            size_t seed = (size_t)orc_rng_gen_range_usize(rng, 0, n);
+            memset(in_cluster, 0, n);
+            size_t top = 0;
+            in_cluster[seed] = 1;
+            stack[top++] = seed;
+            while (top > 0) { /* dfs_cluster, utils.rs:125-149 */
+                size_t site = stack[--top];
+                for (size_t d = 0; d < nn; ++d)
+                    for (int dir = 0; dir < 2; ++dir) {
+                        size_t nb = dir == 0 ? lat->fwd[site * nn + d] : lat->bwd[site * nn + d];
+                        if (in_cluster[nb]) continue;
+                        float coupling = dir == 0 ? real->couplings[site * nn + d]
+                                                  : real->couplings[nb * nn + d];
+                        float inter = (float)spin[site] * (float)spin[nb] * coupling;
+                        if (inter <= 0.0f) continue;
+                        if (orc_rng_gen_f32(rng) < 1.0f - expf(-2.0f * inter / temp)) {
+                            in_cluster[nb] = 1;
+                            stack[top++] = nb;
+                        }
+                    }
+            }
+            for (size_t i = 0; i < n; ++i)
+                if (in_cluster[i]) spin[i] = (int8_t)-spin[i];
+        } else {
+            for (size_t i = 0; i < n; ++i) parent[i] = (uint32_t)i;
+            memset(rank, 0, n);
+            for (size_t i = 0; i < n; ++i) /* activate_bonds, utils.rs:225-241 */
+                for (size_t d = 0; d < nn; ++d) {
+                    size_t j = lat->fwd[i * nn + d];
+                    float inter = (float)spin[i] * (float)spin[j] * real->couplings[i * nn + d];
+                    if (inter <= 0.0f) continue;
+                    if (orc_rng_gen_f32(rng) < 1.0f - expf(-2.0f * inter / temp))
+                        orc_uf_union(parent, rank, (uint32_t)i, (uint32_t)j);
+                }
+            for (size_t i = 0; i < n; ++i) parent[i] = orc_uf_find(parent, (uint32_t)i); /* uf_flatten */
+            memset(rank, 2, n); /* 2 = undecided (fk.rs:182-192): every cluster draws, singletons too */
+            for (size_t i = 0; i < n; ++i) {
+                uint32_t root = parent[i];
+                if (rank[root] == 2) rank[root] = (uint8_t)(orc_rng_gen_f32(rng) < 0.5f);
+                if (rank[root] == 1) spin[i] = (int8_t)-spin[i];
+            }
+        }
+    }
+    free(in_cluster);
+    free(stack);
+    free(parent);
+    free(rank);
+}
+
+/* ========================================================================== */
 /* Driver loop                                                                */
 /* ========================================================================== */
 
@@ -897,6 +965,9 @@ static void run_sweep_loop(const orc_lattice *lat, realization *real, size_t n_r
         else
             orc_gibbs_sweep(lat, real->spins, real->couplings, real->temperatures, real->system_ids,
                             n_systems, real->rngs);
+
+        if (cfg->cluster_interval > 0 && sweep_id % cfg->cluster_interval == 0) /* mod.rs:434-469 */
+            fk_update(lat, real, n_systems, cfg->cluster_mode == ORC_CLUSTER_WOLFF);
 
         int pt_this_sweep = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0; /* :486-488 */
 

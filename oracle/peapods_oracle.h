@@ -145,6 +145,8 @@ typedef struct {
     int32_t n_overlap_cluster_modes;
     int32_t overlap_cluster_mode; /* ORC_CLUSTER_* */
     int32_t n_threads;            /* realisations are distributed over threads; <=1 = serial */
+    uint64_t cluster_interval;    /* FK cluster update every k sweeps (ss/clusters/fk.rs); 0 = none */
+    int32_t cluster_mode;         /* ORC_CLUSTER_* */
 } orc_config;
 
 typedef struct orc_sim orc_sim;

@@ -163,9 +163,10 @@ class IsingSimulation:
                 raise ValueError("cluster_update interval must be >= 1")
             if action == "observe" and mode == "wolff":
                 raise ValueError("cluster_action='observe' requires cluster_mode='sw'")
-            raise NotImplementedError(
-                "FK cluster updates (cluster_update_interval) are outside the HIP hot path"
-            )
+            if action == "observe" or collect_cluster_stats:
+                raise NotImplementedError("cluster observers are outside the HIP hot path")
+            cfg.cluster_interval = int(cluster_update_interval)
+            cfg.cluster_mode = _CLUSTER_MODES[mode]
         if overlap_cluster_update_interval is not None:
             modes = _parse_overlap_modes(
                 "houdayer" if overlap_cluster_build_mode is None else overlap_cluster_build_mode

@@ -42,6 +42,8 @@ class PaSampleConfig(C.Structure):
         ("n_overlap_cluster_modes", C.c_int32),
         ("overlap_cluster_mode", C.c_int32),
         ("measure_overlap", C.c_int32),
+        ("cluster_interval", C.c_uint64),
+        ("cluster_mode", C.c_int32),
     ]
 
 

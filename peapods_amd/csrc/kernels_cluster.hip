@@ -17,8 +17,13 @@
 //   hooking + pointer jumping in LDS -> cluster ranks -> coin draws -> flips (atomic XOR on the
 //   two bit columns of the pair).
 //
+// The same machinery serves the Fortuin-Kasteleyn Swendsen-Wang update of single systems
+// (clusters/fk.rs:102-196): eligible = satisfied non-zero bond, p = 1 - exp(-2 J s_i s_j / T), the
+// system's own generator (its sweep cursor), and a coin for EVERY cluster, singletons included.
+//
 //   k_pairing      per realisation: the per-temperature shuffles of build_tasks (:35-56)
-//   k_cluster_sw   workgroup = (realisation, temperature, pair)
+//   k_cluster_sw   workgroup = (realisation, temperature, pair) or (realisation, slot)
+//   k_fk_wolff     FK single-cluster update: the reference's depth-first search, one lane per system
 #include "engine.hpp"
 
 #include <cstdlib>
@@ -106,10 +111,12 @@ __host__ __device__ inline size_t cluster_sw_lds_words(const SimDims &d) {
     return 2 * static_cast<size_t>(d.N) + 7 * static_cast<size_t>(d.MW) + 1 + cluster_sw_bit_words(d) + 12;
 }
 
-// Position-dependent helpers on the 32-site word bitmaps: number of set (site, dim) entries
-// strictly before (i, dd) in (site, dim) order, within site i's word.
-template <bool JORG>
+enum { kSwHoudayer = 0, kSwJorg = 1, kSwFk = 2 };
+
+template <int MODE>
 __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p) {
+    constexpr bool JORG = MODE == kSwJorg, FK = MODE == kSwFk;
+    constexpr bool STOCHASTIC = JORG || FK; // bonds are drawn
     extern __shared__ uint32_t lds[];
     SwLds L;
     {
@@ -126,16 +133,16 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p)
         L.misc = q;
     }
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t n_lanes = d.n_temps * d.n_pairs;
+    const uint32_t n_lanes = FK ? d.n_sys : d.n_temps * d.n_pairs;
     const uint32_t real = blockIdx.x / n_lanes, task = blockIdx.x % n_lanes;
-    const uint32_t t = task / d.n_pairs;
-    const uint32_t sa = p.pair_slots[(static_cast<size_t>(real) * n_lanes + task) * 2 + 0];
-    const uint32_t sb = p.pair_slots[(static_cast<size_t>(real) * n_lanes + task) * 2 + 1];
+    const uint32_t t = FK ? task % d.n_temps : task / d.n_pairs;
+    const uint32_t sa = FK ? task : p.pair_slots[(static_cast<size_t>(real) * n_lanes + task) * 2 + 0];
+    const uint32_t sb = FK ? task : p.pair_slots[(static_cast<size_t>(real) * n_lanes + task) * 2 + 1];
     uint32_t *Sa = p.S + (static_cast<size_t>(real) * d.W + (sa >> 5)) * d.N;
     uint32_t *Sb = p.S + (static_cast<size_t>(real) * d.W + (sb >> 5)) * d.N;
     const uint32_t ba = sa & 31u, bb = sb & 31u;
     const uint16_t *jsite = p.jsite + static_cast<size_t>(real) * d.N;
-    uint64_t *rng_state = p.pair_rng + (static_cast<size_t>(real) * n_lanes + task) * 4;
+    uint64_t *rng_state = FK ? nullptr : p.pair_rng + (static_cast<size_t>(real) * n_lanes + task) * 4;
     const uint32_t n_rounds = (d.N + kSwThreads - 1) / kSwThreads; // site i = r * 256 + tid
     // write the ballot of a predicate over sites r*256 + tid into a bitmap (two words per wave)
     auto put_ballot = [&](uint32_t *bitmap, uint32_t r, bool pred) {
@@ -154,22 +161,22 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p)
             a = (Sa[i] >> ba) & 1u;
             b = (Sb[i] >> bb) & 1u;
         }
-        put_ballot(L.act, r, (a ^ b) != 0);
+        put_ballot(L.act, r, FK ? i < d.N : (a ^ b) != 0);
         put_ballot(L.spa, r, a != 0);
     }
     __syncthreads();
 
     // ---- B: eligible forward bonds.  Houdayer: both ends active (overlap.rs:228-231).
-    // Joerg: both ends active and s_a(i) s_a(j) J > 0 (:417-429).
+    // Joerg: both ends active and s_a(i) s_a(j) J > 0 (:417-429).  FK: s_i s_j J > 0 (fk.rs:113-120).
     for (uint32_t r = 0; r < n_rounds; ++r) {
         const uint32_t i = r * kSwThreads + tid;
         bool e[3] = {false, false, false};
         if (i < d.N && get_bit(L.act, i)) {
-            const uint32_t jm = JORG ? jsite[i] : 0u;
+            const uint32_t jm = STOCHASTIC ? jsite[i] : 0u;
             for (uint32_t dd = 0; dd < d.nn; ++dd) {
                 const uint32_t j = p.nbr_site[i * 6 + 2 * dd];
                 bool ok = get_bit(L.act, j) != 0;
-                if (JORG && ok) {
+                if (STOCHASTIC && ok) {
                     const bool nz = (jm >> (6 + 2 * dd)) & 1u;
                     const uint32_t unsat = get_bit(L.spa, i) ^ get_bit(L.spa, j) ^ ((jm >> (2 * dd)) & 1u);
                     ok = nz && unsat == 0;
@@ -211,10 +218,14 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p)
     // the pair's generator, advanced by `offset` draws through the stride-256 jump tables:
     // returns the state at draw 256 * block
     uint32_t base_state[8];
+    if (FK) {
+        load_cursor(p.cursor, real, d.SP, sa, base_state);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        base_state[2 * k] = static_cast<uint32_t>(rng_state[k]);
-        base_state[2 * k + 1] = static_cast<uint32_t>(rng_state[k] >> 32);
+        for (int k = 0; k < 4; ++k) {
+            base_state[2 * k] = static_cast<uint32_t>(rng_state[k]);
+            base_state[2 * k + 1] = static_cast<uint32_t>(rng_state[k] >> 32);
+        }
     }
     auto stream_at_block = [&](uint32_t block) -> Rng32 {
         uint32_t st[8];
@@ -226,16 +237,16 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p)
         return rng;
     };
 
-    // ---- C, D (Joerg only): draw positions of the eligible bonds, accept bits of the stream
+    // ---- C, D (stochastic bonds): draw positions of the eligible bonds, accept bits of the stream
     uint32_t n_eligible = 0;
-    if (JORG) {
+    if (STOCHASTIC) {
         n_eligible = scan_words([&](uint32_t m) {
             uint32_t c = 0;
             for (uint32_t x = 0; x < d.nn; ++x) c += __popc(L.bond[x * d.MW + m]);
             return c;
         });
         const uint32_t n_blocks = (n_eligible + 255) / 256;
-        const uint32_t threshold = p.jorg_thr[t]; // draw < ceil(p 2^24)  <=>  gen::<f32>() < p
+        const uint32_t threshold = FK ? p.fk_thr[t] : p.jorg_thr[t]; // draw < ceil(p 2^24) <=> gen::<f32>() < p
         for (uint32_t blk = tid; blk < n_blocks; blk += kSwThreads) {
             Rng32 rng = stream_at_block(blk);
             for (uint32_t wd = 0; wd < 8; ++wd) {
@@ -299,7 +310,8 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p)
         __syncthreads();
     }
 
-    // ---- G: clusters of more than one site, ranked by their smallest site (overlap.rs:312-318)
+    // ---- G: clusters that receive a coin -- more than one site for the overlap moves
+    // (overlap.rs:312-318), every cluster for FK (fk.rs:182-192) -- ranked by their smallest site
     for (uint32_t i = tid; i < d.N; i += kSwThreads) L.aux[i] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < d.N; i += kSwThreads)
@@ -307,7 +319,7 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p)
     __syncthreads();
     for (uint32_t r = 0; r < n_rounds; ++r) {
         const uint32_t i = r * kSwThreads + tid;
-        put_ballot(L.roots, r, i < d.N && L.label[i] == i && L.aux[i] != 0);
+        put_ballot(L.roots, r, i < d.N && L.label[i] == i && (FK || L.aux[i] != 0));
     }
     __syncthreads();
     const uint32_t n_clusters = scan_words([&](uint32_t m) { return static_cast<uint32_t>(__popc(L.roots[m])); });
@@ -324,8 +336,12 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p)
                 if (blk == last_block && blk * 256 + wd * 32 + k == end_pos) {
                     uint32_t st[8];
                     rng.store(st);
-                    for (int q = 0; q < 4; ++q)
-                        rng_state[q] = (static_cast<uint64_t>(st[2 * q + 1]) << 32) | st[2 * q];
+                    if (FK) {
+                        store_cursor(p.cursor, real, d.SP, sa, st);
+                    } else {
+                        for (int q = 0; q < 4; ++q)
+                            rng_state[q] = (static_cast<uint64_t>(st[2 * q + 1]) << 32) | st[2 * q];
+                    }
                 }
                 acc |= ((rng.next_top() >> 8) < (1u << 23) ? 1u : 0u) << k; // gen::<f32>() < 0.5
             }
@@ -337,21 +353,111 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p)
     // ---- I: flip both replicas on the clusters whose coin is 1
     for (uint32_t i = tid; i < d.N; i += kSwThreads) {
         const uint32_t root = L.label[i];
-        if (!L.aux[root]) continue;
+        if (!FK && !L.aux[root]) continue;
         const uint32_t rank = L.wbase[root >> 5] + __popc(L.roots[root >> 5] & ((1u << (root & 31u)) - 1u));
         const uint32_t pos = n_eligible + rank - first_block * 256;
         if ((L.bits[pos >> 5] >> (pos & 31u)) & 1u) {
             atomicXor(&Sa[i], 1u << ba);
-            atomicXor(&Sb[i], 1u << bb);
+            if (!FK) atomicXor(&Sb[i], 1u << bb);
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// k_fk_wolff: FK single-cluster update (fk.rs:42-86): seed = gen_range(0..N) of the system's
+// generator, then dfs_cluster (utils.rs:125-149) with bonds drawn in the order the search meets
+// them, so the search is replayed draw for draw: one lane per system, the tile in LDS, stacks in
+// global scratch.  p = 1 - exp(-2/T) for a satisfied unit bond (host expf -> integer threshold).
+// ---------------------------------------------------------------------------
+__host__ __device__ inline size_t fk_wolff_lds_words(const SimDims &d) {
+    return static_cast<size_t>(d.N) * d.W + static_cast<size_t>(d.n_sys) * d.MW + 4;
+}
+
+__global__ __launch_bounds__(1024) void k_fk_wolff(SimDims d, DevPtrs p) {
+    extern __shared__ uint32_t lds[];
+    const size_t tile_words = static_cast<size_t>(d.N) * d.W;
+    uint32_t *tile = lds;                 // [W][N] spins
+    uint32_t *member = lds + tile_words;  // [n_sys][MW] cluster bitmaps
+    const uint32_t real = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
+    uint32_t *Sg = p.S + static_cast<size_t>(real) * tile_words;
+    const uint16_t *jsite = p.jsite + static_cast<size_t>(real) * d.N;
+
+    copy_to_lds(tile, Sg, static_cast<uint32_t>(tile_words), tid, nthreads);
+    for (size_t i = tid; i < static_cast<size_t>(d.n_sys) * d.MW; i += nthreads) member[i] = 0;
+    __syncthreads();
+
+    for (uint32_t slot = tid; slot < d.n_sys; slot += nthreads) {
+        uint16_t *stack = p.dfs_stack + (static_cast<size_t>(real) * d.n_sys + slot) * d.N;
+        uint32_t st[8];
+        load_cursor(p.cursor, real, d.SP, slot, st);
+        DevRng rng;
+        rng.s0 = (static_cast<uint64_t>(st[1]) << 32) | st[0];
+        rng.s1 = (static_cast<uint64_t>(st[3]) << 32) | st[2];
+        rng.s2 = (static_cast<uint64_t>(st[5]) << 32) | st[4];
+        rng.s3 = (static_cast<uint64_t>(st[7]) << 32) | st[6];
+        const uint32_t *wa = tile + (slot >> 5) * d.N;
+        const uint32_t ba = slot & 31u;
+        const uint32_t threshold = p.fk_thr[slot % d.n_temps];
+        uint32_t *mine = member + static_cast<size_t>(slot) * d.MW;
+        // rand 0.8.5 gen_range(0..N) on usize: widening multiply + zone rejection
+        uint32_t seed;
+        {
+            const uint64_t range = d.N;
+            const uint64_t zone = (range << __clzll(range)) - 1ull;
+            for (;;) {
+                const uint64_t v = rng.next();
+                if (v * range <= zone) {
+                    seed = static_cast<uint32_t>(__umul64hi(v, range));
+                    break;
+                }
+            }
+        }
+        uint32_t top = 0;
+        mine[seed >> 5] |= 1u << (seed & 31u);
+        stack[top++] = static_cast<uint16_t>(seed);
+        while (top > 0) {
+            const uint32_t site = stack[--top];
+            const uint32_t jm = jsite[site];
+            const uint32_t s_site = (wa[site] >> ba) & 1u;
+            for (uint32_t dir = 0; dir < 2 * d.nn; ++dir) { // f0, b0, f1, b1, ...
+                const uint32_t nb = p.nbr_site[site * 6 + dir];
+                if ((mine[nb >> 5] >> (nb & 31u)) & 1u) continue;
+                if (!((jm >> (6 + dir)) & 1u)) continue;                       // J = 0
+                if ((s_site ^ ((wa[nb] >> ba) & 1u) ^ ((jm >> dir) & 1u)) != 0) continue; // s s J <= 0
+                const uint32_t draw = static_cast<uint32_t>(rng.next() >> 40);
+                if (draw < threshold) {
+                    mine[nb >> 5] |= 1u << (nb & 31u);
+                    stack[top++] = static_cast<uint16_t>(nb);
+                }
+            }
+        }
+        st[0] = static_cast<uint32_t>(rng.s0); st[1] = static_cast<uint32_t>(rng.s0 >> 32);
+        st[2] = static_cast<uint32_t>(rng.s1); st[3] = static_cast<uint32_t>(rng.s1 >> 32);
+        st[4] = static_cast<uint32_t>(rng.s2); st[5] = static_cast<uint32_t>(rng.s2 >> 32);
+        st[6] = static_cast<uint32_t>(rng.s3); st[7] = static_cast<uint32_t>(rng.s3 >> 32);
+        store_cursor(p.cursor, real, d.SP, slot, st);
+    }
+    __syncthreads();
+    for (uint32_t item = tid; item < d.n_sys * d.MW; item += nthreads) {
+        const uint32_t slot = item / d.MW, mw = item % d.MW;
+        uint32_t bits = member[item];
+        while (bits) {
+            const uint32_t site = mw * 32 + (__ffs(bits) - 1);
+            bits &= bits - 1;
+            atomicXor(&tile[(slot >> 5) * d.N + site], 1u << (slot & 31u));
+        }
+    }
+    __syncthreads();
+    for (size_t i = tid; i < tile_words; i += nthreads) Sg[i] = tile[i];
 }
 
 size_t cluster_sw_lds_bytes(const SimDims &d) { return cluster_sw_lds_words(d) * 4; }
 
 hipError_t configure_cluster_kernels() {
-    for (const void *fn : {reinterpret_cast<const void *>(k_cluster_sw<false>),
-                           reinterpret_cast<const void *>(k_cluster_sw<true>)}) {
+    for (const void *fn : {reinterpret_cast<const void *>(k_cluster_sw<kSwHoudayer>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwJorg>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwFk>),
+                           reinterpret_cast<const void *>(k_fk_wolff)}) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
@@ -362,9 +468,20 @@ hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, bool jorg, hipS
     hipLaunchKernelGGL(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
     const dim3 grid(d.n_real * d.n_temps * d.n_pairs), block(kSwThreads);
     if (jorg)
-        hipLaunchKernelGGL(k_cluster_sw<true>, grid, block, cluster_sw_lds_bytes(d), stream, d, p);
+        hipLaunchKernelGGL(k_cluster_sw<kSwJorg>, grid, block, cluster_sw_lds_bytes(d), stream, d, p);
     else
-        hipLaunchKernelGGL(k_cluster_sw<false>, grid, block, cluster_sw_lds_bytes(d), stream, d, p);
+        hipLaunchKernelGGL(k_cluster_sw<kSwHoudayer>, grid, block, cluster_sw_lds_bytes(d), stream, d, p);
+    return hipGetLastError();
+}
+
+size_t fk_wolff_lds_bytes(const SimDims &d) { return fk_wolff_lds_words(d) * 4; }
+
+hipError_t launch_fk(const SimDims &d, const DevPtrs &p, bool wolff, hipStream_t stream) {
+    if (wolff)
+        hipLaunchKernelGGL(k_fk_wolff, dim3(d.n_real), dim3(1024), fk_wolff_lds_bytes(d), stream, d, p);
+    else
+        hipLaunchKernelGGL(k_cluster_sw<kSwFk>, dim3(d.n_real * d.n_sys), dim3(kSwThreads),
+                           cluster_sw_lds_bytes(d), stream, d, p);
     return hipGetLastError();
 }
 

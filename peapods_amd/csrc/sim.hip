@@ -67,7 +67,7 @@ struct pa_sim {
     float *jorg_p = nullptr;
     uint32_t *thr_gibbs = nullptr; // built by the first Gibbs sample (ensure_gibbs)
     float *Jf = nullptr, *temps_dev = nullptr; // general-coupling path
-    uint32_t *jump256 = nullptr, *jorg_thr = nullptr; // "sw" overlap-cluster variant (ensure_cluster_sw)
+    uint32_t *jump256 = nullptr, *jorg_thr = nullptr, *fk_thr = nullptr; // cluster kernels (ensure_cluster_sw)
     int32_t *nz_bonds = nullptr;
     float *dbeta = nullptr;
     // bookkeeping of the last sample()
@@ -297,7 +297,7 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     q.swap_masks += static_cast<size_t>(2) * d.W * r0;
     q.pair_rng += static_cast<size_t>(4) * d.n_temps * d.n_pairs * r0;
     q.jsite += static_cast<size_t>(d.N) * r0;
-    q.dfs_stack += static_cast<size_t>(d.n_temps) * d.n_pairs * d.N * r0;
+    q.dfs_stack += static_cast<size_t>(std::max(d.n_temps * d.n_pairs, d.n_sys)) * d.N * r0;
     return q;
 }
 
@@ -402,25 +402,35 @@ int ensure_cluster_sw(pa_sim *sim) {
             if (b + 1 < n_tab) acc = step.compose(acc);
         }
     }
-    std::vector<uint32_t> thr(d.n_temps);
-    for (uint32_t t = 0; t < d.n_temps; ++t) { // gen::<f32>() < p on the 2^24 grid (overlap.rs:430)
-        const float bond_p = 1.0f - expf(-4.0f * 1.0f / sim->temps[t]);
+    // gen::<f32>() < p on the 2^24 grid as an integer threshold; p by the host's expf for a
+    // satisfied unit bond: Joerg 1 - exp(-4/T) (overlap.rs:430), FK 1 - exp(-2/T) (fk.rs:74,119)
+    std::vector<uint32_t> thr(d.n_temps), thr_fk(d.n_temps);
+    auto as_threshold = [](float bond_p) {
         const double scaled = std::ceil(static_cast<double>(bond_p) * 16777216.0);
-        thr[t] = scaled <= 0.0 ? 0u : (scaled >= 16777216.0 ? (1u << 24) : static_cast<uint32_t>(scaled));
+        return scaled <= 0.0 ? 0u : (scaled >= 16777216.0 ? (1u << 24) : static_cast<uint32_t>(scaled));
+    };
+    for (uint32_t t = 0; t < d.n_temps; ++t) {
+        thr[t] = as_threshold(1.0f - expf(-4.0f * 1.0f / sim->temps[t]));
+        thr_fk[t] = as_threshold(1.0f - expf(-2.0f * 1.0f / sim->temps[t]));
     }
     const size_t n_lanes = static_cast<size_t>(d.n_temps) * d.n_pairs;
     PA_HIP(sim, sim->buffers.alloc(&sim->jump256, jump.size()));
     PA_HIP(sim, sim->buffers.alloc(&sim->jorg_thr, thr.size()));
+    PA_HIP(sim, sim->buffers.alloc(&sim->fk_thr, thr_fk.size()));
     PA_HIP(sim, sim->buffers.alloc(&sim->p.pair_slots, n_lanes * 2 * d.n_real));
     int rc;
-    if ((rc = upload(sim, sim->jump256, jump)) || (rc = upload(sim, sim->jorg_thr, thr))) return rc;
+    if ((rc = upload(sim, sim->jump256, jump)) || (rc = upload(sim, sim->jorg_thr, thr)) ||
+        (rc = upload(sim, sim->fk_thr, thr_fk)))
+        return rc;
     if (configure_cluster_kernels() != hipSuccess) return fail(sim, PA_ERR_DEVICE, "kernel LDS configuration failed");
     sim->p.jump256 = sim->jump256;
     sim->p.jorg_thr = sim->jorg_thr;
+    sim->p.fk_thr = sim->fk_thr;
     uint32_t r0 = 0;
     for (auto &g : sim->groups) {
         g.p.jump256 = sim->jump256;
         g.p.jorg_thr = sim->jorg_thr;
+        g.p.fk_thr = sim->fk_thr;
         g.p.pair_slots = sim->p.pair_slots + n_lanes * 2 * r0;
         r0 += g.d.n_real;
     }
@@ -443,6 +453,8 @@ std::string validate_text(const pa_sample_config *cfg, uint64_t n_replicas, int 
             return "overlap cluster requires n_replicas >= max group_size (" +
                    std::to_string(n_replicas) + " < 2)";
     }
+    if (cfg->cluster_interval > 0 && cfg->cluster_mode != PA_CLUSTER_WOLFF && cfg->cluster_mode != PA_CLUSTER_SW)
+        return "unknown cluster_mode, expected 'wolff' or 'sw'";
     *code = PA_ERR_UNSUPPORTED;
     if (cfg->overlap_cluster_interval > 0) {
         for (int k = 0; k < cfg->n_overlap_cluster_modes && k < 4; ++k)
@@ -475,7 +487,14 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     int rc = gibbs ? ensure_gibbs(sim) : PA_OK;
     if (rc) return rc;
     const bool oc_sw = cfg->overlap_cluster_interval > 0 && cfg->overlap_cluster_mode == PA_CLUSTER_SW;
-    if (oc_sw && (rc = ensure_cluster_sw(sim))) return rc;
+    const bool fk = cfg->cluster_interval > 0;
+    if (fk && d.general)
+        return fail(sim, PA_ERR_UNSUPPORTED,
+                    "FK cluster updates need expf of arbitrary couplings, which is not built on the "
+                    "HIP path yet (unit couplings only)");
+    if (fk && cfg->cluster_mode == PA_CLUSTER_WOLFF && (d.big || fk_wolff_lds_bytes(d) > 160 * 1024))
+        return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the FK cluster kernel");
+    if ((oc_sw || fk) && (rc = ensure_cluster_sw(sim))) return rc;
     if ((rc = zero_accumulators(sim))) return rc;
     const bool want_overlap = d.n_pairs > 0 && cfg->measure_overlap;
     sim->n_recorded = 0;
@@ -493,13 +512,19 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         }
         const bool record = sweep_id >= cfg->warmup_sweeps; // mod.rs:410
         const bool pt_this = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0; // :486-488
+        const bool fk_this = fk && sweep_id % cfg->cluster_interval == 0;               // :434-437
         for (auto &g : sim->groups) {
             PA_HIP(sim, launch_rng(g.d, g.p, gibbs, g.stream));                         // :412-432
-            PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, record || pt_this, gibbs, g.stream)); // :492-509
+            // energies are computed after every mutating move of the sweep (:492-509)
+            PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, (record || pt_this) && !fk_this, gibbs, g.stream));
         }
         sim->swaps_pending = false;
         toggle_spin_buffers(sim);
         for (auto &g : sim->groups) {
+            if (fk_this) { // clusters::fk_update (:439-469), then the energies
+                PA_HIP(sim, launch_fk(g.d, g.p, cfg->cluster_mode == PA_CLUSTER_WOLFF, g.stream));
+                if (record || pt_this) PA_HIP(sim, launch_sweep(g.d, g.p, true, false, false, g.stream));
+            }
             if (record && want_overlap) PA_HIP(sim, launch_overlap(g.d, g.p, g.stream)); // :527-529
             const bool oc_this = cfg->overlap_cluster_interval > 0 &&
                                  sweep_id % cfg->overlap_cluster_interval == 0; // :598-599
@@ -909,7 +934,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     ok(bufs.alloc(&sim->nbr_site, nbr_site.size()));
     ok(bufs.alloc(&sim->jsite, jsite.size()));
     ok(bufs.alloc(&sim->jorg_p, jorg_p.size()));
-    ok(bufs.alloc(&p.dfs_stack, d.big ? 1 : static_cast<size_t>(d.n_real) * d.n_temps * d.n_pairs * d.N));
+    ok(bufs.alloc(&p.dfs_stack, d.big ? 1 : static_cast<size_t>(d.n_real) * std::max(d.n_temps * d.n_pairs, d.n_sys) * d.N));
     ok(bufs.alloc(&p.big_counts, static_cast<size_t>(d.n_real) * d.n_sys * 4));
     if (e != hipSuccess) {
         sim->error = std::string("hipMalloc: ") + hipGetErrorString(e);
@@ -1011,6 +1036,8 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
     if (code != PA_OK) return fail(sim, code, text);
     PA_HIP(sim, hipSetDevice(sim->device));
     const SimDims &d = sim->d;
+    if (cfg->cluster_interval > 0 || cfg->overlap_cluster_interval > 0)
+        return fail(sim, PA_ERR_UNSUPPORTED, "kernel profiling covers the sweep pipeline without cluster moves");
     const bool gibbs = cfg->sweep_mode == PA_SWEEP_GIBBS;
     int rc = gibbs ? ensure_gibbs(sim) : PA_OK;
     if (rc) return rc;

@@ -385,6 +385,63 @@ def test_sw_variant_with_diluted_couplings(oracle):
     assert_state_equal(gpu, cpu)
 
 
+@pytest.mark.parametrize("cluster_mode", ["sw", "wolff"])
+@pytest.mark.parametrize("shape,kind,n_temps,n_rep,n_dis,offsets", [
+    ((8, 8), "ferro", 4, 1, 1, None),
+    ((6, 6, 6), "ferro", 5, 2, 1, None),
+    ((6, 6, 6), "bimodal", 4, 2, 2, None),
+    ((5, 7), "diluted", 3, 2, 1, None),
+    ((6, 6), "ferro", 3, 2, 1, [[1, 0], [0, 1], [1, -1]]),
+    ((2, 4, 6), "bimodal", 3, 2, 1, None),
+])
+def test_fk_cluster_update_matches_oracle(oracle, cluster_mode, shape, kind, n_temps, n_rep, n_dis, offsets):
+    """cluster_update_interval (clusters/fk.rs): Swendsen-Wang = union-find over every forward
+    bond in (site, dim) order, one draw per satisfied bond, one coin per cluster in the order of
+    its smallest site; Wolff = seed + depth-first search with bonds drawn as they are met.  Both use
+    the system's own generator between the sweep draws and the tempering draws."""
+    nn = len(offsets) if offsets else len(shape)
+    full = ((n_dis,) if n_dis > 1 else ()) + tuple(shape) + (nn,)
+    rng = np.random.default_rng(2)
+    if kind == "ferro":
+        couplings = np.ones(full, np.float32)
+        temps = np.linspace(1.8, 3.2, n_temps) if len(shape) == 2 else np.linspace(3.8, 5.2, n_temps)
+    elif kind == "bimodal":
+        couplings = (2 * rng.integers(0, 2, size=full) - 1).astype(np.float32)
+        temps = np.linspace(0.8, 2.0, n_temps)
+    else:
+        couplings = rng.integers(-1, 2, size=full).astype(np.float32)
+        temps = np.linspace(0.8, 2.0, n_temps)
+    gpu, cpu = make_pair(oracle, shape, couplings, temps, n_rep, 31, offsets)
+    kwargs = dict(cluster_update_interval=1, cluster_mode=cluster_mode, pt_interval=1, warmup_ratio=0.25)
+    a = gpu.sample(12, "metropolis", **kwargs)
+    b = cpu.sample(12, "metropolis", **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+    kwargs = dict(cluster_update_interval=3, cluster_mode=cluster_mode, warmup_ratio=0.0)
+    a = gpu.sample(7, "gibbs", **kwargs)
+    b = cpu.sample(7, "gibbs", **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+
+
+def test_ferromagnet_binder_crossing_with_swendsen_wang():
+    """The reference's physics check of this protocol (tests/binder_crossings.py:21-53, 2D square,
+    tests/utils.py:39-47): Metropolis + SW + tempering, 2 replicas, Binder curves of L = 8, 16, 32
+    cross at the exact T_c within 0.05."""
+    import peapods_amd as peapods
+
+    tc = 2.0 / np.log(1 + np.sqrt(2))
+    temps = np.linspace(tc - 0.3, tc + 0.3, 32).astype(np.float32)
+    at_tc = []
+    for size in (8, 16, 32):
+        model = peapods.Ising((size, size), temperatures=temps, n_replicas=2, seed=42)
+        model.sample(10000, sweep_mode="metropolis", cluster_update_interval=1, cluster_mode="sw",
+                     pt_interval=1, warmup_ratio=0.25)
+        at_tc.append(np.interp(tc, temps, model.binder_cumulant))
+    assert max(at_tc) - min(at_tc) < 0.05, at_tc
+    assert all(0.55 < b < 0.66 for b in at_tc), at_tc  # universal value U* = 0.61 of the 2D class
+
+
 def test_unbuilt_overlap_modes_are_refused_not_emulated():
     from peapods_amd import IsingSimulation
 

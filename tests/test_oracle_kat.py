@@ -279,3 +279,23 @@ def test_uf_csd_bond_based_and_top4(oracle):
     top = np.zeros(4, dtype=np.uint32)
     lib.orc_top4_sizes(ptr(counts), 16, ptr(top))
     assert top.tolist() == [4, 3, 1, 1]
+
+
+# ---- statistical fixtures of the reference: tests/binder_crossings.py:21-71, tests/utils.py:7,39-47
+
+def test_2d_ferromagnet_binder_curves_cross_at_the_exact_tc(oracle):
+    """The reference's own physics check of Metropolis + Swendsen-Wang (fk.rs) + tempering:
+    2D square ferromagnet, 32 temperatures T_c +- 0.3, 2 replicas, seed 42, 10000 sweeps with 25 %
+    warm-up; Binder cumulants of L = 8, 16, 32 agree at the exact T_c within 0.05.  (The couplings
+    of a ferromagnet are all +1, so the Python-side seed material does not enter.)"""
+    tc = 2.0 / np.log(1 + np.sqrt(2))
+    temps = np.linspace(tc - 0.3, tc + 0.3, 32).astype(np.float32)
+    at_tc = []
+    for size in (8, 16, 32):
+        sim = oracle.OracleSimulation([size, size], np.ones((size, size, 2), np.float32), temps, 2,
+                                      None, 42)
+        res = sim.sample(10000, "metropolis", pt_interval=1, warmup_ratio=0.25,
+                         cluster_update_interval=1, cluster_mode="sw")
+        binder = 1 - res["mags4"] / (3 * res["mags2"] ** 2)
+        at_tc.append(float(np.interp(tc, temps, binder)))
+    assert max(at_tc) - min(at_tc) < 0.05, at_tc

@@ -40,6 +40,8 @@ struct SimDims {
     uint32_t thr_preshifted; // 1 if every threshold is < 2^24, so thr[6..12) = thr[0..6) << 8 is exact
     uint32_t big;        // 1: lattice too large for the LDS kernels (spins stay in global memory)
     uint32_t dense_nn;   // = nn when every bond of every realisation is non-zero, else 0
+    uint32_t pipe_K;     // large unit-coupling lattices: slabs of the pipelined sweep (0 = not used)
+    uint32_t n_levels;   // dependency levels of the schedule
     uint32_t general;    // 1: arbitrary f32 couplings / temperatures -> the reference's logarithmic rule
                          //    (kernels_general.hip); Esum then holds raw f32 bits of the energy sum
 };
@@ -62,6 +64,8 @@ struct DevPtrs {
                              //   site,f0 | b0,f1 | b1,f2 | b2,jmeta
                              //   jmeta = neg[0..5] | nz[6..11] | h[12..13] for bonds f0,b0,f1,b1,f2,b2
     const uint32_t *pass_start; // [n_passes + 1]
+    const uint32_t *seg;     // [n_levels][pipe_K + 1] schedule positions where each slab's part of a level starts
+    uint32_t *progress;      // [n_real * W][pipe_K] levels completed by each slab workgroup (epoch-based, monotone)
     const uint32_t *jump;    // [B][64][16][8] nibble tables of T^(b*BS)
     int32_t *Esum;           // [n_real][n_sys] by slot: sum_{i,d} J s s (exact integer)
     int32_t *Msum;           // [n_real][n_sys] by slot: sum_i s_i
@@ -111,6 +115,7 @@ hipError_t launch_rng(const SimDims &d, const DevPtrs &p, bool gibbs, hipStream_
 hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,
                         bool gibbs, hipStream_t stream);
 hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream);
+hipError_t launch_sweep_pipe(const SimDims &d, const DevPtrs &p, bool gibbs, uint32_t epoch, hipStream_t stream);
 hipError_t launch_apply_swaps(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 hipError_t launch_houdayer(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 size_t houdayer_lds_bytes(const SimDims &d);

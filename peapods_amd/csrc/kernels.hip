@@ -1414,6 +1414,78 @@ __global__ __launch_bounds__(1024) void k_sweep_big(SimDims d, DevPtrs p, int gi
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_sweep_pipe: the large-lattice sweep spread over pipe_K workgroups per (realisation, word).
+// The sites are cut into pipe_K slabs of consecutive indices (x-slabs of a cubic lattice).  A
+// site needs the NEW value of its smaller neighbours and the OLD value of its larger ones; old
+// values are read from S (not written during the sweep), new ones from S_next.  Slab k may run
+// level l once slab k-1 has finished levels < l: by induction slab k-m has then finished levels
+// <= l-m, which covers every smaller neighbour (the host checks level(j) + m <= level(i) for
+// every such edge before enabling this kernel).  So the slabs form a software pipeline along the
+// dependency levels: about n_levels + pipe_K steps instead of n_levels steps of one workgroup,
+// with pipe_K times the workgroups.  Progress counters are epoch-based (never reset); a slab
+// only ever waits for a workgroup with a smaller blockIdx (dispatched no later than itself), and
+// the wait is bounded.  blockIdx is laid out so that all slabs of a word share an XCD (and its
+// L2): block = k * n_tw_pad + tw with n_tw_pad a multiple of 8.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sweep_pipe(SimDims d, DevPtrs p, int gibbs, uint32_t epoch,
+                                                    uint32_t n_tw_pad) {
+    const uint32_t tw = blockIdx.x % n_tw_pad, k = blockIdx.x / n_tw_pad;
+    if (tw >= d.n_real * d.W) return;
+    const uint32_t real = tw / d.W, w = tw % d.W;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t *Sold = p.S + static_cast<size_t>(tw) * d.N;
+    uint32_t *Snew = p.S_next + static_cast<size_t>(tw) * d.N;
+    const uint2 *planes = p.planes + static_cast<size_t>(tw) * d.N;
+    const uint32_t *planes_hi = p.planes_hi + static_cast<size_t>(tw) * d.N;
+    const uint4 *rec = p.rec + static_cast<size_t>(real) * (d.N + 1) * 2;
+    uint32_t *progress = p.progress + static_cast<size_t>(tw) * d.pipe_K;
+    const uint32_t live = d.n_sys - w * 32;
+    const uint32_t valid_bits = live >= 32 ? 0xFFFFFFFFu : ((1u << live) - 1u);
+    const uint32_t base = epoch * (d.n_levels + 1);
+    __shared__ uint32_t gave_up;
+    if (tid == 0) gave_up = 0;
+    __syncthreads();
+    for (uint32_t level = 0; level < d.n_levels; ++level) {
+        if (k > 0) {
+            if (tid == 0) {
+                uint32_t spins = 0;
+                // wait until slab k-1 has completed `level` levels of this epoch (signed distance:
+                // values of earlier epochs are smaller than base)
+                // (relaxed: the data itself moves through agent-coherent accesses, and an acquire at
+                // agent scope would invalidate the XCD's whole L2 at every level)
+                while (static_cast<int32_t>(__hip_atomic_load(&progress[k - 1], __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_AGENT) -
+                                            (base + level)) < 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 26)) { // never reached unless a predecessor died: leave
+                        gave_up = 1;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            if (gave_up) return;
+        }
+        const uint32_t begin = p.seg[level * (d.pipe_K + 1) + k], end = p.seg[level * (d.pipe_K + 1) + k + 1];
+        for (uint32_t pos = begin + tid; pos < end; pos += 256) {
+            const BigRec r(rec[2 * pos], rec[2 * pos + 1]);
+            uint32_t nb[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                nb[q] = r.nb[q] < r.site ? coherent_load(Snew + r.nb[q]) : Sold[r.nb[q]];
+            const uint32_t s = Sold[r.site];
+            const uint2 lv = planes[r.site];
+            const uint32_t acc = (gibbs ? accept_mask_gibbs(s, nb, r.jm, d.nn, lv.x, lv.y, planes_hi[r.site])
+                                        : accept_mask(s, nb, r.jm, lv.x, lv.y)) & valid_bits;
+            coherent_store(Snew + r.site, s ^ acc);
+        }
+        __syncthreads(); // every wave's stores have completed (vmcnt 0) before the counter moves
+        if (tid == 0)
+            __hip_atomic_store(&progress[k], base + level + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // chunk = 4096 schedule positions per workgroup; counts go to cnt[real][n_sys][3] (u32 atomics)
 __global__ __launch_bounds__(256) void k_energy_big(SimDims d, DevPtrs p, uint32_t n_chunks) {
     __shared__ uint32_t scratch[5 * 48];
@@ -1616,6 +1688,14 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
     case 3: hipLaunchKernelGGL((k_sweep<false, 3>), grid, block, lds, stream, d, p, e, s, no_stamps); break;
     default: hipLaunchKernelGGL((k_sweep<false, 0>), grid, block, lds, stream, d, p, e, s, no_stamps); break;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_sweep_pipe(const SimDims &d, const DevPtrs &p, bool gibbs, uint32_t epoch,
+                             hipStream_t stream) {
+    const uint32_t n_tw_pad = (d.n_real * d.W + 7u) & ~7u;
+    hipLaunchKernelGGL(k_sweep_pipe, dim3(n_tw_pad * d.pipe_K), dim3(256), 0, stream, d, p,
+                       gibbs ? 1 : 0, epoch, n_tw_pad);
     return hipGetLastError();
 }
 

@@ -66,6 +66,8 @@ struct pa_sim {
     uint16_t *nbr_site = nullptr, *jsite = nullptr;
     float *jorg_p = nullptr;
     uint32_t *thr_gibbs = nullptr; // built by the first Gibbs sample (ensure_gibbs)
+    uint32_t *seg = nullptr;       // slab segments of the pipelined large-lattice sweep
+    uint32_t pipe_epoch = 1;       // bumped by every k_sweep_pipe launch (progress counters are monotone)
     float *Jf = nullptr, *temps_dev = nullptr; // general-coupling path
     uint32_t *jump256 = nullptr, *jorg_thr = nullptr, *fk_thr = nullptr; // cluster kernels (ensure_cluster_sw)
     int32_t *nz_bonds = nullptr;
@@ -277,6 +279,7 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     q.slot_of += static_cast<size_t>(d.n_sys) * r0;
     q.mpar += static_cast<size_t>(d.MW) * r0;
     q.rec += (static_cast<size_t>(d.N) + 1) * (d.big ? 2 : 1) * r0;
+    if (d.pipe_K) q.progress += static_cast<size_t>(d.W) * d.pipe_K * r0;
     q.big_counts += static_cast<size_t>(4) * d.n_sys * r0;
     q.Esum += static_cast<size_t>(d.n_sys) * r0;
     q.Msum += static_cast<size_t>(d.n_sys) * r0;
@@ -324,7 +327,7 @@ int make_groups(pa_sim *sim) {
 
 // k_sweep reads S and writes S_next: exchange the roles everywhere after every sweep launch.
 void toggle_spin_buffers(pa_sim *sim) {
-    if (sim->d.big || sim->d.general) return; // those paths sweep in place
+    if (sim->p.S_next == sim->p.S) return; // paths that sweep in place
     std::swap(sim->p.S, sim->p.S_next);
     for (auto &g : sim->groups) std::swap(g.p.S, g.p.S_next);
 }
@@ -336,6 +339,13 @@ hipError_t enqueue_sweep(pa_sim *sim, const SimDims &d, const DevPtrs &p, bool w
     if ((d.big || d.general) && sim->swaps_pending) {
         hipError_t e = launch_apply_swaps(d, p, stream);
         if (e != hipSuccess) return e;
+    }
+    if (d.pipe_K) { // pipelined large-lattice sweep S -> S_next, then the energies of the new state
+        hipError_t e = launch_sweep_pipe(d, p, gibbs, sim->pipe_epoch++, stream);
+        if (e != hipSuccess || !with_energy) return e;
+        DevPtrs q = p;
+        q.S = p.S_next;
+        return launch_sweep(d, q, true, false, false, stream);
     }
     return launch_sweep(d, p, with_energy, true, gibbs, stream);
 }
@@ -795,6 +805,52 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     pass_start.push_back(d.N);
     d.n_passes = static_cast<uint32_t>(pass_start.size()) - 1;
 
+    // ---- large unit-coupling lattices: slabs of the pipelined sweep (k_sweep_pipe).  K slabs of
+    // consecutive site indices are admissible when every smaller neighbour j of a site i that lies
+    // m >= 1 slabs below satisfies level(j) + m <= level(i).
+    d.n_levels = n_levels;
+    d.pipe_K = 0;
+    std::vector<uint32_t> seg;
+    if (d.big && !d.general) {
+        uint32_t widest = 1;
+        for (uint32_t l = 0; l < n_levels; ++l) widest = std::max(widest, level_start[l + 1] - level_start[l]);
+        // about 96 sites per slab and level, with slabs made of whole hyperplanes of the slowest
+        // dimension (the largest divisor of its extent that does not exceed the target)
+        const uint32_t target = std::min<uint32_t>(64, std::max<uint32_t>(1, widest / 96));
+        uint32_t K = 1;
+        for (uint32_t c = 1; c <= target; ++c)
+            if (lat.shape[0] % c == 0) K = c;
+        if (const char *env = std::getenv("PEAPODS_PIPE_K")) {
+            const long v = std::strtol(env, nullptr, 10);
+            if (v >= 1 && v <= 256) K = static_cast<uint32_t>(v);
+        }
+        auto admissible = [&](uint32_t slabs) {
+            const uint32_t slab = (d.N + slabs - 1) / slabs;
+            for (uint32_t i = 0; i < d.N; ++i)
+                for (uint32_t q = 0; q < d.nn; ++q)
+                    for (uint32_t j : {lat.fwd[i * d.nn + q], lat.bwd[i * d.nn + q]}) {
+                        if (j >= i) continue;
+                        const uint32_t m = i / slab - j / slab;
+                        if (m >= 1 && level[j] + m > level[i]) return false;
+                    }
+            return true;
+        };
+        while (K > 1 && !admissible(K)) --K;
+        if (K > 1) {
+            d.pipe_K = K;
+            const uint32_t slab = (d.N + K - 1) / K;
+            seg.assign(static_cast<size_t>(n_levels) * (K + 1), 0u);
+            for (uint32_t l = 0; l < n_levels; ++l) {
+                uint32_t pos = level_start[l];
+                for (uint32_t k = 0; k <= K; ++k) {
+                    // positions of a level are in ascending site order
+                    while (k < K && pos < level_start[l + 1] && order[pos] < k * slab) ++pos;
+                    seg[static_cast<size_t>(l) * (K + 1) + k] = k == K ? level_start[l + 1] : pos;
+                }
+            }
+        }
+    }
+
     // ---- per-realisation site records in schedule order (neighbours + coupling metadata)
     const size_t rec_stride = (static_cast<size_t>(d.N) + 1) * (d.big ? 2 : 1); // uint4 per realisation
     std::vector<uint4> rec(static_cast<size_t>(d.n_real) * rec_stride);
@@ -893,10 +949,14 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         if (e == hipSuccess) e = r;
     };
     ok(bufs.alloc(&p.S, tile_words * d.n_real));
-    if (d.big || d.general)
+    if ((d.big && !d.pipe_K) || d.general)
         p.S_next = p.S; // these paths sweep in place
     else
         ok(bufs.alloc(&p.S_next, tile_words * d.n_real));
+    if (d.pipe_K) {
+        ok(bufs.alloc(&sim->seg, seg.size()));
+        ok(bufs.alloc(&p.progress, static_cast<size_t>(d.n_real) * d.W * d.pipe_K));
+    }
     ok(bufs.alloc(&p.swap_epoch, static_cast<size_t>(d.n_real)));
     ok(bufs.alloc(&p.applied_epoch, static_cast<size_t>(d.n_real) * d.W));
     ok(bufs.alloc(&p.planes, d.general ? 1 : tile_words * d.n_real));
@@ -950,6 +1010,14 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     p.nbr_site = sim->nbr_site;
     p.jsite = sim->jsite;
     p.jorg_p = sim->jorg_p;
+    p.seg = sim->seg;
+    if (d.pipe_K) {
+        if ((rc = upload(sim, sim->seg, seg))) return bail(rc);
+        if (hipMemsetAsync(p.progress, 0, sizeof(uint32_t) * d.n_real * d.W * d.pipe_K, sim->stream) != hipSuccess) {
+            sim->error = "hipMemsetAsync failed";
+            return bail(PA_ERR_DEVICE);
+        }
+    }
     p.Jf = sim->Jf;
     p.temps = sim->temps_dev;
     if (d.general) {

@@ -115,6 +115,7 @@ hipError_t launch_rng(const SimDims &d, const DevPtrs &p, bool gibbs, hipStream_
 hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,
                         bool gibbs, hipStream_t stream);
 hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream);
+hipError_t launch_rng_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 hipError_t launch_sweep_pipe(const SimDims &d, const DevPtrs &p, bool gibbs, uint32_t epoch, hipStream_t stream);
 hipError_t launch_apply_swaps(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 hipError_t launch_houdayer(const SimDims &d, const DevPtrs &p, hipStream_t stream);

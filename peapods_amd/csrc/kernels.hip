@@ -104,10 +104,10 @@ __device__ __forceinline__ void rng_chunk32_gibbs(Rng32 &rng, const uint32_t c[7
 // GIBBS: seven thresholds per parity class and a third level plane (planes_hi); thresholds are
 // compared unshifted (a Gibbs threshold can be 2^24 = "every draw").
 template <bool PRESHIFTED, bool GIBBS>
-__global__ __launch_bounds__(256) void k_rng(SimDims d, DevPtrs p) {
-    extern __shared__ uint32_t tab[]; // [64 * 16 * 8] (+ padding that caps workgroups per CU)
-    const uint32_t block = blockIdx.x % d.B;
-    const uint32_t group = blockIdx.x / d.B;
+__device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, uint32_t bid, uint32_t *tab) {
+    // tab: [64 * 16 * 8] dwords of LDS for the block's jump table
+    const uint32_t block = bid % d.B;
+    const uint32_t group = bid / d.B;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t bit = lane & 31u, half = lane >> 5;
     const uint32_t n_tw = d.n_real * d.W;
@@ -227,6 +227,12 @@ __global__ __launch_bounds__(256) void k_rng(SimDims d, DevPtrs p) {
         rng.store(st);
         store_cursor(p.cursor, real, d.SP, slot, st);
     }
+}
+
+template <bool PRESHIFTED, bool GIBBS>
+__global__ __launch_bounds__(256) void k_rng(SimDims d, DevPtrs p) {
+    extern __shared__ uint32_t lds_dyn[];
+    rng_block<PRESHIFTED, GIBBS>(d, p, blockIdx.x, lds_dyn);
 }
 
 // ---------------------------------------------------------------------------
@@ -729,26 +735,37 @@ __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_en
 // gives the bond products, and q_i q_k = +1 <=> both replicas agree on the bond
 // (overlap.rs:259-282).  Per-bit counts by byte-sliced counters -> dot_spin, dot_link.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_overlap(SimDims d, DevPtrs p) {
-    extern __shared__ uint32_t lds[];
+__device__ __forceinline__ void overlap_block(const SimDims &d, const DevPtrs &p, uint32_t bid, uint32_t *lds) {
     const uint32_t n1 = d.N + 1;
-    uint32_t *A = lds;            // word w
-    uint32_t *B0 = lds + n1;      // word w + q
-    uint32_t *B1 = lds + 2 * n1;  // word w + q + 1
-    uint32_t *scratch = lds + 3 * static_cast<size_t>(n1);
-    const uint32_t real = blockIdx.x / d.W, w = blockIdx.x % d.W;
+    uint32_t *Y = lds;                 // [N + 1] pair-difference word: 1 where replicas 2p, 2p+1 disagree
+    uint32_t *scratch = lds + n1;      // [5][48]
+    const uint32_t real = bid / d.W, w = bid % d.W;
     const uint32_t tid = threadIdx.x;
     const uint32_t q = d.n_temps >> 5, r = d.n_temps & 31u;
     const uint32_t wa = w + q, wb = w + q + 1;
     const uint32_t *Sg = p.S + static_cast<size_t>(real) * d.W * d.N;
     const uint4 *rec = p.rec + static_cast<size_t>(real) * n1;
-    copy_to_lds(A, Sg + static_cast<size_t>(w) * d.N, d.N, tid, 256);
-    if (wa < d.W) copy_to_lds(B0, Sg + static_cast<size_t>(wa) * d.N, d.N, tid, 256);
-    if (wb < d.W) copy_to_lds(B1, Sg + static_cast<size_t>(wb) * d.N, d.N, tid, 256);
-    if (wa >= d.W)
-        for (uint32_t i = tid; i < d.N; i += 256) B0[i] = 0;
-    if (wb >= d.W)
-        for (uint32_t i = tid; i < d.N; i += 256) B1[i] = 0;
+    {
+        const uint32_t *A = Sg + static_cast<size_t>(w) * d.N;
+        const uint32_t *B0 = wa < d.W ? Sg + static_cast<size_t>(wa) * d.N : nullptr;
+        const uint32_t *B1 = (r && wb < d.W) ? Sg + static_cast<size_t>(wb) * d.N : nullptr;
+        for (uint32_t base = 0; base < d.N; base += 8 * 256) { // 8 x 3 loads in flight
+            uint32_t va[8], v0[8], v1[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t i = base + k * 256 + tid;
+                va[k] = i < d.N ? A[i] : 0u;
+                v0[k] = (B0 && i < d.N) ? B0[i] : 0u;
+                v1[k] = (B1 && i < d.N) ? B1[i] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t i = base + k * 256 + tid;
+                if (i < d.N) Y[i] = va[k] ^ (r ? ((v0[k] >> r) | (v1[k] << (32 - r))) : v0[k]);
+            }
+        }
+        if (tid == 0) Y[d.N] = 0;
+    }
     __syncthreads();
     uint32_t c[3][8];
 #pragma unroll
@@ -767,22 +784,11 @@ __global__ __launch_bounds__(256) void k_overlap(SimDims d, DevPtrs p) {
         for (int k = 0; k < 16; ++k) {
             const bool live_site = base + k * 256 + tid < d.N;
             const SiteRec sr(rr[k]);
-            const uint32_t a = lds_word(A, sr.site);
-            const uint32_t b0 = lds_word(B0, sr.site), b1 = lds_word(B1, sr.site);
-            const uint32_t sh = r ? ((b0 >> r) | (b1 << (32 - r))) : b0;
-            const uint32_t y = a ^ sh; // 1 where the pair disagrees at this site
+            const uint32_t y = lds_word(Y, sr.site);
             uint32_t z[3];
 #pragma unroll
-            for (int dir = 0; dir < 3; ++dir) {
-                z[dir] = 0;
-                if (dir < static_cast<int>(d.nn)) {
-                    const uint32_t nbr = sr.nb[2 * dir];
-                    const uint32_t fa = lds_word(A, nbr);
-                    const uint32_t f0 = lds_word(B0, nbr), f1 = lds_word(B1, nbr);
-                    const uint32_t fsh = r ? ((f0 >> r) | (f1 << (32 - r))) : f0;
-                    z[dir] = y ^ fa ^ fsh; // 1 where q_i * q_k = -1
-                }
-            }
+            for (int dir = 0; dir < 3; ++dir) // 1 where q_i * q_k = -1
+                z[dir] = dir < static_cast<int>(d.nn) ? (y ^ lds_word(Y, sr.nb[2 * dir])) : 0u;
             qa[k] = live_site ? y : 0u;
             qb[k] = live_site ? (z[0] ^ z[1] ^ z[2]) : 0u;
             qc[k] = live_site ? maj3(z[0], z[1], z[2]) : 0u;
@@ -803,6 +809,24 @@ __global__ __launch_bounds__(256) void k_overlap(SimDims d, DevPtrs p) {
                             2 * static_cast<int32_t>(tot[1] + 2 * tot[2]);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_overlap(SimDims d, DevPtrs p) {
+    extern __shared__ uint32_t lds_dyn[];
+    overlap_block(d, p, blockIdx.x, lds_dyn);
+}
+
+// One launch, two kinds of workgroups: the first n_overlap blocks measure the overlap of the
+// state the previous sweep left (latency-bound, few waves), the others draw the random stream
+// of the next sweep (VALU-bound); the two do not depend on each other, so the measurement hides
+// under the random stream instead of costing a launch of its own.
+template <bool PRESHIFTED>
+__global__ __launch_bounds__(256) void k_rng_overlap(SimDims d, DevPtrs p, uint32_t n_overlap) {
+    extern __shared__ uint32_t lds_dyn[];
+    if (blockIdx.x < n_overlap)
+        overlap_block(d, p, blockIdx.x, lds_dyn);
+    else
+        rng_block<PRESHIFTED, false>(d, p, blockIdx.x - n_overlap, lds_dyn);
 }
 
 // ---------------------------------------------------------------------------
@@ -901,9 +925,10 @@ __global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams
     __syncthreads();
     PA_STAMP(2)
     // ---- (2) running statistics ---------------------------------------------
-    if (do_accum && tid < d.n_temps) {
+    if ((do_accum || accum_overlap) && tid < d.n_temps) {
         const uint32_t t = tid;
         const float n_f = static_cast<float>(d.N);
+        if (do_accum) {
         double *mom = p.mom + static_cast<size_t>(real) * 5 * d.n_temps;
         double m0 = mom[0 * d.n_temps + t], m1 = mom[1 * d.n_temps + t], m2s = mom[2 * d.n_temps + t];
         double e0 = mom[3 * d.n_temps + t], e1 = mom[4 * d.n_temps + t];
@@ -925,6 +950,7 @@ __global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams
         mom[2 * d.n_temps + t] = m2s;
         mom[3 * d.n_temps + t] = e0;
         mom[4 * d.n_temps + t] = e1;
+        }
         if (accum_overlap && d.n_pairs) {
             double *ovm = p.ovm + static_cast<size_t>(real) * 6 * d.n_temps;
             double o[6];
@@ -1615,7 +1641,7 @@ size_t sweep_lds_bytes(const SimDims &d, bool gibbs) {
 }
 size_t measure_lds_bytes(const SimDims &d) { return measure_lds_words(d) * 4; }
 static size_t overlap_lds_bytes(const SimDims &d) {
-    return (3 * (static_cast<size_t>(d.N) + 1) + 5 * 48) * 4;
+    return ((static_cast<size_t>(d.N) + 1) + 5 * 48) * 4;
 }
 
 hipError_t configure_kernels(const SimDims &) {
@@ -1630,6 +1656,8 @@ hipError_t configure_kernels(const SimDims &) {
                            reinterpret_cast<const void *>(k_sweep<true, 0>),
                            reinterpret_cast<const void *>(k_sweep<true, 3>),
                            reinterpret_cast<const void *>(k_overlap),
+                           reinterpret_cast<const void *>(k_rng_overlap<false>),
+                           reinterpret_cast<const void *>(k_rng_overlap<true>),
                            reinterpret_cast<const void *>(k_houdayer),
                            reinterpret_cast<const void *>(k_jorg),
                            reinterpret_cast<const void *>(k_measure<false>),
@@ -1651,6 +1679,20 @@ hipError_t launch_rng(const SimDims &d, const DevPtrs &p, bool gibbs, hipStream_
         hipLaunchKernelGGL((k_rng<true, false>), dim3(groups * d.B), dim3(256), kRngLds, stream, d, p);
     else
         hipLaunchKernelGGL((k_rng<false, false>), dim3(groups * d.B), dim3(256), kRngLds, stream, d, p);
+    return hipGetLastError();
+}
+
+// Random stream of the next Metropolis sweep fused with the overlap measurement of the current
+// state (LDS kernels, unit couplings only).
+hipError_t launch_rng_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
+    const uint32_t n_pairs_tw = (d.n_real * d.W + 1) / 2;
+    const uint32_t groups = (n_pairs_tw + 3) / 4;
+    const uint32_t n_overlap = d.n_real * d.W;
+    const size_t lds = std::max(kRngLds, overlap_lds_bytes(d));
+    if (d.thr_preshifted)
+        hipLaunchKernelGGL(k_rng_overlap<true>, dim3(n_overlap + groups * d.B), dim3(256), lds, stream, d, p, n_overlap);
+    else
+        hipLaunchKernelGGL(k_rng_overlap<false>, dim3(n_overlap + groups * d.B), dim3(256), lds, stream, d, p, n_overlap);
     return hipGetLastError();
 }
 

@@ -514,6 +514,9 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     for (auto &g : sim->groups) PA_HIP(sim, hipStreamWaitEvent(g.stream, sim->fork, 0));
     int status = PA_OK;
     uint64_t overlap_call_count = 0; // mod.rs:300
+    const bool fused = want_overlap && !gibbs && !fk && cfg->overlap_cluster_interval == 0 && !d.big &&
+                       !d.general && !std::getenv("PEAPODS_NO_FUSE");
+    bool overlap_owed = false; // the last recorded sweep's overlap has not been measured yet
     for (uint64_t sweep_id = 0; sweep_id < cfg->n_sweeps && status == PA_OK; ++sweep_id) {
         if ((sweep_id & 31u) == 0 && sim->interrupt.load(std::memory_order_relaxed)) {
             sim->interrupt.store(false);
@@ -523,6 +526,30 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         const bool record = sweep_id >= cfg->warmup_sweeps; // mod.rs:410
         const bool pt_this = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0; // :486-488
         const bool fk_this = fk && sweep_id % cfg->cluster_interval == 0;               // :434-437
+        if (fused) {
+            // Plain protocol on the LDS kernels: the overlap of the state sweep s-1 left is measured
+            // inside the launch that draws the random stream of sweep s, and its statistics are
+            // accumulated by the measurement kernel of sweep s.  Every accumulator still receives
+            // its values in sweep order, so the f64 sums are unchanged.
+            for (auto &g : sim->groups) {
+                if (overlap_owed)
+                    PA_HIP(sim, launch_rng_overlap(g.d, g.p, g.stream));
+                else
+                    PA_HIP(sim, launch_rng(g.d, g.p, false, g.stream));
+                PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, record || pt_this, false, g.stream));
+            }
+            sim->swaps_pending = false;
+            toggle_spin_buffers(sim);
+            PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
+            if (record || pt_this || overlap_owed)
+                for (auto &g : sim->groups)
+                    PA_HIP(sim, launch_measure(g.d, g.p, pt, false, record, overlap_owed, pt_this, g.stream));
+            overlap_owed = record;
+            if (pt_this) sim->swaps_pending = true;
+            if (record) sim->n_recorded += 1;
+            if (pt_this && cfg->pt_schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
+            continue;
+        }
         for (auto &g : sim->groups) {
             PA_HIP(sim, launch_rng(g.d, g.p, gibbs, g.stream));                         // :412-432
             // energies are computed after every mutating move of the sweep (:492-509)
@@ -541,7 +568,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
             if (!oc_this) {
                 if (record || pt_this) // statistics :543-578, tempering :748-796
-                    PA_HIP(sim, launch_measure(g.d, g.p, pt, false, record, want_overlap, pt_this,
+                    PA_HIP(sim, launch_measure(g.d, g.p, pt, false, record, record && want_overlap, pt_this,
                                                g.stream));
             } else {
                 if (record)
@@ -567,6 +594,13 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         if (cfg->overlap_cluster_interval > 0 && sweep_id % cfg->overlap_cluster_interval == 0)
             overlap_call_count += 1; // :744
         if (pt_this && cfg->pt_schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
+    }
+    if (overlap_owed && status == PA_OK) {
+        PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
+        for (auto &g : sim->groups) {
+            PA_HIP(sim, launch_overlap(g.d, g.p, g.stream));
+            PA_HIP(sim, launch_measure(g.d, g.p, pt, false, false, true, false, g.stream));
+        }
     }
     // join: the main stream continues after every group
     for (auto &g : sim->groups) {
@@ -1131,7 +1165,7 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
         if (measured) {
             if (record && want_overlap) PA_HIP(sim, launch_overlap(d, sim->p, sim->stream));
             PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
-            PA_HIP(sim, launch_measure(d, sim->p, pt, record && want_overlap, record, want_overlap,
+            PA_HIP(sim, launch_measure(d, sim->p, pt, record && want_overlap, record, record && want_overlap,
                                        pt_this, sim->stream));
             if (pt_this && cfg->pt_schedule == PA_PT_FULL_LADDER)
                 sim->next_parity = 1 - sim->next_parity;

@@ -122,8 +122,9 @@ void pa_sim_request_interrupt(pa_sim *sim);
 
 /* Per-kernel device time of the sweep pipeline, measured with HIP events on the handle's stream
  * while running `n_sweeps` sweeps of `cfg`'s protocol (state advances like sample()).
- * ms_out[3] = average milliseconds per launch of: k_rng (random stream -> acceptance levels),
- * k_sweep (level-ordered Metropolis sweep + energies), k_measure (overlap + statistics + tempering). */
+ * ms_out[3] = average milliseconds per launch of: k_rng (random stream -> acceptance levels; on the
+ * fused path this launch also measures the previous sweep's overlap), k_sweep (level-ordered sweep +
+ * energies), k_measure (statistics + tempering; plus the overlap kernel when it is not fused). */
 int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_sweeps,
                            double ms_out[3]);
 

@@ -870,11 +870,11 @@ __host__ __device__ inline size_t measure_lds_words(const SimDims &d) {
            2 * static_cast<size_t>(d.n_edges) + 2 * static_cast<size_t>(d.W) + 4;
 }
 
+// Works for any workgroup size >= max(n_temps, n_replicas, 2 W) with n_sys <= 2 * blockDim.x.
 template <bool STAMPS>
-__global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams pt, int do_overlap,
-                                                  int do_accum, int accum_overlap, int do_pt,
-                                                  unsigned long long *stamps) {
-    extern __shared__ uint32_t lds[];
+__device__ __forceinline__ void measure_block(const SimDims &d, const DevPtrs &p, const PtParams &pt,
+                                              int do_accum, int accum_overlap, int do_pt,
+                                              unsigned long long *stamps, uint32_t real, uint32_t *lds) {
     PA_STAMP(0)
     MeasureLds m;
     {
@@ -892,13 +892,12 @@ __global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams
         m.masks = q; q += 2 * d.W;
         m.flags = q;
     }
-    const uint32_t real = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
     int32_t *Eg = p.Esum + static_cast<size_t>(real) * d.n_sys;
     int32_t *Mg = p.Msum + static_cast<size_t>(real) * d.n_sys;
     uint32_t *sidg = p.system_ids + static_cast<size_t>(real) * d.n_sys;
     uint32_t *sofg = p.slot_of + static_cast<size_t>(real) * d.n_sys;
 
-    (void)do_overlap;
     for (uint32_t k = tid; k < d.n_sys; k += nthreads) {
         m.E[k] = Eg[k];
         m.M[k] = Mg[k];
@@ -1068,26 +1067,29 @@ __global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams
     const bool any_swap = m.flags[0] != 0;
     // cursors follow their systems: new cursor[slot] = old cursor[old slot of the system now there].
     // All loads complete (registers) before any store, so the permutation needs no ordering.
-    uint32_t moved[2] = {0, 0};
-    const uint32_t n_items = d.n_sys * 8;
+    // (a thread owns up to two slots: n_sys <= 2 * blockDim.x, checked on the host)
+    uint32_t moved[2][8];
     if (any_swap) {
+#pragma unroll
         for (uint32_t it = 0; it < 2; ++it) {
-            const uint32_t item = tid + it * nthreads;
-            if (item < n_items) {
-                const uint32_t slot = item >> 3, j = item & 7u;
+            const uint32_t slot = tid + it * nthreads;
+            if (slot < d.n_sys && m.sid[slot] != m.sid0[slot]) {
                 const uint32_t src = m.sof0[m.sid[slot]];
-                moved[it] = p.cursor[(static_cast<size_t>(real) * 8 + j) * d.SP + src];
+#pragma unroll
+                for (uint32_t j = 0; j < 8; ++j)
+                    moved[it][j] = p.cursor[(static_cast<size_t>(real) * 8 + j) * d.SP + src];
             }
         }
     }
     __syncthreads();
     if (any_swap) {
+#pragma unroll
         for (uint32_t it = 0; it < 2; ++it) {
-            const uint32_t item = tid + it * nthreads;
-            if (item < n_items) {
-                const uint32_t slot = item >> 3, j = item & 7u;
-                if (m.sid[slot] != m.sid0[slot])
-                    p.cursor[(static_cast<size_t>(real) * 8 + j) * d.SP + slot] = moved[it];
+            const uint32_t slot = tid + it * nthreads;
+            if (slot < d.n_sys && m.sid[slot] != m.sid0[slot]) {
+#pragma unroll
+                for (uint32_t j = 0; j < 8; ++j)
+                    p.cursor[(static_cast<size_t>(real) * 8 + j) * d.SP + slot] = moved[it][j];
             }
         }
         for (uint32_t k = tid; k < d.n_sys; k += nthreads) {
@@ -1122,6 +1124,15 @@ __global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams
     if (tid < 2 * d.W) p.swap_masks[static_cast<size_t>(real) * 2 * d.W + tid] = m.masks[tid];
     if (tid == 0 && any_swap) p.swap_epoch[real] += 1;
     PA_STAMP(6)
+}
+
+template <bool STAMPS>
+__global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams pt, int do_overlap,
+                                                  int do_accum, int accum_overlap, int do_pt,
+                                                  unsigned long long *stamps) {
+    extern __shared__ uint32_t lds_dyn[];
+    (void)do_overlap;
+    measure_block<STAMPS>(d, p, pt, do_accum, accum_overlap, do_pt, stamps, blockIdx.x, lds_dyn);
 }
 
 // ---------------------------------------------------------------------------

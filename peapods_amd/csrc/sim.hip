@@ -280,6 +280,7 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     q.mpar += static_cast<size_t>(d.MW) * r0;
     q.rec += (static_cast<size_t>(d.N) + 1) * (d.big ? 2 : 1) * r0;
     if (d.pipe_K) q.progress += static_cast<size_t>(d.W) * d.pipe_K * r0;
+
     q.big_counts += static_cast<size_t>(4) * d.n_sys * r0;
     q.Esum += static_cast<size_t>(d.n_sys) * r0;
     q.Msum += static_cast<size_t>(d.n_sys) * r0;
@@ -531,6 +532,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             // inside the launch that draws the random stream of sweep s, and its statistics are
             // accumulated by the measurement kernel of sweep s.  Every accumulator still receives
             // its values in sweep order, so the f64 sums are unchanged.
+            PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
             for (auto &g : sim->groups) {
                 if (overlap_owed)
                     PA_HIP(sim, launch_rng_overlap(g.d, g.p, g.stream));
@@ -540,7 +542,6 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             }
             sim->swaps_pending = false;
             toggle_spin_buffers(sim);
-            PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
             if (record || pt_this || overlap_owed)
                 for (auto &g : sim->groups)
                     PA_HIP(sim, launch_measure(g.d, g.p, pt, false, record, overlap_owed, pt_this, g.stream));
@@ -992,6 +993,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         ok(bufs.alloc(&p.progress, static_cast<size_t>(d.n_real) * d.W * d.pipe_K));
     }
     ok(bufs.alloc(&p.swap_epoch, static_cast<size_t>(d.n_real)));
+
     ok(bufs.alloc(&p.applied_epoch, static_cast<size_t>(d.n_real) * d.W));
     ok(bufs.alloc(&p.planes, d.general ? 1 : tile_words * d.n_real));
     if (d.general) {
@@ -1151,26 +1153,38 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
     for (auto &e : ev) PA_HIP(sim, hipEventCreate(&e));
     double total[3] = {0, 0, 0};
     uint64_t count[3] = {0, 0, 0};
+    // same launch sequence as run_sweeps on one stream; with the fused path the overlap of the
+    // previous sweep rides in the random-stream launch (reported under k_rng)
+    const bool fused = want_overlap && !gibbs && !d.big && !d.general && !std::getenv("PEAPODS_NO_FUSE");
+    bool overlap_owed = false;
     for (uint64_t sweep_id = 0; sweep_id < n_sweeps; ++sweep_id) {
         const bool record = sweep_id >= cfg->warmup_sweeps;
         const bool pt_this = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0;
         PA_HIP(sim, hipEventRecord(ev[0], sim->stream));
-        PA_HIP(sim, launch_rng(d, sim->p, gibbs, sim->stream));
+        if (fused && overlap_owed)
+            PA_HIP(sim, launch_rng_overlap(d, sim->p, sim->stream));
+        else
+            PA_HIP(sim, launch_rng(d, sim->p, gibbs, sim->stream));
         PA_HIP(sim, hipEventRecord(ev[1], sim->stream));
+        const bool measured = record || pt_this || (fused && overlap_owed);
+        PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
         PA_HIP(sim, enqueue_sweep(sim, d, sim->p, record || pt_this, gibbs, sim->stream));
         sim->swaps_pending = false;
         toggle_spin_buffers(sim);
         PA_HIP(sim, hipEventRecord(ev[2], sim->stream));
-        const bool measured = record || pt_this;
         if (measured) {
-            if (record && want_overlap) PA_HIP(sim, launch_overlap(d, sim->p, sim->stream));
-            PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
-            PA_HIP(sim, launch_measure(d, sim->p, pt, record && want_overlap, record, record && want_overlap,
-                                       pt_this, sim->stream));
+            if (fused) {
+                PA_HIP(sim, launch_measure(d, sim->p, pt, false, record, overlap_owed, pt_this, sim->stream));
+            } else {
+                if (record && want_overlap) PA_HIP(sim, launch_overlap(d, sim->p, sim->stream));
+                PA_HIP(sim, launch_measure(d, sim->p, pt, false, record, record && want_overlap, pt_this,
+                                           sim->stream));
+            }
             if (pt_this && cfg->pt_schedule == PA_PT_FULL_LADDER)
                 sim->next_parity = 1 - sim->next_parity;
             if (pt_this) sim->swaps_pending = true;
         }
+        if (fused) overlap_owed = record;
         if (record) sim->n_recorded += 1;
         PA_HIP(sim, hipEventRecord(ev[3], sim->stream));
         PA_HIP(sim, hipEventSynchronize(ev[3]));
@@ -1181,6 +1195,11 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
             total[k] += ms;
             count[k] += 1;
         }
+    }
+    if (overlap_owed) {
+        PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
+        PA_HIP(sim, launch_overlap(d, sim->p, sim->stream));
+        PA_HIP(sim, launch_measure(d, sim->p, pt, false, false, true, false, sim->stream));
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
     for (int k = 0; k < 3; ++k) ms_out[k] = count[k] ? total[k] / static_cast<double>(count[k]) : 0.0;

@@ -213,6 +213,20 @@ def test_sample_matches_oracle(oracle, schedule, shape, n_temps, n_rep, n_dis):
     assert_state_equal(gpu, cpu)
 
 
+def test_more_than_256_systems_per_realization(oracle):
+    # 40 temperatures x 8 replicas = 320 systems (10 tile words): the tempering kernel moves the
+    # generator cursors of every swapped slot, two slots per thread
+    shape = (4, 4)
+    couplings = bimodal(shape, 2, 2, 13)
+    gpu, cpu = make_pair(oracle, shape, couplings, np.linspace(0.6, 3.0, 40), 8, 77)
+    for schedule in ("full_ladder", "single_random_edge"):
+        kwargs = dict(pt_interval=1, pt_schedule=schedule, warmup_ratio=0.2)
+        a = gpu.sample(15, "metropolis", **kwargs)
+        b = cpu.sample(15, "metropolis", **kwargs)
+        assert_results_equal(a, b)
+        assert_state_equal(gpu, cpu)
+
+
 def test_ferromagnet_without_replicas_or_pt(oracle):
     shape = (8, 8)
     couplings = np.ones(shape + (2,), np.float32)

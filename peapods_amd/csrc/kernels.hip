@@ -1,12 +1,14 @@
 // HIP kernels of the MI355X spin-sim engine (gfx950 only; wave = 64 lanes).
 //
 //   k_rng        reference-exact random stream -> acceptance-level bit planes
-//   k_sweep      level-ordered Metropolis sweep on 32 slots per word (+ energy / magnetisation)
+//   k_sweep      level-ordered Metropolis / Gibbs sweep on 32 slots per word (+ energy / magnetisation)
 //   k_overlap    replica-overlap and link-overlap dot products
+//   k_rng_overlap         both of the above in one launch (overlap hides under the random stream)
 //   k_measure    running f64 statistics, P(q) histograms, parallel tempering
-//   k_houdayer / k_jorg   overlap-cluster moves
-//   k_*_big      the same algorithm for lattices that do not fit the LDS
+//   k_houdayer / k_jorg   overlap-cluster moves, single-cluster variants
+//   k_sweep_pipe, k_*_big the same algorithm for lattices that do not fit the LDS
 //   k_apply_swaps         materialises deferred tempering swaps
+// (kernels_general.hip: arbitrary f32 couplings; kernels_cluster.hip: union-find cluster moves)
 //
 // Decisions are integer throughout (24-bit draw < table threshold); floating
 // point appears only where the reference has it (one f32 division per

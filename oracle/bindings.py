@@ -22,7 +22,7 @@ _LIB = None
 
 SWEEP_MODES = {"metropolis": 0, "gibbs": 1}
 PT_SCHEDULES = {"single_random_edge": 0, "full_ladder": 1}
-OC_MODES = {"houdayer": 1, "houd2": 1, "jorg": 2}
+OC_MODES = {"houdayer": 1, "houd2": 1, "jorg": 2, "cmr": 3, "cmr2": 3}
 CLUSTER_MODES = {"wolff": 0, "sw": 1}
 
 

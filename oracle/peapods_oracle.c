@@ -110,6 +110,21 @@ static uint32_t gen_range_u32(orc_rng *rng, uint32_t low, uint32_t high) {
     }
 }
 
+/* rand 0.8.5 UniformInt<u8>::sample_single_inclusive (uniform.rs, uniform_int_impl! with
+ * $u_large = u32): zone = u32::MAX - (u32::MAX - range + 1) % range, one u32 per attempt.
+ * Call sites: ss/clusters/overlap.rs:808 (1..=3), :827 (0..=3), :950 (1..=3). */
+static uint8_t gen_range_u8_inclusive(orc_rng *rng, uint8_t low, uint8_t high) {
+    uint32_t range = (uint32_t)(uint8_t)(high - low + 1);
+    uint32_t ints_to_reject = (UINT32_MAX - range + 1) % range;
+    uint32_t zone = UINT32_MAX - ints_to_reject;
+    for (;;) {
+        uint32_t v = orc_rng_next_u32(rng);
+        uint64_t m = (uint64_t)v * (uint64_t)range;
+        uint32_t hi = (uint32_t)(m >> 32), lo = (uint32_t)m;
+        if (lo <= zone) return (uint8_t)(low + hi);
+    }
+}
+
 /* rand 0.8.5 SliceRandom::shuffle: for i in (1..len).rev() swap(i, gen_index(i+1)).
  * Call site: ss/clusters/overlap.rs:48. */
 void orc_rng_shuffle_usize(orc_rng *rng, uint64_t *values, size_t len) {
@@ -822,6 +837,141 @@ static void overlap_update(const orc_lattice *lat, realization *real, size_t n_r
     free(rank);
 }
 
+/* ss/clusters/overlap.rs:555-971: CMR two-phase move (blue clusters of doubly satisfied bonds with
+ * p = 1 - r^2, then grey clusters = blue + singly satisfied "red" bonds with p = 1 - r,
+ * r = exp(-2|J|/T)).  Update action without observers: cluster_mode sw = union-find path
+ * (:690-843), wolff = the two-phase depth-first search (:845-965). */
+static void cmr_update(const orc_lattice *lat, realization *real, size_t n_replicas, size_t n_temps,
+                       int cluster_mode) {
+    size_t n = lat->n_spins, nn = lat->n_neighbors;
+    size_t n_pairs = n_replicas / 2;
+    uint64_t *systems = (uint64_t *)malloc(sizeof(uint64_t) * (n_temps * n_replicas + 1));
+    for (size_t t = 0; t < n_temps; ++t) { /* build_tasks, :35-56 */
+        for (size_t k = 0; k < n_replicas; ++k)
+            systems[t * n_replicas + k] = real->system_ids[k * n_temps + t];
+        orc_rng_shuffle_usize(&real->pair_rngs[t * n_pairs], systems + t * n_replicas, n_replicas);
+    }
+    uint8_t *in_cluster = (uint8_t *)malloc(n + 1);
+    size_t *stack = (size_t *)malloc(sizeof(size_t) * (n + 1));
+    uint32_t *parent = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
+    uint32_t *counts = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
+    uint8_t *rank = (uint8_t *)malloc(n + 1);
+    uint8_t *flag = (uint8_t *)malloc(n + 1);
+
+    for (size_t task = 0; task < n_temps * n_pairs; ++task) {
+        size_t t = task / n_pairs, g = task % n_pairs;
+        const uint64_t *grp = systems + t * n_replicas + g * 2;
+        orc_rng *rng = &real->pair_rngs[t * n_pairs + g];
+        float temp = real->temperatures[t];
+        int8_t *a = real->spins + (size_t)grp[0] * n;
+        int8_t *b = real->spins + (size_t)grp[1] * n;
+#define SAT(s, i, j, c) ((float)(s)[i] * (float)(s)[j] * (c) > 0.0f)
+        if (cluster_mode == ORC_CLUSTER_WOLFF) {
+            size_t seed = (size_t)orc_rng_gen_range_usize(rng, 0, n);
+            memset(in_cluster, 0, n);
+            size_t top = 0;
+            in_cluster[seed] = 1;
+            stack[top++] = seed;
+            while (top > 0) { /* phase 1: blue cluster, dfs_cluster order */
+                size_t site = stack[--top];
+                for (size_t d = 0; d < nn; ++d)
+                    for (int dir = 0; dir < 2; ++dir) {
+                        size_t nb = dir == 0 ? lat->fwd[site * nn + d] : lat->bwd[site * nn + d];
+                        if (in_cluster[nb]) continue;
+                        float c = dir == 0 ? real->couplings[site * nn + d] : real->couplings[nb * nn + d];
+                        if (!SAT(a, site, nb, c) || !SAT(b, site, nb, c)) continue;
+                        float r = expf(-2.0f * fabsf(c) / temp);
+                        if (orc_rng_gen_f32(rng) < 1.0f - r * r) {
+                            in_cluster[nb] = 1;
+                            stack[top++] = nb;
+                        }
+                    }
+            }
+            for (size_t i = 0; i < n; ++i)
+                if (in_cluster[i]) {
+                    a[i] = (int8_t)-a[i];
+                    b[i] = (int8_t)-b[i];
+                }
+            for (size_t i = 0; i < n; ++i) /* phase 2 starts from every blue site */
+                if (in_cluster[i]) stack[top++] = i;
+            while (top > 0) {
+                size_t site = stack[--top];
+                for (size_t d = 0; d < nn; ++d)
+                    for (int dir = 0; dir < 2; ++dir) {
+                        size_t nb = dir == 0 ? lat->fwd[site * nn + d] : lat->bwd[site * nn + d];
+                        if (in_cluster[nb]) continue;
+                        float c = dir == 0 ? real->couplings[site * nn + d] : real->couplings[nb * nn + d];
+                        if (SAT(a, site, nb, c) == SAT(b, site, nb, c)) continue;
+                        float r = expf(-2.0f * fabsf(c) / temp);
+                        if (orc_rng_gen_f32(rng) < 1.0f - r) {
+                            in_cluster[nb] = 1;
+                            stack[top++] = nb;
+                        }
+                    }
+            }
+            uint8_t k = gen_range_u8_inclusive(rng, 1, 3);
+            for (size_t i = 0; i < n; ++i)
+                if (in_cluster[i]) {
+                    if (k & 1) a[i] = (int8_t)-a[i];
+                    if (k & 2) b[i] = (int8_t)-b[i];
+                }
+        } else {
+            for (size_t i = 0; i < n; ++i) parent[i] = (uint32_t)i;
+            memset(rank, 0, n);
+            for (size_t i = 0; i < n; ++i) /* blue bonds, :582-605 */
+                for (size_t d = 0; d < nn; ++d) {
+                    size_t j = lat->fwd[i * nn + d];
+                    float c = real->couplings[i * nn + d];
+                    if (!SAT(a, i, j, c) || !SAT(b, i, j, c)) continue;
+                    float r = expf(-2.0f * fabsf(c) / temp);
+                    if (orc_rng_gen_f32(rng) < 1.0f - r * r)
+                        orc_uf_union(parent, rank, (uint32_t)i, (uint32_t)j);
+                }
+            uf_flatten_counts(parent, n, counts);
+            memset(flag, 0xFF, n); /* :757-770 */
+            for (size_t i = 0; i < n; ++i) {
+                uint32_t root = parent[i];
+                if (counts[root] > 1 && flag[root] == 0xFF)
+                    flag[root] = (uint8_t)(orc_rng_gen_f32(rng) < 0.5f);
+            }
+            for (size_t i = 0; i < n; ++i)
+                if (flag[parent[i]] == 1) {
+                    a[i] = (int8_t)-a[i];
+                    b[i] = (int8_t)-b[i];
+                }
+            for (size_t i = 0; i < n; ++i) /* red bonds extend the blue forest, :777-795 */
+                for (size_t d = 0; d < nn; ++d) {
+                    size_t j = lat->fwd[i * nn + d];
+                    float c = real->couplings[i * nn + d];
+                    if (SAT(a, i, j, c) == SAT(b, i, j, c)) continue;
+                    float r = expf(-2.0f * fabsf(c) / temp);
+                    if (orc_rng_gen_f32(rng) < 1.0f - r)
+                        orc_uf_union(parent, rank, (uint32_t)i, (uint32_t)j);
+                }
+            uf_flatten_counts(parent, n, counts);
+            memset(flag, 0xFF, n); /* :822-841 */
+            for (size_t i = 0; i < n; ++i) {
+                uint32_t root = parent[i];
+                if (counts[root] > 1 && flag[root] == 0xFF) flag[root] = gen_range_u8_inclusive(rng, 0, 3);
+            }
+            for (size_t i = 0; i < n; ++i) {
+                uint8_t k = flag[parent[i]];
+                if (k == 0 || k == 0xFF) continue;
+                if (k & 1) a[i] = (int8_t)-a[i];
+                if (k & 2) b[i] = (int8_t)-b[i];
+            }
+        }
+#undef SAT
+    }
+    free(systems);
+    free(in_cluster);
+    free(stack);
+    free(parent);
+    free(counts);
+    free(rank);
+    free(flag);
+}
+
 /* ========================================================================== */
 /* Fortuin-Kasteleyn cluster update of every system (ss/clusters/fk.rs:27-200) */
 /* ========================================================================== */
@@ -1036,7 +1186,10 @@ static void run_sweep_loop(const orc_lattice *lat, realization *real, size_t n_r
             did_overlap_mutate = 1;
             int mode = cfg->overlap_cluster_modes[overlap_call_count %
                                                   (size_t)cfg->n_overlap_cluster_modes];
-            overlap_update(lat, real, n_replicas, n_temps, mode, cfg->overlap_cluster_mode);
+            if (mode == ORC_OC_CMR)
+                cmr_update(lat, real, n_replicas, n_temps, cfg->overlap_cluster_mode);
+            else
+                overlap_update(lat, real, n_replicas, n_temps, mode, cfg->overlap_cluster_mode);
             overlap_call_count += 1;
         }
 

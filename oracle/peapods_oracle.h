@@ -131,7 +131,7 @@ void orc_top4_sizes(const uint32_t *counts, size_t n, uint32_t out[4]);
 /* ---- full simulation (ss/simulation/{mod.rs,realization.rs}, src/lib.rs) -- */
 enum { ORC_SWEEP_METROPOLIS = 0, ORC_SWEEP_GIBBS = 1 };
 enum { ORC_PT_SINGLE_RANDOM_EDGE = 0, ORC_PT_FULL_LADDER = 1 };
-enum { ORC_OC_NONE = 0, ORC_OC_HOUDAYER = 1, ORC_OC_JORG = 2 };
+enum { ORC_OC_NONE = 0, ORC_OC_HOUDAYER = 1, ORC_OC_JORG = 2, ORC_OC_CMR = 3 };
 enum { ORC_CLUSTER_WOLFF = 0, ORC_CLUSTER_SW = 1 };
 
 typedef struct {

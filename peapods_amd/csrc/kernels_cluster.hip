@@ -96,10 +96,15 @@ struct SwLds {
     uint32_t *aux;     // [N] multi-site flag of roots
     uint32_t *act;     // [MW] active sites (the pair's spins differ)
     uint32_t *spa;     // [MW] spin of the pair's first system (1 <=> -1)
+    uint32_t *spb;     // [MW] spin of the pair's second system
     uint32_t *bond;    // [3][MW] eligible, later accepted, forward bonds per direction
-    uint32_t *wbase;   // [MW + 1] exclusive prefix (eligible bonds / multi-site roots) per 32-site word
-    uint32_t *roots;   // [MW] multi-site roots
-    uint32_t *bits;    // [n_bit_words] accept bits by draw position, later coin bits
+    uint32_t *blue;    // [3][MW] CMR: accepted blue bonds, kept for the grey clusters
+    uint32_t *wbase;   // [MW + 1] exclusive prefix (eligible bonds / drawing roots) per 32-site word
+    uint32_t *roots;   // [MW] roots that draw
+    uint32_t *flip_a;  // [MW] accumulated flips of the first system
+    uint32_t *flip_b;  // [MW] accumulated flips of the second system
+    uint32_t *bits;    // [n_bit_words] accept / coin bits by draw position
+    uint32_t *bits2;   // [n_bit_words] second bit of the CMR grey draw
     uint32_t *scratch; // [8]
     uint32_t *misc;    // [4] changed flag
 };
@@ -108,15 +113,16 @@ __host__ __device__ inline size_t cluster_sw_bit_words(const SimDims &d) {
     return (static_cast<size_t>(d.N) * d.nn + 255) / 256 * 8 + 16;
 }
 __host__ __device__ inline size_t cluster_sw_lds_words(const SimDims &d) {
-    return 2 * static_cast<size_t>(d.N) + 7 * static_cast<size_t>(d.MW) + 1 + cluster_sw_bit_words(d) + 12;
+    return 2 * static_cast<size_t>(d.N) + 14 * static_cast<size_t>(d.MW) + 1 + 2 * cluster_sw_bit_words(d) + 12;
 }
 
-enum { kSwHoudayer = 0, kSwJorg = 1, kSwFk = 2 };
+enum { kSwHoudayer = 0, kSwJorg = 1, kSwFk = 2, kSwCmr = 3 };
 
 template <int MODE>
 __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p) {
-    constexpr bool JORG = MODE == kSwJorg, FK = MODE == kSwFk;
-    constexpr bool STOCHASTIC = JORG || FK; // bonds are drawn
+    constexpr bool JORG = MODE == kSwJorg, FK = MODE == kSwFk, CMR = MODE == kSwCmr;
+    constexpr bool STOCHASTIC = JORG || FK || CMR; // bonds are drawn
+    constexpr uint32_t N_PHASES = CMR ? 2 : 1;     // CMR: blue clusters, then grey = blue + red bonds
     extern __shared__ uint32_t lds[];
     SwLds L;
     {
@@ -125,10 +131,15 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p)
         L.aux = q; q += d.N;
         L.act = q; q += d.MW;
         L.spa = q; q += d.MW;
+        L.spb = q; q += d.MW;
         L.bond = q; q += 3 * d.MW;
+        L.blue = q; q += 3 * d.MW;
         L.wbase = q; q += d.MW + 1;
         L.roots = q; q += d.MW;
+        L.flip_a = q; q += d.MW;
+        L.flip_b = q; q += d.MW;
         L.bits = q; q += cluster_sw_bit_words(d);
+        L.bits2 = q; q += cluster_sw_bit_words(d);
         L.scratch = q; q += 8;
         L.misc = q;
     }
@@ -153,7 +164,7 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p)
     };
     auto get_bit = [&](const uint32_t *bitmap, uint32_t i) -> uint32_t { return (bitmap[i >> 5] >> (i & 31u)) & 1u; };
 
-    // ---- A: active sites and the first system's spins
+    // ---- A: active sites and the systems' spins
     for (uint32_t r = 0; r < n_rounds; ++r) {
         const uint32_t i = r * kSwThreads + tid;
         uint32_t a = 0, b = 0;
@@ -161,30 +172,13 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p)
             a = (Sa[i] >> ba) & 1u;
             b = (Sb[i] >> bb) & 1u;
         }
-        put_ballot(L.act, r, FK ? i < d.N : (a ^ b) != 0);
+        put_ballot(L.act, r, (FK || CMR) ? i < d.N : (a ^ b) != 0);
         put_ballot(L.spa, r, a != 0);
+        put_ballot(L.spb, r, b != 0);
     }
-    __syncthreads();
-
-    // ---- B: eligible forward bonds.  Houdayer: both ends active (overlap.rs:228-231).
-    // Joerg: both ends active and s_a(i) s_a(j) J > 0 (:417-429).  FK: s_i s_j J > 0 (fk.rs:113-120).
-    for (uint32_t r = 0; r < n_rounds; ++r) {
-        const uint32_t i = r * kSwThreads + tid;
-        bool e[3] = {false, false, false};
-        if (i < d.N && get_bit(L.act, i)) {
-            const uint32_t jm = STOCHASTIC ? jsite[i] : 0u;
-            for (uint32_t dd = 0; dd < d.nn; ++dd) {
-                const uint32_t j = p.nbr_site[i * 6 + 2 * dd];
-                bool ok = get_bit(L.act, j) != 0;
-                if (STOCHASTIC && ok) {
-                    const bool nz = (jm >> (6 + 2 * dd)) & 1u;
-                    const uint32_t unsat = get_bit(L.spa, i) ^ get_bit(L.spa, j) ^ ((jm >> (2 * dd)) & 1u);
-                    ok = nz && unsat == 0;
-                }
-                e[dd] = ok;
-            }
-        }
-        for (uint32_t dd = 0; dd < 3; ++dd) put_ballot(L.bond + dd * d.MW, r, e[dd]);
+    for (uint32_t m = tid; m < d.MW; m += kSwThreads) {
+        L.flip_a[m] = 0;
+        L.flip_b[m] = 0;
     }
     __syncthreads();
 
@@ -200,7 +194,7 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p)
     };
     // exclusive scan of a per-word count into wbase[0..MW]; returns the total
     auto scan_words = [&](auto count_of_word) -> uint32_t {
-        uint32_t total = 0, carry = 0;
+        uint32_t carry = 0;
         for (uint32_t m0 = 0; m0 < d.MW; m0 += kSwThreads) {
             const uint32_t m = m0 + tid;
             const uint32_t c = m < d.MW ? count_of_word(m) : 0u;
@@ -209,14 +203,12 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p)
             if (m < d.MW) L.wbase[m] = carry + ex;
             carry += part;
         }
-        total = carry;
-        if (tid == 0) L.wbase[d.MW] = total;
+        if (tid == 0) L.wbase[d.MW] = carry;
         __syncthreads();
-        return total;
+        return carry;
     };
 
-    // the pair's generator, advanced by `offset` draws through the stride-256 jump tables:
-    // returns the state at draw 256 * block
+    // the generator at draw 256 * block after its position at entry (stride-256 jump tables)
     uint32_t base_state[8];
     if (FK) {
         load_cursor(p.cursor, real, d.SP, sa, base_state);
@@ -236,47 +228,30 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p)
         rng.load(st);
         return rng;
     };
-
-    // ---- C, D (stochastic bonds): draw positions of the eligible bonds, accept bits of the stream
-    uint32_t n_eligible = 0;
-    if (STOCHASTIC) {
-        n_eligible = scan_words([&](uint32_t m) {
-            uint32_t c = 0;
-            for (uint32_t x = 0; x < d.nn; ++x) c += __popc(L.bond[x * d.MW + m]);
-            return c;
-        });
-        const uint32_t n_blocks = (n_eligible + 255) / 256;
-        const uint32_t threshold = FK ? p.fk_thr[t] : p.jorg_thr[t]; // draw < ceil(p 2^24) <=> gen::<f32>() < p
-        for (uint32_t blk = tid; blk < n_blocks; blk += kSwThreads) {
+    // Bits of the draws at stream positions [start, start + count): bit = draw < threshold (and,
+    // with two_bits, the top two bits of the draw: rand's u8 gen_range(0..=3), overlap.rs:827).
+    // Position q lands at bit q - 256 * (start / 256) of bits / bits2.
+    auto draw_bits = [&](uint32_t start, uint32_t count, uint32_t threshold, bool two_bits) {
+        if (count == 0) return;
+        const uint32_t first_block = start / 256, last_block = (start + count - 1) / 256;
+        for (uint32_t blk = first_block + tid; blk <= last_block; blk += kSwThreads) {
             Rng32 rng = stream_at_block(blk);
             for (uint32_t wd = 0; wd < 8; ++wd) {
-                uint32_t acc = 0;
-                for (uint32_t k = 0; k < 32; ++k) acc |= ((rng.next_top() >> 8) < threshold ? 1u : 0u) << k;
-                L.bits[blk * 8 + wd] = acc;
+                uint32_t acc = 0, acc2 = 0;
+                for (uint32_t k = 0; k < 32; ++k) {
+                    const uint32_t top = rng.next_top();
+                    if (two_bits) {
+                        acc |= ((top >> 30) & 1u) << k;
+                        acc2 |= (top >> 31) << k;
+                    } else {
+                        acc |= ((top >> 8) < threshold ? 1u : 0u) << k;
+                    }
+                }
+                L.bits[(blk - first_block) * 8 + wd] = acc;
+                if (two_bits) L.bits2[(blk - first_block) * 8 + wd] = acc2;
             }
         }
-        __syncthreads();
-        // ---- E: accepted bonds
-        for (uint32_t r = 0; r < n_rounds; ++r) {
-            const uint32_t i = r * kSwThreads + tid;
-            bool e[3] = {false, false, false};
-            if (i < d.N)
-                for (uint32_t dd = 0; dd < d.nn; ++dd)
-                    if (get_bit(L.bond + dd * d.MW, i)) {
-                        const uint32_t pos = entries_before(i, dd);
-                        e[dd] = (L.bits[pos >> 5] >> (pos & 31u)) & 1u;
-                    }
-            __syncthreads(); // every thread has read its bond words before any is replaced
-            for (uint32_t dd = 0; dd < 3; ++dd) put_ballot(L.bond + dd * d.MW, r, e[dd]);
-            __syncthreads();
-        }
-    }
-
-    // ---- F: connected components.  Roots are hooked under the smaller root, so a component's
-    // final root is its smallest site -- the order in which the reference meets the clusters.
-    for (uint32_t i = tid; i < d.N; i += kSwThreads) L.label[i] = i;
-    if (tid == 0) L.misc[0] = 0;
-    __syncthreads();
+    };
     auto find_root = [&](uint32_t x) -> uint32_t {
         for (;;) {
             const uint32_t up = L.label[x];
@@ -284,82 +259,179 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p)
             x = up;
         }
     };
-    for (uint32_t iter = 0; iter <= d.N; ++iter) {
-        bool hooked = false;
-        for (uint32_t i = tid; i < d.N; i += kSwThreads)
-            for (uint32_t dd = 0; dd < d.nn; ++dd)
-                if (get_bit(L.bond + dd * d.MW, i)) {
+
+    uint32_t pos = 0; // draws of the generator consumed so far
+    for (uint32_t phase = 0; phase < N_PHASES; ++phase) {
+        // ---- B: eligible forward bonds.  Houdayer: both ends active (overlap.rs:228-231).
+        // Joerg: both ends active and s_a(i) s_a(j) J > 0 (:417-429).  FK: s_i s_j J > 0
+        // (fk.rs:113-120).  CMR: blue = satisfied in both systems (:588-596), red = satisfied in
+        // exactly one (:779-792).
+        for (uint32_t r = 0; r < n_rounds; ++r) {
+            const uint32_t i = r * kSwThreads + tid;
+            bool e[3] = {false, false, false};
+            if (i < d.N && get_bit(L.act, i)) {
+                const uint32_t jm = STOCHASTIC ? jsite[i] : 0u;
+                for (uint32_t dd = 0; dd < d.nn; ++dd) {
                     const uint32_t j = p.nbr_site[i * 6 + 2 * dd];
-                    const uint32_t ra = find_root(i), rb = find_root(j);
-                    if (ra != rb) {
-                        atomicMin(&L.label[max(ra, rb)], min(ra, rb));
-                        hooked = true;
+                    bool ok = get_bit(L.act, j) != 0;
+                    if (STOCHASTIC && ok) {
+                        const bool nz = (jm >> (6 + 2 * dd)) & 1u;
+                        const uint32_t neg = (jm >> (2 * dd)) & 1u;
+                        const bool a_sat = (get_bit(L.spa, i) ^ get_bit(L.spa, j) ^ neg) == 0;
+                        if (CMR) {
+                            const bool b_sat = (get_bit(L.spb, i) ^ get_bit(L.spb, j) ^ neg) == 0;
+                            ok = nz && (phase == 0 ? (a_sat && b_sat) : (a_sat != b_sat));
+                        } else {
+                            ok = nz && a_sat;
+                        }
                     }
+                    e[dd] = ok;
                 }
-        if (hooked) L.misc[0] = 1;
-        __syncthreads();
-        for (uint32_t i = tid; i < d.N; i += kSwThreads) { // pointer jumping
-            uint32_t x = L.label[i];
-            while (L.label[x] != x) x = L.label[x];
-            L.label[i] = x;
+            }
+            for (uint32_t dd = 0; dd < 3; ++dd) put_ballot(L.bond + dd * d.MW, r, e[dd]);
         }
-        const bool again = L.misc[0] != 0;
         __syncthreads();
-        if (!again) break;
+
+        // ---- C, D, E (stochastic bonds): the bond at rank k of the eligible ones, in (site, dim)
+        // order, sees draw pos + k of the generator
+        if (STOCHASTIC) {
+            const uint32_t n_eligible = scan_words([&](uint32_t m) {
+                uint32_t c = 0;
+                for (uint32_t x = 0; x < d.nn; ++x) c += __popc(L.bond[x * d.MW + m]);
+                return c;
+            });
+            // draw < ceil(p 2^24)  <=>  gen::<f32>() < p
+            const uint32_t threshold = FK ? p.fk_thr[t] : (CMR ? (phase == 0 ? p.cmr_thr[t] : p.fk_thr[t]) : p.jorg_thr[t]);
+            draw_bits(pos, n_eligible, threshold, false);
+            __syncthreads();
+            const uint32_t rel = pos - (pos / 256) * 256;
+            for (uint32_t r = 0; r < n_rounds; ++r) {
+                const uint32_t i = r * kSwThreads + tid;
+                bool e[3] = {false, false, false};
+                if (i < d.N)
+                    for (uint32_t dd = 0; dd < d.nn; ++dd)
+                        if (get_bit(L.bond + dd * d.MW, i)) {
+                            const uint32_t q = rel + entries_before(i, dd);
+                            e[dd] = (L.bits[q >> 5] >> (q & 31u)) & 1u;
+                        }
+                __syncthreads(); // every thread has read its bond words before any is replaced
+                for (uint32_t dd = 0; dd < 3; ++dd) put_ballot(L.bond + dd * d.MW, r, e[dd]);
+                __syncthreads();
+            }
+            pos += n_eligible;
+            if (CMR && phase == 0) { // keep the blue bonds: grey clusters are blue + red
+                for (uint32_t m = tid; m < 3 * d.MW; m += kSwThreads) L.blue[m] = L.bond[m];
+                __syncthreads();
+            }
+        }
+
+        // ---- F: connected components.  Roots are hooked under the smaller root, so a component's
+        // final root is its smallest site -- the order in which the reference meets the clusters.
+        for (uint32_t i = tid; i < d.N; i += kSwThreads) L.label[i] = i;
         if (tid == 0) L.misc[0] = 0;
         __syncthreads();
-    }
+        auto bonded = [&](uint32_t dd, uint32_t i) -> bool {
+            return get_bit(L.bond + dd * d.MW, i) || (CMR && phase == 1 && get_bit(L.blue + dd * d.MW, i));
+        };
+        for (uint32_t iter = 0; iter <= d.N; ++iter) {
+            bool hooked = false;
+            for (uint32_t i = tid; i < d.N; i += kSwThreads)
+                for (uint32_t dd = 0; dd < d.nn; ++dd)
+                    if (bonded(dd, i)) {
+                        const uint32_t j = p.nbr_site[i * 6 + 2 * dd];
+                        const uint32_t ra = find_root(i), rb = find_root(j);
+                        if (ra != rb) {
+                            atomicMin(&L.label[max(ra, rb)], min(ra, rb));
+                            hooked = true;
+                        }
+                    }
+            if (hooked) L.misc[0] = 1;
+            __syncthreads();
+            for (uint32_t i = tid; i < d.N; i += kSwThreads) { // pointer jumping
+                uint32_t x = L.label[i];
+                while (L.label[x] != x) x = L.label[x];
+                L.label[i] = x;
+            }
+            const bool again = L.misc[0] != 0;
+            __syncthreads();
+            if (!again) break;
+            if (tid == 0) L.misc[0] = 0;
+            __syncthreads();
+        }
 
-    // ---- G: clusters that receive a coin -- more than one site for the overlap moves
-    // (overlap.rs:312-318), every cluster for FK (fk.rs:182-192) -- ranked by their smallest site
-    for (uint32_t i = tid; i < d.N; i += kSwThreads) L.aux[i] = 0;
-    __syncthreads();
-    for (uint32_t i = tid; i < d.N; i += kSwThreads)
-        if (L.label[i] != i) L.aux[L.label[i]] = 1;
-    __syncthreads();
-    for (uint32_t r = 0; r < n_rounds; ++r) {
-        const uint32_t i = r * kSwThreads + tid;
-        put_ballot(L.roots, r, i < d.N && L.label[i] == i && (FK || L.aux[i] != 0));
-    }
-    __syncthreads();
-    const uint32_t n_clusters = scan_words([&](uint32_t m) { return static_cast<uint32_t>(__popc(L.roots[m])); });
+        // ---- G: clusters that draw -- more than one site for the overlap moves (overlap.rs:312-318,
+        // :757-762, :822-828), every cluster for FK (fk.rs:182-192) -- ranked by their smallest site
+        for (uint32_t i = tid; i < d.N; i += kSwThreads) L.aux[i] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < d.N; i += kSwThreads)
+            if (L.label[i] != i) L.aux[L.label[i]] = 1;
+        __syncthreads();
+        for (uint32_t r = 0; r < n_rounds; ++r) {
+            const uint32_t i = r * kSwThreads + tid;
+            put_ballot(L.roots, r, i < d.N && L.label[i] == i && (FK || L.aux[i] != 0));
+        }
+        __syncthreads();
+        const uint32_t n_clusters = scan_words([&](uint32_t m) { return static_cast<uint32_t>(__popc(L.roots[m])); });
 
-    // ---- H: coin draws continue the stream after the bond draws; the generator ends
-    // n_eligible + n_clusters draws after where it started
-    const uint32_t first_block = n_eligible / 256, end_pos = n_eligible + n_clusters;
-    const uint32_t last_block = end_pos / 256;
-    for (uint32_t blk = first_block + tid; blk <= last_block; blk += kSwThreads) {
-        Rng32 rng = stream_at_block(blk);
-        for (uint32_t wd = 0; wd < 8; ++wd) {
-            uint32_t acc = 0;
-            for (uint32_t k = 0; k < 32; ++k) {
-                if (blk == last_block && blk * 256 + wd * 32 + k == end_pos) {
-                    uint32_t st[8];
-                    rng.store(st);
-                    if (FK) {
-                        store_cursor(p.cursor, real, d.SP, sa, st);
+        // ---- H: the cluster draws continue the stream after the bond draws: a coin
+        // gen::<f32>() < 0.5, or for the grey clusters of CMR gen_range(0..=3) = the top two bits
+        const bool grey = CMR && phase == 1;
+        draw_bits(pos, n_clusters, 1u << 23, grey);
+        __syncthreads();
+        const uint32_t rel = pos - (pos / 256) * 256;
+
+        // ---- I: flips (both systems for a coin; bit 0 / bit 1 of k for the two systems of a grey cluster)
+        for (uint32_t r = 0; r < n_rounds; ++r) {
+            const uint32_t i = r * kSwThreads + tid;
+            bool fa = false, fb = false;
+            if (i < d.N) {
+                const uint32_t root = L.label[i];
+                if (FK || L.aux[root]) {
+                    const uint32_t q = rel + L.wbase[root >> 5] + __popc(L.roots[root >> 5] & ((1u << (root & 31u)) - 1u));
+                    const uint32_t b0 = (L.bits[q >> 5] >> (q & 31u)) & 1u;
+                    if (grey) {
+                        fa = b0 != 0;
+                        fb = ((L.bits2[q >> 5] >> (q & 31u)) & 1u) != 0;
                     } else {
-                        for (int q = 0; q < 4; ++q)
-                            rng_state[q] = (static_cast<uint64_t>(st[2 * q + 1]) << 32) | st[2 * q];
+                        fa = fb = b0 != 0;
                     }
                 }
-                acc |= ((rng.next_top() >> 8) < (1u << 23) ? 1u : 0u) << k; // gen::<f32>() < 0.5
             }
-            L.bits[(blk - first_block) * 8 + wd] = acc;
+            const unsigned long long va = __ballot(fa), vb = __ballot(fb);
+            const uint32_t word = (r * kSwThreads + (tid & ~63u)) >> 5;
+            if (lane == 0 && word < d.MW) {
+                L.flip_a[word] ^= static_cast<uint32_t>(va);
+                L.flip_b[word] ^= static_cast<uint32_t>(vb);
+                L.spa[word] ^= static_cast<uint32_t>(va);
+                L.spb[word] ^= static_cast<uint32_t>(vb);
+            }
+            if (lane == 32 && word + 1 < d.MW) {
+                L.flip_a[word + 1] ^= static_cast<uint32_t>(va >> 32);
+                L.flip_b[word + 1] ^= static_cast<uint32_t>(vb >> 32);
+                L.spa[word + 1] ^= static_cast<uint32_t>(va >> 32);
+                L.spb[word + 1] ^= static_cast<uint32_t>(vb >> 32);
+            }
+        }
+        pos += n_clusters;
+        __syncthreads();
+    }
+
+    // ---- the generator ends `pos` draws after where it started
+    if (tid == 0) {
+        Rng32 rng = stream_at_block(pos / 256);
+        for (uint32_t k = 0; k < pos % 256; ++k) (void)rng.next_top();
+        uint32_t st[8];
+        rng.store(st);
+        if (FK) {
+            store_cursor(p.cursor, real, d.SP, sa, st);
+        } else {
+            for (int q = 0; q < 4; ++q) rng_state[q] = (static_cast<uint64_t>(st[2 * q + 1]) << 32) | st[2 * q];
         }
     }
-    __syncthreads();
-
-    // ---- I: flip both replicas on the clusters whose coin is 1
+    // ---- apply the accumulated flips to the bit columns of the systems
     for (uint32_t i = tid; i < d.N; i += kSwThreads) {
-        const uint32_t root = L.label[i];
-        if (!FK && !L.aux[root]) continue;
-        const uint32_t rank = L.wbase[root >> 5] + __popc(L.roots[root >> 5] & ((1u << (root & 31u)) - 1u));
-        const uint32_t pos = n_eligible + rank - first_block * 256;
-        if ((L.bits[pos >> 5] >> (pos & 31u)) & 1u) {
-            atomicXor(&Sa[i], 1u << ba);
-            if (!FK) atomicXor(&Sb[i], 1u << bb);
-        }
+        if (get_bit(L.flip_a, i)) atomicXor(&Sa[i], 1u << ba);
+        if (!FK && get_bit(L.flip_b, i)) atomicXor(&Sb[i], 1u << bb);
     }
 }
 
@@ -451,24 +523,149 @@ __global__ __launch_bounds__(1024) void k_fk_wolff(SimDims d, DevPtrs p) {
     for (size_t i = tid; i < tile_words; i += nthreads) Sg[i] = tile[i];
 }
 
+// ---------------------------------------------------------------------------
+// k_cmr_wolff: CMR move, single-cluster variant without statistics (overlap.rs:845-965): seed =
+// gen_range(0..N); depth-first search over doubly satisfied bonds (p = 1 - r^2) -> flip both
+// systems; the search continues from every blue site over singly satisfied bonds (p = 1 - r) on
+// the flipped spins; k = gen_range(1..=3) decides which system(s) flip on the grey cluster.
+// Draws come in search order, so one lane per pair replays the search (as k_jorg does).
+// ---------------------------------------------------------------------------
+__host__ __device__ inline size_t cmr_wolff_lds_words(const SimDims &d) {
+    const size_t n_lanes = static_cast<size_t>(d.n_temps) * d.n_pairs;
+    return static_cast<size_t>(d.N) * d.W + n_lanes * d.MW + 4;
+}
+
+__global__ __launch_bounds__(1024) void k_cmr_wolff(SimDims d, DevPtrs p) {
+    extern __shared__ uint32_t lds[];
+    const size_t tile_words = static_cast<size_t>(d.N) * d.W;
+    const uint32_t n_lanes = d.n_temps * d.n_pairs;
+    uint32_t *tile = lds;                  // [W][N] spins
+    uint32_t *member = lds + tile_words;   // [n_lanes][MW] cluster bitmaps
+    const uint32_t real = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
+    uint32_t *Sg = p.S + static_cast<size_t>(real) * tile_words;
+    const uint16_t *jsite = p.jsite + static_cast<size_t>(real) * d.N;
+
+    copy_to_lds(tile, Sg, static_cast<uint32_t>(tile_words), tid, nthreads);
+    for (size_t i = tid; i < static_cast<size_t>(n_lanes) * d.MW; i += nthreads) member[i] = 0;
+    __syncthreads();
+
+    for (uint32_t task = tid; task < n_lanes; task += nthreads) {
+        uint16_t *stack = p.dfs_stack + (static_cast<size_t>(real) * n_lanes + task) * d.N;
+        uint64_t *st = p.pair_rng + (static_cast<size_t>(real) * n_lanes + task) * 4;
+        DevRng rng;
+        rng.s0 = st[0]; rng.s1 = st[1]; rng.s2 = st[2]; rng.s3 = st[3];
+        const uint32_t sa = p.pair_slots[(static_cast<size_t>(real) * n_lanes + task) * 2 + 0];
+        const uint32_t sb = p.pair_slots[(static_cast<size_t>(real) * n_lanes + task) * 2 + 1];
+        uint32_t *wa = tile + (sa >> 5) * d.N, *wb = tile + (sb >> 5) * d.N;
+        const uint32_t ba = sa & 31u, bb = sb & 31u;
+        const uint32_t t = task / d.n_pairs;
+        const uint32_t thr_blue = p.cmr_thr[t], thr_red = p.fk_thr[t];
+        uint32_t *mine = member + static_cast<size_t>(task) * d.MW;
+        auto in_cluster = [&](uint32_t i) { return (mine[i >> 5] >> (i & 31u)) & 1u; };
+        // satisfied in system a / b: s_i s_j J > 0 for the bond in direction slot `dir` of `site`
+        auto sat = [&](const uint32_t *wv, uint32_t bit, uint32_t site, uint32_t nb, uint32_t jm, uint32_t dir) {
+            return (((wv[site] >> bit) ^ (wv[nb] >> bit) ^ (jm >> dir)) & 1u) == 0;
+        };
+        uint32_t seed;
+        {
+            const uint64_t range = d.N; // rand 0.8.5 gen_range(0..N) on usize
+            const uint64_t zone = (range << __clzll(range)) - 1ull;
+            for (;;) {
+                const uint64_t v = rng.next();
+                if (v * range <= zone) {
+                    seed = static_cast<uint32_t>(__umul64hi(v, range));
+                    break;
+                }
+            }
+        }
+        uint32_t top = 0;
+        mine[seed >> 5] |= 1u << (seed & 31u);
+        stack[top++] = static_cast<uint16_t>(seed);
+        for (int phase = 0; phase < 2; ++phase) {
+            while (top > 0) {
+                const uint32_t site = stack[--top];
+                const uint32_t jm = jsite[site];
+                for (uint32_t dir = 0; dir < 2 * d.nn; ++dir) { // f0, b0, f1, b1, ...
+                    const uint32_t nb = p.nbr_site[site * 6 + dir];
+                    if (in_cluster(nb)) continue;
+                    if (!((jm >> (6 + dir)) & 1u)) continue; // J = 0: neither system is satisfied
+                    const bool a_sat = sat(wa, ba, site, nb, jm, dir), b_sat = sat(wb, bb, site, nb, jm, dir);
+                    if (phase == 0 ? !(a_sat && b_sat) : (a_sat == b_sat)) continue;
+                    const uint32_t draw = static_cast<uint32_t>(rng.next() >> 40);
+                    if (draw < (phase == 0 ? thr_blue : thr_red)) {
+                        mine[nb >> 5] |= 1u << (nb & 31u);
+                        stack[top++] = static_cast<uint16_t>(nb);
+                    }
+                }
+            }
+            if (phase == 0) {
+                // flip the blue cluster in both systems, then restart the search from all its sites
+                for (uint32_t mw = 0; mw < d.MW; ++mw) {
+                    uint32_t bits = mine[mw];
+                    while (bits) {
+                        const uint32_t site = mw * 32 + (__ffs(bits) - 1);
+                        bits &= bits - 1;
+                        atomicXor(&wa[site], 1u << ba);
+                        atomicXor(&wb[site], 1u << bb);
+                        stack[top++] = static_cast<uint16_t>(site);
+                    }
+                }
+            }
+        }
+        uint32_t k; // rand 0.8.5 u8 gen_range(1..=3): u32 draw, zone = u32::MAX - (2^32 - 3) % 3
+        for (;;) {
+            const uint32_t v = static_cast<uint32_t>(rng.next() >> 32);
+            const uint64_t m = static_cast<uint64_t>(v) * 3u;
+            if (static_cast<uint32_t>(m) <= 0xFFFFFFFFu - ((0xFFFFFFFFu - 3u + 1u) % 3u)) {
+                k = 1u + static_cast<uint32_t>(m >> 32);
+                break;
+            }
+        }
+        for (uint32_t mw = 0; mw < d.MW; ++mw) {
+            uint32_t bits = mine[mw];
+            while (bits) {
+                const uint32_t site = mw * 32 + (__ffs(bits) - 1);
+                bits &= bits - 1;
+                if (k & 1u) atomicXor(&wa[site], 1u << ba);
+                if (k & 2u) atomicXor(&wb[site], 1u << bb);
+            }
+        }
+        st[0] = rng.s0; st[1] = rng.s1; st[2] = rng.s2; st[3] = rng.s3;
+    }
+    __syncthreads();
+    for (size_t i = tid; i < tile_words; i += nthreads) Sg[i] = tile[i];
+}
+
+size_t cmr_wolff_lds_bytes(const SimDims &d) { return cmr_wolff_lds_words(d) * 4; }
+
+hipError_t launch_cmr_wolff(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
+    hipLaunchKernelGGL(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
+    hipLaunchKernelGGL(k_cmr_wolff, dim3(d.n_real), dim3(1024), cmr_wolff_lds_bytes(d), stream, d, p);
+    return hipGetLastError();
+}
+
 size_t cluster_sw_lds_bytes(const SimDims &d) { return cluster_sw_lds_words(d) * 4; }
 
 hipError_t configure_cluster_kernels() {
     for (const void *fn : {reinterpret_cast<const void *>(k_cluster_sw<kSwHoudayer>),
                            reinterpret_cast<const void *>(k_cluster_sw<kSwJorg>),
                            reinterpret_cast<const void *>(k_cluster_sw<kSwFk>),
-                           reinterpret_cast<const void *>(k_fk_wolff)}) {
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwCmr>),
+                           reinterpret_cast<const void *>(k_fk_wolff),
+                           reinterpret_cast<const void *>(k_cmr_wolff)}) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
 }
 
-hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, bool jorg, hipStream_t stream) {
+hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, hipStream_t stream) {
     hipLaunchKernelGGL(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
     const dim3 grid(d.n_real * d.n_temps * d.n_pairs), block(kSwThreads);
-    if (jorg)
+    if (oc_mode == 2) // PA_OC_JORG
         hipLaunchKernelGGL(k_cluster_sw<kSwJorg>, grid, block, cluster_sw_lds_bytes(d), stream, d, p);
+    else if (oc_mode == 3) // PA_OC_CMR
+        hipLaunchKernelGGL(k_cluster_sw<kSwCmr>, grid, block, cluster_sw_lds_bytes(d), stream, d, p);
     else
         hipLaunchKernelGGL(k_cluster_sw<kSwHoudayer>, grid, block, cluster_sw_lds_bytes(d), stream, d, p);
     return hipGetLastError();

@@ -69,7 +69,7 @@ struct pa_sim {
     uint32_t *seg = nullptr;       // slab segments of the pipelined large-lattice sweep
     uint32_t pipe_epoch = 1;       // bumped by every k_sweep_pipe launch (progress counters are monotone)
     float *Jf = nullptr, *temps_dev = nullptr; // general-coupling path
-    uint32_t *jump256 = nullptr, *jorg_thr = nullptr, *fk_thr = nullptr; // cluster kernels (ensure_cluster_sw)
+    uint32_t *jump256 = nullptr, *jorg_thr = nullptr, *fk_thr = nullptr, *cmr_thr = nullptr; // cluster kernels
     int32_t *nz_bonds = nullptr;
     float *dbeta = nullptr;
     // bookkeeping of the last sample()
@@ -415,7 +415,8 @@ int ensure_cluster_sw(pa_sim *sim) {
     }
     // gen::<f32>() < p on the 2^24 grid as an integer threshold; p by the host's expf for a
     // satisfied unit bond: Joerg 1 - exp(-4/T) (overlap.rs:430), FK 1 - exp(-2/T) (fk.rs:74,119)
-    std::vector<uint32_t> thr(d.n_temps), thr_fk(d.n_temps);
+    // CMR (overlap.rs:601-603): blue bonds 1 - r * r with r = exp(-2|J|/T) in f32, red bonds 1 - r
+    std::vector<uint32_t> thr(d.n_temps), thr_fk(d.n_temps), thr_cmr(d.n_temps);
     auto as_threshold = [](float bond_p) {
         const double scaled = std::ceil(static_cast<double>(bond_p) * 16777216.0);
         return scaled <= 0.0 ? 0u : (scaled >= 16777216.0 ? (1u << 24) : static_cast<uint32_t>(scaled));
@@ -423,25 +424,30 @@ int ensure_cluster_sw(pa_sim *sim) {
     for (uint32_t t = 0; t < d.n_temps; ++t) {
         thr[t] = as_threshold(1.0f - expf(-4.0f * 1.0f / sim->temps[t]));
         thr_fk[t] = as_threshold(1.0f - expf(-2.0f * 1.0f / sim->temps[t]));
+        const float r = expf(-2.0f * 1.0f / sim->temps[t]);
+        thr_cmr[t] = as_threshold(1.0f - r * r);
     }
     const size_t n_lanes = static_cast<size_t>(d.n_temps) * d.n_pairs;
     PA_HIP(sim, sim->buffers.alloc(&sim->jump256, jump.size()));
     PA_HIP(sim, sim->buffers.alloc(&sim->jorg_thr, thr.size()));
     PA_HIP(sim, sim->buffers.alloc(&sim->fk_thr, thr_fk.size()));
+    PA_HIP(sim, sim->buffers.alloc(&sim->cmr_thr, thr_cmr.size()));
     PA_HIP(sim, sim->buffers.alloc(&sim->p.pair_slots, n_lanes * 2 * d.n_real));
     int rc;
     if ((rc = upload(sim, sim->jump256, jump)) || (rc = upload(sim, sim->jorg_thr, thr)) ||
-        (rc = upload(sim, sim->fk_thr, thr_fk)))
+        (rc = upload(sim, sim->fk_thr, thr_fk)) || (rc = upload(sim, sim->cmr_thr, thr_cmr)))
         return rc;
     if (configure_cluster_kernels() != hipSuccess) return fail(sim, PA_ERR_DEVICE, "kernel LDS configuration failed");
     sim->p.jump256 = sim->jump256;
     sim->p.jorg_thr = sim->jorg_thr;
     sim->p.fk_thr = sim->fk_thr;
+    sim->p.cmr_thr = sim->cmr_thr;
     uint32_t r0 = 0;
     for (auto &g : sim->groups) {
         g.p.jump256 = sim->jump256;
         g.p.jorg_thr = sim->jorg_thr;
         g.p.fk_thr = sim->fk_thr;
+        g.p.cmr_thr = sim->cmr_thr;
         g.p.pair_slots = sim->p.pair_slots + n_lanes * 2 * r0;
         r0 += g.d.n_real;
     }
@@ -469,8 +475,9 @@ std::string validate_text(const pa_sample_config *cfg, uint64_t n_replicas, int 
     *code = PA_ERR_UNSUPPORTED;
     if (cfg->overlap_cluster_interval > 0) {
         for (int k = 0; k < cfg->n_overlap_cluster_modes && k < 4; ++k)
-            if (cfg->overlap_cluster_modes[k] != PA_OC_HOUDAYER && cfg->overlap_cluster_modes[k] != PA_OC_JORG)
-                return "only the 'houdayer' and 'jorg' overlap-cluster moves are built on the HIP path yet";
+            if (cfg->overlap_cluster_modes[k] != PA_OC_HOUDAYER && cfg->overlap_cluster_modes[k] != PA_OC_JORG &&
+                cfg->overlap_cluster_modes[k] != PA_OC_CMR)
+                return "unknown overlap-cluster build mode";
         if (cfg->overlap_cluster_mode != PA_CLUSTER_WOLFF && cfg->overlap_cluster_mode != PA_CLUSTER_SW) {
             *code = PA_ERR_INVALID;
             return "unknown overlap_cluster_mode, expected 'wolff' or 'sw'";
@@ -488,16 +495,19 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                     "overlap-cluster moves are not built for lattices above 12000 sites yet");
     if (d.general && cfg->overlap_cluster_interval > 0)
         for (int k = 0; k < cfg->n_overlap_cluster_modes && k < 4; ++k)
-            if (cfg->overlap_cluster_modes[k] == PA_OC_JORG)
+            if (cfg->overlap_cluster_modes[k] == PA_OC_JORG || cfg->overlap_cluster_modes[k] == PA_OC_CMR)
                 return fail(sim, PA_ERR_UNSUPPORTED,
-                            "the 'jorg' move needs expf of arbitrary couplings, which is not built on "
-                            "the HIP path yet (unit couplings only)");
+                            "the 'jorg' and 'cmr' moves need expf of arbitrary couplings, which is not "
+                            "built on the HIP path yet (unit couplings only)");
     if (cfg->overlap_cluster_interval > 0 && d.n_temps * d.n_pairs > 1024)
         return fail(sim, PA_ERR_UNSUPPORTED, "overlap-cluster moves support at most 1024 pairs per realisation");
     const bool gibbs = cfg->sweep_mode == PA_SWEEP_GIBBS;
     int rc = gibbs ? ensure_gibbs(sim) : PA_OK;
     if (rc) return rc;
     const bool oc_sw = cfg->overlap_cluster_interval > 0 && cfg->overlap_cluster_mode == PA_CLUSTER_SW;
+    bool oc_cmr = false;
+    for (int k = 0; cfg->overlap_cluster_interval > 0 && k < cfg->n_overlap_cluster_modes && k < 4; ++k)
+        oc_cmr = oc_cmr || cfg->overlap_cluster_modes[k] == PA_OC_CMR;
     const bool fk = cfg->cluster_interval > 0;
     if (fk && d.general)
         return fail(sim, PA_ERR_UNSUPPORTED,
@@ -505,7 +515,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                     "HIP path yet (unit couplings only)");
     if (fk && cfg->cluster_mode == PA_CLUSTER_WOLFF && (d.big || fk_wolff_lds_bytes(d) > 160 * 1024))
         return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the FK cluster kernel");
-    if ((oc_sw || fk) && (rc = ensure_cluster_sw(sim))) return rc;
+    if ((oc_sw || fk || oc_cmr) && (rc = ensure_cluster_sw(sim))) return rc;
     if ((rc = zero_accumulators(sim))) return rc;
     const bool want_overlap = d.n_pairs > 0 && cfg->measure_overlap;
     sim->n_recorded = 0;
@@ -579,7 +589,9 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                 const int oc_mode = cfg->overlap_cluster_modes[overlap_call_count %
                                                                static_cast<uint64_t>(cfg->n_overlap_cluster_modes)];
                 if (oc_sw)
-                    PA_HIP(sim, launch_cluster_sw(g.d, g.p, oc_mode == PA_OC_JORG, g.stream));
+                    PA_HIP(sim, launch_cluster_sw(g.d, g.p, oc_mode, g.stream));
+                else if (oc_mode == PA_OC_CMR)
+                    PA_HIP(sim, launch_cmr_wolff(g.d, g.p, g.stream)); // :845-965
                 else if (oc_mode == PA_OC_JORG)
                     PA_HIP(sim, launch_jorg(g.d, g.p, g.stream)); // :601-602,660-680
                 else

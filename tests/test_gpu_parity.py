@@ -386,6 +386,39 @@ def test_sw_variant_of_the_overlap_moves_matches_oracle(oracle, mode, shape, n_t
     assert_state_equal(gpu, cpu, check_energy=False)
 
 
+@pytest.mark.parametrize("inner", ["sw", "wolff"])
+@pytest.mark.parametrize("mode", ["cmr", "houdayer+cmr+jorg"])
+@pytest.mark.parametrize("shape,n_temps,n_rep,n_dis", [((4, 4), 3, 2, 1), ((6, 6, 6), 5, 4, 2),
+                                                       ((12, 12, 12), 4, 2, 1), ((2, 4, 6), 3, 2, 1)])
+def test_cmr_overlap_cluster_move_matches_oracle(oracle, inner, mode, shape, n_temps, n_rep, n_dis):
+    """CMR (overlap.rs:555-971): blue clusters over doubly satisfied bonds (p = 1 - r^2), joint
+    flips, then grey clusters = blue + singly satisfied red bonds (p = 1 - r) with a 2-bit draw
+    deciding which system flips; sw = union-find path, wolff = two-phase depth-first search."""
+    couplings = bimodal(shape, len(shape), n_dis, 41)
+    temps = np.linspace(0.7, 1.9, n_temps)
+    gpu, cpu = make_pair(oracle, shape, couplings, temps, n_rep, 29)
+    kwargs = dict(pt_interval=2, overlap_cluster_update_interval=1, overlap_cluster_build_mode=mode,
+                  overlap_cluster_mode=inner, warmup_ratio=0.25)
+    a = gpu.sample(10, "metropolis", **kwargs)
+    b = cpu.sample(10, "metropolis", **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu, check_energy=False)
+
+
+def test_cmr_with_diluted_couplings(oracle):
+    shape = (8, 8, 8)
+    rng = np.random.default_rng(4)
+    couplings = rng.integers(-1, 2, size=shape + (3,)).astype(np.float32)
+    for inner in ("sw", "wolff"):
+        gpu, cpu = make_pair(oracle, shape, couplings, np.linspace(0.6, 2.2, 6), 4, 37)
+        kwargs = dict(pt_interval=1, overlap_cluster_update_interval=2, overlap_cluster_build_mode="cmr",
+                      overlap_cluster_mode=inner, warmup_ratio=0.0)
+        a = gpu.sample(12, "metropolis", **kwargs)
+        b = cpu.sample(12, "metropolis", **kwargs)
+        assert_results_equal(a, b)
+        assert_state_equal(gpu, cpu)
+
+
 def test_sw_variant_with_diluted_couplings(oracle):
     shape = (8, 8, 8)
     rng = np.random.default_rng(3)
@@ -464,5 +497,5 @@ def test_unbuilt_overlap_modes_are_refused_not_emulated():
     before = sim.get_spins().copy()
     with pytest.raises(NotImplementedError):
         sim.sample(2, "metropolis", overlap_cluster_update_interval=1,
-                   overlap_cluster_build_mode="cmr")
+                   overlap_cluster_build_mode="houd4")
     np.testing.assert_array_equal(sim.get_spins(), before)

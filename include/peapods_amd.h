@@ -99,6 +99,9 @@ typedef struct {
     uint64_t cluster_interval;    /* FK cluster update of every system each k sweeps
                                      (cluster_update_interval, ss/clusters/fk.rs); 0 = none */
     int32_t cluster_mode;         /* PA_CLUSTER_*: Swendsen-Wang or Wolff */
+    int32_t equilibration_diagnostic; /* 1 = running means of the replica-averaged energy and the
+                                     pair-averaged link overlap at sweeps 128, 256, ..., n_sweeps
+                                     (ss/statistics/equilibration.rs, driver ss/simulation/mod.rs:511-541) */
 } pa_sample_config;
 
 /* ---- lifecycle ----------------------------------------------------------- */
@@ -168,6 +171,11 @@ int pa_sim_get_result_histograms(pa_sim *sim, uint64_t realization, uint64_t *hi
  * [5][n_temps] moments then (if pairs) [6][n_temps] overlap moments. Used for the
  * multi-GPU all-gather of observables. */
 uint64_t pa_sim_result_block_len(const pa_sim *sim);
+/* Equilibration checkpoints of the last sample() (EquilCheckpoint, ss/statistics/equilibration.rs:1-5):
+ * sweeps [n], energy_avg [n][n_temps], link_overlap_avg [n][n_temps] of one realisation. */
+uint64_t pa_sim_n_equil_checkpoints(const pa_sim *sim);
+int pa_sim_get_equilibration(pa_sim *sim, uint64_t realization, uint64_t *sweeps, double *energy_avg,
+                             double *link_overlap_avg);
 int pa_sim_get_result_blocks(pa_sim *sim, double *out /* [n_realizations][block_len] */);
 
 /* ---- host-only helpers (no device needed) --------------------------------- */

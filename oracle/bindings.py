@@ -40,6 +40,7 @@ class OrcConfig(C.Structure):
         ("n_threads", C.c_int32),
         ("cluster_interval", C.c_uint64),
         ("cluster_mode", C.c_int32),
+        ("equilibration_diagnostic", C.c_int32),
     ]
 
 
@@ -133,6 +134,8 @@ def load(path=None):
         "orc_sim_get_pt_counters": (None, [vp, C.c_size_t, vp, vp, vp]),
         "orc_sim_get_result_moments": (None, [vp, C.c_size_t, vp]),
         "orc_sim_has_overlap": (C.c_int, [vp]),
+        "orc_sim_n_equil_checkpoints": (C.c_size_t, [vp]),
+        "orc_sim_get_equil": (None, [vp, C.c_size_t, vp, vp, vp]),
         "orc_sim_get_result_overlap": (None, [vp, C.c_size_t, vp]),
         "orc_sim_get_result_histograms": (None, [vp, C.c_size_t, vp, vp, vp]),
     }
@@ -221,6 +224,13 @@ def aggregate_results(per_real, n_temps, has_overlap, with_samples):
             out["per_sample_overlap_histogram"] = np.stack([r["histogram"] for r in per_real])
             out["per_sample_ql_at_q_sum"] = np.stack([r["ql_at_q_sum"] for r in per_real])
             out["per_sample_ql2_at_q_sum"] = np.stack([r["ql2_at_q_sum"] for r in per_real])
+    if "equil_sweeps" in per_real[0]:  # results.rs:229-244,275-282; src/lib.rs:559-574
+        out["equil_sweeps"] = per_real[0]["equil_sweeps"]
+        for key in ("equil_energy_avg", "equil_link_overlap_avg"):
+            acc = np.zeros_like(per_real[0][key])
+            for res in per_real:
+                acc = acc + res[key]
+            out[key] = acc / n if len(per_real) > 1 else acc
     return out
 
 
@@ -302,7 +312,7 @@ class OracleSimulation:
     def make_config(self, n_sweeps, sweep_mode, pt_interval=None, pt_schedule=None,
                     overlap_cluster_update_interval=None, overlap_cluster_build_mode=None,
                     overlap_cluster_mode=None, warmup_ratio=None, n_threads=1,
-                    cluster_update_interval=None, cluster_mode=None):
+                    cluster_update_interval=None, cluster_mode=None, equilibration_diagnostic=False):
         warmup = 0.25 if warmup_ratio is None else warmup_ratio
         cfg = OrcConfig()
         cfg.n_sweeps = int(n_sweeps)
@@ -337,6 +347,7 @@ class OracleSimulation:
                 raise ValueError("cluster_update interval must be >= 1")
             cfg.cluster_interval = int(cluster_update_interval)
             cfg.cluster_mode = CLUSTER_MODES[cluster_mode or "sw"]  # src/lib.rs:233
+        cfg.equilibration_diagnostic = 1 if equilibration_diagnostic else 0
         return cfg
 
     def run(self, cfg):
@@ -361,6 +372,14 @@ class OracleSimulation:
                     self.handle, r, _ptr(res["histogram"]), _ptr(res["ql_at_q_sum"]),
                     _ptr(res["ql2_at_q_sum"]),
                 )
+            n_ck = int(self.lib.orc_sim_n_equil_checkpoints(self.handle))
+            if n_ck:
+                res["equil_sweeps"] = np.empty(n_ck, dtype=np.uint64)
+                res["equil_energy_avg"] = np.empty((n_ck, n_t), dtype=np.float64)
+                res["equil_link_overlap_avg"] = np.empty((n_ck, n_t), dtype=np.float64)
+                self.lib.orc_sim_get_equil(self.handle, r, _ptr(res["equil_sweeps"]),
+                                           _ptr(res["equil_energy_avg"]),
+                                           _ptr(res["equil_link_overlap_avg"]))
             per_real.append(res)
         return per_real, has_ov
 
@@ -378,11 +397,11 @@ class OracleSimulation:
     def sample(self, n_sweeps, sweep_mode, pt_interval=None, pt_schedule=None,
                overlap_cluster_update_interval=None, overlap_cluster_build_mode=None,
                overlap_cluster_mode=None, warmup_ratio=None, n_threads=1,
-               cluster_update_interval=None, cluster_mode=None):
+               cluster_update_interval=None, cluster_mode=None, equilibration_diagnostic=False):
         cfg = self.make_config(n_sweeps, sweep_mode, pt_interval, pt_schedule,
                                overlap_cluster_update_interval, overlap_cluster_build_mode,
                                overlap_cluster_mode, warmup_ratio, n_threads,
-                               cluster_update_interval, cluster_mode)
+                               cluster_update_interval, cluster_mode, equilibration_diagnostic)
         self.run(cfg)
         per_real, has_ov = self.per_realization_results()
         out = aggregate_results(per_real, self.n_temps, has_ov, self.n_realizations > 1)

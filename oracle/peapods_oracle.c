@@ -546,6 +546,10 @@ typedef struct {
     uint64_t *histogram;  /* [n_temps][N+1] */
     double *ql_at_q_sum;  /* [n_temps][N+1] */
     double *ql2_at_q_sum; /* [n_temps][N+1] */
+    size_t n_equil;       /* equilibration checkpoints (statistics/equilibration.rs) */
+    uint64_t *equil_sweeps;
+    double *equil_energy; /* [n_equil][n_temps] */
+    double *equil_ql;     /* [n_equil][n_temps] */
 } sweep_result;
 
 struct orc_sim {
@@ -1061,6 +1065,9 @@ static void result_free(sweep_result *res) {
     free(res->histogram);
     free(res->ql_at_q_sum);
     free(res->ql2_at_q_sum);
+    free(res->equil_sweeps);
+    free(res->equil_energy);
+    free(res->equil_ql);
     memset(res, 0, sizeof(*res));
 }
 
@@ -1106,6 +1113,23 @@ static void run_sweep_loop(const orc_lattice *lat, realization *real, size_t n_r
         (orc_tempering_attempt *)malloc(sizeof(orc_tempering_attempt) * (n_temps + 1));
     size_t overlap_call_count = 0;
 
+    /* EquilDiagnosticAccum::new (equilibration.rs:18-38): checkpoints 128, 256, ... < n_sweeps, n_sweeps */
+    int equil_diag = cfg->equilibration_diagnostic != 0;
+    size_t equil_next = 0, equil_count = 0;
+    double *equil_sum_e = (double *)calloc(n_temps + 1, sizeof(double));
+    double *equil_sum_ql = (double *)calloc(n_temps + 1, sizeof(double));
+    float *diag_e_buf = (float *)calloc(n_temps + 1, sizeof(float));
+    float *diag_ql_buf = (float *)calloc(n_temps + 1, sizeof(float));
+    if (equil_diag) {
+        size_t cap = 70;
+        res->equil_sweeps = (uint64_t *)calloc(cap, sizeof(uint64_t));
+        for (uint64_t pw = 128; pw < cfg->n_sweeps; pw *= 2) res->equil_sweeps[res->n_equil++] = pw;
+        if (res->n_equil == 0 || res->equil_sweeps[res->n_equil - 1] != cfg->n_sweeps)
+            res->equil_sweeps[res->n_equil++] = cfg->n_sweeps;
+        res->equil_energy = (double *)calloc(res->n_equil * n_temps + 1, sizeof(double));
+        res->equil_ql = (double *)calloc(res->n_equil * n_temps + 1, sizeof(double));
+    }
+
     for (uint64_t sweep_id = 0; sweep_id < cfg->n_sweeps; ++sweep_id) {
         int record = sweep_id >= cfg->warmup_sweeps; /* mod.rs:410 */
 
@@ -1121,11 +1145,21 @@ static void run_sweep_loop(const orc_lattice *lat, realization *real, size_t n_r
 
         int pt_this_sweep = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0; /* :486-488 */
 
-        if (record || pt_this_sweep) /* mod.rs:492-509 */
+        if (record || pt_this_sweep || equil_diag) /* mod.rs:492-509 */
             orc_compute_energies(lat, real->spins, real->couplings, n_systems, real->energies,
                                  record ? magnetization_sums : NULL, NULL);
 
-        if (record && n_pairs > 0) { /* mod.rs:527-529 -> overlap.rs:251-333 */
+        if (equil_diag) { /* mod.rs:511-525 */
+            for (size_t t = 0; t < n_temps; ++t) diag_e_buf[t] = 0.0f;
+            for (size_t r = 0; r < n_replicas; ++r)
+                for (size_t t = 0; t < n_temps; ++t)
+                    diag_e_buf[t] += real->energies[(size_t)real->system_ids[r * n_temps + t]];
+            float inv = 1.0f / (float)n_replicas;
+            for (size_t t = 0; t < n_temps; ++t) diag_e_buf[t] *= inv;
+            for (size_t t = 0; t < n_temps; ++t) diag_ql_buf[t] = 0.0f;
+        }
+
+        if ((equil_diag || record) && n_pairs > 0) { /* mod.rs:527-529 -> overlap.rs:251-333 */
             for (size_t pair_idx = 0; pair_idx < n_pairs; ++pair_idx) {
                 size_t r_a = 2 * pair_idx, r_b = 2 * pair_idx + 1;
                 for (size_t t = 0; t < n_temps; ++t) {
@@ -1143,6 +1177,8 @@ static void run_sweep_loop(const orc_lattice *lat, realization *real, size_t n_r
                         }
                     }
                     float ql = (float)dot_link / (float)n_bonds;
+                    if (equil_diag) diag_ql_buf[t] += ql; /* overlap.rs:285-287 */
+                    if (!record) continue;
                     float q = (float)dot_spin / (float)n;
                     float q2 = q * q;
                     ovbuf[0 * n_temps + t] = q;
@@ -1157,7 +1193,28 @@ static void run_sweep_loop(const orc_lattice *lat, realization *real, size_t n_r
                     res->ql_at_q_sum[t * (n + 1) + idx] += (double)ql;
                     res->ql2_at_q_sum[t * (n + 1) + idx] += (double)(ql * ql);
                 }
-                for (int k = 0; k < 6; ++k) stat_update(&ov[k], ovbuf + k * n_temps, n_temps);
+                if (record)
+                    for (int k = 0; k < 6; ++k) stat_update(&ov[k], ovbuf + k * n_temps, n_temps);
+            }
+            if (equil_diag) { /* overlap.rs:327-332 */
+                float inv = 1.0f / (float)n_pairs;
+                for (size_t t = 0; t < n_temps; ++t) diag_ql_buf[t] *= inv;
+            }
+        }
+
+        if (equil_diag) { /* mod.rs:531-541, equilibration.rs:40-58 */
+            equil_count += 1;
+            for (size_t t = 0; t < n_temps; ++t) {
+                equil_sum_e[t] += (double)diag_e_buf[t];
+                equil_sum_ql[t] += (double)diag_ql_buf[t];
+            }
+            if (equil_next < res->n_equil && equil_count == res->equil_sweeps[equil_next]) {
+                double c = (double)equil_count;
+                for (size_t t = 0; t < n_temps; ++t) {
+                    res->equil_energy[equil_next * n_temps + t] = equil_sum_e[t] / c;
+                    res->equil_ql[equil_next * n_temps + t] = equil_sum_ql[t] / c;
+                }
+                equil_next += 1;
             }
         }
 
@@ -1237,6 +1294,10 @@ static void run_sweep_loop(const orc_lattice *lat, realization *real, size_t n_r
     free(ovbuf);
     free(magnetization_sums);
     free(attempts);
+    free(equil_sum_e);
+    free(equil_sum_ql);
+    free(diag_e_buf);
+    free(diag_ql_buf);
     orc_lookup_free(lookup);
 }
 
@@ -1383,6 +1444,15 @@ void orc_sim_get_result_moments(const orc_sim *sim, size_t r, double *out) {
     memcpy(out, sim->results[r].moments, sizeof(double) * 5 * sim->n_temps);
 }
 int orc_sim_has_overlap(const orc_sim *sim) { return sim->n_replicas / 2 > 0; }
+
+size_t orc_sim_n_equil_checkpoints(const orc_sim *sim) { return sim->results[0].n_equil; }
+void orc_sim_get_equil(const orc_sim *sim, size_t r, uint64_t *sweeps, double *energy_avg,
+                       double *link_overlap_avg) {
+    const sweep_result *res = &sim->results[r];
+    memcpy(sweeps, res->equil_sweeps, sizeof(uint64_t) * res->n_equil);
+    memcpy(energy_avg, res->equil_energy, sizeof(double) * res->n_equil * sim->n_temps);
+    memcpy(link_overlap_avg, res->equil_ql, sizeof(double) * res->n_equil * sim->n_temps);
+}
 void orc_sim_get_result_overlap(const orc_sim *sim, size_t r, double *out) {
     memcpy(out, sim->results[r].overlap, sizeof(double) * 6 * sim->n_temps);
 }

@@ -147,6 +147,8 @@ typedef struct {
     int32_t n_threads;            /* realisations are distributed over threads; <=1 = serial */
     uint64_t cluster_interval;    /* FK cluster update every k sweeps (ss/clusters/fk.rs); 0 = none */
     int32_t cluster_mode;         /* ORC_CLUSTER_* */
+    int32_t equilibration_diagnostic; /* running means of E and q_l at log-spaced checkpoints
+                                         (ss/statistics/equilibration.rs) */
 } orc_config;
 
 typedef struct orc_sim orc_sim;
@@ -177,6 +179,11 @@ void orc_sim_get_pt_counters(const orc_sim *sim, size_t realization, uint64_t *e
 void orc_sim_get_result_moments(const orc_sim *sim, size_t realization,
                                 double *out /* [5][n_temps]: mags,mags2,mags4,energies,energies2 */);
 int orc_sim_has_overlap(const orc_sim *sim);
+/* equilibration checkpoints of the last sample(): count, then sweeps[n], energy_avg[n][n_temps],
+ * link_overlap_avg[n][n_temps] of one realisation */
+size_t orc_sim_n_equil_checkpoints(const orc_sim *sim);
+void orc_sim_get_equil(const orc_sim *sim, size_t realization, uint64_t *sweeps, double *energy_avg,
+                       double *link_overlap_avg);
 void orc_sim_get_result_overlap(const orc_sim *sim, size_t realization,
                                 double *out /* [6][n_temps]: q,q2,q4,ql,ql2,ql4 */);
 void orc_sim_get_result_histograms(const orc_sim *sim, size_t realization,

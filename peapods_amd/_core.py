@@ -194,8 +194,7 @@ class IsingSimulation:
             cfg.overlap_cluster_mode = _CLUSTER_MODES[oc_mode]
         if autocorrelation_max_lag is not None:
             raise NotImplementedError("autocorrelation diagnostics are outside the HIP hot path")
-        if equilibration_diagnostic:
-            raise NotImplementedError("equilibration diagnostics are outside the HIP hot path")
+        cfg.equilibration_diagnostic = 1 if equilibration_diagnostic else 0
         cfg.measure_overlap = 1 if measure_overlap else 0
         err = C.create_string_buffer(512)
         code = self._lib.pa_validate_sample_config(C.byref(cfg), self.n_replicas, err, len(err))
@@ -312,12 +311,32 @@ class IsingSimulation:
         """Runs the sweeps and returns the reference's result dictionary (src/lib.rs:337-617)."""
         cfg = self.make_config(n_sweeps, sweep_mode, **kwargs)
         self.run(cfg)
-        return assemble_results(
+        out = assemble_results(
             self._lib, self.result_blocks(),
             self.result_histograms() if self.n_replicas >= 2 else None,
             self.pt_diagnostics() if kwargs.get("pt_interval") is not None else None,
             self.n_temps, self.n_replicas // 2,
         )
+        if cfg.equilibration_diagnostic:
+            out.update(self.equilibration_checkpoints())
+        return out
+
+    def equilibration_checkpoints(self):
+        """equil_sweeps / equil_energy_avg / equil_link_overlap_avg of the last sample(), averaged
+        over the realisations in order (results.rs:229-244,275-282; src/lib.rs:559-574)."""
+        n_ck = int(self._lib.pa_sim_n_equil_checkpoints(self._handle))
+        sweeps = np.zeros(n_ck, dtype=np.uint64)
+        energy = np.zeros((self.n_realizations, n_ck, self.n_temps), dtype=np.float64)
+        link = np.zeros_like(energy)
+        for r in range(self.n_realizations):
+            self._check(self._lib.pa_sim_get_equilibration(self._handle, r, nat.ptr(sweeps),
+                                                           nat.ptr(energy[r]), nat.ptr(link[r])))
+        e_mean = np.empty(n_ck * self.n_temps, dtype=np.float64)
+        l_mean = np.empty_like(e_mean)
+        self._lib.pa_aggregate_mean(nat.ptr(energy), self.n_realizations, e_mean.size, nat.ptr(e_mean))
+        self._lib.pa_aggregate_mean(nat.ptr(link), self.n_realizations, l_mean.size, nat.ptr(l_mean))
+        return {"equil_sweeps": sweeps, "equil_energy_avg": e_mean.reshape(n_ck, self.n_temps),
+                "equil_link_overlap_avg": l_mean.reshape(n_ck, self.n_temps)}
 
 
 def assemble_results(lib, blocks, histograms, pt, n_temps, n_pairs):

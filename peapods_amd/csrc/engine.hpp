@@ -98,6 +98,8 @@ struct DevPtrs {
     const uint32_t *jorg_thr;// [n_temps] ceil((1 - exp(-4/T)) 2^24): draw < thr <=> gen::<f32>() < p
     const uint32_t *cmr_thr; // [n_temps] CMR blue bonds: 1 - r^2, r = exp(-2/T) (red bonds use fk_thr = 1 - r)
     const uint32_t *fk_thr;  // [n_temps] the same for the FK bond probability 1 - exp(-2/T)
+    double *eq_sum;          // [n_real][2][n_temps] running sums of the equilibration diagnostic
+    double *eq_ckpt;         // [n_real][64][2][n_temps] checkpoint averages
     // general-coupling path only
     const float *Jf;         // [n_real][N][nn] forward couplings as given
     const float *temps;      // [n_temps]
@@ -109,6 +111,9 @@ struct PtParams {
     int32_t schedule;     // PA_PT_*
     uint32_t first_parity;
     uint32_t hot_slot, cold_slot;
+    // equilibration diagnostic (statistics/equilibration.rs): accumulate this sweep's replica-averaged
+    // energy and pair-averaged link overlap; equil_ckpt = 1 + checkpoint index to snapshot, 0 = none
+    uint32_t equil, equil_ckpt, equil_count;
 };
 
 // All launchers enqueue on `stream` and return the hipGetLastError() of the launch.

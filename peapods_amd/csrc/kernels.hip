@@ -918,7 +918,7 @@ __device__ __forceinline__ void measure_block(const SimDims &d, const DevPtrs &p
     PA_STAMP(1)
 
     // ---- (1) overlap dots come from k_overlap (previous launch on this stream) --------
-    if (accum_overlap && d.n_pairs)
+    if ((accum_overlap || pt.equil) && d.n_pairs)
         for (uint32_t k = tid; k < d.n_pairs * d.n_temps; k += nthreads) {
             m.dot_spin[k] = p.dot_spin[static_cast<size_t>(real) * d.n_pairs * d.n_temps + k];
             m.dot_link[k] = p.dot_link[static_cast<size_t>(real) * d.n_pairs * d.n_temps + k];
@@ -980,6 +980,33 @@ __device__ __forceinline__ void measure_block(const SimDims &d, const DevPtrs &p
                 p.ql2q[bin] = __dadd_rn(p.ql2q[bin], static_cast<double>(ql2));
             }
             for (int k = 0; k < 6; ++k) ovm[k * d.n_temps + t] = o[k];
+        }
+    }
+    // ---- equilibration diagnostic (mod.rs:511-541, overlap.rs:285-287,327-332, equilibration.rs:40-58)
+    if (pt.equil && tid < d.n_temps) {
+        const uint32_t t = tid;
+        const float n_f = static_cast<float>(d.N);
+        float de = 0.0f;
+        for (uint32_t rep = 0; rep < d.n_replicas; ++rep)
+            de = __fadd_rn(de, __fdiv_rn(energy_sum(m.E[rep * d.n_temps + t], d.general), n_f));
+        de = __fmul_rn(de, __fdiv_rn(1.0f, static_cast<float>(d.n_replicas)));
+        float dq = 0.0f;
+        if (d.n_pairs) {
+            const float n_bonds_f = static_cast<float>(d.N * d.nn);
+            for (uint32_t pr = 0; pr < d.n_pairs; ++pr)
+                dq = __fadd_rn(dq, __fdiv_rn(static_cast<float>(m.dot_link[pr * d.n_temps + t]), n_bonds_f));
+            dq = __fmul_rn(dq, __fdiv_rn(1.0f, static_cast<float>(d.n_pairs)));
+        }
+        double *sum = p.eq_sum + static_cast<size_t>(real) * 2 * d.n_temps;
+        const double se = __dadd_rn(sum[t], static_cast<double>(de));
+        const double sq = __dadd_rn(sum[d.n_temps + t], static_cast<double>(dq));
+        sum[t] = se;
+        sum[d.n_temps + t] = sq;
+        if (pt.equil_ckpt) {
+            double *ck = p.eq_ckpt + ((static_cast<size_t>(real) * 64 + (pt.equil_ckpt - 1)) * 2) * d.n_temps;
+            const double c = static_cast<double>(pt.equil_count);
+            ck[t] = __ddiv_rn(se, c);
+            ck[d.n_temps + t] = __ddiv_rn(sq, c);
         }
     }
     PA_STAMP(3)

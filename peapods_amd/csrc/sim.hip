@@ -68,6 +68,7 @@ struct pa_sim {
     uint32_t *thr_gibbs = nullptr; // built by the first Gibbs sample (ensure_gibbs)
     uint32_t *seg = nullptr;       // slab segments of the pipelined large-lattice sweep
     uint32_t pipe_epoch = 1;       // bumped by every k_sweep_pipe launch (progress counters are monotone)
+    std::vector<uint64_t> equil_sweeps; // checkpoints of the last sample() with the equilibration diagnostic
     float *Jf = nullptr, *temps_dev = nullptr; // general-coupling path
     uint32_t *jump256 = nullptr, *jorg_thr = nullptr, *fk_thr = nullptr, *cmr_thr = nullptr; // cluster kernels
     int32_t *nz_bonds = nullptr;
@@ -301,6 +302,10 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     q.swap_masks += static_cast<size_t>(2) * d.W * r0;
     q.pair_rng += static_cast<size_t>(4) * d.n_temps * d.n_pairs * r0;
     q.jsite += static_cast<size_t>(d.N) * r0;
+    if (q.eq_sum) {
+        q.eq_sum += static_cast<size_t>(2) * d.n_temps * r0;
+        q.eq_ckpt += static_cast<size_t>(64) * 2 * d.n_temps * r0;
+    }
     q.dfs_stack += static_cast<size_t>(std::max(d.n_temps * d.n_pairs, d.n_sys)) * d.N * r0;
     return q;
 }
@@ -454,6 +459,23 @@ int ensure_cluster_sw(pa_sim *sim) {
     return PA_OK;
 }
 
+// Buffers of the equilibration diagnostic, built by the first call that asks for it.
+int ensure_equil(pa_sim *sim) {
+    const SimDims &d = sim->d;
+    if (!sim->p.eq_sum) {
+        PA_HIP(sim, sim->buffers.alloc(&sim->p.eq_sum, static_cast<size_t>(d.n_real) * 2 * d.n_temps));
+        PA_HIP(sim, sim->buffers.alloc(&sim->p.eq_ckpt, static_cast<size_t>(d.n_real) * 64 * 2 * d.n_temps));
+        uint32_t r0 = 0;
+        for (auto &g : sim->groups) {
+            g.p.eq_sum = sim->p.eq_sum + static_cast<size_t>(2) * d.n_temps * r0;
+            g.p.eq_ckpt = sim->p.eq_ckpt + static_cast<size_t>(64) * 2 * d.n_temps * r0;
+            r0 += g.d.n_real;
+        }
+    }
+    PA_HIP(sim, hipMemsetAsync(sim->p.eq_sum, 0, sizeof(double) * d.n_real * 2 * d.n_temps, sim->stream));
+    return PA_OK;
+}
+
 std::string validate_text(const pa_sample_config *cfg, uint64_t n_replicas, int *code) {
     *code = PA_ERR_INVALID;
     // spin-sim/src/config.rs:180-247 (message texts are the reference's)
@@ -516,6 +538,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     if (fk && cfg->cluster_mode == PA_CLUSTER_WOLFF && (d.big || fk_wolff_lds_bytes(d) > 160 * 1024))
         return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the FK cluster kernel");
     if ((oc_sw || fk || oc_cmr) && (rc = ensure_cluster_sw(sim))) return rc;
+    if (cfg->equilibration_diagnostic && (rc = ensure_equil(sim))) return rc;
     if ((rc = zero_accumulators(sim))) return rc;
     const bool want_overlap = d.n_pairs > 0 && cfg->measure_overlap;
     sim->n_recorded = 0;
@@ -525,7 +548,17 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     for (auto &g : sim->groups) PA_HIP(sim, hipStreamWaitEvent(g.stream, sim->fork, 0));
     int status = PA_OK;
     uint64_t overlap_call_count = 0; // mod.rs:300
-    const bool fused = want_overlap && !gibbs && !fk && cfg->overlap_cluster_interval == 0 && !d.big &&
+    // equilibration diagnostic: energies and the link overlap of EVERY sweep (mod.rs:492,527)
+    const bool equil = cfg->equilibration_diagnostic != 0;
+    sim->equil_sweeps.clear();
+    if (equil) { // EquilDiagnosticAccum::new, equilibration.rs:18-38
+        for (uint64_t pw = 128; pw < cfg->n_sweeps; pw *= 2) sim->equil_sweeps.push_back(pw);
+        if (sim->equil_sweeps.empty() || sim->equil_sweeps.back() != cfg->n_sweeps)
+            sim->equil_sweeps.push_back(cfg->n_sweeps);
+        if (sim->equil_sweeps.size() > 64) return fail(sim, PA_ERR_UNSUPPORTED, "more than 64 equilibration checkpoints");
+    }
+    size_t equil_next = 0;
+    const bool fused = want_overlap && !gibbs && !fk && !equil && cfg->overlap_cluster_interval == 0 && !d.big &&
                        !d.general && !std::getenv("PEAPODS_NO_FUSE");
     bool overlap_owed = false; // the last recorded sweep's overlap has not been measured yet
     for (uint64_t sweep_id = 0; sweep_id < cfg->n_sweeps && status == PA_OK; ++sweep_id) {
@@ -564,26 +597,31 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         for (auto &g : sim->groups) {
             PA_HIP(sim, launch_rng(g.d, g.p, gibbs, g.stream));                         // :412-432
             // energies are computed after every mutating move of the sweep (:492-509)
-            PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, (record || pt_this) && !fk_this, gibbs, g.stream));
+            PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, (record || pt_this || equil) && !fk_this, gibbs, g.stream));
         }
         sim->swaps_pending = false;
         toggle_spin_buffers(sim);
+        uint32_t equil_ckpt = 0; // 1 + index of the checkpoint this sweep completes
+        if (equil && equil_next < sim->equil_sweeps.size() && sweep_id + 1 == sim->equil_sweeps[equil_next])
+            equil_ckpt = static_cast<uint32_t>(++equil_next);
         for (auto &g : sim->groups) {
             if (fk_this) { // clusters::fk_update (:439-469), then the energies
                 PA_HIP(sim, launch_fk(g.d, g.p, cfg->cluster_mode == PA_CLUSTER_WOLFF, g.stream));
-                if (record || pt_this) PA_HIP(sim, launch_sweep(g.d, g.p, true, false, false, g.stream));
+                if (record || pt_this || equil) PA_HIP(sim, launch_sweep(g.d, g.p, true, false, false, g.stream));
             }
-            if (record && want_overlap) PA_HIP(sim, launch_overlap(g.d, g.p, g.stream)); // :527-529
+            if (((record && want_overlap) || equil) && d.n_pairs) PA_HIP(sim, launch_overlap(g.d, g.p, g.stream)); // :527-529
             const bool oc_this = cfg->overlap_cluster_interval > 0 &&
                                  sweep_id % cfg->overlap_cluster_interval == 0; // :598-599
-            PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
+            PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot,
+                        equil ? 1u : 0u, equil_ckpt, static_cast<uint32_t>(sweep_id + 1)};
             if (!oc_this) {
-                if (record || pt_this) // statistics :543-578, tempering :748-796
+                if (record || pt_this || equil) // statistics :543-578, tempering :748-796
                     PA_HIP(sim, launch_measure(g.d, g.p, pt, false, record, record && want_overlap, pt_this,
                                                g.stream));
             } else {
-                if (record)
-                    PA_HIP(sim, launch_measure(g.d, g.p, pt, false, true, want_overlap, false, g.stream));
+                if (record || equil)
+                    PA_HIP(sim, launch_measure(g.d, g.p, pt, false, record, record && want_overlap, false, g.stream));
+                pt.equil = 0; // the tempering launch below must not accumulate the diagnostic again
                 if (g.d.N * g.d.W * 12 + 4096 > 160 * 1024)
                     return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the overlap-cluster kernel");
                 const int oc_mode = cfg->overlap_cluster_modes[overlap_call_count %
@@ -1464,6 +1502,27 @@ int pa_sim_get_result_histograms(pa_sim *sim, uint64_t realization, uint64_t *hi
     PA_HIP(sim, hipMemcpyAsync(ql2_at_q_sum, sim->p.ql2q + bins * realization, bins * sizeof(double),
                                hipMemcpyDeviceToHost, sim->stream));
     PA_HIP(sim, hipStreamSynchronize(sim->stream));
+    return PA_OK;
+}
+
+uint64_t pa_sim_n_equil_checkpoints(const pa_sim *sim) { return sim->equil_sweeps.size(); }
+
+int pa_sim_get_equilibration(pa_sim *sim, uint64_t realization, uint64_t *sweeps, double *energy_avg,
+                             double *link_overlap_avg) {
+    PA_CHECK_REAL(sim, realization);
+    const SimDims &d = sim->d;
+    const size_t n_ck = sim->equil_sweeps.size();
+    if (!n_ck) return fail(sim, PA_ERR_INVALID, "the last sample() did not run the equilibration diagnostic");
+    PA_HIP(sim, hipSetDevice(sim->device));
+    std::vector<double> ck;
+    int rc = download(sim, ck, sim->p.eq_ckpt + static_cast<size_t>(realization) * 64 * 2 * d.n_temps,
+                      n_ck * 2 * d.n_temps);
+    if (rc) return rc;
+    for (size_t k = 0; k < n_ck; ++k) {
+        sweeps[k] = sim->equil_sweeps[k];
+        std::memcpy(energy_avg + k * d.n_temps, &ck[(k * 2 + 0) * d.n_temps], sizeof(double) * d.n_temps);
+        std::memcpy(link_overlap_avg + k * d.n_temps, &ck[(k * 2 + 1) * d.n_temps], sizeof(double) * d.n_temps);
+    }
     return PA_OK;
 }
 

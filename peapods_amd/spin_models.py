@@ -169,7 +169,21 @@ class Ising:
                     "per_sample_ql2_at_q_sum"):
             if key in result:
                 setattr(self, key, result[key])
+        if "equil_sweeps" in result:  # spin_models.py:330-333
+            self._equil_sweeps = result["equil_sweeps"]
+            self._equil_energy_avg = result["equil_energy_avg"]
+            self._equil_link_overlap_avg = result["equil_link_overlap_avg"]
         self.per_disorder = result.get("per_disorder", {})
+
+    def equilibration_delta(self, j_squared=1.0):
+        """Delta(t) = e(t) - J^2 beta z (1 - q_l(t)) at the checkpoints of the last run with
+        `equilibration_diagnostic=True` (spin_models.py:339-358; the engine's energy is
+        +sum J s s / N, so the sign is that of the reference).  Returns (sweeps, delta[n_ckpt, n_temps])."""
+        beta = 1.0 / self.temperatures
+        delta = self._equil_energy_avg - j_squared * beta * self.n_neighbors * (
+            1 - self._equil_link_overlap_avg
+        )
+        return self._equil_sweeps, delta
 
     def get_energies(self):
         """Mean energies per temperature from the last `sample` run."""

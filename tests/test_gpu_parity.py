@@ -489,6 +489,48 @@ def test_ferromagnet_binder_crossing_with_swendsen_wang():
     assert all(0.55 < b < 0.66 for b in at_tc), at_tc  # universal value U* = 0.61 of the 2D class
 
 
+@pytest.mark.parametrize("kind", ["bimodal", "gaussian"])
+def test_equilibration_diagnostic_matches_oracle(oracle, kind):
+    """equilibration_diagnostic=True (equilibration.rs, mod.rs:511-541): energies and the link
+    overlap of every sweep, warm-up included, averaged up to the checkpoints 128, 256, ..., n."""
+    shape = (4, 4, 4)
+    couplings = bimodal(shape, 3, 2, 5) if kind == "bimodal" else gaussian(shape, 3, 2, 5)
+    gpu, cpu = make_pair(oracle, shape, couplings, np.linspace(0.9, 2.1, 5), 4, 3)
+    kwargs = dict(pt_interval=1, overlap_cluster_update_interval=2, warmup_ratio=0.25,
+                  equilibration_diagnostic=True)
+    a = gpu.sample(300, "metropolis", **kwargs)
+    b = cpu.sample(300, "metropolis", **kwargs)
+    np.testing.assert_array_equal(a["equil_sweeps"], [128, 256, 300])
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+    # without replicas the link overlap column is zero (mod.rs:537-540)
+    gpu1, cpu1 = make_pair(oracle, shape, couplings, [1.5, 2.5], 1, 3)
+    a = gpu1.sample(130, "gibbs", equilibration_diagnostic=True)
+    b = cpu1.sample(130, "gibbs", equilibration_diagnostic=True)
+    assert_results_equal(a, b)
+    assert not a["equil_link_overlap_avg"].any()
+
+
+def test_gaussian_glass_overlap_histogram_protocol():
+    """The reference's physics check for Gaussian couplings (tests/overlap_histogram.py, shortened
+    from 40000 to 12000 sweeps): 8^3 Gaussian glass at T = 1.4 (paramagnetic), 2 replicas, 64
+    disorder samples, Metropolis + tempering + Houdayer every sweep: <q> ~ 0, P(q) symmetric,
+    equilibration Delta -> 0, per-sample shapes."""
+    import peapods_amd as peapods
+
+    model = peapods.Ising((8, 8, 8), couplings="gaussian", temperatures=np.array([1.4], np.float32),
+                          n_replicas=2, n_disorder=64, seed=42)
+    model.sample(12000, sweep_mode="metropolis", pt_interval=1, overlap_cluster_update_interval=1,
+                 warmup_ratio=0.25, equilibration_diagnostic=True)
+    assert abs(model.overlap[0]) < 0.1
+    hist = model.overlap_histogram[0].astype(float)
+    assert np.linalg.norm(hist - hist[::-1]) / np.linalg.norm(hist) < 0.25
+    assert model.per_sample_overlap_histogram.shape == (64, 1, 513)
+    assert model.per_sample_ql_at_q_sum.shape == (64, 1, 513)
+    sweeps, delta = model.equilibration_delta(j_squared=1.0)
+    assert sweeps[-1] == 12000 and abs(delta[-1, 0]) < 0.15
+
+
 def test_unbuilt_overlap_modes_are_refused_not_emulated():
     from peapods_amd import IsingSimulation
 

@@ -102,6 +102,9 @@ typedef struct {
     int32_t equilibration_diagnostic; /* 1 = running means of the replica-averaged energy and the
                                      pair-averaged link overlap at sweeps 128, 256, ..., n_sweeps
                                      (ss/statistics/equilibration.rs, driver ss/simulation/mod.rs:511-541) */
+    uint64_t autocorrelation_max_lag; /* 0 = none; else the integrated autocorrelation times of m^2 and
+                                     q^2 are collected (ring backend, ss/statistics/autocorrelation.rs,
+                                     driver ss/simulation/mod.rs:342-371,580-595) */
 } pa_sample_config;
 
 /* ---- lifecycle ----------------------------------------------------------- */
@@ -173,6 +176,10 @@ int pa_sim_get_result_histograms(pa_sim *sim, uint64_t realization, uint64_t *hi
 uint64_t pa_sim_result_block_len(const pa_sim *sim);
 /* Equilibration checkpoints of the last sample() (EquilCheckpoint, ss/statistics/equilibration.rs:1-5):
  * sweeps [n], energy_avg [n][n_temps], link_overlap_avg [n][n_temps] of one realisation. */
+/* Sokal-window integrated autocorrelation times per temperature of the last sample() with
+ * autocorrelation_max_lag > 0 (sokal_tau over AutocorrAccum::finish, autocorrelation.rs:116-208):
+ * mags2_tau [n_temps], overlap2_tau [n_temps] (untouched without replica pairs). */
+int pa_sim_get_autocorrelation_tau(pa_sim *sim, uint64_t realization, double *mags2_tau, double *overlap2_tau);
 uint64_t pa_sim_n_equil_checkpoints(const pa_sim *sim);
 int pa_sim_get_equilibration(pa_sim *sim, uint64_t realization, uint64_t *sweeps, double *energy_avg,
                              double *link_overlap_avg);

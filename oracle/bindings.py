@@ -40,6 +40,7 @@ class OrcConfig(C.Structure):
         ("n_threads", C.c_int32),
         ("cluster_interval", C.c_uint64),
         ("cluster_mode", C.c_int32),
+        ("autocorrelation_max_lag", C.c_uint64),
         ("equilibration_diagnostic", C.c_int32),
     ]
 
@@ -134,6 +135,7 @@ def load(path=None):
         "orc_sim_get_pt_counters": (None, [vp, C.c_size_t, vp, vp, vp]),
         "orc_sim_get_result_moments": (None, [vp, C.c_size_t, vp]),
         "orc_sim_has_overlap": (C.c_int, [vp]),
+        "orc_sim_get_tau": (C.c_int, [vp, C.c_size_t, vp, vp]),
         "orc_sim_n_equil_checkpoints": (C.c_size_t, [vp]),
         "orc_sim_get_equil": (None, [vp, C.c_size_t, vp, vp, vp]),
         "orc_sim_get_result_overlap": (None, [vp, C.c_size_t, vp]),
@@ -224,6 +226,12 @@ def aggregate_results(per_real, n_temps, has_overlap, with_samples):
             out["per_sample_overlap_histogram"] = np.stack([r["histogram"] for r in per_real])
             out["per_sample_ql_at_q_sum"] = np.stack([r["ql_at_q_sum"] for r in per_real])
             out["per_sample_ql2_at_q_sum"] = np.stack([r["ql2_at_q_sum"] for r in per_real])
+    for key in ("mags2_tau", "overlap2_tau"):  # results.rs:213-228,267-274; src/lib.rs:545-557
+        if key in per_real[0]:
+            acc = np.zeros(n_temps, dtype=np.float64)
+            for res in per_real:
+                acc = acc + res[key]
+            out[key] = acc / n if len(per_real) > 1 else acc
     if "equil_sweeps" in per_real[0]:  # results.rs:229-244,275-282; src/lib.rs:559-574
         out["equil_sweeps"] = per_real[0]["equil_sweeps"]
         for key in ("equil_energy_avg", "equil_link_overlap_avg"):
@@ -312,7 +320,8 @@ class OracleSimulation:
     def make_config(self, n_sweeps, sweep_mode, pt_interval=None, pt_schedule=None,
                     overlap_cluster_update_interval=None, overlap_cluster_build_mode=None,
                     overlap_cluster_mode=None, warmup_ratio=None, n_threads=1,
-                    cluster_update_interval=None, cluster_mode=None, equilibration_diagnostic=False):
+                    cluster_update_interval=None, cluster_mode=None, equilibration_diagnostic=False,
+                    autocorrelation_max_lag=None):
         warmup = 0.25 if warmup_ratio is None else warmup_ratio
         cfg = OrcConfig()
         cfg.n_sweeps = int(n_sweeps)
@@ -348,6 +357,7 @@ class OracleSimulation:
             cfg.cluster_interval = int(cluster_update_interval)
             cfg.cluster_mode = CLUSTER_MODES[cluster_mode or "sw"]  # src/lib.rs:233
         cfg.equilibration_diagnostic = 1 if equilibration_diagnostic else 0
+        cfg.autocorrelation_max_lag = 0 if autocorrelation_max_lag is None else int(autocorrelation_max_lag)
         return cfg
 
     def run(self, cfg):
@@ -372,6 +382,13 @@ class OracleSimulation:
                     self.handle, r, _ptr(res["histogram"]), _ptr(res["ql_at_q_sum"]),
                     _ptr(res["ql2_at_q_sum"]),
                 )
+            m2_tau = np.zeros(n_t, dtype=np.float64)
+            q2_tau = np.zeros(n_t, dtype=np.float64)
+            got = self.lib.orc_sim_get_tau(self.handle, r, _ptr(m2_tau), _ptr(q2_tau))
+            if got >= 1:
+                res["mags2_tau"] = m2_tau
+            if got >= 2:
+                res["overlap2_tau"] = q2_tau
             n_ck = int(self.lib.orc_sim_n_equil_checkpoints(self.handle))
             if n_ck:
                 res["equil_sweeps"] = np.empty(n_ck, dtype=np.uint64)
@@ -397,11 +414,13 @@ class OracleSimulation:
     def sample(self, n_sweeps, sweep_mode, pt_interval=None, pt_schedule=None,
                overlap_cluster_update_interval=None, overlap_cluster_build_mode=None,
                overlap_cluster_mode=None, warmup_ratio=None, n_threads=1,
-               cluster_update_interval=None, cluster_mode=None, equilibration_diagnostic=False):
+               cluster_update_interval=None, cluster_mode=None, equilibration_diagnostic=False,
+               autocorrelation_max_lag=None):
         cfg = self.make_config(n_sweeps, sweep_mode, pt_interval, pt_schedule,
                                overlap_cluster_update_interval, overlap_cluster_build_mode,
                                overlap_cluster_mode, warmup_ratio, n_threads,
-                               cluster_update_interval, cluster_mode, equilibration_diagnostic)
+                               cluster_update_interval, cluster_mode, equilibration_diagnostic,
+                               autocorrelation_max_lag)
         self.run(cfg)
         per_real, has_ov = self.per_realization_results()
         out = aggregate_results(per_real, self.n_temps, has_ov, self.n_realizations > 1)

@@ -546,6 +546,8 @@ typedef struct {
     uint64_t *histogram;  /* [n_temps][N+1] */
     double *ql_at_q_sum;  /* [n_temps][N+1] */
     double *ql2_at_q_sum; /* [n_temps][N+1] */
+    double *mags2_tau;    /* [n_temps] or NULL */
+    double *overlap2_tau; /* [n_temps] or NULL */
     size_t n_equil;       /* equilibration checkpoints (statistics/equilibration.rs) */
     uint64_t *equil_sweeps;
     double *equil_energy; /* [n_equil][n_temps] */
@@ -1045,6 +1047,86 @@ static void fk_update(const orc_lattice *lat, realization *real, size_t n_system
 }
 
 /* ========================================================================== */
+/* Autocorrelation, ring backend (ss/statistics/autocorrelation.rs:22-124,165-208) */
+/* ========================================================================== */
+
+typedef struct {
+    size_t max_lag, n_temps, ring_len, ring_pos, n_recorded;
+    double *sum_o, *sum_o2; /* [n_temps] */
+    float *ring;            /* [n_temps][ring_len] */
+    double *sum_prod;       /* [n_temps][max_lag + 1] */
+} autocorr;
+
+static void autocorr_init(autocorr *a, size_t max_lag, size_t n_temps) {
+    memset(a, 0, sizeof(*a));
+    a->max_lag = max_lag;
+    a->n_temps = n_temps;
+    a->ring_len = max_lag + 1;
+    a->sum_o = (double *)calloc(n_temps + 1, sizeof(double));
+    a->sum_o2 = (double *)calloc(n_temps + 1, sizeof(double));
+    a->ring = (float *)calloc(n_temps * a->ring_len + 1, sizeof(float));
+    a->sum_prod = (double *)calloc(n_temps * (max_lag + 1) + 1, sizeof(double));
+}
+
+static void autocorr_free(autocorr *a) {
+    free(a->sum_o);
+    free(a->sum_o2);
+    free(a->ring);
+    free(a->sum_prod);
+}
+
+/* :70-124 */
+static void autocorr_push(autocorr *a, const double *values) {
+    for (size_t t = 0; t < a->n_temps; ++t) {
+        float o = (float)values[t];
+        a->sum_o[t] += (double)o;
+        a->sum_o2[t] += (double)o * (double)o;
+    }
+    size_t pos = a->ring_pos;
+    size_t n_back = a->n_recorded < a->max_lag ? a->n_recorded : a->max_lag;
+    for (size_t t = 0; t < a->n_temps; ++t) {
+        float o = (float)values[t];
+        float *ring = a->ring + t * a->ring_len;
+        double *sp = a->sum_prod + t * (a->max_lag + 1);
+        ring[pos] = o;
+        size_t no_wrap = pos < n_back ? pos : n_back;
+        for (size_t delta = 0; delta <= no_wrap; ++delta) sp[delta] += (double)o * (double)ring[pos - delta];
+        for (size_t delta = pos + 1; delta <= n_back; ++delta)
+            sp[delta] += (double)o * (double)ring[pos + a->ring_len - delta];
+    }
+    a->ring_pos = (pos + 1) % a->ring_len;
+    a->n_recorded += 1;
+}
+
+/* finish -> normalize_products (:165-189) -> sokal_tau (:199-208) per temperature */
+static void autocorr_tau(const autocorr *a, double *tau_out) {
+    double *gamma = (double *)malloc(sizeof(double) * (a->max_lag + 1));
+    for (size_t t = 0; t < a->n_temps; ++t) {
+        for (size_t delta = 0; delta <= a->max_lag; ++delta) gamma[delta] = delta == 0 ? 1.0 : 0.0;
+        if (a->n_recorded > 0) {
+            double m = (double)a->n_recorded;
+            double mean = a->sum_o[t] / m;
+            double var = a->sum_o2[t] / m - mean * mean;
+            if (var > 0.0)
+                for (size_t delta = 0; delta <= a->max_lag; ++delta) {
+                    double count = a->n_recorded > delta ? (double)(a->n_recorded - delta) : 0.0;
+                    if (count <= 0.0)
+                        gamma[delta] = delta == 0 ? 1.0 : 0.0;
+                    else
+                        gamma[delta] = (a->sum_prod[t * (a->max_lag + 1) + delta] / count - mean * mean) / var;
+                }
+        }
+        double tau = 0.5;
+        for (size_t w = 1; w <= a->max_lag; ++w) {
+            tau += gamma[w];
+            if ((double)w >= 5.0 * tau) break;
+        }
+        tau_out[t] = tau;
+    }
+    free(gamma);
+}
+
+/* ========================================================================== */
 /* Driver loop                                                                */
 /* ========================================================================== */
 
@@ -1065,6 +1147,8 @@ static void result_free(sweep_result *res) {
     free(res->histogram);
     free(res->ql_at_q_sum);
     free(res->ql2_at_q_sum);
+    free(res->mags2_tau);
+    free(res->overlap2_tau);
     free(res->equil_sweeps);
     free(res->equil_energy);
     free(res->equil_ql);
@@ -1113,6 +1197,19 @@ static void run_sweep_loop(const orc_lattice *lat, realization *real, size_t n_r
         (orc_tempering_attempt *)malloc(sizeof(orc_tempering_attempt) * (n_temps + 1));
     size_t overlap_call_count = 0;
 
+    /* mod.rs:342-371: max_lag capped at a quarter of the measurement sweeps, at least 1 */
+    int collect_ac = cfg->autocorrelation_max_lag > 0;
+    autocorr m2_acc, q2_acc;
+    double *m2_ac_buf = (double *)calloc(n_temps + 1, sizeof(double));
+    double *q2_ac_buf = (double *)calloc(n_temps + 1, sizeof(double));
+    if (collect_ac) {
+        uint64_t n_meas = cfg->n_sweeps - cfg->warmup_sweeps;
+        uint64_t lag = cfg->autocorrelation_max_lag < n_meas / 4 ? cfg->autocorrelation_max_lag : n_meas / 4;
+        if (lag < 1) lag = 1;
+        autocorr_init(&m2_acc, (size_t)lag, n_temps);
+        if (n_pairs > 0) autocorr_init(&q2_acc, (size_t)lag, n_temps);
+    }
+
     /* EquilDiagnosticAccum::new (equilibration.rs:18-38): checkpoints 128, 256, ... < n_sweeps, n_sweeps */
     int equil_diag = cfg->equilibration_diagnostic != 0;
     size_t equil_next = 0, equil_count = 0;
@@ -1159,6 +1256,8 @@ static void run_sweep_loop(const orc_lattice *lat, realization *real, size_t n_r
             for (size_t t = 0; t < n_temps; ++t) diag_ql_buf[t] = 0.0f;
         }
 
+        if (collect_ac && record)
+            for (size_t t = 0; t < n_temps; ++t) q2_ac_buf[t] = 0.0; /* overlap.rs:255-257 */
         if ((equil_diag || record) && n_pairs > 0) { /* mod.rs:527-529 -> overlap.rs:251-333 */
             for (size_t pair_idx = 0; pair_idx < n_pairs; ++pair_idx) {
                 size_t r_a = 2 * pair_idx, r_b = 2 * pair_idx + 1;
@@ -1193,8 +1292,11 @@ static void run_sweep_loop(const orc_lattice *lat, realization *real, size_t n_r
                     res->ql_at_q_sum[t * (n + 1) + idx] += (double)ql;
                     res->ql2_at_q_sum[t * (n + 1) + idx] += (double)(ql * ql);
                 }
-                if (record)
+                if (record) {
+                    if (collect_ac) /* overlap.rs:310-314 */
+                        for (size_t t = 0; t < n_temps; ++t) q2_ac_buf[t] += (double)ovbuf[1 * n_temps + t];
                     for (int k = 0; k < 6; ++k) stat_update(&ov[k], ovbuf + k * n_temps, n_temps);
+                }
             }
             if (equil_diag) { /* overlap.rs:327-332 */
                 float inv = 1.0f / (float)n_pairs;
@@ -1219,6 +1321,7 @@ static void run_sweep_loop(const orc_lattice *lat, realization *real, size_t n_r
         }
 
         if (record) { /* mod.rs:543-578 */
+            for (size_t t = 0; t < n_temps; ++t) m2_ac_buf[t] = 0.0;
             for (size_t r = 0; r < n_replicas; ++r) {
                 size_t offset = r * n_temps;
                 for (size_t t = 0; t < n_temps; ++t) {
@@ -1230,11 +1333,23 @@ static void run_sweep_loop(const orc_lattice *lat, realization *real, size_t n_r
                     mags4_buf[t] = m2 * m2;
                     energies_buf[t] = real->energies[system_id];
                 }
+                if (collect_ac)
+                    for (size_t t = 0; t < n_temps; ++t) m2_ac_buf[t] += (double)mags2_buf[t];
                 stat_update(&mags, mags_buf, n_temps);
                 stat_update(&mags2, mags2_buf, n_temps);
                 stat_update(&mags4, mags4_buf, n_temps);
                 stat_update(&energies, energies_buf, n_temps);
                 stat_update(&energies2, energies_buf, n_temps);
+            }
+            if (collect_ac) { /* mod.rs:580-595 */
+                double inv = 1.0 / (double)n_replicas;
+                for (size_t t = 0; t < n_temps; ++t) m2_ac_buf[t] *= inv;
+                autocorr_push(&m2_acc, m2_ac_buf);
+                if (n_pairs > 0) {
+                    double inv_p = 1.0 / (double)n_pairs;
+                    for (size_t t = 0; t < n_temps; ++t) q2_ac_buf[t] *= inv_p;
+                    autocorr_push(&q2_acc, q2_ac_buf);
+                }
             }
         }
 
@@ -1294,6 +1409,18 @@ static void run_sweep_loop(const orc_lattice *lat, realization *real, size_t n_r
     free(ovbuf);
     free(magnetization_sums);
     free(attempts);
+    if (collect_ac) { /* mod.rs:825-832 */
+        res->mags2_tau = (double *)calloc(n_temps + 1, sizeof(double));
+        autocorr_tau(&m2_acc, res->mags2_tau);
+        autocorr_free(&m2_acc);
+        if (n_pairs > 0) {
+            res->overlap2_tau = (double *)calloc(n_temps + 1, sizeof(double));
+            autocorr_tau(&q2_acc, res->overlap2_tau);
+            autocorr_free(&q2_acc);
+        }
+    }
+    free(m2_ac_buf);
+    free(q2_ac_buf);
     free(equil_sum_e);
     free(equil_sum_ql);
     free(diag_e_buf);
@@ -1444,6 +1571,14 @@ void orc_sim_get_result_moments(const orc_sim *sim, size_t r, double *out) {
     memcpy(out, sim->results[r].moments, sizeof(double) * 5 * sim->n_temps);
 }
 int orc_sim_has_overlap(const orc_sim *sim) { return sim->n_replicas / 2 > 0; }
+
+int orc_sim_get_tau(const orc_sim *sim, size_t r, double *mags2_tau, double *overlap2_tau) {
+    const sweep_result *res = &sim->results[r];
+    if (!res->mags2_tau) return 0;
+    memcpy(mags2_tau, res->mags2_tau, sizeof(double) * sim->n_temps);
+    if (res->overlap2_tau) memcpy(overlap2_tau, res->overlap2_tau, sizeof(double) * sim->n_temps);
+    return res->overlap2_tau ? 2 : 1;
+}
 
 size_t orc_sim_n_equil_checkpoints(const orc_sim *sim) { return sim->results[0].n_equil; }
 void orc_sim_get_equil(const orc_sim *sim, size_t r, uint64_t *sweeps, double *energy_avg,

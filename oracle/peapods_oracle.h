@@ -147,6 +147,7 @@ typedef struct {
     int32_t n_threads;            /* realisations are distributed over threads; <=1 = serial */
     uint64_t cluster_interval;    /* FK cluster update every k sweeps (ss/clusters/fk.rs); 0 = none */
     int32_t cluster_mode;         /* ORC_CLUSTER_* */
+    uint64_t autocorrelation_max_lag; /* 0 = none; ring backend of ss/statistics/autocorrelation.rs */
     int32_t equilibration_diagnostic; /* running means of E and q_l at log-spaced checkpoints
                                          (ss/statistics/equilibration.rs) */
 } orc_config;
@@ -181,6 +182,9 @@ void orc_sim_get_result_moments(const orc_sim *sim, size_t realization,
 int orc_sim_has_overlap(const orc_sim *sim);
 /* equilibration checkpoints of the last sample(): count, then sweeps[n], energy_avg[n][n_temps],
  * link_overlap_avg[n][n_temps] of one realisation */
+/* integrated autocorrelation times of m^2 and q^2 per temperature (Sokal window) of one realisation;
+ * returns 0 when the last sample() did not collect them (overlap2_tau only with >= 2 replicas) */
+int orc_sim_get_tau(const orc_sim *sim, size_t realization, double *mags2_tau, double *overlap2_tau);
 size_t orc_sim_n_equil_checkpoints(const orc_sim *sim);
 void orc_sim_get_equil(const orc_sim *sim, size_t realization, uint64_t *sweeps, double *energy_avg,
                        double *link_overlap_avg);

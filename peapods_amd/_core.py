@@ -193,7 +193,10 @@ class IsingSimulation:
             cfg.n_overlap_cluster_modes = len(modes)
             cfg.overlap_cluster_mode = _CLUSTER_MODES[oc_mode]
         if autocorrelation_max_lag is not None:
-            raise NotImplementedError("autocorrelation diagnostics are outside the HIP hot path")
+            if backend == "fft":
+                raise NotImplementedError("the FFT autocorrelation backend is not built on the HIP path "
+                                          "(use the exact ring backend)")
+            cfg.autocorrelation_max_lag = int(autocorrelation_max_lag)
         cfg.equilibration_diagnostic = 1 if equilibration_diagnostic else 0
         cfg.measure_overlap = 1 if measure_overlap else 0
         err = C.create_string_buffer(512)
@@ -317,8 +320,26 @@ class IsingSimulation:
             self.pt_diagnostics() if kwargs.get("pt_interval") is not None else None,
             self.n_temps, self.n_replicas // 2,
         )
+        if cfg.autocorrelation_max_lag:
+            out.update(self.autocorrelation_times())
         if cfg.equilibration_diagnostic:
             out.update(self.equilibration_checkpoints())
+        return out
+
+    def autocorrelation_times(self):
+        """mags2_tau (and overlap2_tau with replica pairs) of the last sample(), averaged over the
+        realisations in order (results.rs:213-228,267-274; src/lib.rs:545-557)."""
+        m2 = np.zeros((self.n_realizations, self.n_temps), dtype=np.float64)
+        q2 = np.zeros_like(m2)
+        for r in range(self.n_realizations):
+            self._check(self._lib.pa_sim_get_autocorrelation_tau(self._handle, r, nat.ptr(m2[r]), nat.ptr(q2[r])))
+        out = {}
+        for key, arr in (("mags2_tau", m2), ("overlap2_tau", q2)):
+            if key == "overlap2_tau" and self.n_replicas < 2:
+                continue
+            mean = np.empty(self.n_temps, dtype=np.float64)
+            self._lib.pa_aggregate_mean(nat.ptr(arr), self.n_realizations, self.n_temps, nat.ptr(mean))
+            out[key] = mean
         return out
 
     def equilibration_checkpoints(self):

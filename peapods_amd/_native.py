@@ -45,6 +45,7 @@ class PaSampleConfig(C.Structure):
         ("cluster_interval", C.c_uint64),
         ("cluster_mode", C.c_int32),
         ("equilibration_diagnostic", C.c_int32),
+        ("autocorrelation_max_lag", C.c_uint64),
     ]
 
 
@@ -80,6 +81,7 @@ SIGNATURES = {
     "pa_sim_get_result_overlap": (C.c_int, [_vp, _u64, _vp]),
     "pa_sim_get_result_histograms": (C.c_int, [_vp, _u64, _vp, _vp, _vp]),
     "pa_sim_result_block_len": (_u64, [_vp]),
+    "pa_sim_get_autocorrelation_tau": (C.c_int, [_vp, _u64, _vp, _vp]),
     "pa_sim_n_equil_checkpoints": (_u64, [_vp]),
     "pa_sim_get_equilibration": (C.c_int, [_vp, _u64, _vp, _vp, _vp]),
     "pa_sim_get_result_blocks": (C.c_int, [_vp, _vp]),

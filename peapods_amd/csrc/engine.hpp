@@ -98,6 +98,7 @@ struct DevPtrs {
     const uint32_t *jorg_thr;// [n_temps] ceil((1 - exp(-4/T)) 2^24): draw < thr <=> gen::<f32>() < p
     const uint32_t *cmr_thr; // [n_temps] CMR blue bonds: 1 - r^2, r = exp(-2/T) (red bonds use fk_thr = 1 - r)
     const uint32_t *fk_thr;  // [n_temps] the same for the FK bond probability 1 - exp(-2/T)
+    float *ac_m2, *ac_q2;    // [n_real][ac_stride][n_temps] per-sweep series of <m^2> and <q^2> (f32, as pushed)
     double *eq_sum;          // [n_real][2][n_temps] running sums of the equilibration diagnostic
     double *eq_ckpt;         // [n_real][64][2][n_temps] checkpoint averages
     // general-coupling path only
@@ -114,6 +115,9 @@ struct PtParams {
     // equilibration diagnostic (statistics/equilibration.rs): accumulate this sweep's replica-averaged
     // energy and pair-averaged link overlap; equil_ckpt = 1 + checkpoint index to snapshot, 0 = none
     uint32_t equil, equil_ckpt, equil_count;
+    // autocorrelation series (autocorrelation.rs): ac_index = 1 + index of this recorded sweep in the
+    // per-realisation history of ac_stride entries, 0 = not collected
+    uint32_t ac_index, ac_stride;
 };
 
 // All launchers enqueue on `stream` and return the hipGetLastError() of the launch.

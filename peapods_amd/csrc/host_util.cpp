@@ -270,6 +270,40 @@ bool build_gibbs_table(const float *couplings, uint64_t n_couplings, const float
     return true;
 }
 
+void autocorrelation_tau(const float *series, size_t n_samples, size_t n_cols, size_t max_lag, double *tau_out) {
+    std::vector<double> sum_prod(max_lag + 1), gamma(max_lag + 1);
+    for (size_t t = 0; t < n_cols; ++t) {
+        double sum_o = 0.0, sum_o2 = 0.0;
+        std::fill(sum_prod.begin(), sum_prod.end(), 0.0);
+        // push(): every accumulator receives its terms in sample order; the ring only bounds memory
+        for (size_t i = 0; i < n_samples; ++i) {
+            const double o = static_cast<double>(series[i * n_cols + t]);
+            sum_o += o;
+            sum_o2 += o * o;
+            const size_t n_back = std::min(i, max_lag);
+            for (size_t delta = 0; delta <= n_back; ++delta)
+                sum_prod[delta] += o * static_cast<double>(series[(i - delta) * n_cols + t]);
+        }
+        for (size_t delta = 0; delta <= max_lag; ++delta) gamma[delta] = delta == 0 ? 1.0 : 0.0;
+        if (n_samples > 0) {
+            const double m = static_cast<double>(n_samples);
+            const double mean = sum_o / m;
+            const double var = sum_o2 / m - mean * mean;
+            if (var > 0.0)
+                for (size_t delta = 0; delta <= max_lag; ++delta) {
+                    const double count = n_samples > delta ? static_cast<double>(n_samples - delta) : 0.0;
+                    gamma[delta] = count <= 0.0 ? (delta == 0 ? 1.0 : 0.0) : (sum_prod[delta] / count - mean * mean) / var;
+                }
+        }
+        double tau = 0.5; // sokal_tau
+        for (size_t w = 1; w <= max_lag; ++w) {
+            tau += gamma[w];
+            if (static_cast<double>(w) >= 5.0 * tau) break;
+        }
+        tau_out[t] = tau;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Dependency levels.  In the reference a sweep visits sites 0..N-1 in order
 // (sweep.rs:58-61); site i therefore sees the NEW value of every neighbour

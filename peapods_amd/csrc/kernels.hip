@@ -933,10 +933,12 @@ __device__ __forceinline__ void measure_block(const SimDims &d, const DevPtrs &p
         double *mom = p.mom + static_cast<size_t>(real) * 5 * d.n_temps;
         double m0 = mom[0 * d.n_temps + t], m1 = mom[1 * d.n_temps + t], m2s = mom[2 * d.n_temps + t];
         double e0 = mom[3 * d.n_temps + t], e1 = mom[4 * d.n_temps + t];
+        double m2_ac = 0.0;
         for (uint32_t rep = 0; rep < d.n_replicas; ++rep) {
             const uint32_t slot = rep * d.n_temps + t;
             const float mag = __fdiv_rn(static_cast<float>(m.M[slot]), n_f);
             const float mag2 = __fmul_rn(mag, mag);
+            m2_ac = __dadd_rn(m2_ac, static_cast<double>(mag2)); // mod.rs:567-571
             const float mag4 = __fmul_rn(mag2, mag2);
             const float energy = __fdiv_rn(energy_sum(m.E[slot], d.general), n_f);
             const double ed = static_cast<double>(energy);
@@ -951,6 +953,9 @@ __device__ __forceinline__ void measure_block(const SimDims &d, const DevPtrs &p
         mom[2 * d.n_temps + t] = m2s;
         mom[3 * d.n_temps + t] = e0;
         mom[4 * d.n_temps + t] = e1;
+        if (pt.ac_index) // the value pushed to the m^2 autocorrelation accumulator (mod.rs:580-586)
+            p.ac_m2[(static_cast<size_t>(real) * pt.ac_stride + (pt.ac_index - 1)) * d.n_temps + t] =
+                static_cast<float>(__dmul_rn(m2_ac, __ddiv_rn(1.0, static_cast<double>(d.n_replicas))));
         }
         if (accum_overlap && d.n_pairs) {
             double *ovm = p.ovm + static_cast<size_t>(real) * 6 * d.n_temps;
@@ -958,6 +963,7 @@ __device__ __forceinline__ void measure_block(const SimDims &d, const DevPtrs &p
             for (int k = 0; k < 6; ++k) o[k] = ovm[k * d.n_temps + t];
             const float n_bonds_f = static_cast<float>(d.N * d.nn);
             const size_t hbase = (static_cast<size_t>(real) * d.n_temps + t) * (d.N + 1);
+            double q2_ac = 0.0;
             for (uint32_t pr = 0; pr < d.n_pairs; ++pr) {
                 const int32_t dot_spin = m.dot_spin[pr * d.n_temps + t];
                 const int32_t dot_link = m.dot_link[pr * d.n_temps + t];
@@ -965,6 +971,7 @@ __device__ __forceinline__ void measure_block(const SimDims &d, const DevPtrs &p
                 const float qv = __fdiv_rn(static_cast<float>(dot_spin), n_f);
                 const float q2 = __fmul_rn(qv, qv);
                 const float q4 = __fmul_rn(q2, q2);
+                q2_ac = __dadd_rn(q2_ac, static_cast<double>(q2)); // overlap.rs:310-314
                 const float ql2 = __fmul_rn(ql, ql);
                 const float ql4 = __fmul_rn(ql2, ql2);
                 o[0] = __dadd_rn(o[0], static_cast<double>(qv));
@@ -980,6 +987,9 @@ __device__ __forceinline__ void measure_block(const SimDims &d, const DevPtrs &p
                 p.ql2q[bin] = __dadd_rn(p.ql2q[bin], static_cast<double>(ql2));
             }
             for (int k = 0; k < 6; ++k) ovm[k * d.n_temps + t] = o[k];
+            if (pt.ac_index) // mod.rs:588-594
+                p.ac_q2[(static_cast<size_t>(real) * pt.ac_stride + (pt.ac_index - 1)) * d.n_temps + t] =
+                    static_cast<float>(__dmul_rn(q2_ac, __ddiv_rn(1.0, static_cast<double>(d.n_pairs))));
         }
     }
     // ---- equilibration diagnostic (mod.rs:511-541, overlap.rs:285-287,327-332, equilibration.rs:40-58)

@@ -69,6 +69,7 @@ struct pa_sim {
     uint32_t *seg = nullptr;       // slab segments of the pipelined large-lattice sweep
     uint32_t pipe_epoch = 1;       // bumped by every k_sweep_pipe launch (progress counters are monotone)
     std::vector<uint64_t> equil_sweeps; // checkpoints of the last sample() with the equilibration diagnostic
+    uint64_t ac_lag = 0, ac_samples = 0, ac_capacity = 0; // autocorrelation series of the last sample()
     float *Jf = nullptr, *temps_dev = nullptr; // general-coupling path
     uint32_t *jump256 = nullptr, *jorg_thr = nullptr, *fk_thr = nullptr, *cmr_thr = nullptr; // cluster kernels
     int32_t *nz_bonds = nullptr;
@@ -476,6 +477,27 @@ int ensure_equil(pa_sim *sim) {
     return PA_OK;
 }
 
+// Per-sweep series of the autocorrelation observables: [n_real][capacity][n_temps] f32, grown on demand.
+int ensure_autocorr(pa_sim *sim, uint64_t n_samples) {
+    const SimDims &d = sim->d;
+    if (n_samples > sim->ac_capacity) {
+        const size_t count = static_cast<size_t>(d.n_real) * n_samples * d.n_temps;
+        if (count * 2 * sizeof(float) > (size_t(8) << 30))
+            return fail(sim, PA_ERR_UNSUPPORTED, "autocorrelation history above 8 GiB");
+        // (earlier, smaller buffers stay with the handle until it is destroyed)
+        PA_HIP(sim, sim->buffers.alloc(&sim->p.ac_m2, count));
+        PA_HIP(sim, sim->buffers.alloc(&sim->p.ac_q2, count));
+        sim->ac_capacity = n_samples;
+    }
+    uint32_t r0 = 0;
+    for (auto &g : sim->groups) {
+        g.p.ac_m2 = sim->p.ac_m2 + static_cast<size_t>(sim->ac_capacity) * d.n_temps * r0;
+        g.p.ac_q2 = sim->p.ac_q2 + static_cast<size_t>(sim->ac_capacity) * d.n_temps * r0;
+        r0 += g.d.n_real;
+    }
+    return PA_OK;
+}
+
 std::string validate_text(const pa_sample_config *cfg, uint64_t n_replicas, int *code) {
     *code = PA_ERR_INVALID;
     // spin-sim/src/config.rs:180-247 (message texts are the reference's)
@@ -539,6 +561,12 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the FK cluster kernel");
     if ((oc_sw || fk || oc_cmr) && (rc = ensure_cluster_sw(sim))) return rc;
     if (cfg->equilibration_diagnostic && (rc = ensure_equil(sim))) return rc;
+    // autocorrelation (mod.rs:342-345): max_lag capped at a quarter of the measurement sweeps, at least 1
+    const uint64_t n_meas = cfg->n_sweeps - cfg->warmup_sweeps;
+    const bool autocorr = cfg->autocorrelation_max_lag > 0;
+    sim->ac_lag = autocorr ? std::max<uint64_t>(1, std::min<uint64_t>(cfg->autocorrelation_max_lag, n_meas / 4)) : 0;
+    sim->ac_samples = 0;
+    if (autocorr && n_meas > 0 && (rc = ensure_autocorr(sim, n_meas))) return rc;
     if ((rc = zero_accumulators(sim))) return rc;
     const bool want_overlap = d.n_pairs > 0 && cfg->measure_overlap;
     sim->n_recorded = 0;
@@ -558,7 +586,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         if (sim->equil_sweeps.size() > 64) return fail(sim, PA_ERR_UNSUPPORTED, "more than 64 equilibration checkpoints");
     }
     size_t equil_next = 0;
-    const bool fused = want_overlap && !gibbs && !fk && !equil && cfg->overlap_cluster_interval == 0 && !d.big &&
+    const bool fused = want_overlap && !gibbs && !fk && !equil && !autocorr && cfg->overlap_cluster_interval == 0 && !d.big &&
                        !d.general && !std::getenv("PEAPODS_NO_FUSE");
     bool overlap_owed = false; // the last recorded sweep's overlap has not been measured yet
     for (uint64_t sweep_id = 0; sweep_id < cfg->n_sweeps && status == PA_OK; ++sweep_id) {
@@ -613,7 +641,9 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             const bool oc_this = cfg->overlap_cluster_interval > 0 &&
                                  sweep_id % cfg->overlap_cluster_interval == 0; // :598-599
             PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot,
-                        equil ? 1u : 0u, equil_ckpt, static_cast<uint32_t>(sweep_id + 1)};
+                        equil ? 1u : 0u, equil_ckpt, static_cast<uint32_t>(sweep_id + 1),
+                        (autocorr && record) ? static_cast<uint32_t>(sim->n_recorded + 1) : 0u,
+                        static_cast<uint32_t>(sim->ac_capacity)};
             if (!oc_this) {
                 if (record || pt_this || equil) // statistics :543-578, tempering :748-796
                     PA_HIP(sim, launch_measure(g.d, g.p, pt, false, record, record && want_overlap, pt_this,
@@ -646,6 +676,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             overlap_call_count += 1; // :744
         if (pt_this && cfg->pt_schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
     }
+    sim->ac_samples = autocorr ? sim->n_recorded : 0;
     if (overlap_owed && status == PA_OK) {
         PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
         for (auto &g : sim->groups) {
@@ -1502,6 +1533,24 @@ int pa_sim_get_result_histograms(pa_sim *sim, uint64_t realization, uint64_t *hi
     PA_HIP(sim, hipMemcpyAsync(ql2_at_q_sum, sim->p.ql2q + bins * realization, bins * sizeof(double),
                                hipMemcpyDeviceToHost, sim->stream));
     PA_HIP(sim, hipStreamSynchronize(sim->stream));
+    return PA_OK;
+}
+
+int pa_sim_get_autocorrelation_tau(pa_sim *sim, uint64_t realization, double *mags2_tau, double *overlap2_tau) {
+    PA_CHECK_REAL(sim, realization);
+    const SimDims &d = sim->d;
+    if (!sim->ac_lag) return fail(sim, PA_ERR_INVALID, "the last sample() did not collect autocorrelations");
+    PA_HIP(sim, hipSetDevice(sim->device));
+    std::vector<float> series;
+    const size_t n = static_cast<size_t>(sim->ac_samples) * d.n_temps;
+    const size_t base = static_cast<size_t>(realization) * sim->ac_capacity * d.n_temps;
+    int rc = download(sim, series, sim->p.ac_m2 + base, n);
+    if (rc) return rc;
+    autocorrelation_tau(series.data(), sim->ac_samples, d.n_temps, sim->ac_lag, mags2_tau);
+    if (d.n_pairs) {
+        if ((rc = download(sim, series, sim->p.ac_q2 + base, n))) return rc;
+        autocorrelation_tau(series.data(), sim->ac_samples, d.n_temps, sim->ac_lag, overlap2_tau);
+    }
     return PA_OK;
 }
 

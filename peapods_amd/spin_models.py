@@ -169,6 +169,9 @@ class Ising:
                     "per_sample_ql2_at_q_sum"):
             if key in result:
                 setattr(self, key, result[key])
+        for key in ("mags2_tau", "overlap2_tau"):  # spin_models.py:325-328
+            if key in result:
+                setattr(self, key, result[key])
         if "equil_sweeps" in result:  # spin_models.py:330-333
             self._equil_sweeps = result["equil_sweeps"]
             self._equil_energy_avg = result["equil_energy_avg"]

@@ -511,6 +511,26 @@ def test_equilibration_diagnostic_matches_oracle(oracle, kind):
     assert not a["equil_link_overlap_avg"].any()
 
 
+@pytest.mark.parametrize("n_rep", [1, 4])
+def test_autocorrelation_times_match_oracle(oracle, n_rep):
+    """autocorrelation_max_lag (autocorrelation.rs ring backend + Sokal window, mod.rs:342-371,
+    580-595): per-sweep <m^2> and <q^2> series in f32, products in f64, tau_int per temperature."""
+    shape = (8, 8)
+    couplings = np.ones((2,) + shape + (2,), np.float32)
+    gpu, cpu = make_pair(oracle, shape, couplings, [2.0, 2.269, 2.6], n_rep, 6)
+    kwargs = dict(cluster_update_interval=2, cluster_mode="sw", pt_interval=1, warmup_ratio=0.25,
+                  autocorrelation_max_lag=150)
+    a = gpu.sample(1200, "metropolis", **kwargs)
+    b = cpu.sample(1200, "metropolis", **kwargs)
+    assert ("overlap2_tau" in a) == (n_rep >= 2)
+    assert_results_equal(a, b)
+    assert np.all(a["mags2_tau"] > 0.4)
+    # the lag is capped at a quarter of the measurement sweeps (mod.rs:343-345)
+    a = gpu.sample(40, "gibbs", warmup_ratio=0.5, autocorrelation_max_lag=1000)
+    b = cpu.sample(40, "gibbs", warmup_ratio=0.5, autocorrelation_max_lag=1000)
+    assert_results_equal(a, b)
+
+
 def test_gaussian_glass_overlap_histogram_protocol():
     """The reference's physics check for Gaussian couplings (tests/overlap_histogram.py, shortened
     from 40000 to 12000 sweeps): 8^3 Gaussian glass at T = 1.4 (paramagnetic), 2 replicas, 64

@@ -531,6 +531,22 @@ def test_autocorrelation_times_match_oracle(oracle, n_rep):
     assert_results_equal(a, b)
 
 
+def test_swendsen_wang_autocorrelation_scaling():
+    """The reference's dynamic-exponent check (tests/autocorrelation_scaling.py): 2D ferromagnet at
+    the exact T_c, Metropolis + Swendsen-Wang every sweep, 16 independent chains, 40000 sweeps,
+    tau_int(m^2) from the Sokal window with max lag 2000: tau(L=64) / tau(L=32) = 2^0.25 +- 0.1."""
+    import peapods_amd as peapods
+
+    tc = 2.0 / np.log(1 + np.sqrt(2))
+    taus = {}
+    for size in (32, 64):
+        model = peapods.Ising([size, size], temperatures=np.array([tc], np.float32), n_disorder=16, seed=42)
+        model.sample(40000, cluster_update_interval=1, cluster_mode="sw", autocorrelation_max_lag=2000,
+                     warmup_ratio=0.25)
+        taus[size] = model.mags2_tau[0]
+    assert abs(taus[64] / taus[32] - 2 ** 0.25) < 0.1, taus
+
+
 def test_gaussian_glass_overlap_histogram_protocol():
     """The reference's physics check for Gaussian couplings (tests/overlap_histogram.py, shortened
     from 40000 to 12000 sweeps): 8^3 Gaussian glass at T = 1.4 (paramagnetic), 2 replicas, 64

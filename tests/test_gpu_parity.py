@@ -531,6 +531,33 @@ def test_autocorrelation_times_match_oracle(oracle, n_rep):
     assert_results_equal(a, b)
 
 
+@pytest.mark.parametrize("move", [dict(), dict(overlap_cluster_build_mode="cmr", overlap_cluster_mode="sw"),
+                                  dict(overlap_cluster_build_mode="jorg", overlap_cluster_mode="sw")])
+def test_3d_ea_glass_binder_curves_cross(move):
+    """The reference's spin-glass checks (tests/spin_glass_crossings.py:14-128, tests/utils.py:15-47):
+    3D +-J glass, L = 8 and 10, 12 temperatures 0.8..1.4, 2 replicas, 25 disorder samples, 10000
+    sweeps of Metropolis + tempering + the overlap move; the spin-glass Binder ratios of the two
+    sizes agree at T_c = 1.102 within 0.3 and the histogram Binder matches the direct one."""
+    import peapods_amd as peapods
+
+    tc = 1.102
+    temps = np.linspace(0.8, 1.4, 12).astype(np.float32)
+    at_tc = []
+    for size in (8, 10):
+        model = peapods.Ising((size, size, size), couplings="bimodal", temperatures=temps, n_replicas=2,
+                              n_disorder=25, seed=42)
+        model.sample(10000, sweep_mode="metropolis", pt_interval=1, overlap_cluster_update_interval=1,
+                     warmup_ratio=0.25, **move)
+        q = np.linspace(-1, 1, size ** 3 + 1)
+        for t in range(len(temps)):  # assert_overlap_binder
+            p = model.overlap_histogram[t].astype(np.float64)
+            p /= p.sum()
+            binder_hist = 1 - (q ** 4 * p).sum() / (3 * (q ** 2 * p).sum() ** 2)
+            assert abs(binder_hist - model.sg_binder[t]) < 0.05
+        at_tc.append(np.interp(tc, temps, model.sg_binder))
+    assert max(at_tc) - min(at_tc) < 0.3, at_tc
+
+
 def test_swendsen_wang_autocorrelation_scaling():
     """The reference's dynamic-exponent check (tests/autocorrelation_scaling.py): 2D ferromagnet at
     the exact T_c, Metropolis + Swendsen-Wang every sweep, 16 independent chains, 40000 sweeps,

@@ -345,9 +345,16 @@ class OracleSimulation:
             cfg.overlap_cluster_interval = int(overlap_cluster_update_interval)
             modes = [m.strip() for m in (overlap_cluster_build_mode or "houdayer").split("+")]
             for k, m in enumerate(modes):
-                if m not in OC_MODES:
+                if m in OC_MODES:
+                    cfg.overlap_cluster_modes[k] = OC_MODES[m]
+                elif m.startswith("houd") and m[4:].isdigit() and int(m[4:]) % 2 == 0:
+                    group = int(m[4:])  # config.rs:124-141; simulation/mod.rs:207-214
+                    if group > self.n_replicas:
+                        raise ValueError(f"overlap cluster requires n_replicas >= max group_size "
+                                         f"({self.n_replicas} < {group})")
+                    cfg.overlap_cluster_modes[k] = OC_MODES["houdayer"] | (group << 8)
+                else:
                     raise ValueError(f"oracle does not restate overlap mode '{m}'")
-                cfg.overlap_cluster_modes[k] = OC_MODES[m]
             cfg.n_overlap_cluster_modes = len(modes)
             cfg.overlap_cluster_mode = CLUSTER_MODES[overlap_cluster_mode or "wolff"]
         cfg.n_threads = int(n_threads)

@@ -843,6 +843,91 @@ static void overlap_update(const orc_lattice *lat, realization *real, size_t n_r
     free(rank);
 }
 
+/* ss/clusters/overlap.rs:153-339 with group_size N > 2 ("houdN", flagged experimental upstream):
+ * groups of N consecutive replicas of the shuffled order, active sites = the N spins sum to
+ * zero, deterministic bonds between active neighbours, every replica of the group flips. */
+static void houdayer_n_update(const orc_lattice *lat, realization *real, size_t n_replicas, size_t n_temps,
+                              size_t group_size, int cluster_mode) {
+    size_t n = lat->n_spins, nn = lat->n_neighbors;
+    size_t n_pairs = n_replicas / 2, n_groups = n_replicas / group_size;
+    uint64_t *systems = (uint64_t *)malloc(sizeof(uint64_t) * (n_temps * n_replicas + 1));
+    for (size_t t = 0; t < n_temps; ++t) {
+        for (size_t k = 0; k < n_replicas; ++k)
+            systems[t * n_replicas + k] = real->system_ids[k * n_temps + t];
+        orc_rng_shuffle_usize(&real->pair_rngs[t * n_pairs], systems + t * n_replicas, n_replicas);
+    }
+    uint8_t *active = (uint8_t *)malloc(n + 1);
+    uint8_t *in_cluster = (uint8_t *)malloc(n + 1);
+    size_t *stack = (size_t *)malloc(sizeof(size_t) * (n + 1));
+    uint32_t *parent = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
+    uint32_t *counts = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
+    uint8_t *rank = (uint8_t *)malloc(n + 1);
+    for (size_t task = 0; task < n_temps * n_groups; ++task) {
+        size_t t = task / n_groups, g = task % n_groups;
+        const uint64_t *grp = systems + t * n_replicas + g * group_size;
+        orc_rng *rng = &real->pair_rngs[t * n_pairs + g];
+        for (size_t i = 0; i < n; ++i) { /* is_active, :199-205 (the spins do not change before the flips) */
+            int sum = 0;
+            for (size_t k = 0; k < group_size; ++k) sum += real->spins[(size_t)grp[k] * n + i];
+            active[i] = sum == 0;
+        }
+        memset(in_cluster, 0, n);
+        if (cluster_mode == ORC_CLUSTER_WOLFF) {
+            int64_t seed = -1;
+            for (int probe = 0; probe < 64; ++probe) { /* find_seed, utils.rs:107-119 */
+                size_t i = (size_t)orc_rng_gen_range_usize(rng, 0, n);
+                if (active[i]) {
+                    seed = (int64_t)i;
+                    break;
+                }
+            }
+            if (seed < 0) continue;
+            size_t top = 0;
+            in_cluster[seed] = 1;
+            stack[top++] = (size_t)seed;
+            while (top > 0) {
+                size_t site = stack[--top];
+                for (size_t d = 0; d < nn; ++d)
+                    for (int dir = 0; dir < 2; ++dir) {
+                        size_t nb = dir == 0 ? lat->fwd[site * nn + d] : lat->bwd[site * nn + d];
+                        if (!in_cluster[nb] && active[site] && active[nb]) {
+                            in_cluster[nb] = 1;
+                            stack[top++] = nb;
+                        }
+                    }
+            }
+        } else {
+            for (size_t i = 0; i < n; ++i) parent[i] = (uint32_t)i;
+            memset(rank, 0, n);
+            for (size_t i = 0; i < n; ++i)
+                for (size_t d = 0; d < nn; ++d) {
+                    size_t j = lat->fwd[i * nn + d];
+                    if (active[i] && active[j]) orc_uf_union(parent, rank, (uint32_t)i, (uint32_t)j);
+                }
+            uf_flatten_counts(parent, n, counts);
+            memset(rank, 0xFF, n);
+            for (size_t i = 0; i < n; ++i) {
+                uint32_t root = parent[i];
+                if (counts[root] > 1 && rank[root] == 0xFF) rank[root] = (uint8_t)(orc_rng_gen_f32(rng) < 0.5f);
+            }
+            for (size_t i = 0; i < n; ++i) in_cluster[i] = rank[parent[i]] == 1;
+        }
+        for (size_t i = 0; i < n; ++i)
+            if (in_cluster[i])
+                for (size_t k = 0; k < group_size; ++k) {
+                    int8_t *sp = real->spins + (size_t)grp[k] * n + i;
+                    *sp = (int8_t)-*sp;
+                }
+    }
+    free(systems);
+    free(active);
+    free(in_cluster);
+    free(stack);
+    free(parent);
+    free(counts);
+    free(rank);
+}
+
 /* ss/clusters/overlap.rs:555-971: CMR two-phase move (blue clusters of doubly satisfied bonds with
  * p = 1 - r^2, then grey clusters = blue + singly satisfied "red" bonds with p = 1 - r,
  * r = exp(-2|J|/T)).  Update action without observers: cluster_mode sw = union-find path
@@ -1358,10 +1443,13 @@ static void run_sweep_loop(const orc_lattice *lat, realization *real, size_t n_r
             did_overlap_mutate = 1;
             int mode = cfg->overlap_cluster_modes[overlap_call_count %
                                                   (size_t)cfg->n_overlap_cluster_modes];
-            if (mode == ORC_OC_CMR)
+            /* mode = kind | group_size << 8 (group size 0 or 2: pairs) */
+            if ((mode & 0xFF) == ORC_OC_CMR)
                 cmr_update(lat, real, n_replicas, n_temps, cfg->overlap_cluster_mode);
+            else if ((mode & 0xFF) == ORC_OC_HOUDAYER && (mode >> 8) > 2)
+                houdayer_n_update(lat, real, n_replicas, n_temps, (size_t)(mode >> 8), cfg->overlap_cluster_mode);
             else
-                overlap_update(lat, real, n_replicas, n_temps, mode, cfg->overlap_cluster_mode);
+                overlap_update(lat, real, n_replicas, n_temps, mode & 0xFF, cfg->overlap_cluster_mode);
             overlap_call_count += 1;
         }
 

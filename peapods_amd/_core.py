@@ -43,7 +43,9 @@ def _parse_overlap_modes(text):
                 ) from None
             if n < 2 or n % 2:
                 raise ValueError(f"Houdayer group size must be even and >= 2, got {n}")
-            raise NotImplementedError(f"houd{n} (group_size > 2) is not built on the HIP path")
+            if n > 32:
+                raise NotImplementedError(f"houd{n}: groups above 32 replicas are not built on the HIP path")
+            modes.append(_OC_MODES["houdayer"] | (n << 8))  # experimental upstream (config.rs:135-140)
         else:
             raise ValueError(
                 f"unknown overlap_cluster_build_mode '{name}', expected 'houdayer', 'houdN', "

@@ -93,7 +93,7 @@ struct DevPtrs {
     uint16_t *dfs_stack;      // [n_real][n_temps * n_pairs][N] scratch of k_jorg
     uint64_t *pair_rng;      // [n_real][n_temps * n_pairs][4] xoshiro state of the overlap-move generators
     // "sw" inner variant of the overlap-cluster moves (kernels_cluster.hip; built on first use)
-    uint32_t *pair_slots;    // [n_real][n_temps * n_pairs][2] slots of every group of two
+    uint32_t *pair_slots;    // [n_real][n_temps][n_replicas] slots in the shuffled order of each temperature
     const uint32_t *jump256; // [n_jump256][64][16][8] nibble tables of T^(256 b)
     const uint32_t *jorg_thr;// [n_temps] ceil((1 - exp(-4/T)) 2^24): draw < thr <=> gen::<f32>() < p
     const uint32_t *cmr_thr; // [n_temps] CMR blue bonds: 1 - r^2, r = exp(-2/T) (red bonds use fk_thr = 1 - r)
@@ -140,7 +140,8 @@ hipError_t launch_measure_stamped(const SimDims &d, const DevPtrs &p, const PtPa
                                   unsigned long long *stamps, hipStream_t stream);
 size_t sweep_lds_bytes(const SimDims &d, bool gibbs);
 // kernels_cluster.hip
-hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, hipStream_t stream);
+hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, uint32_t group, bool wolff,
+                             hipStream_t stream);
 hipError_t launch_cmr_wolff(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 size_t cmr_wolff_lds_bytes(const SimDims &d);
 size_t cluster_sw_lds_bytes(const SimDims &d);

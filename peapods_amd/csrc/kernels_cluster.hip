@@ -43,7 +43,8 @@ __device__ __forceinline__ uint32_t gen_range_u32(DevRng &rng, uint32_t range) {
 }
 
 // One thread per temperature: shuffle the replicas with pair generator t * n_pairs (reverse
-// Fisher-Yates, SliceRandom::shuffle) and write the slots of every group of two.
+// Fisher-Yates, SliceRandom::shuffle) and write the slots in the shuffled order
+// (pair_slots[real][t][n_replicas]).
 __global__ void k_pairing(SimDims d, DevPtrs p) {
     const uint32_t real = blockIdx.x, t = threadIdx.x;
     if (t >= d.n_temps) return;
@@ -59,11 +60,9 @@ __global__ void k_pairing(SimDims d, DevPtrs p) {
         order[i] = order[j];
         order[j] = tmp;
     }
-    uint32_t *slots = p.pair_slots + (static_cast<size_t>(real) * n_lanes + static_cast<size_t>(t) * d.n_pairs) * 2;
-    for (uint32_t g = 0; g < d.n_pairs; ++g) {
-        slots[2 * g + 0] = order[2 * g] * d.n_temps + t;
-        slots[2 * g + 1] = order[2 * g + 1] * d.n_temps + t;
-    }
+    // slots of the shuffled order; groups of g consecutive entries form the tasks of temperature t
+    uint32_t *slots = p.pair_slots + (static_cast<size_t>(real) * d.n_temps + t) * d.n_replicas;
+    for (uint32_t k = 0; k < d.n_replicas; ++k) slots[k] = order[k] * d.n_temps + t;
     st[0] = rng.s0; st[1] = rng.s1; st[2] = rng.s2; st[3] = rng.s3;
 }
 
@@ -118,8 +117,11 @@ __host__ __device__ inline size_t cluster_sw_lds_words(const SimDims &d) {
 
 enum { kSwHoudayer = 0, kSwJorg = 1, kSwFk = 2, kSwCmr = 3 };
 
+// group: replicas per task (2 except for the experimental "houdN" moves: N replicas whose spins
+// sum to zero on the active sites, all of them flipped).  wolff: single-cluster variant of a
+// deterministic-bond move (find_seed, utils.rs:107-119, then flip the seed's component).
 template <int MODE>
-__global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p) {
+__global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p, uint32_t group, int wolff) {
     constexpr bool JORG = MODE == kSwJorg, FK = MODE == kSwFk, CMR = MODE == kSwCmr;
     constexpr bool STOCHASTIC = JORG || FK || CMR; // bonds are drawn
     constexpr uint32_t N_PHASES = CMR ? 2 : 1;     // CMR: blue clusters, then grey = blue + red bonds
@@ -144,16 +146,22 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p)
         L.misc = q;
     }
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t n_lanes = FK ? d.n_sys : d.n_temps * d.n_pairs;
+    const uint32_t n_groups = FK ? 1u : d.n_replicas / group;
+    const uint32_t n_lanes = FK ? d.n_sys : d.n_temps * n_groups;
     const uint32_t real = blockIdx.x / n_lanes, task = blockIdx.x % n_lanes;
-    const uint32_t t = FK ? task % d.n_temps : task / d.n_pairs;
-    const uint32_t sa = FK ? task : p.pair_slots[(static_cast<size_t>(real) * n_lanes + task) * 2 + 0];
-    const uint32_t sb = FK ? task : p.pair_slots[(static_cast<size_t>(real) * n_lanes + task) * 2 + 1];
+    const uint32_t t = FK ? task % d.n_temps : task / n_groups;
+    const uint32_t g = FK ? 0u : task % n_groups;
+    const uint32_t *members = p.pair_slots + (static_cast<size_t>(real) * d.n_temps + t) * d.n_replicas + g * group;
+    const uint32_t sa = FK ? task : members[0];
+    const uint32_t sb = FK ? task : members[1];
     uint32_t *Sa = p.S + (static_cast<size_t>(real) * d.W + (sa >> 5)) * d.N;
     uint32_t *Sb = p.S + (static_cast<size_t>(real) * d.W + (sb >> 5)) * d.N;
     const uint32_t ba = sa & 31u, bb = sb & 31u;
     const uint16_t *jsite = p.jsite + static_cast<size_t>(real) * d.N;
-    uint64_t *rng_state = FK ? nullptr : p.pair_rng + (static_cast<size_t>(real) * n_lanes + task) * 4;
+    // generator of the task: pair generator t * n_pairs + g (overlap.rs:197), or the system's cursor
+    uint64_t *rng_state = FK ? nullptr : p.pair_rng + (static_cast<size_t>(real) * d.n_temps * d.n_pairs +
+                                                       static_cast<size_t>(t) * d.n_pairs + g) * 4;
+    uint32_t *Stile = p.S + static_cast<size_t>(real) * d.W * d.N; // all words (groups above two)
     const uint32_t n_rounds = (d.N + kSwThreads - 1) / kSwThreads; // site i = r * 256 + tid
     // write the ballot of a predicate over sites r*256 + tid into a bitmap (two words per wave)
     auto put_ballot = [&](uint32_t *bitmap, uint32_t r, bool pred) {
@@ -172,7 +180,15 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p)
             a = (Sa[i] >> ba) & 1u;
             b = (Sb[i] >> bb) & 1u;
         }
-        put_ballot(L.act, r, (FK || CMR) ? i < d.N : (a ^ b) != 0);
+        bool active = (FK || CMR) ? i < d.N : (a ^ b) != 0;
+        if (MODE == kSwHoudayer && group > 2) { // the group's spins sum to zero (overlap.rs:199-205)
+            uint32_t minus = 0;
+            if (i < d.N)
+                for (uint32_t k = 0; k < group; ++k)
+                    minus += (Stile[static_cast<size_t>(members[k] >> 5) * d.N + i] >> (members[k] & 31u)) & 1u;
+            active = i < d.N && 2 * minus == group;
+        }
+        put_ballot(L.act, r, active);
         put_ballot(L.spa, r, a != 0);
         put_ballot(L.spb, r, b != 0);
     }
@@ -359,6 +375,34 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p)
             __syncthreads();
         }
 
+        if (MODE == kSwHoudayer && wolff) {
+            // single-cluster variant: up to 64 probes for an active seed (utils.rs:107-119), flip its component
+            if (tid == 0) {
+                DevRng rng;
+                rng.s0 = (static_cast<uint64_t>(base_state[1]) << 32) | base_state[0];
+                rng.s1 = (static_cast<uint64_t>(base_state[3]) << 32) | base_state[2];
+                rng.s2 = (static_cast<uint64_t>(base_state[5]) << 32) | base_state[4];
+                rng.s3 = (static_cast<uint64_t>(base_state[7]) << 32) | base_state[6];
+                uint32_t root = 0xFFFFFFFFu;
+                const uint64_t range = d.N, zone = (range << __clzll(range)) - 1ull;
+                for (int probe = 0; probe < 64 && root == 0xFFFFFFFFu; ++probe) {
+                    uint64_t v;
+                    do v = rng.next(); while (v * range > zone);
+                    const uint32_t i = static_cast<uint32_t>(__umul64hi(v, range));
+                    if (get_bit(L.act, i)) root = L.label[i];
+                }
+                L.misc[1] = root;
+                rng_state[0] = rng.s0; rng_state[1] = rng.s1; rng_state[2] = rng.s2; rng_state[3] = rng.s3;
+            }
+            __syncthreads();
+            const uint32_t root = L.misc[1];
+            for (uint32_t i = tid; i < d.N; i += kSwThreads)
+                if (root != 0xFFFFFFFFu && L.label[i] == root)
+                    for (uint32_t k = 0; k < group; ++k)
+                        atomicXor(&Stile[static_cast<size_t>(members[k] >> 5) * d.N + i], 1u << (members[k] & 31u));
+            return;
+        }
+
         // ---- G: clusters that draw -- more than one site for the overlap moves (overlap.rs:312-318,
         // :757-762, :822-828), every cluster for FK (fk.rs:182-192) -- ranked by their smallest site
         for (uint32_t i = tid; i < d.N; i += kSwThreads) L.aux[i] = 0;
@@ -430,6 +474,12 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p)
     }
     // ---- apply the accumulated flips to the bit columns of the systems
     for (uint32_t i = tid; i < d.N; i += kSwThreads) {
+        if (MODE == kSwHoudayer && group > 2) { // every replica of the group flips with the cluster
+            if (get_bit(L.flip_a, i))
+                for (uint32_t k = 0; k < group; ++k)
+                    atomicXor(&Stile[static_cast<size_t>(members[k] >> 5) * d.N + i], 1u << (members[k] & 31u));
+            continue;
+        }
         if (get_bit(L.flip_a, i)) atomicXor(&Sa[i], 1u << ba);
         if (!FK && get_bit(L.flip_b, i)) atomicXor(&Sb[i], 1u << bb);
     }
@@ -554,8 +604,9 @@ __global__ __launch_bounds__(1024) void k_cmr_wolff(SimDims d, DevPtrs p) {
         uint64_t *st = p.pair_rng + (static_cast<size_t>(real) * n_lanes + task) * 4;
         DevRng rng;
         rng.s0 = st[0]; rng.s1 = st[1]; rng.s2 = st[2]; rng.s3 = st[3];
-        const uint32_t sa = p.pair_slots[(static_cast<size_t>(real) * n_lanes + task) * 2 + 0];
-        const uint32_t sb = p.pair_slots[(static_cast<size_t>(real) * n_lanes + task) * 2 + 1];
+        const uint32_t *members = p.pair_slots + (static_cast<size_t>(real) * d.n_temps + task / d.n_pairs) * d.n_replicas +
+                                  2 * (task % d.n_pairs);
+        const uint32_t sa = members[0], sb = members[1];
         uint32_t *wa = tile + (sa >> 5) * d.N, *wb = tile + (sb >> 5) * d.N;
         const uint32_t ba = sa & 31u, bb = sb & 31u;
         const uint32_t t = task / d.n_pairs;
@@ -659,15 +710,17 @@ hipError_t configure_cluster_kernels() {
     return hipSuccess;
 }
 
-hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, hipStream_t stream) {
+hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, uint32_t group, bool wolff,
+                             hipStream_t stream) {
     hipLaunchKernelGGL(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
-    const dim3 grid(d.n_real * d.n_temps * d.n_pairs), block(kSwThreads);
+    const dim3 grid(d.n_real * d.n_temps * (d.n_replicas / group)), block(kSwThreads);
+    const size_t lds = cluster_sw_lds_bytes(d);
     if (oc_mode == 2) // PA_OC_JORG
-        hipLaunchKernelGGL(k_cluster_sw<kSwJorg>, grid, block, cluster_sw_lds_bytes(d), stream, d, p);
+        hipLaunchKernelGGL(k_cluster_sw<kSwJorg>, grid, block, lds, stream, d, p, 2u, 0);
     else if (oc_mode == 3) // PA_OC_CMR
-        hipLaunchKernelGGL(k_cluster_sw<kSwCmr>, grid, block, cluster_sw_lds_bytes(d), stream, d, p);
+        hipLaunchKernelGGL(k_cluster_sw<kSwCmr>, grid, block, lds, stream, d, p, 2u, 0);
     else
-        hipLaunchKernelGGL(k_cluster_sw<kSwHoudayer>, grid, block, cluster_sw_lds_bytes(d), stream, d, p);
+        hipLaunchKernelGGL(k_cluster_sw<kSwHoudayer>, grid, block, lds, stream, d, p, group, wolff ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -678,7 +731,7 @@ hipError_t launch_fk(const SimDims &d, const DevPtrs &p, bool wolff, hipStream_t
         hipLaunchKernelGGL(k_fk_wolff, dim3(d.n_real), dim3(1024), fk_wolff_lds_bytes(d), stream, d, p);
     else
         hipLaunchKernelGGL(k_cluster_sw<kSwFk>, dim3(d.n_real * d.n_sys), dim3(kSwThreads),
-                           cluster_sw_lds_bytes(d), stream, d, p);
+                           cluster_sw_lds_bytes(d), stream, d, p, 1u, 0);
     return hipGetLastError();
 }
 

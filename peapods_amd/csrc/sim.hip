@@ -433,12 +433,12 @@ int ensure_cluster_sw(pa_sim *sim) {
         const float r = expf(-2.0f * 1.0f / sim->temps[t]);
         thr_cmr[t] = as_threshold(1.0f - r * r);
     }
-    const size_t n_lanes = static_cast<size_t>(d.n_temps) * d.n_pairs;
     PA_HIP(sim, sim->buffers.alloc(&sim->jump256, jump.size()));
     PA_HIP(sim, sim->buffers.alloc(&sim->jorg_thr, thr.size()));
     PA_HIP(sim, sim->buffers.alloc(&sim->fk_thr, thr_fk.size()));
     PA_HIP(sim, sim->buffers.alloc(&sim->cmr_thr, thr_cmr.size()));
-    PA_HIP(sim, sim->buffers.alloc(&sim->p.pair_slots, n_lanes * 2 * d.n_real));
+    const size_t slots_per_real = static_cast<size_t>(d.n_temps) * d.n_replicas;
+    PA_HIP(sim, sim->buffers.alloc(&sim->p.pair_slots, slots_per_real * d.n_real));
     int rc;
     if ((rc = upload(sim, sim->jump256, jump)) || (rc = upload(sim, sim->jorg_thr, thr)) ||
         (rc = upload(sim, sim->fk_thr, thr_fk)) || (rc = upload(sim, sim->cmr_thr, thr_cmr)))
@@ -454,7 +454,7 @@ int ensure_cluster_sw(pa_sim *sim) {
         g.p.jorg_thr = sim->jorg_thr;
         g.p.fk_thr = sim->fk_thr;
         g.p.cmr_thr = sim->cmr_thr;
-        g.p.pair_slots = sim->p.pair_slots + n_lanes * 2 * r0;
+        g.p.pair_slots = sim->p.pair_slots + slots_per_real * r0;
         r0 += g.d.n_real;
     }
     return PA_OK;
@@ -518,10 +518,23 @@ std::string validate_text(const pa_sample_config *cfg, uint64_t n_replicas, int 
         return "unknown cluster_mode, expected 'wolff' or 'sw'";
     *code = PA_ERR_UNSUPPORTED;
     if (cfg->overlap_cluster_interval > 0) {
-        for (int k = 0; k < cfg->n_overlap_cluster_modes && k < 4; ++k)
-            if (cfg->overlap_cluster_modes[k] != PA_OC_HOUDAYER && cfg->overlap_cluster_modes[k] != PA_OC_JORG &&
-                cfg->overlap_cluster_modes[k] != PA_OC_CMR)
+        for (int k = 0; k < cfg->n_overlap_cluster_modes && k < 4; ++k) {
+            // mode = PA_OC_* | group_size << 8 (group size 0 = 2; "houdN", config.rs:124-141)
+            const int kind = cfg->overlap_cluster_modes[k] & 0xFF, group = cfg->overlap_cluster_modes[k] >> 8;
+            if (kind != PA_OC_HOUDAYER && kind != PA_OC_JORG && kind != PA_OC_CMR) {
+                *code = PA_ERR_INVALID;
                 return "unknown overlap-cluster build mode";
+            }
+            if (group != 0 && (kind != PA_OC_HOUDAYER || group < 2 || group % 2 != 0 || group > 32)) {
+                *code = PA_ERR_INVALID;
+                return "Houdayer group size must be even and >= 2, got " + std::to_string(group);
+            }
+            if (group > 2 && static_cast<uint64_t>(group) > n_replicas) { // simulation/mod.rs:207-214
+                *code = PA_ERR_INVALID;
+                return "overlap cluster requires n_replicas >= max group_size (" + std::to_string(n_replicas) +
+                       " < " + std::to_string(group) + ")";
+            }
+        }
         if (cfg->overlap_cluster_mode != PA_CLUSTER_WOLFF && cfg->overlap_cluster_mode != PA_CLUSTER_SW) {
             *code = PA_ERR_INVALID;
             return "unknown overlap_cluster_mode, expected 'wolff' or 'sw'";
@@ -539,7 +552,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                     "overlap-cluster moves are not built for lattices above 12000 sites yet");
     if (d.general && cfg->overlap_cluster_interval > 0)
         for (int k = 0; k < cfg->n_overlap_cluster_modes && k < 4; ++k)
-            if (cfg->overlap_cluster_modes[k] == PA_OC_JORG || cfg->overlap_cluster_modes[k] == PA_OC_CMR)
+            if ((cfg->overlap_cluster_modes[k] & 0xFF) == PA_OC_JORG || (cfg->overlap_cluster_modes[k] & 0xFF) == PA_OC_CMR)
                 return fail(sim, PA_ERR_UNSUPPORTED,
                             "the 'jorg' and 'cmr' moves need expf of arbitrary couplings, which is not "
                             "built on the HIP path yet (unit couplings only)");
@@ -551,7 +564,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     const bool oc_sw = cfg->overlap_cluster_interval > 0 && cfg->overlap_cluster_mode == PA_CLUSTER_SW;
     bool oc_cmr = false;
     for (int k = 0; cfg->overlap_cluster_interval > 0 && k < cfg->n_overlap_cluster_modes && k < 4; ++k)
-        oc_cmr = oc_cmr || cfg->overlap_cluster_modes[k] == PA_OC_CMR;
+        oc_cmr = oc_cmr || (cfg->overlap_cluster_modes[k] & 0xFF) == PA_OC_CMR || (cfg->overlap_cluster_modes[k] >> 8) > 2;
     const bool fk = cfg->cluster_interval > 0;
     if (fk && d.general)
         return fail(sim, PA_ERR_UNSUPPORTED,
@@ -656,8 +669,10 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                     return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the overlap-cluster kernel");
                 const int oc_mode = cfg->overlap_cluster_modes[overlap_call_count %
                                                                static_cast<uint64_t>(cfg->n_overlap_cluster_modes)];
-                if (oc_sw)
-                    PA_HIP(sim, launch_cluster_sw(g.d, g.p, oc_mode, g.stream));
+                const int oc_kind = oc_mode & 0xFF;
+                const uint32_t oc_group = (oc_mode >> 8) > 2 ? static_cast<uint32_t>(oc_mode >> 8) : 2u;
+                if (oc_sw || oc_group > 2) // union-find variants; groups above two also for the single-cluster variant
+                    PA_HIP(sim, launch_cluster_sw(g.d, g.p, oc_kind, oc_group, !oc_sw, g.stream));
                 else if (oc_mode == PA_OC_CMR)
                     PA_HIP(sim, launch_cmr_wolff(g.d, g.p, g.stream)); // :845-965
                 else if (oc_mode == PA_OC_JORG)

@@ -405,6 +405,24 @@ def test_cmr_overlap_cluster_move_matches_oracle(oracle, inner, mode, shape, n_t
     assert_state_equal(gpu, cpu, check_energy=False)
 
 
+@pytest.mark.parametrize("inner", ["sw", "wolff"])
+@pytest.mark.parametrize("mode,n_rep", [("houd4", 4), ("houd4", 8), ("houd6", 6), ("cmr+houd4", 4),
+                                        ("houdayer+houd4+jorg", 5)])
+def test_houdayer_groups_of_n_replicas_match_oracle(oracle, inner, mode, n_rep):
+    """"houdN" (overlap.rs:153-339 with group_size N; experimental upstream but part of its test
+    protocols, tests/spin_glass_crossings.py:139-176): N replicas whose spins sum to zero on the
+    active sites flip together."""
+    shape = (6, 6, 6)
+    couplings = bimodal(shape, 3, 2, 51)
+    gpu, cpu = make_pair(oracle, shape, couplings, np.linspace(0.8, 1.8, 4), n_rep, 61)
+    kwargs = dict(pt_interval=1, overlap_cluster_update_interval=1, overlap_cluster_build_mode=mode,
+                  overlap_cluster_mode=inner, warmup_ratio=0.25)
+    a = gpu.sample(12, "metropolis", **kwargs)
+    b = cpu.sample(12, "metropolis", **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+
+
 def test_cmr_with_diluted_couplings(oracle):
     shape = (8, 8, 8)
     rng = np.random.default_rng(4)
@@ -531,11 +549,15 @@ def test_autocorrelation_times_match_oracle(oracle, n_rep):
     assert_results_equal(a, b)
 
 
-@pytest.mark.parametrize("move", [dict(), dict(overlap_cluster_build_mode="cmr", overlap_cluster_mode="sw"),
-                                  dict(overlap_cluster_build_mode="jorg", overlap_cluster_mode="sw")])
-def test_3d_ea_glass_binder_curves_cross(move):
-    """The reference's spin-glass checks (tests/spin_glass_crossings.py:14-128, tests/utils.py:15-47):
-    3D +-J glass, L = 8 and 10, 12 temperatures 0.8..1.4, 2 replicas, 25 disorder samples, 10000
+@pytest.mark.parametrize("n_rep,move", [
+    (2, dict()),
+    (2, dict(overlap_cluster_build_mode="cmr", overlap_cluster_mode="sw")),
+    (2, dict(overlap_cluster_build_mode="jorg", overlap_cluster_mode="sw")),
+    (4, dict(overlap_cluster_build_mode="cmr+houd4", overlap_cluster_mode="sw")),
+])
+def test_3d_ea_glass_binder_curves_cross(n_rep, move):
+    """The reference's spin-glass checks (tests/spin_glass_crossings.py:14-176, tests/utils.py:15-47):
+    3D +-J glass, L = 8 and 10, 12 temperatures 0.8..1.4, 2 (4) replicas, 25 disorder samples, 10000
     sweeps of Metropolis + tempering + the overlap move; the spin-glass Binder ratios of the two
     sizes agree at T_c = 1.102 within 0.3 and the histogram Binder matches the direct one."""
     import peapods_amd as peapods
@@ -544,7 +566,7 @@ def test_3d_ea_glass_binder_curves_cross(move):
     temps = np.linspace(0.8, 1.4, 12).astype(np.float32)
     at_tc = []
     for size in (8, 10):
-        model = peapods.Ising((size, size, size), couplings="bimodal", temperatures=temps, n_replicas=2,
+        model = peapods.Ising((size, size, size), couplings="bimodal", temperatures=temps, n_replicas=n_rep,
                               n_disorder=25, seed=42)
         model.sample(10000, sweep_mode="metropolis", pt_interval=1, overlap_cluster_update_interval=1,
                      warmup_ratio=0.25, **move)
@@ -601,6 +623,8 @@ def test_unbuilt_overlap_modes_are_refused_not_emulated():
     sim = IsingSimulation([4, 4], couplings, np.array([1.0, 2.0], np.float32), 2, None, 1)
     before = sim.get_spins().copy()
     with pytest.raises(NotImplementedError):
-        sim.sample(2, "metropolis", overlap_cluster_update_interval=1,
-                   overlap_cluster_build_mode="houd4")
+        sim.sample(2, "metropolis", overlap_cluster_update_interval=1, overlap_cluster_action="observe",
+                   overlap_cluster_mode="sw")
+    with pytest.raises(ValueError, match="n_replicas >= max group_size"):
+        sim.sample(2, "metropolis", overlap_cluster_update_interval=1, overlap_cluster_build_mode="houd4")
     np.testing.assert_array_equal(sim.get_spins(), before)

@@ -42,6 +42,7 @@ struct SimDims {
     uint32_t dense_nn;   // = nn when every bond of every realisation is non-zero, else 0
     uint32_t pipe_K;     // large unit-coupling lattices: slabs of the pipelined sweep (0 = not used)
     uint32_t n_levels;   // dependency levels of the schedule
+    uint32_t unit;       // 1: every coupling is -1, 0 or +1 and every T/2 > 0 (cluster moves use integer thresholds)
     uint32_t general;    // 1: arbitrary f32 couplings / temperatures -> the reference's logarithmic rule
                          //    (kernels_general.hip); Esum then holds raw f32 bits of the energy sum
 };
@@ -87,8 +88,9 @@ struct DevPtrs {
     uint32_t *swap_epoch;    // [n_real] bumped by every event that accepted a swap
     uint32_t *applied_epoch; // [n_real][W] epoch whose swaps are already in S
     uint32_t *big_counts;     // [n_real][n_sys][4] u32 scratch counters of the large-lattice kernels
-    const uint16_t *nbr_site; // [N][6] neighbours by site: f0, b0, f1, b1, f2, b2 (self when unused)
-    const uint16_t *jsite;    // [n_real][N] by site: neg[0..5] | nz[6..11] for bonds f0,b0,f1,b1,f2,b2
+    const uint16_t *nbr_site; // [N][12] neighbours by site: f0, b0, f1, b1, ... f5, b5 (self when unused)
+    const uint32_t *jsite;    // [n_real][N] by site: neg[0..11] | nz[12..23] for bonds f0,b0,...,f5,b5
+    const uint32_t *nbr_wide; // [N][16] in schedule order: site, f0, b0, ..., f5, b5, 0, 0, 0 (general path)
     const float *jorg_p;      // [n_temps] 1 - exp(-4 / T) by the host libm (Joerg bond probability)
     uint16_t *dfs_stack;      // [n_real][n_temps * n_pairs][N] scratch of k_jorg
     uint64_t *pair_rng;      // [n_real][n_temps * n_pairs][4] xoshiro state of the overlap-move generators

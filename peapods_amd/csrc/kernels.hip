@@ -813,6 +813,71 @@ __device__ __forceinline__ void overlap_block(const SimDims &d, const DevPtrs &p
     }
 }
 
+// Lattices with four to six forward directions (bcc, fcc): the same pair-difference word, neighbours
+// from the wide table, and the up to six bond terms of a site counted as two groups of three.
+__global__ __launch_bounds__(256) void k_overlap_wide(SimDims d, DevPtrs p) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t n1 = d.N + 1;
+    uint32_t *Y = lds;
+    uint32_t *scratch = lds + n1; // [5][80]
+    const uint32_t real = blockIdx.x / d.W, w = blockIdx.x % d.W;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t q = d.n_temps >> 5, r = d.n_temps & 31u;
+    const uint32_t wa = w + q, wb = w + q + 1;
+    const uint32_t *Sg = p.S + static_cast<size_t>(real) * d.W * d.N;
+    const uint32_t *A = Sg + static_cast<size_t>(w) * d.N;
+    const uint32_t *B0 = wa < d.W ? Sg + static_cast<size_t>(wa) * d.N : nullptr;
+    const uint32_t *B1 = (r && wb < d.W) ? Sg + static_cast<size_t>(wb) * d.N : nullptr;
+    for (uint32_t i = tid; i < d.N; i += 256) {
+        const uint32_t v0 = B0 ? B0[i] : 0u, v1 = B1 ? B1[i] : 0u;
+        Y[i] = A[i] ^ (r ? ((v0 >> r) | (v1 << (32 - r))) : v0);
+    }
+    __syncthreads();
+    uint32_t c[5][8];
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[s][j] = 0;
+    for (uint32_t base = 0; base < d.N; base += 16 * 256) {
+        uint32_t qa[16], s1[16], c1[16], s2[16], c2[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t pos = base + k * 256 + tid;
+            qa[k] = s1[k] = c1[k] = s2[k] = c2[k] = 0;
+            if (pos < d.N) {
+                const uint32_t *row = p.nbr_wide + static_cast<size_t>(pos) * 16;
+                const uint32_t y = Y[row[0]];
+                uint32_t z[6];
+#pragma unroll
+                for (int dir = 0; dir < 6; ++dir) // 1 where q_i * q_k = -1
+                    z[dir] = dir < static_cast<int>(d.nn) ? (y ^ Y[row[1 + 2 * dir]]) : 0u;
+                qa[k] = y;
+                s1[k] = z[0] ^ z[1] ^ z[2];
+                c1[k] = maj3(z[0], z[1], z[2]);
+                s2[k] = z[3] ^ z[4] ^ z[5];
+                c2[k] = maj3(z[3], z[4], z[5]);
+            }
+        }
+        count16(qa, c[0]);
+        count16(s1, c[1]);
+        count16(c1, c[2]);
+        count16(s2, c[3]);
+        count16(c2, c[4]);
+    }
+    uint32_t tot[5];
+    block_bit_totals<5>(c, scratch, tot);
+    if (tid < 32) {
+        const uint32_t k = w * 32 + tid;
+        const uint32_t rep = k / d.n_temps, t = k % d.n_temps;
+        if (k < d.n_sys && (rep & 1u) == 0 && rep + 1 < d.n_replicas) {
+            const size_t o = (static_cast<size_t>(real) * d.n_pairs + (rep >> 1)) * d.n_temps + t;
+            p.dot_spin[o] = static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(tot[0]);
+            p.dot_link[o] = static_cast<int32_t>(d.N * d.nn) -
+                            2 * static_cast<int32_t>(tot[1] + tot[3] + 2 * (tot[2] + tot[4]));
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_overlap(SimDims d, DevPtrs p) {
     extern __shared__ uint32_t lds_dyn[];
     overlap_block(d, p, blockIdx.x, lds_dyn);
@@ -1357,7 +1422,7 @@ __global__ __launch_bounds__(1024) void k_jorg(SimDims d, DevPtrs p) {
     uint32_t *pair_slots = member + static_cast<size_t>(n_lanes) * d.MW; // [n_lanes][2]
     const uint32_t real = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
     uint32_t *Sg = p.S + static_cast<size_t>(real) * tile_words;
-    const uint16_t *jsite = p.jsite + static_cast<size_t>(real) * d.N;
+    const uint32_t *jsite = p.jsite + static_cast<size_t>(real) * d.N;
     uint64_t *prng = p.pair_rng + static_cast<size_t>(real) * n_lanes * 4;
     uint16_t *stack = p.dfs_stack + (static_cast<size_t>(real) * n_lanes + tid) * d.N;
 
@@ -1416,11 +1481,11 @@ __global__ __launch_bounds__(1024) void k_jorg(SimDims d, DevPtrs p) {
                 const uint32_t site = stack[--top];
                 const uint32_t jm = jsite[site];
                 for (uint32_t dir = 0; dir < 2 * d.nn; ++dir) { // f0, b0, f1, b1, ...
-                    const uint32_t nb = p.nbr_site[site * 6 + dir];
+                    const uint32_t nb = p.nbr_site[site * 12 + dir];
                     if ((mine[nb >> 5] >> (nb & 31u)) & 1u) continue;
                     if (!active(nb)) continue;
                     // inter = s_a(site) * s_a(nb) * J(bond) must be > 0
-                    if (!((jm >> (6 + dir)) & 1u)) continue;
+                    if (!((jm >> (12 + dir)) & 1u)) continue;
                     if ((spin_a(site) ^ spin_a(nb) ^ ((jm >> dir) & 1u)) != 0) continue;
                     const uint32_t draw = static_cast<uint32_t>(rng.next() >> 40);
                     const float u = __fmul_rn(static_cast<float>(draw), 1.0f / 16777216.0f);
@@ -1706,6 +1771,7 @@ hipError_t configure_kernels(const SimDims &) {
                            reinterpret_cast<const void *>(k_sweep<true, 0>),
                            reinterpret_cast<const void *>(k_sweep<true, 3>),
                            reinterpret_cast<const void *>(k_overlap),
+                           reinterpret_cast<const void *>(k_overlap_wide),
                            reinterpret_cast<const void *>(k_rng_overlap<false>),
                            reinterpret_cast<const void *>(k_rng_overlap<true>),
                            reinterpret_cast<const void *>(k_houdayer),
@@ -1816,6 +1882,11 @@ hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream
                            n_chunks);
         hipLaunchKernelGGL(k_big_finalize, dim3((d.n_real * d.n_sys + 255) / 256), dim3(256), 0,
                            stream, d, p, 1);
+        return hipGetLastError();
+    }
+    if (d.nn > 3) {
+        hipLaunchKernelGGL(k_overlap_wide, dim3(d.n_real * d.W), dim3(256),
+                           ((static_cast<size_t>(d.N) + 1) + 5 * 80) * 4, stream, d, p);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_overlap, dim3(d.n_real * d.W), dim3(256), overlap_lds_bytes(d), stream, d, p);

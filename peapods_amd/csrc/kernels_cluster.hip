@@ -96,8 +96,8 @@ struct SwLds {
     uint32_t *act;     // [MW] active sites (the pair's spins differ)
     uint32_t *spa;     // [MW] spin of the pair's first system (1 <=> -1)
     uint32_t *spb;     // [MW] spin of the pair's second system
-    uint32_t *bond;    // [3][MW] eligible, later accepted, forward bonds per direction
-    uint32_t *blue;    // [3][MW] CMR: accepted blue bonds, kept for the grey clusters
+    uint32_t *bond;    // [6][MW] eligible, later accepted, forward bonds per direction
+    uint32_t *blue;    // [6][MW] CMR: accepted blue bonds, kept for the grey clusters
     uint32_t *wbase;   // [MW + 1] exclusive prefix (eligible bonds / drawing roots) per 32-site word
     uint32_t *roots;   // [MW] roots that draw
     uint32_t *flip_a;  // [MW] accumulated flips of the first system
@@ -112,7 +112,7 @@ __host__ __device__ inline size_t cluster_sw_bit_words(const SimDims &d) {
     return (static_cast<size_t>(d.N) * d.nn + 255) / 256 * 8 + 16;
 }
 __host__ __device__ inline size_t cluster_sw_lds_words(const SimDims &d) {
-    return 2 * static_cast<size_t>(d.N) + 14 * static_cast<size_t>(d.MW) + 1 + 2 * cluster_sw_bit_words(d) + 12;
+    return 2 * static_cast<size_t>(d.N) + 20 * static_cast<size_t>(d.MW) + 1 + 2 * cluster_sw_bit_words(d) + 12;
 }
 
 enum { kSwHoudayer = 0, kSwJorg = 1, kSwFk = 2, kSwCmr = 3 };
@@ -134,8 +134,8 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
         L.act = q; q += d.MW;
         L.spa = q; q += d.MW;
         L.spb = q; q += d.MW;
-        L.bond = q; q += 3 * d.MW;
-        L.blue = q; q += 3 * d.MW;
+        L.bond = q; q += 6 * d.MW;
+        L.blue = q; q += 6 * d.MW;
         L.wbase = q; q += d.MW + 1;
         L.roots = q; q += d.MW;
         L.flip_a = q; q += d.MW;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
     uint32_t *Sa = p.S + (static_cast<size_t>(real) * d.W + (sa >> 5)) * d.N;
     uint32_t *Sb = p.S + (static_cast<size_t>(real) * d.W + (sb >> 5)) * d.N;
     const uint32_t ba = sa & 31u, bb = sb & 31u;
-    const uint16_t *jsite = p.jsite + static_cast<size_t>(real) * d.N;
+    const uint32_t *jsite = p.jsite + static_cast<size_t>(real) * d.N;
     // generator of the task: pair generator t * n_pairs + g (overlap.rs:197), or the system's cursor
     uint64_t *rng_state = FK ? nullptr : p.pair_rng + (static_cast<size_t>(real) * d.n_temps * d.n_pairs +
                                                        static_cast<size_t>(t) * d.n_pairs + g) * 4;
@@ -284,14 +284,14 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
         // exactly one (:779-792).
         for (uint32_t r = 0; r < n_rounds; ++r) {
             const uint32_t i = r * kSwThreads + tid;
-            bool e[3] = {false, false, false};
+            bool e[6] = {false, false, false, false, false, false};
             if (i < d.N && get_bit(L.act, i)) {
                 const uint32_t jm = STOCHASTIC ? jsite[i] : 0u;
                 for (uint32_t dd = 0; dd < d.nn; ++dd) {
-                    const uint32_t j = p.nbr_site[i * 6 + 2 * dd];
+                    const uint32_t j = p.nbr_site[i * 12 + 2 * dd];
                     bool ok = get_bit(L.act, j) != 0;
                     if (STOCHASTIC && ok) {
-                        const bool nz = (jm >> (6 + 2 * dd)) & 1u;
+                        const bool nz = (jm >> (12 + 2 * dd)) & 1u;
                         const uint32_t neg = (jm >> (2 * dd)) & 1u;
                         const bool a_sat = (get_bit(L.spa, i) ^ get_bit(L.spa, j) ^ neg) == 0;
                         if (CMR) {
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
                     e[dd] = ok;
                 }
             }
-            for (uint32_t dd = 0; dd < 3; ++dd) put_ballot(L.bond + dd * d.MW, r, e[dd]);
+            for (uint32_t dd = 0; dd < 6; ++dd) put_ballot(L.bond + dd * d.MW, r, e[dd]);
         }
         __syncthreads();
 
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
             const uint32_t rel = pos - (pos / 256) * 256;
             for (uint32_t r = 0; r < n_rounds; ++r) {
                 const uint32_t i = r * kSwThreads + tid;
-                bool e[3] = {false, false, false};
+                bool e[6] = {false, false, false, false, false, false};
                 if (i < d.N)
                     for (uint32_t dd = 0; dd < d.nn; ++dd)
                         if (get_bit(L.bond + dd * d.MW, i)) {
@@ -331,12 +331,12 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
                             e[dd] = (L.bits[q >> 5] >> (q & 31u)) & 1u;
                         }
                 __syncthreads(); // every thread has read its bond words before any is replaced
-                for (uint32_t dd = 0; dd < 3; ++dd) put_ballot(L.bond + dd * d.MW, r, e[dd]);
+                for (uint32_t dd = 0; dd < 6; ++dd) put_ballot(L.bond + dd * d.MW, r, e[dd]);
                 __syncthreads();
             }
             pos += n_eligible;
             if (CMR && phase == 0) { // keep the blue bonds: grey clusters are blue + red
-                for (uint32_t m = tid; m < 3 * d.MW; m += kSwThreads) L.blue[m] = L.bond[m];
+                for (uint32_t m = tid; m < 6 * d.MW; m += kSwThreads) L.blue[m] = L.bond[m];
                 __syncthreads();
             }
         }
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
             for (uint32_t i = tid; i < d.N; i += kSwThreads)
                 for (uint32_t dd = 0; dd < d.nn; ++dd)
                     if (bonded(dd, i)) {
-                        const uint32_t j = p.nbr_site[i * 6 + 2 * dd];
+                        const uint32_t j = p.nbr_site[i * 12 + 2 * dd];
                         const uint32_t ra = find_root(i), rb = find_root(j);
                         if (ra != rb) {
                             atomicMin(&L.label[max(ra, rb)], min(ra, rb));
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(1024) void k_fk_wolff(SimDims d, DevPtrs p) {
     uint32_t *member = lds + tile_words;  // [n_sys][MW] cluster bitmaps
     const uint32_t real = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
     uint32_t *Sg = p.S + static_cast<size_t>(real) * tile_words;
-    const uint16_t *jsite = p.jsite + static_cast<size_t>(real) * d.N;
+    const uint32_t *jsite = p.jsite + static_cast<size_t>(real) * d.N;
 
     copy_to_lds(tile, Sg, static_cast<uint32_t>(tile_words), tid, nthreads);
     for (size_t i = tid; i < static_cast<size_t>(d.n_sys) * d.MW; i += nthreads) member[i] = 0;
@@ -542,9 +542,9 @@ __global__ __launch_bounds__(1024) void k_fk_wolff(SimDims d, DevPtrs p) {
             const uint32_t jm = jsite[site];
             const uint32_t s_site = (wa[site] >> ba) & 1u;
             for (uint32_t dir = 0; dir < 2 * d.nn; ++dir) { // f0, b0, f1, b1, ...
-                const uint32_t nb = p.nbr_site[site * 6 + dir];
+                const uint32_t nb = p.nbr_site[site * 12 + dir];
                 if ((mine[nb >> 5] >> (nb & 31u)) & 1u) continue;
-                if (!((jm >> (6 + dir)) & 1u)) continue;                       // J = 0
+                if (!((jm >> (12 + dir)) & 1u)) continue;                      // J = 0
                 if ((s_site ^ ((wa[nb] >> ba) & 1u) ^ ((jm >> dir) & 1u)) != 0) continue; // s s J <= 0
                 const uint32_t draw = static_cast<uint32_t>(rng.next() >> 40);
                 if (draw < threshold) {
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(1024) void k_cmr_wolff(SimDims d, DevPtrs p) {
     uint32_t *member = lds + tile_words;   // [n_lanes][MW] cluster bitmaps
     const uint32_t real = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
     uint32_t *Sg = p.S + static_cast<size_t>(real) * tile_words;
-    const uint16_t *jsite = p.jsite + static_cast<size_t>(real) * d.N;
+    const uint32_t *jsite = p.jsite + static_cast<size_t>(real) * d.N;
 
     copy_to_lds(tile, Sg, static_cast<uint32_t>(tile_words), tid, nthreads);
     for (size_t i = tid; i < static_cast<size_t>(n_lanes) * d.MW; i += nthreads) member[i] = 0;
@@ -637,9 +637,9 @@ __global__ __launch_bounds__(1024) void k_cmr_wolff(SimDims d, DevPtrs p) {
                 const uint32_t site = stack[--top];
                 const uint32_t jm = jsite[site];
                 for (uint32_t dir = 0; dir < 2 * d.nn; ++dir) { // f0, b0, f1, b1, ...
-                    const uint32_t nb = p.nbr_site[site * 6 + dir];
+                    const uint32_t nb = p.nbr_site[site * 12 + dir];
                     if (in_cluster(nb)) continue;
-                    if (!((jm >> (6 + dir)) & 1u)) continue; // J = 0: neither system is satisfied
+                    if (!((jm >> (12 + dir)) & 1u)) continue; // J = 0: neither system is satisfied
                     const bool a_sat = sat(wa, ba, site, nb, jm, dir), b_sat = sat(wb, bb, site, nb, jm, dir);
                     if (phase == 0 ? !(a_sat && b_sat) : (a_sat == b_sat)) continue;
                     const uint32_t draw = static_cast<uint32_t>(rng.next() >> 40);

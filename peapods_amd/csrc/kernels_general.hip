@@ -157,9 +157,12 @@ __global__ __launch_bounds__(256) void k_rng_f(SimDims d, DevPtrs p) {
 //  BIG: both stay in global memory (spins through agent-scope atomics, as in k_sweep_big).
 // ---------------------------------------------------------------------------
 constexpr uint32_t kSweepFThreads = 512;
+// couplings per site in the LDS copy (float4 up to three directions, two float4 up to six)
+template <int NN> struct JRow { static constexpr int kWidth = NN <= 3 ? 4 : 8; };
 
 template <bool BIG, int NN>
 __global__ __launch_bounds__(kSweepFThreads) void k_sweep_f(SimDims d, DevPtrs p) {
+    constexpr int JW = JRow<NN>::kWidth;
     extern __shared__ uint32_t lds[];
     const uint32_t real = blockIdx.x / d.W, w = blockIdx.x % d.W;
     const uint32_t tid = threadIdx.x;
@@ -169,43 +172,34 @@ __global__ __launch_bounds__(kSweepFThreads) void k_sweep_f(SimDims d, DevPtrs p
     const float4 *thr = reinterpret_cast<const float4 *>(p.thr_f + static_cast<size_t>(tw) * d.N * 32);
     const uint32_t n_pad = (d.N + 3u) & ~3u;
     uint32_t *sw = lds;                                      // [N]
-    float4 *J4 = reinterpret_cast<float4 *>(lds + n_pad);    // [N] forward couplings of each site
+    float *Jl = reinterpret_cast<float *>(lds + n_pad);      // [N][JW] forward couplings of each site
     if (!BIG) {
         copy_to_lds(sw, Sg, d.N, tid, kSweepFThreads);
-        for (uint32_t i = tid; i < d.N; i += kSweepFThreads) {
-            float4 j = make_float4(0.f, 0.f, 0.f, 0.f);
-            j.x = Jg[i * NN + 0];
-            if (NN > 1) j.y = Jg[i * NN + 1];
-            if (NN > 2) j.z = Jg[i * NN + 2];
-            J4[i] = j;
-        }
+        for (uint32_t i = tid; i < d.N; i += kSweepFThreads)
+#pragma unroll
+            for (int dd = 0; dd < JW; ++dd) Jl[i * JW + dd] = dd < NN ? Jg[i * NN + dd] : 0.0f;
         __syncthreads();
     }
     const uint32_t live = d.n_sys - w * 32;
     const uint32_t valid_bits = live >= 32 ? 0xFFFFFFFFu : ((1u << live) - 1u);
     const uint32_t g = tid & 7u, shift = g * 4;              // this lane's four slots: bits shift..shift+3
     const uint32_t valid4 = (valid_bits >> shift) & 15u;
-    const uint4 *rec = p.rec + static_cast<size_t>(real) * (d.N + 1) * (BIG ? 2 : 1);
+    // neighbour table in schedule order, shared by all realisations: site, f0, b0, f1, b1, ...
+    const uint4 *nbr = reinterpret_cast<const uint4 *>(p.nbr_wide);
 
     struct Item {
-        uint4 r0, r1;  // record (r1: BIG only)
-        float4 t;      // thresholds of the four slots
+        uint4 r[NN <= 3 ? 2 : 4]; // site + 2 NN neighbours
+        float4 t;                 // thresholds of the four slots
     };
     auto fetch = [&](uint32_t pos, bool live_item) -> Item {
         Item it;
-        it.r0 = it.r1 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < (NN <= 3 ? 2 : 4); ++k) it.r[k] = make_uint4(0, 0, 0, 0);
         it.t = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!live_item) return it;
-        uint32_t site;
-        if (BIG) {
-            it.r0 = rec[2 * pos];
-            it.r1 = rec[2 * pos + 1];
-            site = it.r0.x;
-        } else {
-            it.r0 = rec[pos];
-            site = (it.r0.x & 0xFFFFu) >> 2;
-        }
-        it.t = thr[static_cast<size_t>(site) * 8 + g];
+#pragma unroll
+        for (int k = 0; k < (NN <= 3 ? 2 : 4); ++k) it.r[k] = nbr[static_cast<size_t>(pos) * 4 + k];
+        it.t = thr[static_cast<size_t>(it.r[0].x) * 8 + g];
         return it;
     };
     // s * J for the lane's four slots of neighbour word `word`, added to h[0..3]
@@ -217,45 +211,17 @@ __global__ __launch_bounds__(kSweepFThreads) void k_sweep_f(SimDims d, DevPtrs p
                                        x << (31 - k), 0x80000000u, __float_as_uint(j), 0x6A)));
     };
     auto run = [&](const Item &it) {
-        uint32_t site, nb[6];
-        if (BIG) {
-            const BigRec r(it.r0, it.r1);
-            site = r.site;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) nb[k] = r.nb[k];
-        } else {
-            const SiteRec r(it.r0); // LDS byte offsets = 4 * index
-            site = r.site >> 2;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) nb[k] = r.nb[k] >> 2;
-        }
+        const uint32_t *flat = reinterpret_cast<const uint32_t *>(it.r);
+        const uint32_t site = flat[0];
         const uint32_t s = BIG ? coherent_load(Sg + site) : sw[site];
-        float jf[3] = {0.f, 0.f, 0.f}, jb[3] = {0.f, 0.f, 0.f};
-        uint32_t wf[3] = {0, 0, 0}, wb[3] = {0, 0, 0};
-        if (BIG) {
-#pragma unroll
-            for (int dd = 0; dd < NN; ++dd) {
-                jf[dd] = Jg[static_cast<size_t>(site) * NN + dd];
-                jb[dd] = Jg[static_cast<size_t>(nb[2 * dd + 1]) * NN + dd];
-                wf[dd] = coherent_load(Sg + nb[2 * dd]);
-                wb[dd] = coherent_load(Sg + nb[2 * dd + 1]);
-            }
-        } else {
-            const float4 own = J4[site];
-            jf[0] = own.x; jf[1] = own.y; jf[2] = own.z;
-#pragma unroll
-            for (int dd = 0; dd < NN; ++dd) {
-                const float *jrow = reinterpret_cast<const float *>(&J4[nb[2 * dd + 1]]);
-                jb[dd] = jrow[dd];
-                wf[dd] = sw[nb[2 * dd]];
-                wb[dd] = sw[nb[2 * dd + 1]];
-            }
-        }
         float h[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int dd = 0; dd < NN; ++dd) { // sweep.rs:11-17: forward then backward bond of each direction
-            add_bond(h, wf[dd], jf[dd]);
-            add_bond(h, wb[dd], jb[dd]);
+            const uint32_t jf = flat[1 + 2 * dd], jb = flat[2 + 2 * dd];
+            const float cf = BIG ? Jg[static_cast<size_t>(site) * NN + dd] : Jl[site * JW + dd];
+            const float cb = BIG ? Jg[static_cast<size_t>(jb) * NN + dd] : Jl[jb * JW + dd];
+            add_bond(h, BIG ? coherent_load(Sg + jf) : sw[jf], cf);
+            add_bond(h, BIG ? coherent_load(Sg + jb) : sw[jb], cb);
         }
         // eng_change = -s_i * h (sweep.rs:43-44): s_i = +1 (bit clear) negates h
         const uint32_t xs = (~s) >> shift;
@@ -292,28 +258,28 @@ __global__ __launch_bounds__(kSweepFThreads) void k_sweep_f(SimDims d, DevPtrs p
         for (uint32_t i = tid; i < d.N; i += kSweepFThreads) Sg[i] = sw[i];
 }
 
-// xw[tile word][site] = (S_i ^ S_fwd(i,0), S_i ^ S_fwd(i,1), S_i ^ S_fwd(i,2), S_i):
-// bond sign words (bit set <=> s_i s_j = -1) and the spin word itself, for k_energy_f.
+// xw[tile word][site][XW] = S_i ^ S_fwd(i, d) for every direction, then S_i itself (XW = 4 for up
+// to three directions, 8 for up to six): bond sign words (bit set <=> s_i s_j = -1) and the spin
+// word, for k_energy_f.
+template <int NN>
 __global__ __launch_bounds__(256) void k_bonds_f(SimDims d, DevPtrs p) {
-    const uint32_t tw = blockIdx.y, real = tw / d.W;
+    constexpr int XW = JRow<NN>::kWidth;
+    const uint32_t tw = blockIdx.y;
     const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= d.N) return;
     const uint32_t *Sg = p.S + static_cast<size_t>(tw) * d.N;
-    uint32_t site, f[3];
-    if (d.big) {
-        const uint4 *rec = p.rec + static_cast<size_t>(real) * (d.N + 1) * 2;
-        const BigRec r(rec[2 * pos], rec[2 * pos + 1]);
-        site = r.site; f[0] = r.nb[0]; f[1] = r.nb[2]; f[2] = r.nb[4];
-    } else {
-        const SiteRec r(p.rec[static_cast<size_t>(real) * (d.N + 1) + pos]);
-        site = r.site >> 2; f[0] = r.nb[0] >> 2; f[1] = r.nb[2] >> 2; f[2] = r.nb[4] >> 2;
-    }
+    const uint32_t *row = p.nbr_wide + static_cast<size_t>(pos) * 16;
+    const uint32_t site = row[0];
     const uint32_t s = Sg[site];
-    uint4 out = make_uint4(0, 0, 0, s);
-    out.x = s ^ Sg[f[0]];
-    if (d.nn > 1) out.y = s ^ Sg[f[1]];
-    if (d.nn > 2) out.z = s ^ Sg[f[2]];
-    reinterpret_cast<uint4 *>(p.xw)[static_cast<size_t>(tw) * d.N + site] = out;
+    uint32_t out[XW];
+#pragma unroll
+    for (int k = 0; k < XW; ++k) out[k] = 0;
+#pragma unroll
+    for (int dd = 0; dd < NN; ++dd) out[dd] = s ^ Sg[row[1 + 2 * dd]];
+    out[XW - 1] = s;
+    uint32_t *dst = p.xw + (static_cast<size_t>(tw) * d.N + site) * XW;
+#pragma unroll
+    for (int k = 0; k < XW; ++k) dst[k] = out[k];
 }
 
 // ---------------------------------------------------------------------------
@@ -322,28 +288,30 @@ __global__ __launch_bounds__(256) void k_bonds_f(SimDims d, DevPtrs p) {
 // additions (about 8 cycles each on a lone wave: ~40 us at 16^3 whatever else happens).
 // Workgroup = (realisation, pair of tile words), 8 waves.  Wave 0 CONSUMES: lane = one of the
 // pair's 64 slots, nothing but LDS reads and the additions.  Waves 1-7 PRODUCE the signed terms
-// +-J of the next chunk of 64 sites into LDS (sign = the bond word's bit of the lane's slot):
-// one pass of a producer wave serves 4 consecutive sites of both words (12 terms = three
+// +-J of the next chunk of sites into LDS (sign = the bond word's bit of the lane's slot):
+// one pass of a producer wave serves 4 consecutive sites of both words (4 z' terms = z'
 // 16-byte LDS writes per lane).  The producers' inputs (bond words, couplings) are loaded from
 // global memory two chunks ahead and staged through LDS; one barrier per chunk.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kEnergyChunk = 64;     // sites per chunk
 constexpr uint32_t kEnergyThreads = 512;  // 1 consumer + 7 producer waves
 constexpr uint32_t kProducers = kEnergyThreads / 64 - 1;
 
 template <int NN> struct EnergyLds {
-    static constexpr uint32_t kTerms = kEnergyChunk * NN;   // terms per chunk and word
+    static constexpr uint32_t kChunk = NN <= 3 ? 64 : 32;   // sites per chunk
+    static constexpr uint32_t kTerms = kChunk * NN;          // terms per chunk and word
     static constexpr uint32_t kQuads = kTerms / 4;
+    static constexpr int XW = JRow<NN>::kWidth;
     float4 terms[2][2][kQuads][32];   // [buffer][word of the pair][term / 4][slot] -> 4 terms
-    uint4 rawx[2][2][kEnergyChunk];   // [buffer][word][site] bond words + spin word
-    float4 rawj[2][kEnergyChunk];     // [buffer][site] forward couplings
+    uint32_t rawx[2][2][kChunk][XW];  // [buffer][word][site] bond words + spin word
+    float rawj[2][kChunk][XW];        // [buffer][site] forward couplings
     uint32_t neg_total[64];
 };
 
 template <int NN>
 __global__ __launch_bounds__(kEnergyThreads) void k_energy_f(SimDims d, DevPtrs p) {
     using Lds = EnergyLds<NN>;
-    constexpr uint32_t kTerms = Lds::kTerms, kQuads = Lds::kQuads;
+    constexpr uint32_t kChunk = Lds::kChunk, kTerms = Lds::kTerms, kQuads = Lds::kQuads;
+    constexpr int XW = Lds::XW;
     extern __shared__ uint32_t lds_raw[];
     Lds &L = *reinterpret_cast<Lds *>(lds_raw);
     const uint32_t n_pairs_w = (d.W + 1) / 2;
@@ -352,36 +320,46 @@ __global__ __launch_bounds__(kEnergyThreads) void k_energy_f(SimDims d, DevPtrs 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool word_ok = w0 + half < d.W; // the pair's second word may not exist
     const uint32_t tw0 = real * d.W + w0;
-    const uint4 *__restrict__ xw = reinterpret_cast<const uint4 *>(p.xw);
+    const uint32_t *__restrict__ xw = p.xw;
     const float *__restrict__ J = p.Jf + static_cast<size_t>(real) * d.N * NN;
-    const uint32_t n_chunks = (d.N + kEnergyChunk - 1) / kEnergyChunk;
+    const uint32_t n_chunks = (d.N + kChunk - 1) / kChunk;
     if (tid < 64) L.neg_total[tid] = 0;
 
-    // raw inputs of one chunk: producer thread pt < 128 holds a (word, site) uint4,
-    // 128 <= pt < 128 + 64 NN one coupling
+    // raw inputs of one chunk, element-wise over the producer threads: 2 kChunk XW bond words, then
+    // kTerms couplings (at most 2 * 32 * 8 + 192 = 704 <= 3 x 448 elements)
+    constexpr uint32_t kRawX = 2 * kChunk * XW, kRaw = kRawX + kTerms;
+    constexpr uint32_t kPerThread = (kRaw + kProducers * 64 - 1) / (kProducers * 64);
     const uint32_t pt = tid - 64; // producer thread index (meaningless for wave 0)
-    uint4 reg_x = make_uint4(0, 0, 0, 0);
-    float reg_j = 0.0f;
+    uint32_t reg[kPerThread];
     auto load_raw = [&](uint32_t chunk) {
         if (chunk >= n_chunks) return;
-        const uint32_t base = chunk * kEnergyChunk;
-        if (pt < 2 * kEnergyChunk) {
-            const uint32_t wsel = pt / kEnergyChunk, k = pt % kEnergyChunk;
-            reg_x = (base + k < d.N && w0 + wsel < d.W)
-                        ? xw[static_cast<size_t>(tw0 + wsel) * d.N + base + k]
-                        : make_uint4(0, 0, 0, 0);
-        } else if (pt < 2 * kEnergyChunk + kTerms) {
-            const size_t e = static_cast<size_t>(base) * NN + (pt - 2 * kEnergyChunk);
-            reg_j = e < static_cast<size_t>(d.N) * NN ? J[e] : 0.0f;
+        const uint32_t base = chunk * kChunk;
+#pragma unroll
+        for (uint32_t r = 0; r < kPerThread; ++r) {
+            const uint32_t e = r * kProducers * 64 + pt;
+            uint32_t v = 0;
+            if (e < kRawX) {
+                const uint32_t wsel = e / (kChunk * XW), k = (e / XW) % kChunk, c = e % XW;
+                if (base + k < d.N && w0 + wsel < d.W)
+                    v = xw[(static_cast<size_t>(tw0 + wsel) * d.N + base + k) * XW + c];
+            } else if (e < kRaw) {
+                const size_t q = static_cast<size_t>(base) * NN + (e - kRawX);
+                if (q < static_cast<size_t>(d.N) * NN) v = __float_as_uint(J[q]);
+            }
+            reg[r] = v;
         }
     };
     auto stash_raw = [&](uint32_t chunk) {
         if (chunk >= n_chunks) return;
-        if (pt < 2 * kEnergyChunk) {
-            L.rawx[chunk & 1u][pt / kEnergyChunk][pt % kEnergyChunk] = reg_x;
-        } else if (pt < 2 * kEnergyChunk + kTerms) {
-            const uint32_t e = pt - 2 * kEnergyChunk;
-            reinterpret_cast<float *>(L.rawj[chunk & 1u])[(e / NN) * 4 + e % NN] = reg_j;
+#pragma unroll
+        for (uint32_t r = 0; r < kPerThread; ++r) {
+            const uint32_t e = r * kProducers * 64 + pt;
+            if (e < kRawX) {
+                reinterpret_cast<uint32_t *>(L.rawx[chunk & 1u])[e] = reg[r];
+            } else if (e < kRaw) {
+                const uint32_t q = e - kRawX;
+                L.rawj[chunk & 1u][q / NN][q % NN] = __uint_as_float(reg[r]);
+            }
         }
     };
 
@@ -396,16 +374,15 @@ __global__ __launch_bounds__(kEnergyThreads) void k_energy_f(SimDims d, DevPtrs 
     auto produce = [&](uint32_t chunk) {
         if (chunk >= n_chunks) return;
         const uint32_t buf = chunk & 1u;
-        for (uint32_t g = wave - 1; g < kEnergyChunk / 4; g += kProducers) {
+        for (uint32_t g = wave - 1; g < kChunk / 4; g += kProducers) {
             float t[4 * NN];
 #pragma unroll
             for (uint32_t s4 = 0; s4 < 4; ++s4) {
-                const uint4 x = L.rawx[buf][half][4 * g + s4];
-                const float4 j = L.rawj[buf][4 * g + s4];
-                t[s4 * NN + 0] = signed_term(x.x, j.x);
-                if (NN > 1) t[s4 * NN + 1] = signed_term(x.y, j.y);
-                if (NN > 2) t[s4 * NN + 2] = signed_term(x.z, j.z);
-                neg += (x.w >> bit) & 1u;
+                const uint32_t *x = L.rawx[buf][half][4 * g + s4];
+                const float *j = L.rawj[buf][4 * g + s4];
+#pragma unroll
+                for (int dd = 0; dd < NN; ++dd) t[s4 * NN + dd] = signed_term(x[dd], j[dd]);
+                neg += (x[XW - 1] >> bit) & 1u;
             }
 #pragma unroll
             for (uint32_t q = 0; q < NN; ++q)
@@ -419,7 +396,7 @@ __global__ __launch_bounds__(kEnergyThreads) void k_energy_f(SimDims d, DevPtrs 
         total = __fadd_rn(total, v.w);
     };
     auto consume = [&](uint32_t chunk) {
-        const uint32_t n_terms = min(kEnergyChunk, d.N - chunk * kEnergyChunk) * NN;
+        const uint32_t n_terms = min(kChunk, d.N - chunk * kChunk) * NN;
         const float4(*buf)[32] = L.terms[chunk & 1u][half];
         if (n_terms == kTerms) {
             // full chunk: LDS reads run one batch of 8 quads ahead of the additions
@@ -487,30 +464,27 @@ __global__ __launch_bounds__(kEnergyThreads) void k_energy_f(SimDims d, DevPtrs 
 // Launchers
 // ---------------------------------------------------------------------------
 size_t sweep_f_lds_bytes(const SimDims &d) {
-    return ((static_cast<size_t>(d.N) + 3) / 4 * 4 + static_cast<size_t>(d.N) * 4) * 4;
+    const size_t jw = d.nn <= 3 ? 4 : 8;
+    return ((static_cast<size_t>(d.N) + 3) / 4 * 4 + static_cast<size_t>(d.N) * jw) * 4;
 }
 
-hipError_t configure_general_kernels() {
-    for (const void *fn : {reinterpret_cast<const void *>(k_sweep_f<false, 1>),
-                           reinterpret_cast<const void *>(k_sweep_f<false, 2>),
-                           reinterpret_cast<const void *>(k_sweep_f<false, 3>),
-                           reinterpret_cast<const void *>(k_energy_f<1>),
-                           reinterpret_cast<const void *>(k_energy_f<2>),
-                           reinterpret_cast<const void *>(k_energy_f<3>)}) {
+template <int NN> static hipError_t configure_general_nn() {
+    for (const void *fn : {reinterpret_cast<const void *>(k_sweep_f<false, NN>),
+                           reinterpret_cast<const void *>(k_energy_f<NN>)}) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
 }
 
-template <bool BIG>
-static void launch_sweep_f_nn(const SimDims &d, const DevPtrs &p, size_t lds, hipStream_t stream) {
-    const dim3 grid(d.n_real * d.W), block(kSweepFThreads);
-    switch (d.nn) {
-    case 1: hipLaunchKernelGGL((k_sweep_f<BIG, 1>), grid, block, lds, stream, d, p); break;
-    case 2: hipLaunchKernelGGL((k_sweep_f<BIG, 2>), grid, block, lds, stream, d, p); break;
-    default: hipLaunchKernelGGL((k_sweep_f<BIG, 3>), grid, block, lds, stream, d, p); break;
-    }
+hipError_t configure_general_kernels() {
+    hipError_t e = configure_general_nn<1>();
+    if (e == hipSuccess) e = configure_general_nn<2>();
+    if (e == hipSuccess) e = configure_general_nn<3>();
+    if (e == hipSuccess) e = configure_general_nn<4>();
+    if (e == hipSuccess) e = configure_general_nn<5>();
+    if (e == hipSuccess) e = configure_general_nn<6>();
+    return e;
 }
 
 hipError_t launch_log_selftest(float *out_ln, float *out_logit, hipStream_t stream) {
@@ -529,22 +503,31 @@ hipError_t launch_rng_f(const SimDims &d, const DevPtrs &p, bool gibbs, hipStrea
     return hipGetLastError();
 }
 
-hipError_t launch_sweep_f(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,
-                          hipStream_t stream) {
+template <int NN>
+static void launch_sweep_f_nn(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep, hipStream_t stream) {
     if (do_sweep) {
+        const dim3 grid(d.n_real * d.W), block(kSweepFThreads);
         if (d.big)
-            launch_sweep_f_nn<true>(d, p, 0, stream);
+            hipLaunchKernelGGL((k_sweep_f<true, NN>), grid, block, 0, stream, d, p);
         else
-            launch_sweep_f_nn<false>(d, p, sweep_f_lds_bytes(d), stream);
+            hipLaunchKernelGGL((k_sweep_f<false, NN>), grid, block, sweep_f_lds_bytes(d), stream, d, p);
     }
     if (with_energy) {
-        hipLaunchKernelGGL(k_bonds_f, dim3((d.N + 255) / 256, d.n_real * d.W), dim3(256), 0, stream, d, p);
-        const dim3 grid(d.n_real * ((d.W + 1) / 2)), block(kEnergyThreads);
-        switch (d.nn) {
-        case 1: hipLaunchKernelGGL(k_energy_f<1>, grid, block, sizeof(EnergyLds<1>), stream, d, p); break;
-        case 2: hipLaunchKernelGGL(k_energy_f<2>, grid, block, sizeof(EnergyLds<2>), stream, d, p); break;
-        default: hipLaunchKernelGGL(k_energy_f<3>, grid, block, sizeof(EnergyLds<3>), stream, d, p); break;
-        }
+        hipLaunchKernelGGL(k_bonds_f<NN>, dim3((d.N + 255) / 256, d.n_real * d.W), dim3(256), 0, stream, d, p);
+        hipLaunchKernelGGL(k_energy_f<NN>, dim3(d.n_real * ((d.W + 1) / 2)), dim3(kEnergyThreads),
+                           sizeof(EnergyLds<NN>), stream, d, p);
+    }
+}
+
+hipError_t launch_sweep_f(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,
+                          hipStream_t stream) {
+    switch (d.nn) {
+    case 1: launch_sweep_f_nn<1>(d, p, with_energy, do_sweep, stream); break;
+    case 2: launch_sweep_f_nn<2>(d, p, with_energy, do_sweep, stream); break;
+    case 3: launch_sweep_f_nn<3>(d, p, with_energy, do_sweep, stream); break;
+    case 4: launch_sweep_f_nn<4>(d, p, with_energy, do_sweep, stream); break;
+    case 5: launch_sweep_f_nn<5>(d, p, with_energy, do_sweep, stream); break;
+    default: launch_sweep_f_nn<6>(d, p, with_energy, do_sweep, stream); break;
     }
     return hipGetLastError();
 }

@@ -63,7 +63,8 @@ struct pa_sim {
     // non-const aliases of the static tables (filled once in create)
     uint32_t *thr = nullptr, *mpar = nullptr, *pass_start = nullptr, *jump = nullptr;
     uint4 *rec = nullptr;
-    uint16_t *nbr_site = nullptr, *jsite = nullptr;
+    uint16_t *nbr_site = nullptr;
+    uint32_t *jsite = nullptr, *nbr_wide = nullptr;
     float *jorg_p = nullptr;
     uint32_t *thr_gibbs = nullptr; // built by the first Gibbs sample (ensure_gibbs)
     uint32_t *seg = nullptr;       // slab segments of the pipelined large-lattice sweep
@@ -272,7 +273,7 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     if (d.general) {
         q.Jf += static_cast<size_t>(d.N) * d.nn * r0;
         q.thr_f += tile_words * 32 * r0;
-        q.xw += tile_words * 4 * r0;
+        q.xw += tile_words * (d.nn <= 3 ? 4 : 8) * r0;
     } else {
         q.planes += tile_words * r0;
     }
@@ -550,7 +551,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     if (d.big && cfg->overlap_cluster_interval > 0)
         return fail(sim, PA_ERR_UNSUPPORTED,
                     "overlap-cluster moves are not built for lattices above 12000 sites yet");
-    if (d.general && cfg->overlap_cluster_interval > 0)
+    if (!d.unit && cfg->overlap_cluster_interval > 0)
         for (int k = 0; k < cfg->n_overlap_cluster_modes && k < 4; ++k)
             if ((cfg->overlap_cluster_modes[k] & 0xFF) == PA_OC_JORG || (cfg->overlap_cluster_modes[k] & 0xFF) == PA_OC_CMR)
                 return fail(sim, PA_ERR_UNSUPPORTED,
@@ -564,9 +565,10 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     const bool oc_sw = cfg->overlap_cluster_interval > 0 && cfg->overlap_cluster_mode == PA_CLUSTER_SW;
     bool oc_cmr = false;
     for (int k = 0; cfg->overlap_cluster_interval > 0 && k < cfg->n_overlap_cluster_modes && k < 4; ++k)
-        oc_cmr = oc_cmr || (cfg->overlap_cluster_modes[k] & 0xFF) == PA_OC_CMR || (cfg->overlap_cluster_modes[k] >> 8) > 2;
+        oc_cmr = oc_cmr || (cfg->overlap_cluster_modes[k] & 0xFF) == PA_OC_CMR || (cfg->overlap_cluster_modes[k] >> 8) > 2 ||
+                 d.nn > 3;
     const bool fk = cfg->cluster_interval > 0;
-    if (fk && d.general)
+    if (fk && !d.unit)
         return fail(sim, PA_ERR_UNSUPPORTED,
                     "FK cluster updates need expf of arbitrary couplings, which is not built on the "
                     "HIP path yet (unit couplings only)");
@@ -671,7 +673,9 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                                                                static_cast<uint64_t>(cfg->n_overlap_cluster_modes)];
                 const int oc_kind = oc_mode & 0xFF;
                 const uint32_t oc_group = (oc_mode >> 8) > 2 ? static_cast<uint32_t>(oc_mode >> 8) : 2u;
-                if (oc_sw || oc_group > 2) // union-find variants; groups above two also for the single-cluster variant
+                // union-find variants; groups above two and lattices with more than three forward
+                // directions also for the single-cluster Houdayer move (same components, same seed rule)
+                if (oc_sw || oc_group > 2 || (oc_kind == PA_OC_HOUDAYER && d.nn > 3))
                     PA_HIP(sim, launch_cluster_sw(g.d, g.p, oc_kind, oc_group, !oc_sw, g.stream));
                 else if (oc_mode == PA_OC_CMR)
                     PA_HIP(sim, launch_cmr_wolff(g.d, g.p, g.stream)); // :845-965
@@ -848,8 +852,8 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
                                     desc->neighbor_offsets ? desc->n_neighbors : desc->n_dims,
                                     desc->neighbor_offsets);
     const LatticeTables &lat = sim->lat;
-    if (lat.n_neighbors > 3) {
-        sim->error = "more than 3 forward directions are not built on the HIP path yet";
+    if (lat.n_neighbors > 6) {
+        sim->error = "more than 6 forward directions are not built on the HIP path yet";
         return bail(PA_ERR_UNSUPPORTED);
     }
     if (lat.n_spins > (1u << 22) || desc->n_temps > 1024) {
@@ -886,11 +890,20 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     // ---- acceptance rule: integer table (unit couplings, sweep.rs:109-139) or the logarithm
     const size_t n_coup = static_cast<size_t>(d.N) * d.nn;
     std::vector<uint32_t> table;
-    d.general = build_metropolis_table(desc->couplings, n_coup * d.n_real, sim->temps.data(),
-                                       d.n_temps, d.nn, table) ? 0 : 1;
+    d.unit = build_metropolis_table(desc->couplings, n_coup * d.n_real, sim->temps.data(), d.n_temps, d.nn,
+                                    table) ? 1 : 0;
+    // the bit-sliced table kernels hold up to three forward directions; lattices with four to six
+    // (bcc, fcc, ...) take the logarithmic rule, which decides every flip identically (the table
+    // is the bisection of that rule, sweep.rs:141-155)
+    d.general = (!d.unit || d.nn > 3) ? 1 : 0;
     // the LDS kernels hold a word's N sites (sweep) / the W-word tile (tempering swaps) on chip
     d.big = (d.N > 12000 || static_cast<size_t>(d.N) * d.W * 4 > 150000) ? 1 : 0;
     if (d.general && sweep_f_lds_bytes(d) > 160 * 1024) d.big = 1;
+    if (d.big && d.nn > 3) {
+        sim->error = "lattices with more than 3 forward directions are built for the on-chip kernels only "
+                     "(about 4000 sites)";
+        return bail(PA_ERR_UNSUPPORTED);
+    }
     d.n_edges = std::max<uint32_t>(1, d.n_temps - 1);
     if (d.W > 64) {
         sim->error = "more than 2048 systems per realisation are not built on the HIP path yet";
@@ -985,7 +998,8 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     // ---- per-realisation site records in schedule order (neighbours + coupling metadata)
     const size_t rec_stride = (static_cast<size_t>(d.N) + 1) * (d.big ? 2 : 1); // uint4 per realisation
     std::vector<uint4> rec(static_cast<size_t>(d.n_real) * rec_stride);
-    std::vector<uint16_t> nbr_site(static_cast<size_t>(d.N) * 6), jsite(static_cast<size_t>(d.n_real) * d.N);
+    std::vector<uint16_t> nbr_site(static_cast<size_t>(d.N) * 12);
+    std::vector<uint32_t> jsite(static_cast<size_t>(d.n_real) * d.N), nbr_wide(static_cast<size_t>(d.N) * 16, 0u);
     bool all_nonzero = true;
     std::vector<uint32_t> mpar(static_cast<size_t>(d.n_real) * d.MW, 0u);
     std::vector<int32_t> nz_bonds(d.n_real, 0);
@@ -994,9 +1008,9 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         const float *J = desc->couplings + n_coup * real;
         for (uint32_t pos = 0; pos < d.N; ++pos) {
             const uint32_t site = order[pos];
-            uint32_t nb[6];
+            uint32_t nb[12];
             uint32_t neg = 0, nz = 0, m = 0;
-            for (uint32_t k = 0; k < 3; ++k) {
+            for (uint32_t k = 0; k < 6; ++k) {
                 nb[2 * k] = k < d.nn ? lat.fwd[site * d.nn + k] : site;
                 nb[2 * k + 1] = k < d.nn ? lat.bwd[site * d.nn + k] : site;
                 if (k >= d.nn) continue;
@@ -1007,16 +1021,23 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
                 if (jb != 0.0f) { nz |= 1u << (2 * k + 1); m += 1; }
                 if (jb < 0.0f) neg |= 1u << (2 * k + 1);
             }
+            jsite[static_cast<size_t>(real) * d.N + site] = neg | (nz << 12);
+            if (real == 0) {
+                nbr_wide[static_cast<size_t>(pos) * 16] = site;
+                for (int k = 0; k < 12; ++k) {
+                    nbr_wide[static_cast<size_t>(pos) * 16 + 1 + k] = nb[k];
+                    if (!d.big) nbr_site[static_cast<size_t>(site) * 12 + k] = static_cast<uint16_t>(nb[k]);
+                }
+            }
+            if (d.nn > 3) continue; // the bit-sliced records below hold three directions
             const uint32_t h = (m + 1) / 2;
-            const uint32_t jm = neg | (nz << 6) | (h << 12);
+            const uint32_t jm = (neg & 63u) | ((nz & 63u) << 6) | (h << 12);
             if (m != 2 * d.nn) all_nonzero = false;
-            jsite[static_cast<size_t>(real) * d.N + site] = static_cast<uint16_t>(neg | (nz << 6));
             if (d.big) { // full-width indices, two uint4 per site
                 rec[static_cast<size_t>(real) * rec_stride + 2 * pos] = make_uint4(site, nb[0], nb[1], nb[2]);
                 rec[static_cast<size_t>(real) * rec_stride + 2 * pos + 1] = make_uint4(nb[3], nb[4], nb[5], jm);
                 continue;
             }
-            for (int k = 0; k < 6; ++k) nbr_site[static_cast<size_t>(site) * 6 + k] = static_cast<uint16_t>(nb[k]);
             rec[static_cast<size_t>(real) * rec_stride + pos] = // fields hold LDS byte offsets (4 * index)
                 make_uint4((site * 4) | (nb[0] * 4 << 16), (nb[1] * 4) | (nb[2] * 4 << 16),
                            (nb[3] * 4) | (nb[4] * 4 << 16), (nb[5] * 4) | (jm << 16));
@@ -1096,7 +1117,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         ok(bufs.alloc(&sim->Jf, n_coup * d.n_real));
         ok(bufs.alloc(&sim->temps_dev, static_cast<size_t>(d.n_temps)));
         ok(bufs.alloc(&p.thr_f, tile_words * d.n_real * 32));
-        ok(bufs.alloc(&p.xw, tile_words * d.n_real * 4));
+        ok(bufs.alloc(&p.xw, tile_words * d.n_real * (d.nn <= 3 ? 4 : 8)));
     }
     ok(bufs.alloc(&p.cursor, static_cast<size_t>(d.n_real) * 8 * d.SP));
     ok(bufs.alloc(&p.system_ids, static_cast<size_t>(d.n_real) * d.n_sys));
@@ -1125,6 +1146,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     ok(bufs.alloc(&p.pair_rng, static_cast<size_t>(d.n_real) * d.n_temps * d.n_pairs * 4));
     ok(bufs.alloc(&sim->nbr_site, nbr_site.size()));
     ok(bufs.alloc(&sim->jsite, jsite.size()));
+    ok(bufs.alloc(&sim->nbr_wide, nbr_wide.size()));
     ok(bufs.alloc(&sim->jorg_p, jorg_p.size()));
     ok(bufs.alloc(&p.dfs_stack, d.big ? 1 : static_cast<size_t>(d.n_real) * std::max(d.n_temps * d.n_pairs, d.n_sys) * d.N));
     ok(bufs.alloc(&p.big_counts, static_cast<size_t>(d.n_real) * d.n_sys * 4));
@@ -1141,6 +1163,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     p.dbeta = sim->dbeta;
     p.nbr_site = sim->nbr_site;
     p.jsite = sim->jsite;
+    p.nbr_wide = sim->nbr_wide;
     p.jorg_p = sim->jorg_p;
     p.seg = sim->seg;
     if (d.pipe_K) {
@@ -1163,7 +1186,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     if ((rc = upload(sim, sim->thr, thr)) || (rc = upload(sim, sim->mpar, mpar)) ||
         (rc = upload(sim, sim->rec, rec)) || (rc = upload(sim, sim->pass_start, pass_start)) ||
         (rc = upload(sim, sim->jump, jump)) || (rc = upload(sim, sim->nbr_site, nbr_site)) ||
-        (rc = upload(sim, sim->jsite, jsite)) || (rc = upload(sim, sim->jorg_p, jorg_p)) ||
+        (rc = upload(sim, sim->jsite, jsite)) || (rc = upload(sim, sim->nbr_wide, nbr_wide)) || (rc = upload(sim, sim->jorg_p, jorg_p)) ||
         (rc = upload(sim, sim->nz_bonds, nz_bonds)) || (rc = upload(sim, sim->dbeta, dbeta)))
         return bail(rc);
     if (hipMemsetAsync(p.big_counts, 0, sizeof(uint32_t) * d.n_real * d.n_sys * 4, sim->stream) != hipSuccess) {

@@ -169,6 +169,59 @@ def test_unit_couplings_outside_the_table_domain_take_the_logarithmic_rule(oracl
     assert_state_equal(gpu, cpu, check_energy=False)
 
 
+BCC = [[1, 1, 1], [1, 1, -1], [1, -1, 1], [1, -1, -1]]
+FCC = [[1, 1, 0], [1, 0, 1], [0, 1, 1], [1, -1, 0], [1, 0, -1], [0, 1, -1]]
+FIVE = [[1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 0], [0, 1, 1]]
+
+
+@pytest.mark.parametrize("offsets", [BCC, FCC, FIVE], ids=["bcc", "fcc", "five"])
+@pytest.mark.parametrize("kind", ["bimodal", "gaussian", "diluted"])
+def test_lattices_with_four_to_six_forward_directions(oracle, offsets, kind):
+    """bcc / fcc geometries of the reference (python/peapods/spin_models.py:5-10) and any custom
+    lattice with up to six offsets: sweeps (both rules), energies, overlap, tempering, Houdayer."""
+    shape, nn = (4, 6, 4), len(offsets)
+    rng = np.random.default_rng(7)
+    full = (2,) + shape + (nn,)
+    if kind == "bimodal":
+        couplings = (2 * rng.integers(0, 2, size=full) - 1).astype(np.float32)
+    elif kind == "gaussian":
+        couplings = rng.standard_normal(size=full).astype(np.float32)
+    else:
+        couplings = rng.integers(-1, 2, size=full).astype(np.float32)
+    gpu, cpu = make_pair(oracle, shape, couplings, np.linspace(1.0, 6.0, 5), 4, 11, offsets)
+    assert_state_equal(gpu, cpu)
+    gpu.metropolis_sweep(4)
+    cpu.sample(4, "metropolis", warmup_ratio=1.0)
+    assert_state_equal(gpu, cpu, check_energy=False)
+    kwargs = dict(pt_interval=1, pt_schedule="full_ladder", warmup_ratio=0.25)
+    a = gpu.sample(12, "gibbs", **kwargs)
+    b = cpu.sample(12, "gibbs", **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+    for inner in ("wolff", "sw"):
+        kw = dict(pt_interval=2, overlap_cluster_update_interval=1, overlap_cluster_mode=inner, warmup_ratio=0.0)
+        a = gpu.sample(6, "metropolis", **kw)
+        b = cpu.sample(6, "metropolis", **kw)
+        assert_results_equal(a, b)
+        assert_state_equal(gpu, cpu)
+
+
+@pytest.mark.parametrize("offsets", [BCC, FCC], ids=["bcc", "fcc"])
+def test_cluster_moves_on_bcc_and_fcc(oracle, offsets):
+    shape, nn = (4, 4, 6), len(offsets)
+    rng = np.random.default_rng(9)
+    couplings = (2 * rng.integers(0, 2, size=shape + (nn,)) - 1).astype(np.float32)
+    for cluster_mode in ("sw", "wolff"):
+        gpu, cpu = make_pair(oracle, shape, couplings, np.linspace(2.0, 8.0, 4), 2, 13, offsets)
+        kwargs = dict(cluster_update_interval=1, cluster_mode=cluster_mode, pt_interval=1, warmup_ratio=0.25,
+                      overlap_cluster_update_interval=2, overlap_cluster_build_mode="jorg+cmr+houdayer",
+                      overlap_cluster_mode=cluster_mode)
+        a = gpu.sample(12, "metropolis", **kwargs)
+        b = cpu.sample(12, "metropolis", **kwargs)
+        assert_results_equal(a, b)
+        assert_state_equal(gpu, cpu)
+
+
 def test_unit_lookup_case_with_zero_couplings(oracle):
     # the reference's own table test pattern (sweep.rs:382-442): couplings cycle -1, 0, +1
     shape = (8, 8)
@@ -489,22 +542,28 @@ def test_fk_cluster_update_matches_oracle(oracle, cluster_mode, shape, kind, n_t
     assert_state_equal(gpu, cpu)
 
 
-def test_ferromagnet_binder_crossing_with_swendsen_wang():
-    """The reference's physics check of this protocol (tests/binder_crossings.py:21-53, 2D square,
-    tests/utils.py:39-47): Metropolis + SW + tempering, 2 replicas, Binder curves of L = 8, 16, 32
-    cross at the exact T_c within 0.05."""
+@pytest.mark.parametrize("name,geometry,sizes,tc,half_width,n_temps", [
+    ("2D square", None, (8, 16, 32), 2.0 / np.log(1 + np.sqrt(2)), 0.3, 32),
+    ("2D triangular", "tri", (8, 16, 32), 4.0 / np.log(3), 0.4, 32),
+    ("3D cubic", None, (6, 8, 10), 4.511, 0.4, 24),
+    ("3D BCC", "bcc", (6, 8, 10), 6.235, 0.5, 24),
+    ("3D FCC", "fcc", (6, 8, 10), 9.792, 0.6, 24),
+])
+def test_ferromagnet_binder_crossing_with_swendsen_wang(name, geometry, sizes, tc, half_width, n_temps):
+    """The reference's physics checks of this protocol (tests/binder_crossings.py:21-109,
+    tests/utils.py:7-11,39-47): Metropolis + Swendsen-Wang + tempering, 2 replicas, 10000 sweeps;
+    the Binder cumulants of three sizes agree at T_c within 0.05, on every geometry it ships."""
     import peapods_amd as peapods
 
-    tc = 2.0 / np.log(1 + np.sqrt(2))
-    temps = np.linspace(tc - 0.3, tc + 0.3, 32).astype(np.float32)
+    temps = np.linspace(tc - half_width, tc + half_width, n_temps).astype(np.float32)
     at_tc = []
-    for size in (8, 16, 32):
-        model = peapods.Ising((size, size), temperatures=temps, n_replicas=2, seed=42)
+    for size in sizes:
+        shape = (size, size) if name.startswith("2D") else (size, size, size)
+        model = peapods.Ising(shape, temperatures=temps, n_replicas=2, seed=42, geometry=geometry)
         model.sample(10000, sweep_mode="metropolis", cluster_update_interval=1, cluster_mode="sw",
                      pt_interval=1, warmup_ratio=0.25)
         at_tc.append(np.interp(tc, temps, model.binder_cumulant))
-    assert max(at_tc) - min(at_tc) < 0.05, at_tc
-    assert all(0.55 < b < 0.66 for b in at_tc), at_tc  # universal value U* = 0.61 of the 2D class
+    assert max(at_tc) - min(at_tc) < 0.05, (name, at_tc)
 
 
 @pytest.mark.parametrize("kind", ["bimodal", "gaussian"])

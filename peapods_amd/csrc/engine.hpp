@@ -97,6 +97,7 @@ struct DevPtrs {
     // "sw" inner variant of the overlap-cluster moves (kernels_cluster.hip; built on first use)
     uint32_t *pair_slots;    // [n_real][n_temps][n_replicas] slots in the shuffled order of each temperature
     const uint32_t *jump256; // [n_jump256][64][16][8] nibble tables of T^(256 b)
+    const uint32_t *jump64;  // [4][64][16][8] nibble tables of T^(64 s)
     const uint32_t *jorg_thr;// [n_temps] ceil((1 - exp(-4/T)) 2^24): draw < thr <=> gen::<f32>() < p
     const uint32_t *cmr_thr; // [n_temps] CMR blue bonds: 1 - r^2, r = exp(-2/T) (red bonds use fk_thr = 1 - r)
     const uint32_t *fk_thr;  // [n_temps] the same for the FK bond probability 1 - exp(-2/T)

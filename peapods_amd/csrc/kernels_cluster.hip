@@ -98,6 +98,8 @@ struct SwLds {
     uint32_t *spb;     // [MW] spin of the pair's second system
     uint32_t *bond;    // [6][MW] eligible, later accepted, forward bonds per direction
     uint32_t *blue;    // [6][MW] CMR: accepted blue bonds, kept for the grey clusters
+    uint32_t *acc;     // [6][MW] accepted bonds of the current phase
+    uint32_t *blk;     // [n_bit_words] generator states at the 256-draw block boundaries in use
     uint32_t *wbase;   // [MW + 1] exclusive prefix (eligible bonds / drawing roots) per 32-site word
     uint32_t *roots;   // [MW] roots that draw
     uint32_t *flip_a;  // [MW] accumulated flips of the first system
@@ -112,7 +114,7 @@ __host__ __device__ inline size_t cluster_sw_bit_words(const SimDims &d) {
     return (static_cast<size_t>(d.N) * d.nn + 255) / 256 * 8 + 16;
 }
 __host__ __device__ inline size_t cluster_sw_lds_words(const SimDims &d) {
-    return 2 * static_cast<size_t>(d.N) + 20 * static_cast<size_t>(d.MW) + 1 + 2 * cluster_sw_bit_words(d) + 12;
+    return 2 * static_cast<size_t>(d.N) + 26 * static_cast<size_t>(d.MW) + 1 + 3 * cluster_sw_bit_words(d) + 12;
 }
 
 enum { kSwHoudayer = 0, kSwJorg = 1, kSwFk = 2, kSwCmr = 3 };
@@ -136,6 +138,8 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
         L.spb = q; q += d.MW;
         L.bond = q; q += 6 * d.MW;
         L.blue = q; q += 6 * d.MW;
+        L.acc = q; q += 6 * d.MW;
+        L.blk = q; q += cluster_sw_bit_words(d);
         L.wbase = q; q += d.MW + 1;
         L.roots = q; q += d.MW;
         L.flip_a = q; q += d.MW;
@@ -172,25 +176,31 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
     };
     auto get_bit = [&](const uint32_t *bitmap, uint32_t i) -> uint32_t { return (bitmap[i >> 5] >> (i & 31u)) & 1u; };
 
-    // ---- A: active sites and the systems' spins
-    for (uint32_t r = 0; r < n_rounds; ++r) {
-        const uint32_t i = r * kSwThreads + tid;
-        uint32_t a = 0, b = 0;
-        if (i < d.N) {
-            a = (Sa[i] >> ba) & 1u;
-            b = (Sb[i] >> bb) & 1u;
+    // ---- A: active sites and the systems' spins (loads of 8 rounds are issued before their ballots)
+    for (uint32_t r0 = 0; r0 < n_rounds; r0 += 8) {
+        uint32_t va[8], vb[8], minus[8];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; ++q) {
+            const uint32_t i = (r0 + q) * kSwThreads + tid;
+            va[q] = vb[q] = minus[q] = 0;
+            if (r0 + q < n_rounds && i < d.N) {
+                va[q] = (Sa[i] >> ba) & 1u;
+                vb[q] = (Sb[i] >> bb) & 1u;
+                if (MODE == kSwHoudayer && group > 2) // the group's spins sum to zero (overlap.rs:199-205)
+                    for (uint32_t k = 0; k < group; ++k)
+                        minus[q] += (Stile[static_cast<size_t>(members[k] >> 5) * d.N + i] >> (members[k] & 31u)) & 1u;
+            }
         }
-        bool active = (FK || CMR) ? i < d.N : (a ^ b) != 0;
-        if (MODE == kSwHoudayer && group > 2) { // the group's spins sum to zero (overlap.rs:199-205)
-            uint32_t minus = 0;
-            if (i < d.N)
-                for (uint32_t k = 0; k < group; ++k)
-                    minus += (Stile[static_cast<size_t>(members[k] >> 5) * d.N + i] >> (members[k] & 31u)) & 1u;
-            active = i < d.N && 2 * minus == group;
+#pragma unroll
+        for (uint32_t q = 0; q < 8; ++q) {
+            const uint32_t r = r0 + q, i = r * kSwThreads + tid;
+            if (r >= n_rounds) break;
+            bool active = (FK || CMR) ? i < d.N : (va[q] ^ vb[q]) != 0;
+            if (MODE == kSwHoudayer && group > 2) active = i < d.N && 2 * minus[q] == group;
+            put_ballot(L.act, r, active);
+            put_ballot(L.spa, r, va[q] != 0);
+            put_ballot(L.spb, r, vb[q] != 0);
         }
-        put_ballot(L.act, r, active);
-        put_ballot(L.spa, r, a != 0);
-        put_ballot(L.spb, r, b != 0);
     }
     for (uint32_t m = tid; m < d.MW; m += kSwThreads) {
         L.flip_a[m] = 0;
@@ -235,24 +245,34 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
             base_state[2 * k + 1] = static_cast<uint32_t>(rng_state[k] >> 32);
         }
     }
-    auto stream_at_block = [&](uint32_t block) -> Rng32 {
-        uint32_t st[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) st[k] = base_state[k];
-        if (block > 0) jump_state_lds(st, p.jump256 + static_cast<size_t>(block) * (64 * 16 * 8));
-        Rng32 rng;
-        rng.load(st);
-        return rng;
-    };
     // Bits of the draws at stream positions [start, start + count): bit = draw < threshold (and,
     // with two_bits, the top two bits of the draw: rand's u8 gen_range(0..=3), overlap.rs:827).
-    // Position q lands at bit q - 256 * (start / 256) of bits / bits2.
+    // Position q lands at bit q - 256 * (start / 256) of bits / bits2.  Two stages of jump-ahead:
+    // the states at the 256-draw block boundaries (T^(256 b), one lane per block, kept in LDS),
+    // then one lane per 64 draws (T^(64 s) from its block's state).
+    auto block_states = [&](uint32_t first_block, uint32_t last_block) {
+        for (uint32_t b = first_block + tid; b <= last_block; b += kSwThreads) {
+            uint32_t st[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) st[k] = base_state[k];
+            if (b > 0) jump_state_lds(st, p.jump256 + static_cast<size_t>(b) * (64 * 16 * 8));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) L.blk[(b - first_block) * 8 + k] = st[k];
+        }
+        __syncthreads();
+    };
     auto draw_bits = [&](uint32_t start, uint32_t count, uint32_t threshold, bool two_bits) {
         if (count == 0) return;
-        const uint32_t first_block = start / 256, last_block = (start + count - 1) / 256;
-        for (uint32_t blk = first_block + tid; blk <= last_block; blk += kSwThreads) {
-            Rng32 rng = stream_at_block(blk);
-            for (uint32_t wd = 0; wd < 8; ++wd) {
+        const uint32_t first_block = start / 256, last_pos = start + count - 1;
+        block_states(first_block, last_pos / 256);
+        for (uint32_t unit = first_block * 4 + tid; unit <= last_pos / 64; unit += kSwThreads) {
+            uint32_t st[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) st[k] = L.blk[(unit / 4 - first_block) * 8 + k];
+            if (unit & 3u) jump_state_lds(st, p.jump64 + static_cast<size_t>(unit & 3u) * (64 * 16 * 8));
+            Rng32 rng;
+            rng.load(st);
+            for (uint32_t half_unit = 0; half_unit < 2; ++half_unit) {
                 uint32_t acc = 0, acc2 = 0;
                 for (uint32_t k = 0; k < 32; ++k) {
                     const uint32_t top = rng.next_top();
@@ -263,51 +283,74 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
                         acc |= ((top >> 8) < threshold ? 1u : 0u) << k;
                     }
                 }
-                L.bits[(blk - first_block) * 8 + wd] = acc;
-                if (two_bits) L.bits2[(blk - first_block) * 8 + wd] = acc2;
+                const uint32_t wd = (unit - first_block * 4) * 2 + half_unit;
+                L.bits[wd] = acc;
+                if (two_bits) L.bits2[wd] = acc2;
             }
         }
     };
+    // root of x with path halving (only non-roots are rewritten, and a non-root never becomes a
+    // root again, so this cannot disturb a concurrent compare-and-swap on a root)
     auto find_root = [&](uint32_t x) -> uint32_t {
         for (;;) {
             const uint32_t up = L.label[x];
             if (up == x) return x;
-            x = up;
+            const uint32_t upup = L.label[up];
+            if (upup == up) return up;
+            L.label[x] = upup;
+            x = upup;
         }
     };
-
     uint32_t pos = 0; // draws of the generator consumed so far
     for (uint32_t phase = 0; phase < N_PHASES; ++phase) {
         // ---- B: eligible forward bonds.  Houdayer: both ends active (overlap.rs:228-231).
         // Joerg: both ends active and s_a(i) s_a(j) J > 0 (:417-429).  FK: s_i s_j J > 0
         // (fk.rs:113-120).  CMR: blue = satisfied in both systems (:588-596), red = satisfied in
         // exactly one (:779-792).
-        for (uint32_t r = 0; r < n_rounds; ++r) {
-            const uint32_t i = r * kSwThreads + tid;
-            bool e[6] = {false, false, false, false, false, false};
-            if (i < d.N && get_bit(L.act, i)) {
-                const uint32_t jm = STOCHASTIC ? jsite[i] : 0u;
-                for (uint32_t dd = 0; dd < d.nn; ++dd) {
-                    const uint32_t j = p.nbr_site[i * 12 + 2 * dd];
-                    bool ok = get_bit(L.act, j) != 0;
-                    if (STOCHASTIC && ok) {
-                        const bool nz = (jm >> (12 + 2 * dd)) & 1u;
-                        const uint32_t neg = (jm >> (2 * dd)) & 1u;
-                        const bool a_sat = (get_bit(L.spa, i) ^ get_bit(L.spa, j) ^ neg) == 0;
-                        if (CMR) {
-                            const bool b_sat = (get_bit(L.spb, i) ^ get_bit(L.spb, j) ^ neg) == 0;
-                            ok = nz && (phase == 0 ? (a_sat && b_sat) : (a_sat != b_sat));
-                        } else {
-                            ok = nz && a_sat;
-                        }
-                    }
-                    e[dd] = ok;
+        for (uint32_t r0 = 0; r0 < n_rounds; r0 += 4) { // neighbour / coupling loads of 4 rounds in flight
+            uint32_t jm[4], nbj[4][6];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                const uint32_t i = (r0 + q) * kSwThreads + tid;
+                jm[q] = 0;
+#pragma unroll
+                for (uint32_t dd = 0; dd < 6; ++dd) nbj[q][dd] = 0;
+                if (r0 + q < n_rounds && i < d.N) {
+                    if (STOCHASTIC) jm[q] = jsite[i];
+#pragma unroll
+                    for (uint32_t dd = 0; dd < 6; ++dd)
+                        if (dd < d.nn) nbj[q][dd] = p.nbr_site[i * 12 + 2 * dd];
                 }
             }
-            for (uint32_t dd = 0; dd < 6; ++dd) put_ballot(L.bond + dd * d.MW, r, e[dd]);
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                const uint32_t r = r0 + q, i = r * kSwThreads + tid;
+                if (r >= n_rounds) break;
+                bool e[6] = {false, false, false, false, false, false};
+                if (i < d.N && get_bit(L.act, i)) {
+#pragma unroll
+                    for (uint32_t dd = 0; dd < 6; ++dd) {
+                        if (dd >= d.nn) continue;
+                        const uint32_t j = nbj[q][dd];
+                        bool ok = get_bit(L.act, j) != 0;
+                        if (STOCHASTIC && ok) {
+                            const bool nz = (jm[q] >> (12 + 2 * dd)) & 1u;
+                            const uint32_t neg = (jm[q] >> (2 * dd)) & 1u;
+                            const bool a_sat = (get_bit(L.spa, i) ^ get_bit(L.spa, j) ^ neg) == 0;
+                            if (CMR) {
+                                const bool b_sat = (get_bit(L.spb, i) ^ get_bit(L.spb, j) ^ neg) == 0;
+                                ok = nz && (phase == 0 ? (a_sat && b_sat) : (a_sat != b_sat));
+                            } else {
+                                ok = nz && a_sat;
+                            }
+                        }
+                        e[dd] = ok;
+                    }
+                }
+                for (uint32_t dd = 0; dd < d.nn; ++dd) put_ballot(L.bond + dd * d.MW, r, e[dd]);
+            }
         }
         __syncthreads();
-
         // ---- C, D, E (stochastic bonds): the bond at rank k of the eligible ones, in (site, dim)
         // order, sees draw pos + k of the generator
         if (STOCHASTIC) {
@@ -321,6 +364,7 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
             draw_bits(pos, n_eligible, threshold, false);
             __syncthreads();
             const uint32_t rel = pos - (pos / 256) * 256;
+            uint32_t *accepted = (CMR && phase == 0) ? L.blue : L.acc;
             for (uint32_t r = 0; r < n_rounds; ++r) {
                 const uint32_t i = r * kSwThreads + tid;
                 bool e[6] = {false, false, false, false, false, false};
@@ -330,50 +374,46 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
                             const uint32_t q = rel + entries_before(i, dd);
                             e[dd] = (L.bits[q >> 5] >> (q & 31u)) & 1u;
                         }
-                __syncthreads(); // every thread has read its bond words before any is replaced
-                for (uint32_t dd = 0; dd < 6; ++dd) put_ballot(L.bond + dd * d.MW, r, e[dd]);
-                __syncthreads();
+                for (uint32_t dd = 0; dd < d.nn; ++dd) put_ballot(accepted + dd * d.MW, r, e[dd]);
             }
+            __syncthreads();
             pos += n_eligible;
-            if (CMR && phase == 0) { // keep the blue bonds: grey clusters are blue + red
-                for (uint32_t m = tid; m < 6 * d.MW; m += kSwThreads) L.blue[m] = L.bond[m];
-                __syncthreads();
-            }
         }
 
         // ---- F: connected components.  Roots are hooked under the smaller root, so a component's
         // final root is its smallest site -- the order in which the reference meets the clusters.
         for (uint32_t i = tid; i < d.N; i += kSwThreads) L.label[i] = i;
-        if (tid == 0) L.misc[0] = 0;
         __syncthreads();
+        // bonds of this phase: the eligible ones of a deterministic move, else the accepted ones
+        // (CMR keeps the blue bonds: grey clusters are blue + red)
+        const uint32_t *links = !STOCHASTIC ? L.bond : ((CMR && phase == 0) ? L.blue : L.acc);
         auto bonded = [&](uint32_t dd, uint32_t i) -> bool {
-            return get_bit(L.bond + dd * d.MW, i) || (CMR && phase == 1 && get_bit(L.blue + dd * d.MW, i));
+            return get_bit(links + dd * d.MW, i) || (CMR && phase == 1 && get_bit(L.blue + dd * d.MW, i));
         };
-        for (uint32_t iter = 0; iter <= d.N; ++iter) {
-            bool hooked = false;
-            for (uint32_t i = tid; i < d.N; i += kSwThreads)
-                for (uint32_t dd = 0; dd < d.nn; ++dd)
-                    if (bonded(dd, i)) {
-                        const uint32_t j = p.nbr_site[i * 12 + 2 * dd];
-                        const uint32_t ra = find_root(i), rb = find_root(j);
-                        if (ra != rb) {
-                            atomicMin(&L.label[max(ra, rb)], min(ra, rb));
-                            hooked = true;
+        // Lock-free union: every bond is visited once; the larger root is hooked under the smaller
+        // one with a compare-and-swap, retried from the new roots when another lane got there first
+        // (labels only ever decrease, so every chain ends and the loop terminates).
+        for (uint32_t i = tid; i < d.N; i += kSwThreads)
+            for (uint32_t dd = 0; dd < d.nn; ++dd)
+                if (bonded(dd, i)) {
+                    uint32_t ra = find_root(i), rb = find_root(p.nbr_site[i * 12 + 2 * dd]);
+                    while (ra != rb) {
+                        if (ra < rb) {
+                            const uint32_t tmp = ra;
+                            ra = rb;
+                            rb = tmp;
                         }
+                        const uint32_t old = atomicCAS(&L.label[ra], ra, rb); // ra > rb
+                        if (old == ra) break;
+                        ra = find_root(old);
+                        rb = find_root(rb);
                     }
-            if (hooked) L.misc[0] = 1;
-            __syncthreads();
-            for (uint32_t i = tid; i < d.N; i += kSwThreads) { // pointer jumping
-                uint32_t x = L.label[i];
-                while (L.label[x] != x) x = L.label[x];
-                L.label[i] = x;
-            }
-            const bool again = L.misc[0] != 0;
-            __syncthreads();
-            if (!again) break;
-            if (tid == 0) L.misc[0] = 0;
-            __syncthreads();
-        }
+                }
+        __syncthreads();
+        for (uint32_t i = tid; i < d.N; i += kSwThreads) L.aux[i] = find_root(i); // flatten (reads only)
+        __syncthreads();
+        for (uint32_t i = tid; i < d.N; i += kSwThreads) L.label[i] = L.aux[i];
+        __syncthreads();
 
         if (MODE == kSwHoudayer && wolff) {
             // single-cluster variant: up to 64 probes for an active seed (utils.rs:107-119), flip its component
@@ -402,7 +442,6 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
                         atomicXor(&Stile[static_cast<size_t>(members[k] >> 5) * d.N + i], 1u << (members[k] & 31u));
             return;
         }
-
         // ---- G: clusters that draw -- more than one site for the overlap moves (overlap.rs:312-318,
         // :757-762, :822-828), every cluster for FK (fk.rs:182-192) -- ranked by their smallest site
         for (uint32_t i = tid; i < d.N; i += kSwThreads) L.aux[i] = 0;
@@ -416,14 +455,12 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
         }
         __syncthreads();
         const uint32_t n_clusters = scan_words([&](uint32_t m) { return static_cast<uint32_t>(__popc(L.roots[m])); });
-
         // ---- H: the cluster draws continue the stream after the bond draws: a coin
         // gen::<f32>() < 0.5, or for the grey clusters of CMR gen_range(0..=3) = the top two bits
         const bool grey = CMR && phase == 1;
         draw_bits(pos, n_clusters, 1u << 23, grey);
         __syncthreads();
         const uint32_t rel = pos - (pos / 256) * 256;
-
         // ---- I: flips (both systems for a coin; bit 0 / bit 1 of k for the two systems of a grey cluster)
         for (uint32_t r = 0; r < n_rounds; ++r) {
             const uint32_t i = r * kSwThreads + tid;
@@ -459,11 +496,16 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
         pos += n_clusters;
         __syncthreads();
     }
-
     // ---- the generator ends `pos` draws after where it started
     if (tid == 0) {
-        Rng32 rng = stream_at_block(pos / 256);
-        for (uint32_t k = 0; k < pos % 256; ++k) (void)rng.next_top();
+        uint32_t js[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) js[k] = base_state[k];
+        if (pos / 256) jump_state_lds(js, p.jump256 + static_cast<size_t>(pos / 256) * (64 * 16 * 8));
+        if ((pos / 64) & 3u) jump_state_lds(js, p.jump64 + static_cast<size_t>((pos / 64) & 3u) * (64 * 16 * 8));
+        Rng32 rng;
+        rng.load(js);
+        for (uint32_t k = 0; k < (pos & 63u); ++k) (void)rng.next_top();
         uint32_t st[8];
         rng.store(st);
         if (FK) {

@@ -72,6 +72,7 @@ struct pa_sim {
     std::vector<uint64_t> equil_sweeps; // checkpoints of the last sample() with the equilibration diagnostic
     uint64_t ac_lag = 0, ac_samples = 0, ac_capacity = 0; // autocorrelation series of the last sample()
     float *Jf = nullptr, *temps_dev = nullptr; // general-coupling path
+    uint32_t *jump64 = nullptr;
     uint32_t *jump256 = nullptr, *jorg_thr = nullptr, *fk_thr = nullptr, *cmr_thr = nullptr; // cluster kernels
     int32_t *nz_bonds = nullptr;
     float *dbeta = nullptr;
@@ -420,6 +421,15 @@ int ensure_cluster_sw(pa_sim *sim) {
             if (b + 1 < n_tab) acc = step.compose(acc);
         }
     }
+    std::vector<uint32_t> jump_fine(static_cast<size_t>(4) * 64 * 16 * 8);
+    {
+        JumpMatrix step = JumpMatrix::steps(64);
+        JumpMatrix acc = JumpMatrix::identity();
+        for (uint32_t b = 0; b < 4; ++b) {
+            acc.nibble_table(&jump_fine[static_cast<size_t>(b) * 64 * 16 * 8]);
+            if (b + 1 < 4) acc = step.compose(acc);
+        }
+    }
     // gen::<f32>() < p on the 2^24 grid as an integer threshold; p by the host's expf for a
     // satisfied unit bond: Joerg 1 - exp(-4/T) (overlap.rs:430), FK 1 - exp(-2/T) (fk.rs:74,119)
     // CMR (overlap.rs:601-603): blue bonds 1 - r * r with r = exp(-2|J|/T) in f32, red bonds 1 - r
@@ -435,23 +445,27 @@ int ensure_cluster_sw(pa_sim *sim) {
         thr_cmr[t] = as_threshold(1.0f - r * r);
     }
     PA_HIP(sim, sim->buffers.alloc(&sim->jump256, jump.size()));
+    PA_HIP(sim, sim->buffers.alloc(&sim->jump64, jump_fine.size()));
     PA_HIP(sim, sim->buffers.alloc(&sim->jorg_thr, thr.size()));
     PA_HIP(sim, sim->buffers.alloc(&sim->fk_thr, thr_fk.size()));
     PA_HIP(sim, sim->buffers.alloc(&sim->cmr_thr, thr_cmr.size()));
     const size_t slots_per_real = static_cast<size_t>(d.n_temps) * d.n_replicas;
     PA_HIP(sim, sim->buffers.alloc(&sim->p.pair_slots, slots_per_real * d.n_real));
     int rc;
-    if ((rc = upload(sim, sim->jump256, jump)) || (rc = upload(sim, sim->jorg_thr, thr)) ||
+    if ((rc = upload(sim, sim->jump256, jump)) || (rc = upload(sim, sim->jump64, jump_fine)) ||
+        (rc = upload(sim, sim->jorg_thr, thr)) ||
         (rc = upload(sim, sim->fk_thr, thr_fk)) || (rc = upload(sim, sim->cmr_thr, thr_cmr)))
         return rc;
     if (configure_cluster_kernels() != hipSuccess) return fail(sim, PA_ERR_DEVICE, "kernel LDS configuration failed");
     sim->p.jump256 = sim->jump256;
+    sim->p.jump64 = sim->jump64;
     sim->p.jorg_thr = sim->jorg_thr;
     sim->p.fk_thr = sim->fk_thr;
     sim->p.cmr_thr = sim->cmr_thr;
     uint32_t r0 = 0;
     for (auto &g : sim->groups) {
         g.p.jump256 = sim->jump256;
+        g.p.jump64 = sim->jump64;
         g.p.jorg_thr = sim->jorg_thr;
         g.p.fk_thr = sim->fk_thr;
         g.p.cmr_thr = sim->cmr_thr;

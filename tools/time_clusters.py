@@ -35,3 +35,13 @@ for mode in ("houdayer", "jorg"):
         run(f"{mode}/{inner}", overlap_cluster_update_interval=1, overlap_cluster_build_mode=mode,
             overlap_cluster_mode=inner)
 print(json.dumps({"us_per_step": out}, indent=1))
+
+# ---- FK cluster updates on a ferromagnet (16^3, 32 temperatures around T_c, 2 replicas, 16 chains)
+shape = (16, 16, 16)
+Jf = np.ones((16,) + shape + (3,), np.float32)
+sim = IsingSimulation(list(shape), Jf, np.linspace(4.111, 4.911, 32).astype(np.float32), 2, None, 42)
+out = {}
+run("fm no cluster update")
+run("fm fk/sw", cluster_update_interval=1, cluster_mode="sw")
+run("fm fk/wolff", cluster_update_interval=1, cluster_mode="wolff")
+print(json.dumps({"fk_us_per_step": out}, indent=1))

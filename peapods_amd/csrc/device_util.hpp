@@ -195,4 +195,20 @@ __device__ __forceinline__ void coherent_store(uint32_t *ptr, uint32_t v) {
 }
 
 
+// The 12 neighbour slots of a site (f0, b0, ..., f5, b5; u16 each) fetched with three 8-byte loads, so
+// a serial search pays one memory latency per site instead of one per neighbour.
+struct NbrRow {
+    uint64_t q[3];
+    __device__ __forceinline__ NbrRow(const uint16_t *nbr_site, uint32_t site) {
+        const uint64_t *row = reinterpret_cast<const uint64_t *>(nbr_site + static_cast<size_t>(site) * 12);
+        q[0] = row[0];
+        q[1] = row[1];
+        q[2] = row[2];
+    }
+    __device__ __forceinline__ uint32_t at(uint32_t dir) const {
+        const uint64_t v = dir < 4 ? q[0] : (dir < 8 ? q[1] : q[2]);
+        return static_cast<uint32_t>(v >> ((dir & 3u) * 16)) & 0xFFFFu;
+    }
+};
+
 } // namespace pa

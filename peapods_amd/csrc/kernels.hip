@@ -1480,8 +1480,9 @@ __global__ __launch_bounds__(1024) void k_jorg(SimDims d, DevPtrs p) {
             while (top > 0) {
                 const uint32_t site = stack[--top];
                 const uint32_t jm = jsite[site];
+                const NbrRow nbrs(p.nbr_site, site);
                 for (uint32_t dir = 0; dir < 2 * d.nn; ++dir) { // f0, b0, f1, b1, ...
-                    const uint32_t nb = p.nbr_site[site * 12 + dir];
+                    const uint32_t nb = nbrs.at(dir);
                     if ((mine[nb >> 5] >> (nb & 31u)) & 1u) continue;
                     if (!active(nb)) continue;
                     // inter = s_a(site) * s_a(nb) * J(bond) must be > 0

@@ -582,9 +582,10 @@ __global__ __launch_bounds__(1024) void k_fk_wolff(SimDims d, DevPtrs p) {
         while (top > 0) {
             const uint32_t site = stack[--top];
             const uint32_t jm = jsite[site];
+            const NbrRow nbrs(p.nbr_site, site);
             const uint32_t s_site = (wa[site] >> ba) & 1u;
             for (uint32_t dir = 0; dir < 2 * d.nn; ++dir) { // f0, b0, f1, b1, ...
-                const uint32_t nb = p.nbr_site[site * 12 + dir];
+                const uint32_t nb = nbrs.at(dir);
                 if ((mine[nb >> 5] >> (nb & 31u)) & 1u) continue;
                 if (!((jm >> (12 + dir)) & 1u)) continue;                      // J = 0
                 if ((s_site ^ ((wa[nb] >> ba) & 1u) ^ ((jm >> dir) & 1u)) != 0) continue; // s s J <= 0
@@ -678,8 +679,9 @@ __global__ __launch_bounds__(1024) void k_cmr_wolff(SimDims d, DevPtrs p) {
             while (top > 0) {
                 const uint32_t site = stack[--top];
                 const uint32_t jm = jsite[site];
+                const NbrRow nbrs(p.nbr_site, site);
                 for (uint32_t dir = 0; dir < 2 * d.nn; ++dir) { // f0, b0, f1, b1, ...
-                    const uint32_t nb = p.nbr_site[site * 12 + dir];
+                    const uint32_t nb = nbrs.at(dir);
                     if (in_cluster(nb)) continue;
                     if (!((jm >> (12 + dir)) & 1u)) continue; // J = 0: neither system is satisfied
                     const bool a_sat = sat(wa, ba, site, nb, jm, dir), b_sat = sat(wb, bb, site, nb, jm, dir);

@@ -195,6 +195,64 @@ __device__ __forceinline__ void coherent_store(uint32_t *ptr, uint32_t v) {
 }
 
 
+// expf as glibc computes it (sysdeps/ieee754/flt-32/e_expf.c, glibc >= 2.27): x N / ln2 = k + r with
+// N = 32, exp(x) = 2^(k/N) 2^(r/N) ~ T[k mod N] 2^(k div N) (C0 r^3 + C1 r^2 + C2 r + 1), all in f64 with
+// one final rounding.  T[i] = bits(2^(i/32)) - (i << 47).  The engine compares it with the host's
+// expf on 2^24 arguments before the first use on a device (ensure_device_exp).
+__device__ const unsigned long long kExpfTab[32] = {
+    0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL,
+    0x3fef72b83c7d517bULL, 0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL,
+    0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL, 0x3feedea64c123422ULL, 0x3feece086061892dULL,
+    0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL, 0x3feea47eb03a5585ULL,
+    0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL,
+    0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL,
+    0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL,
+    0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL,
+};
+
+__device__ __forceinline__ float dev_expf(float x) {
+    const double xd = static_cast<double>(x);
+    const uint32_t abstop = (__float_as_uint(x) >> 20) & 0x7ffu;
+    if (abstop >= (0x42b00000u >> 20)) { // |x| >= 88 or nan
+        if (__float_as_uint(x) == 0xff800000u) return 0.0f;
+        if (abstop >= (0x7f800000u >> 20)) return __fadd_rn(x, x);
+        if (x > 0x1.62e42ep6f) return __uint_as_float(0x7f800000u);
+        if (x < -0x1.9fe368p6f) return 0.0f;
+    }
+    double z = __dmul_rn(0x1.71547652b82fep+0 * 32, xd);
+    double kd = __dadd_rn(z, 0x1.8p+52);
+    const unsigned long long ki = static_cast<unsigned long long>(__double_as_longlong(kd));
+    kd = __dsub_rn(kd, 0x1.8p+52);
+    const double r = __dsub_rn(z, kd);
+    const unsigned long long t = kExpfTab[ki & 31u] + (ki << 47);
+    const double s = __longlong_as_double(static_cast<long long>(t));
+    z = __dadd_rn(__dmul_rn(0x1.c6af84b912394p-5 / 32 / 32 / 32, r), 0x1.ebfce50fac4f3p-3 / 32 / 32);
+    const double r2 = __dmul_rn(r, r);
+    double y = __dadd_rn(__dmul_rn(0x1.62e42ff0c52d6p-1 / 32, r), 1.0);
+    y = __dadd_rn(__dmul_rn(z, r2), y);
+    y = __dmul_rn(y, s);
+    return static_cast<float>(y);
+}
+
+// gen::<f32>() < p on the 2^24 grid of draws  <=>  draw < ceil(p 2^24)
+__device__ __forceinline__ uint32_t draw_threshold(float p) {
+    const double scaled = ceil(static_cast<double>(p) * 16777216.0);
+    return scaled <= 0.0 ? 0u : (scaled >= 16777216.0 ? (1u << 24) : static_cast<uint32_t>(scaled));
+}
+// bond probabilities of the cluster moves for a satisfied bond of strength |J| at temperature T
+// (overlap.rs:430: 1 - exp(-4 |J| / T); fk.rs:74,119: 1 - exp(-2 |J| / T); overlap.rs:601-603, 792-793:
+// r = exp(-2 |J| / T), blue 1 - r r, red 1 - r), in the reference's f32 operation order
+__device__ __forceinline__ uint32_t jorg_threshold(float j_abs, float temp) {
+    return draw_threshold(__fsub_rn(1.0f, dev_expf(__fdiv_rn(__fmul_rn(-4.0f, j_abs), temp))));
+}
+__device__ __forceinline__ uint32_t fk_threshold(float j_abs, float temp) {
+    return draw_threshold(__fsub_rn(1.0f, dev_expf(__fdiv_rn(__fmul_rn(-2.0f, j_abs), temp))));
+}
+__device__ __forceinline__ uint32_t cmr_blue_threshold(float j_abs, float temp) {
+    const float r = dev_expf(__fdiv_rn(__fmul_rn(-2.0f, j_abs), temp));
+    return draw_threshold(__fsub_rn(1.0f, __fmul_rn(r, r)));
+}
+
 // The 12 neighbour slots of a site (f0, b0, ..., f5, b5; u16 each) fetched with three 8-byte loads, so
 // a serial search pays one memory latency per site instead of one per neighbour.
 struct NbrRow {

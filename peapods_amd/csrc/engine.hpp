@@ -151,6 +151,7 @@ size_t cluster_sw_lds_bytes(const SimDims &d);
 hipError_t launch_fk(const SimDims &d, const DevPtrs &p, bool wolff, hipStream_t stream);
 size_t fk_wolff_lds_bytes(const SimDims &d);
 hipError_t configure_cluster_kernels();
+hipError_t launch_exp_selftest(float *out, hipStream_t stream);
 // kernels_general.hip
 hipError_t launch_rng_f(const SimDims &d, const DevPtrs &p, bool gibbs, hipStream_t stream);
 hipError_t launch_sweep_f(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,

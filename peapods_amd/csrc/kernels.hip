@@ -1489,8 +1489,15 @@ __global__ __launch_bounds__(1024) void k_jorg(SimDims d, DevPtrs p) {
                     if (!((jm >> (12 + dir)) & 1u)) continue;
                     if ((spin_a(site) ^ spin_a(nb) ^ ((jm >> dir) & 1u)) != 0) continue;
                     const uint32_t draw = static_cast<uint32_t>(rng.next() >> 40);
-                    const float u = __fmul_rn(static_cast<float>(draw), 1.0f / 16777216.0f);
-                    if (u < bond_p) {
+                    bool bond;
+                    if (d.unit) {
+                        bond = __fmul_rn(static_cast<float>(draw), 1.0f / 16777216.0f) < bond_p;
+                    } else { // p = 1 - exp(-4 |J| / T) of this bond (overlap.rs:430), owner = forward end
+                        const uint32_t owner = (dir & 1u) ? nb : site;
+                        const float j_abs = fabsf(p.Jf[(static_cast<size_t>(real) * d.N + owner) * d.nn + (dir >> 1)]);
+                        bond = draw < jorg_threshold(j_abs, p.temps[t]);
+                    }
+                    if (bond) {
                         mine[nb >> 5] |= 1u << (nb & 31u);
                         stack[top++] = static_cast<uint16_t>(nb);
                     }

@@ -100,6 +100,7 @@ struct SwLds {
     uint32_t *blue;    // [6][MW] CMR: accepted blue bonds, kept for the grey clusters
     uint32_t *acc;     // [6][MW] accepted bonds of the current phase
     uint32_t *blk;     // [n_bit_words] generator states at the 256-draw block boundaries in use
+    uint32_t *thr;     // [N nn] non-unit couplings: threshold of every eligible bond by its draw rank
     uint32_t *wbase;   // [MW + 1] exclusive prefix (eligible bonds / drawing roots) per 32-site word
     uint32_t *roots;   // [MW] roots that draw
     uint32_t *flip_a;  // [MW] accumulated flips of the first system
@@ -114,7 +115,8 @@ __host__ __device__ inline size_t cluster_sw_bit_words(const SimDims &d) {
     return (static_cast<size_t>(d.N) * d.nn + 255) / 256 * 8 + 16;
 }
 __host__ __device__ inline size_t cluster_sw_lds_words(const SimDims &d) {
-    return 2 * static_cast<size_t>(d.N) + 26 * static_cast<size_t>(d.MW) + 1 + 3 * cluster_sw_bit_words(d) + 12;
+    return 2 * static_cast<size_t>(d.N) + 26 * static_cast<size_t>(d.MW) + 1 + 3 * cluster_sw_bit_words(d) + 12 +
+           (d.unit ? 0 : static_cast<size_t>(d.N) * d.nn);
 }
 
 enum { kSwHoudayer = 0, kSwJorg = 1, kSwFk = 2, kSwCmr = 3 };
@@ -147,7 +149,8 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
         L.bits = q; q += cluster_sw_bit_words(d);
         L.bits2 = q; q += cluster_sw_bit_words(d);
         L.scratch = q; q += 8;
-        L.misc = q;
+        L.misc = q; q += 4;
+        L.thr = q;
     }
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t n_groups = FK ? 1u : d.n_replicas / group;
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
         }
         __syncthreads();
     };
-    auto draw_bits = [&](uint32_t start, uint32_t count, uint32_t threshold, bool two_bits) {
+    auto draw_bits = [&](uint32_t start, uint32_t count, uint32_t threshold, bool two_bits, const uint32_t *thr_by_rank) {
         if (count == 0) return;
         const uint32_t first_block = start / 256, last_pos = start + count - 1;
         block_states(first_block, last_pos / 256);
@@ -280,7 +283,12 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
                         acc |= ((top >> 30) & 1u) << k;
                         acc2 |= (top >> 31) << k;
                     } else {
-                        acc |= ((top >> 8) < threshold ? 1u : 0u) << k;
+                        uint32_t limit = threshold;
+                        if (thr_by_rank) { // the bond of rank q - start owns this draw
+                            const uint32_t q = unit * 64 + half_unit * 32 + k;
+                            limit = (q >= start && q - start < count) ? thr_by_rank[q - start] : 0u;
+                        }
+                        acc |= ((top >> 8) < limit ? 1u : 0u) << k;
                     }
                 }
                 const uint32_t wd = (unit - first_block * 4) * 2 + half_unit;
@@ -361,7 +369,19 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
             });
             // draw < ceil(p 2^24)  <=>  gen::<f32>() < p
             const uint32_t threshold = FK ? p.fk_thr[t] : (CMR ? (phase == 0 ? p.cmr_thr[t] : p.fk_thr[t]) : p.jorg_thr[t]);
-            draw_bits(pos, n_eligible, threshold, false);
+            if (!d.unit) { // every bond has its own probability: thresholds by draw rank
+                const float temp = p.temps[t];
+                for (uint32_t i = tid; i < d.N; i += kSwThreads)
+                    for (uint32_t dd = 0; dd < d.nn; ++dd)
+                        if (get_bit(L.bond + dd * d.MW, i)) {
+                            const float j_abs = fabsf(p.Jf[(static_cast<size_t>(real) * d.N + i) * d.nn + dd]);
+                            L.thr[entries_before(i, dd)] = FK ? fk_threshold(j_abs, temp)
+                                                        : (CMR ? (phase == 0 ? cmr_blue_threshold(j_abs, temp) : fk_threshold(j_abs, temp))
+                                                               : jorg_threshold(j_abs, temp));
+                        }
+                __syncthreads();
+            }
+            draw_bits(pos, n_eligible, threshold, false, d.unit ? nullptr : L.thr);
             __syncthreads();
             const uint32_t rel = pos - (pos / 256) * 256;
             uint32_t *accepted = (CMR && phase == 0) ? L.blue : L.acc;
@@ -458,7 +478,7 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
         // ---- H: the cluster draws continue the stream after the bond draws: a coin
         // gen::<f32>() < 0.5, or for the grey clusters of CMR gen_range(0..=3) = the top two bits
         const bool grey = CMR && phase == 1;
-        draw_bits(pos, n_clusters, 1u << 23, grey);
+        draw_bits(pos, n_clusters, 1u << 23, grey, nullptr);
         __syncthreads();
         const uint32_t rel = pos - (pos / 256) * 256;
         // ---- I: flips (both systems for a coin; bit 0 / bit 1 of k for the two systems of a grey cluster)
@@ -590,7 +610,13 @@ __global__ __launch_bounds__(1024) void k_fk_wolff(SimDims d, DevPtrs p) {
                 if (!((jm >> (12 + dir)) & 1u)) continue;                      // J = 0
                 if ((s_site ^ ((wa[nb] >> ba) & 1u) ^ ((jm >> dir) & 1u)) != 0) continue; // s s J <= 0
                 const uint32_t draw = static_cast<uint32_t>(rng.next() >> 40);
-                if (draw < threshold) {
+                uint32_t thr = threshold;
+                if (!d.unit) { // p = 1 - exp(-2 |J| / T) of this bond (fk.rs:74), owner = forward end
+                    const uint32_t owner = (dir & 1u) ? nb : site;
+                    thr = fk_threshold(fabsf(p.Jf[(static_cast<size_t>(real) * d.N + owner) * d.nn + (dir >> 1)]),
+                                       p.temps[slot % d.n_temps]);
+                }
+                if (draw < thr) {
                     mine[nb >> 5] |= 1u << (nb & 31u);
                     stack[top++] = static_cast<uint16_t>(nb);
                 }
@@ -687,7 +713,13 @@ __global__ __launch_bounds__(1024) void k_cmr_wolff(SimDims d, DevPtrs p) {
                     const bool a_sat = sat(wa, ba, site, nb, jm, dir), b_sat = sat(wb, bb, site, nb, jm, dir);
                     if (phase == 0 ? !(a_sat && b_sat) : (a_sat == b_sat)) continue;
                     const uint32_t draw = static_cast<uint32_t>(rng.next() >> 40);
-                    if (draw < (phase == 0 ? thr_blue : thr_red)) {
+                    uint32_t thr = phase == 0 ? thr_blue : thr_red;
+                    if (!d.unit) { // r = exp(-2 |J| / T): blue 1 - r r, red 1 - r (overlap.rs:899-901, 926-929)
+                        const uint32_t owner = (dir & 1u) ? nb : site;
+                        const float j_abs = fabsf(p.Jf[(static_cast<size_t>(real) * d.N + owner) * d.nn + (dir >> 1)]);
+                        thr = phase == 0 ? cmr_blue_threshold(j_abs, p.temps[t]) : fk_threshold(j_abs, p.temps[t]);
+                    }
+                    if (draw < thr) {
                         mine[nb >> 5] |= 1u << (nb & 31u);
                         stack[top++] = static_cast<uint16_t>(nb);
                     }
@@ -736,6 +768,18 @@ size_t cmr_wolff_lds_bytes(const SimDims &d) { return cmr_wolff_lds_words(d) * 4
 hipError_t launch_cmr_wolff(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
     hipLaunchKernelGGL(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
     hipLaunchKernelGGL(k_cmr_wolff, dim3(d.n_real), dim3(1024), cmr_wolff_lds_bytes(d), stream, d, p);
+    return hipGetLastError();
+}
+
+// out[k] = exp(-k 2^-17), k < 2^24 ([-128, 0] in steps of 7.6e-6): compared with the host libm by
+// the engine before the first cluster move with non-unit couplings.
+__global__ void k_exp_selftest(float *out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < (1u << 24)) out[k] = dev_expf(-__fmul_rn(static_cast<float>(k), 0x1p-17f));
+}
+
+hipError_t launch_exp_selftest(float *out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_exp_selftest, dim3((1u << 24) / 256), dim3(256), 0, stream, out);
     return hipGetLastError();
 }
 

@@ -163,6 +163,40 @@ int ensure_device_log(pa_sim *sim) {
     return PA_OK;
 }
 
+// Cluster moves with non-unit couplings evaluate exp on the device (device_util.hpp restates glibc's
+// expf); before the first such move on a device 2^24 arguments in [-128, 0] are compared with the host.
+std::map<int, bool> g_exp_verified;
+
+int ensure_device_exp(pa_sim *sim) {
+    std::lock_guard<std::mutex> lock(g_ln_mutex);
+    auto it = g_exp_verified.find(sim->device);
+    if (it == g_exp_verified.end()) {
+        const size_t n = size_t(1) << 24;
+        float *dev = nullptr;
+        PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&dev), n * sizeof(float)));
+        std::vector<float> got(n), want(n);
+        hipError_t e = launch_exp_selftest(dev, sim->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(got.data(), dev, n * sizeof(float), hipMemcpyDeviceToHost, sim->stream);
+        const unsigned n_threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> workers;
+        for (unsigned k = 0; k < n_threads; ++k)
+            workers.emplace_back([&, k] {
+                for (size_t v = n * k / n_threads; v < n * (k + 1) / n_threads; ++v)
+                    want[v] = expf(-(static_cast<float>(v) * 0x1p-17f));
+            });
+        for (auto &t : workers) t.join();
+        if (e == hipSuccess) e = hipStreamSynchronize(sim->stream);
+        (void)hipFree(dev);
+        if (e != hipSuccess) return fail(sim, PA_ERR_DEVICE, std::string("exponential self-test: ") + hipGetErrorString(e));
+        it = g_exp_verified.emplace(sim->device, std::memcmp(got.data(), want.data(), n * sizeof(float)) == 0).first;
+    }
+    if (!it->second)
+        return fail(sim, PA_ERR_UNSUPPORTED,
+                    "the device exponential does not reproduce this host's expf; cluster moves with "
+                    "non-unit couplings would not match the reference");
+    return PA_OK;
+}
+
 template <typename T> int upload(pa_sim *sim, T *dst, const std::vector<T> &src) {
     if (src.empty()) return PA_OK;
     PA_HIP(sim, hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice,
@@ -565,12 +599,11 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     if (d.big && cfg->overlap_cluster_interval > 0)
         return fail(sim, PA_ERR_UNSUPPORTED,
                     "overlap-cluster moves are not built for lattices above 12000 sites yet");
+    bool needs_exp = cfg->cluster_interval > 0 && !d.unit; // bond probabilities 1 - exp(-c |J| / T) per bond
     if (!d.unit && cfg->overlap_cluster_interval > 0)
         for (int k = 0; k < cfg->n_overlap_cluster_modes && k < 4; ++k)
-            if ((cfg->overlap_cluster_modes[k] & 0xFF) == PA_OC_JORG || (cfg->overlap_cluster_modes[k] & 0xFF) == PA_OC_CMR)
-                return fail(sim, PA_ERR_UNSUPPORTED,
-                            "the 'jorg' and 'cmr' moves need expf of arbitrary couplings, which is not "
-                            "built on the HIP path yet (unit couplings only)");
+            needs_exp = needs_exp || (cfg->overlap_cluster_modes[k] & 0xFF) == PA_OC_JORG ||
+                        (cfg->overlap_cluster_modes[k] & 0xFF) == PA_OC_CMR;
     if (cfg->overlap_cluster_interval > 0 && d.n_temps * d.n_pairs > 1024)
         return fail(sim, PA_ERR_UNSUPPORTED, "overlap-cluster moves support at most 1024 pairs per realisation");
     const bool gibbs = cfg->sweep_mode == PA_SWEEP_GIBBS;
@@ -582,13 +615,10 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         oc_cmr = oc_cmr || (cfg->overlap_cluster_modes[k] & 0xFF) == PA_OC_CMR || (cfg->overlap_cluster_modes[k] >> 8) > 2 ||
                  d.nn > 3;
     const bool fk = cfg->cluster_interval > 0;
-    if (fk && !d.unit)
-        return fail(sim, PA_ERR_UNSUPPORTED,
-                    "FK cluster updates need expf of arbitrary couplings, which is not built on the "
-                    "HIP path yet (unit couplings only)");
     if (fk && cfg->cluster_mode == PA_CLUSTER_WOLFF && (d.big || fk_wolff_lds_bytes(d) > 160 * 1024))
         return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the FK cluster kernel");
     if ((oc_sw || fk || oc_cmr) && (rc = ensure_cluster_sw(sim))) return rc;
+    if (needs_exp && (rc = ensure_device_exp(sim))) return rc;
     if (cfg->equilibration_diagnostic && (rc = ensure_equil(sim))) return rc;
     // autocorrelation (mod.rs:342-345): max_lag capped at a quarter of the measurement sweeps, at least 1
     const uint64_t n_meas = cfg->n_sweeps - cfg->warmup_sweeps;

@@ -151,9 +151,30 @@ def test_general_couplings_sample_matches_oracle(oracle, schedule):
     b = cpu.sample(6, "metropolis", **kwargs)
     assert_results_equal(a, b)
     assert_state_equal(gpu, cpu)
-    with pytest.raises(NotImplementedError):
-        gpu.sample(2, "metropolis", overlap_cluster_update_interval=1,
-                   overlap_cluster_build_mode="jorg")
+
+
+@pytest.mark.parametrize("inner", ["sw", "wolff"])
+def test_cluster_moves_with_gaussian_couplings(oracle, inner):
+    """Non-unit couplings: every bond has its own probability 1 - exp(-c |J| / T) (overlap.rs:430,
+    601-603, 792-793; fk.rs:74,119), evaluated by the device expf (checked against the host's)."""
+    shape = (6, 6, 6)
+    couplings = gaussian(shape, 3, 2, 77)
+    gpu, cpu = make_pair(oracle, shape, couplings, np.linspace(0.6, 2.0, 5), 4, 15)
+    kwargs = dict(pt_interval=1, overlap_cluster_update_interval=1, overlap_cluster_build_mode="jorg+cmr+houdayer",
+                  overlap_cluster_mode=inner, cluster_update_interval=2, cluster_mode=inner, warmup_ratio=0.25)
+    a = gpu.sample(12, "metropolis", **kwargs)
+    b = cpu.sample(12, "metropolis", **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+    # a custom lattice with five directions and mixed couplings
+    offsets = [[1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 0], [0, 1, 1]]
+    couplings = gaussian((4, 4, 6), 5, 1, 78)
+    couplings[np.random.default_rng(1).random(couplings.shape) < 0.2] = 0.0
+    gpu, cpu = make_pair(oracle, (4, 4, 6), couplings, np.linspace(1.0, 4.0, 4), 2, 16, offsets)
+    a = gpu.sample(10, "gibbs", **kwargs)
+    b = cpu.sample(10, "gibbs", **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
 
 
 def test_unit_couplings_outside_the_table_domain_take_the_logarithmic_rule(oracle):

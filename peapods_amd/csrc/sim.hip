@@ -1077,6 +1077,10 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
             const uint32_t h = (m + 1) / 2;
             const uint32_t jm = (neg & 63u) | ((nz & 63u) << 6) | (h << 12);
             if (m != 2 * d.nn) all_nonzero = false;
+            if (m & 1u) { // odd number of non-zero bonds: the odd threshold set (k_rng)
+                mpar[static_cast<size_t>(real) * d.MW + (site >> 5)] |= 1u << (site & 31u);
+                d.has_odd = 1;
+            }
             if (d.big) { // full-width indices, two uint4 per site
                 rec[static_cast<size_t>(real) * rec_stride + 2 * pos] = make_uint4(site, nb[0], nb[1], nb[2]);
                 rec[static_cast<size_t>(real) * rec_stride + 2 * pos + 1] = make_uint4(nb[3], nb[4], nb[5], jm);
@@ -1085,10 +1089,6 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
             rec[static_cast<size_t>(real) * rec_stride + pos] = // fields hold LDS byte offsets (4 * index)
                 make_uint4((site * 4) | (nb[0] * 4 << 16), (nb[1] * 4) | (nb[2] * 4 << 16),
                            (nb[3] * 4) | (nb[4] * 4 << 16), (nb[5] * 4) | (jm << 16));
-            if (m & 1u) {
-                mpar[static_cast<size_t>(real) * d.MW + (site >> 5)] |= 1u << (site & 31u);
-                d.has_odd = 1;
-            }
         }
         const uint32_t dummy = d.N * 4; // idle lanes of a pass work on the spare slot N
         if (!d.big)

@@ -922,7 +922,9 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     d.n_pairs = d.n_replicas / 2;
     d.n_real = static_cast<uint32_t>(desc->n_realizations);
     d.nn = lat.n_neighbors;
-    uint32_t target_block = 256; // sites per RNG block (tuning knob: PEAPODS_RNG_BLOCK)
+    // sites per RNG block (tuning knob PEAPODS_RNG_BLOCK): 128 gives twice the waves of 256 for 7 % more
+    // jump-ahead work and is 7 % faster per step on the bench workload (64, 96, 160, 256, 512 measured)
+    uint32_t target_block = 128;
     if (const char *env = std::getenv("PEAPODS_RNG_BLOCK")) {
         const long v = std::strtol(env, nullptr, 10);
         if (v >= 16 && v <= 65536) target_block = static_cast<uint32_t>(v);

@@ -60,6 +60,9 @@ enum { PA_SWEEP_METROPOLIS = 0, PA_SWEEP_GIBBS = 1 };
 enum { PA_PT_SINGLE_RANDOM_EDGE = 0, PA_PT_FULL_LADDER = 1 };
 enum { PA_OC_HOUDAYER = 1, PA_OC_JORG = 2, PA_OC_CMR = 3 };
 enum { PA_CLUSTER_WOLFF = 0, PA_CLUSTER_SW = 1 };
+enum { PA_ACTION_UPDATE = 0, PA_ACTION_OBSERVE = 1 }; /* ClusterAction, ss/config.rs:41-59 */
+/* rows of pa_sim_get_observation (per_disorder["cluster_observations"], src/lib.rs:416-445) */
+enum { PA_OBS_FK = 0, PA_OBS_HOUDAYER = 1, PA_OBS_JORG = 2, PA_OBS_CMR_BLUE = 3 };
 
 typedef struct pa_sim pa_sim;
 
@@ -105,6 +108,14 @@ typedef struct {
     uint64_t autocorrelation_max_lag; /* 0 = none; else the integrated autocorrelation times of m^2 and
                                      q^2 are collected (ring backend, ss/statistics/autocorrelation.rs,
                                      driver ss/simulation/mod.rs:342-371,580-595) */
+    int32_t collect_cluster_stats;  /* 1 = cluster-size histograms of the FK / overlap clusters and the four
+                                     largest overlap clusters on recorded sweeps (collect_cluster_stats,
+                                     src/lib.rs:243,266; driver ss/simulation/mod.rs:442-483,604-735).  As in
+                                     the reference, single-cluster moves then take their union-find form. */
+    int32_t cluster_action;         /* PA_ACTION_*: FK update or observation (ss/config.rs:41-59) */
+    int32_t overlap_cluster_action; /* PA_ACTION_* for the overlap move */
+    uint64_t snapshot_interval;     /* 0 = none; cluster ids, spins and systems of the first realisation's
+                                     first pair at every temperature, every k sweeps (mod.rs:302-335,628-714) */
 } pa_sample_config;
 
 /* ---- lifecycle ----------------------------------------------------------- */
@@ -180,6 +191,26 @@ uint64_t pa_sim_result_block_len(const pa_sim *sim);
  * autocorrelation_max_lag > 0 (sokal_tau over AutocorrAccum::finish, autocorrelation.rs:116-208):
  * mags2_tau [n_temps], overlap2_tau [n_temps] (untouched without replica pairs). */
 int pa_sim_get_autocorrelation_tau(pa_sim *sim, uint64_t realization, double *mags2_tau, double *overlap2_tau);
+/* Cluster statistics of the last sample() for one realisation (ClusterStats, ss/statistics/results.rs:12-20;
+ * filled by ss/simulation/mod.rs:471-478,716-735,799-823).  fk_csd u64 [n_temps][n_spins + 1];
+ * overlap_csd u64 [n_modes][n_temps][n_spins + 1]; top_sizes f64 [n_modes][n_temps][4] (mean relative size of
+ * the four largest overlap clusters).  Any pointer may be NULL.  Returns bit 0 = FK histogram present,
+ * bit 1 = overlap statistics present, or a negative PA_ERR_*. */
+int pa_sim_get_cluster_stats(pa_sim *sim, uint64_t realization, uint64_t *fk_csd, uint64_t *overlap_csd,
+                             double *top_sizes);
+/* Graph observation summary `kind` (PA_OBS_*) of one realisation (GraphObservationSummary, results.rs:22-31;
+ * GraphObservationAccum::finish, mod.rs:57-97): observation_count u64 [n_temps], cluster_size_counts u64
+ * [n_temps][n_spins + 1], top_four_component_fractions f64 [n_temps][4], active_bond_density f64 [n_temps],
+ * large_component_count f64 [n_temps], winding f64 [n_temps][4] = x, y, either, both.  Returns 0 = absent,
+ * 1 = present, 3 = present with winding (2D hypercubic lattices), or a negative PA_ERR_*. */
+int pa_sim_get_observation(pa_sim *sim, uint64_t realization, int32_t kind, uint64_t *count, uint64_t *sizes,
+                           double *top4_frac, double *bond_density, double *large_mean, double *winding);
+/* Cluster snapshots of the last sample() (ClusterSnapshot, results.rs:47-54; src/lib.rs:576-614):
+ * cluster_ids / blue_ids u32 [n_temps][n_spins] (union-find roots in the reference's convention), spins i8
+ * [n_temps][2][n_spins], system_ids u64 [n_temps][2].  Returns 1 when blue_ids are present (CMR). */
+uint64_t pa_sim_n_snapshots(const pa_sim *sim);
+int pa_sim_get_snapshot(pa_sim *sim, uint64_t index, uint64_t *sweep_id, int32_t *mode_idx, uint32_t *cluster_ids,
+                        uint32_t *blue_ids, int8_t *spins, uint64_t *system_ids);
 uint64_t pa_sim_n_equil_checkpoints(const pa_sim *sim);
 int pa_sim_get_equilibration(pa_sim *sim, uint64_t realization, uint64_t *sweeps, double *energy_avg,
                              double *link_overlap_avg);

@@ -24,6 +24,8 @@ SWEEP_MODES = {"metropolis": 0, "gibbs": 1}
 PT_SCHEDULES = {"single_random_edge": 0, "full_ladder": 1}
 OC_MODES = {"houdayer": 1, "houd2": 1, "jorg": 2, "cmr": 3, "cmr2": 3}
 CLUSTER_MODES = {"wolff": 0, "sw": 1}
+ACTIONS = {"update": 0, "observe": 1}
+OBSERVATION_KINDS = ("fk", "houdayer", "jorg", "cmr_blue")
 
 
 class OrcConfig(C.Structure):
@@ -42,6 +44,10 @@ class OrcConfig(C.Structure):
         ("cluster_mode", C.c_int32),
         ("autocorrelation_max_lag", C.c_uint64),
         ("equilibration_diagnostic", C.c_int32),
+        ("collect_cluster_stats", C.c_int32),
+        ("cluster_action", C.c_int32),
+        ("overlap_cluster_action", C.c_int32),
+        ("snapshot_interval", C.c_uint64),
     ]
 
 
@@ -114,6 +120,11 @@ def load(path=None):
         "orc_uf_from_bonds": (None, [vp, vp, vp, C.c_size_t, vp, vp]),
         "orc_uf_histogram": (None, [vp, C.c_size_t, vp]),
         "orc_top4_sizes": (None, [vp, C.c_size_t, vp]),
+        "orc_graph_observation": (None, [vp, vp, vp, C.c_size_t, vp]),
+        "orc_sim_get_cluster_stats": (C.c_int, [vp, C.c_size_t, vp, vp, vp]),
+        "orc_sim_get_observation": (C.c_int, [vp, C.c_size_t, C.c_int, vp, vp, vp, vp, vp, vp]),
+        "orc_sim_n_snapshots": (C.c_size_t, [vp]),
+        "orc_sim_get_snapshot": (C.c_int, [vp, C.c_size_t, vp, vp, vp, vp, vp, vp]),
         "orc_sim_create": (
             vp,
             [vp, C.c_int, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, u64],
@@ -239,6 +250,33 @@ def aggregate_results(per_real, n_temps, has_overlap, with_samples):
             for res in per_real:
                 acc = acc + res[key]
             out[key] = acc / n if len(per_real) > 1 else acc
+    # ClusterStats (results.rs:181-214,261-267; src/lib.rs:492-543)
+    if "fk_csd" in per_real[0]:
+        total = np.zeros_like(per_real[0]["fk_csd"])
+        for res in per_real:
+            total = total + res["fk_csd"]
+        if total.any():
+            out["fk_csd"] = [total[t].copy() for t in range(n_temps)]
+    if "overlap_csd" in per_real[0]:
+        total = np.zeros_like(per_real[0]["overlap_csd"])
+        tops = np.zeros_like(per_real[0]["top_sizes"])
+        for res in per_real:
+            total = total + res["overlap_csd"]
+            tops = tops + res["top_sizes"]
+        if len(per_real) > 1:
+            tops = tops / n
+        if total.any():
+            out["overlap_csd"] = [[total[m, t].copy() for t in range(n_temps)] for m in range(total.shape[0])]
+        out["top_cluster_sizes"] = [tops[m].copy() for m in range(tops.shape[0])]
+    # per-disorder graph observations: a kind is reported when every realisation has it (src/lib.rs:414-456)
+    observations = {}
+    for kind in OBSERVATION_KINDS:
+        if all(kind in res.get("observations", {}) for res in per_real):
+            fields = per_real[0]["observations"][kind].keys()
+            observations[kind] = {f: np.stack([res["observations"][kind][f] for res in per_real])
+                                  for f in fields}
+    if observations:
+        out.setdefault("per_disorder", {})["cluster_observations"] = observations
     return out
 
 
@@ -321,7 +359,8 @@ class OracleSimulation:
                     overlap_cluster_update_interval=None, overlap_cluster_build_mode=None,
                     overlap_cluster_mode=None, warmup_ratio=None, n_threads=1,
                     cluster_update_interval=None, cluster_mode=None, equilibration_diagnostic=False,
-                    autocorrelation_max_lag=None):
+                    autocorrelation_max_lag=None, collect_cluster_stats=False, cluster_action=None,
+                    overlap_cluster_action=None, snapshot_interval=None):
         warmup = 0.25 if warmup_ratio is None else warmup_ratio
         cfg = OrcConfig()
         cfg.n_sweeps = int(n_sweeps)
@@ -365,6 +404,13 @@ class OracleSimulation:
             cfg.cluster_mode = CLUSTER_MODES[cluster_mode or "sw"]  # src/lib.rs:233
         cfg.equilibration_diagnostic = 1 if equilibration_diagnostic else 0
         cfg.autocorrelation_max_lag = 0 if autocorrelation_max_lag is None else int(autocorrelation_max_lag)
+        cfg.collect_cluster_stats = 1 if collect_cluster_stats else 0
+        cfg.cluster_action = ACTIONS[cluster_action or "update"]
+        cfg.overlap_cluster_action = ACTIONS[overlap_cluster_action or "update"]
+        if snapshot_interval is not None and overlap_cluster_update_interval is not None:
+            if snapshot_interval < 1:  # config.rs:213-219
+                raise ValueError("snapshot_interval must be a positive multiple of overlap_cluster interval")
+            cfg.snapshot_interval = int(snapshot_interval)
         return cfg
 
     def run(self, cfg):
@@ -404,8 +450,60 @@ class OracleSimulation:
                 self.lib.orc_sim_get_equil(self.handle, r, _ptr(res["equil_sweeps"]),
                                            _ptr(res["equil_energy_avg"]),
                                            _ptr(res["equil_link_overlap_avg"]))
+            self._cluster_results(r, res)
             per_real.append(res)
         return per_real, has_ov
+
+    def _cluster_results(self, r, res):
+        n_t, n_bins = self.n_temps, self.n_spins + 1
+        n_modes = max(getattr(self, "_n_modes", 0), 1)
+        fk = np.zeros((n_t, n_bins), dtype=np.uint64)
+        ov = np.zeros((n_modes, n_t, n_bins), dtype=np.uint64)
+        tops = np.zeros((n_modes, n_t, 4), dtype=np.float64)
+        got = self.lib.orc_sim_get_cluster_stats(self.handle, r, _ptr(fk), _ptr(ov), _ptr(tops))
+        if got & 1:
+            res["fk_csd"] = fk
+        if got & 2:
+            res["overlap_csd"] = ov
+            res["top_sizes"] = tops
+        res["observations"] = {}
+        for kind, name in enumerate(OBSERVATION_KINDS):
+            count = np.zeros(n_t, dtype=np.uint64)
+            sizes = np.zeros((n_t, n_bins), dtype=np.uint64)
+            top4 = np.zeros((n_t, 4), dtype=np.float64)
+            density = np.zeros(n_t, dtype=np.float64)
+            large = np.zeros(n_t, dtype=np.float64)
+            winding = np.zeros((n_t, 4), dtype=np.float64)
+            got = self.lib.orc_sim_get_observation(self.handle, r, kind, _ptr(count), _ptr(sizes), _ptr(top4),
+                                                   _ptr(density), _ptr(large), _ptr(winding))
+            if not got:
+                continue
+            obs = {"observation_count": count, "cluster_size_counts": sizes,
+                   "top_four_component_fractions": top4, "active_bond_density": density,
+                   "large_component_count": large}
+            if got & 2:  # src/lib.rs:84-99
+                for k, key in enumerate(("winding_x", "winding_y", "winding_either", "winding_both")):
+                    obs[key] = winding[:, k].copy()
+            res["observations"][name] = obs
+
+    def snapshots(self):
+        """`cluster_snapshots` of the last sample() (src/lib.rs:576-614)."""
+        out = []
+        n_t, n = self.n_temps, self.n_spins
+        for k in range(int(self.lib.orc_sim_n_snapshots(self.handle))):
+            sweep_id, mode_idx = C.c_uint64(), C.c_int32()
+            ids = np.zeros((n_t, n), dtype=np.uint32)
+            blue = np.zeros((n_t, n), dtype=np.uint32)
+            spins = np.zeros((n_t, 2, n), dtype=np.int8)
+            sids = np.zeros((n_t, 2), dtype=np.uint64)
+            has_blue = self.lib.orc_sim_get_snapshot(self.handle, k, C.byref(sweep_id), C.byref(mode_idx),
+                                                     _ptr(ids), _ptr(blue), _ptr(spins), _ptr(sids))
+            snap = {"sweep_id": int(sweep_id.value), "mode_idx": int(mode_idx.value), "cluster_ids": ids,
+                    "spins": spins, "system_ids": sids}
+            if has_blue:
+                snap["blue_ids"] = blue
+            out.append(snap)
+        return out
 
     def result_blocks(self):
         """Per-realisation f64 blocks in the layout of pa_sim_get_result_blocks."""
@@ -422,22 +520,26 @@ class OracleSimulation:
                overlap_cluster_update_interval=None, overlap_cluster_build_mode=None,
                overlap_cluster_mode=None, warmup_ratio=None, n_threads=1,
                cluster_update_interval=None, cluster_mode=None, equilibration_diagnostic=False,
-               autocorrelation_max_lag=None):
+               autocorrelation_max_lag=None, collect_cluster_stats=False, cluster_action=None,
+               overlap_cluster_action=None, snapshot_interval=None):
         cfg = self.make_config(n_sweeps, sweep_mode, pt_interval, pt_schedule,
                                overlap_cluster_update_interval, overlap_cluster_build_mode,
                                overlap_cluster_mode, warmup_ratio, n_threads,
                                cluster_update_interval, cluster_mode, equilibration_diagnostic,
-                               autocorrelation_max_lag)
+                               autocorrelation_max_lag, collect_cluster_stats, cluster_action,
+                               overlap_cluster_action, snapshot_interval)
+        self._n_modes = int(cfg.n_overlap_cluster_modes)
         self.run(cfg)
         per_real, has_ov = self.per_realization_results()
         out = aggregate_results(per_real, self.n_temps, has_ov, self.n_realizations > 1)
         if pt_interval is not None:  # src/lib.rs:458-487
             att, acc, trips = zip(*(self.get_pt_counters(r) for r in range(self.n_realizations)))
-            out["per_disorder"] = {
-                "parallel_tempering": {
-                    "edge_attempts": np.stack(att),
-                    "edge_acceptances": np.stack(acc),
-                    "round_trips": np.stack(trips),
-                }
+            out.setdefault("per_disorder", {})["parallel_tempering"] = {
+                "edge_attempts": np.stack(att),
+                "edge_acceptances": np.stack(acc),
+                "round_trips": np.stack(trips),
             }
+        snaps = self.snapshots()
+        if snaps:
+            out["cluster_snapshots"] = snaps
         return out

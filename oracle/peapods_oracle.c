@@ -505,6 +505,200 @@ void orc_top4_sizes(const uint32_t *counts, size_t n, uint32_t out[4]) {
     out[3] = top[0];
 }
 
+/* ss/clusters/utils.rs:371-455: union-find that carries every site's displacement to its root;
+ * a bond that closes a cycle with a non-zero net displacement marks the component as winding
+ * around that axis of the torus (2D hypercubic lattices only, lattice.rs:31-38). */
+typedef struct {
+    uint32_t *parent;
+    uint8_t *rank;
+    int64_t *disp; /* [n][2] */
+    uint8_t *wrap; /* [n][2] */
+    int64_t shape[2];
+    size_t n;
+} winding_uf;
+
+static winding_uf *winding_new(size_t n, size_t s0, size_t s1) {
+    winding_uf *w = (winding_uf *)calloc(1, sizeof(*w));
+    w->n = n;
+    w->parent = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
+    for (size_t i = 0; i < n; ++i) w->parent[i] = (uint32_t)i;
+    w->rank = (uint8_t *)calloc(n + 1, 1);
+    w->disp = (int64_t *)calloc(2 * n + 2, sizeof(int64_t));
+    w->wrap = (uint8_t *)calloc(2 * n + 2, 1);
+    w->shape[0] = (int64_t)s0;
+    w->shape[1] = (int64_t)s1;
+    return w;
+}
+
+static void winding_free(winding_uf *w) {
+    if (!w) return;
+    free(w->parent);
+    free(w->rank);
+    free(w->disp);
+    free(w->wrap);
+    free(w);
+}
+
+/* utils.rs:390-402: full path compression, displacements re-based on the root */
+static uint32_t winding_find(winding_uf *w, uint32_t site, int64_t to_root[2]) {
+    uint32_t parent = w->parent[site];
+    if (parent == site) {
+        to_root[0] = to_root[1] = 0;
+        return site;
+    }
+    int64_t own0 = w->disp[2 * site], own1 = w->disp[2 * site + 1], up[2];
+    uint32_t root = winding_find(w, parent, up);
+    to_root[0] = own0 + up[0];
+    to_root[1] = own1 + up[1];
+    w->parent[site] = root;
+    w->disp[2 * site] = to_root[0];
+    w->disp[2 * site + 1] = to_root[1];
+    return root;
+}
+
+/* utils.rs:404-438 */
+static void winding_union_forward(winding_uf *w, uint32_t site, uint32_t neighbor, size_t dim) {
+    int64_t ds[2], dn[2];
+    uint32_t root_site = winding_find(w, site, ds);
+    uint32_t root_neighbor = winding_find(w, neighbor, dn);
+    int64_t rel[2] = {ds[0] - dn[0], ds[1] - dn[1]};
+    rel[dim] += 1;
+    if (root_site == root_neighbor) {
+        for (int axis = 0; axis < 2; ++axis) w->wrap[2 * root_site + axis] |= (uint8_t)(rel[axis] != 0);
+        return;
+    }
+    uint8_t wrap0 = w->wrap[2 * root_site] | w->wrap[2 * root_neighbor];
+    uint8_t wrap1 = w->wrap[2 * root_site + 1] | w->wrap[2 * root_neighbor + 1];
+    if (w->rank[root_site] < w->rank[root_neighbor]) {
+        w->parent[root_site] = root_neighbor;
+        w->disp[2 * root_site] = -rel[0];
+        w->disp[2 * root_site + 1] = -rel[1];
+        w->wrap[2 * root_neighbor] = wrap0;
+        w->wrap[2 * root_neighbor + 1] = wrap1;
+        return;
+    }
+    w->parent[root_neighbor] = root_site;
+    w->disp[2 * root_neighbor] = rel[0];
+    w->disp[2 * root_neighbor + 1] = rel[1];
+    w->wrap[2 * root_site] = wrap0;
+    w->wrap[2 * root_site + 1] = wrap1;
+    if (w->rank[root_site] == w->rank[root_neighbor]) w->rank[root_site] += 1;
+}
+
+/* utils.rs:440-454 */
+static void winding_result(winding_uf *w, int *x, int *y) {
+    int64_t scratch[2];
+    for (size_t i = 0; i < w->n; ++i) winding_find(w, (uint32_t)i, scratch);
+    *x = *y = 0;
+    for (size_t i = 0; i < w->n; ++i) {
+        if (w->parent[i] != i) continue;
+        *x |= w->wrap[2 * i];
+        *y |= w->wrap[2 * i + 1];
+    }
+}
+
+/* ss/clusters/utils.rs:317-369: what one observed bond graph reports */
+typedef struct {
+    uint32_t top4[4];
+    uint32_t active_bonds;
+    uint32_t large_components;
+    uint8_t winding_x, winding_y, observed;
+} graph_slot;
+
+typedef struct {
+    uint32_t active_bonds;
+    winding_uf *winding;
+} bond_metrics;
+
+static void metrics_begin(bond_metrics *m, const orc_lattice *lat) { /* :335-342 */
+    m->active_bonds = 0;
+    m->winding = lat->has_square_shape ? winding_new(lat->n_spins, lat->shape[0], lat->shape[1]) : NULL;
+}
+
+static void metrics_record(bond_metrics *m, const orc_lattice *lat, size_t site, size_t dim) { /* :345-350 */
+    m->active_bonds += 1;
+    if (m->winding)
+        winding_union_forward(m->winding, (uint32_t)site, lat->fwd[site * lat->n_neighbors + dim], dim);
+}
+
+static void metrics_finish(bond_metrics *m, const uint32_t *counts, size_t n, graph_slot *out) { /* :352-368 */
+    int wx = 0, wy = 0;
+    if (m->winding) winding_result(m->winding, &wx, &wy);
+    uint32_t threshold = (uint32_t)ceil((double)n * 0.05);
+    memset(out, 0, sizeof(*out));
+    orc_top4_sizes(counts, n, out->top4);
+    out->active_bonds = m->active_bonds;
+    out->winding_x = (uint8_t)wx;
+    out->winding_y = (uint8_t)wy;
+    for (size_t i = 0; i < n; ++i) out->large_components += counts[i] >= threshold;
+    out->observed = 1;
+    winding_free(m->winding);
+    m->winding = NULL;
+}
+
+/* Known-answer entry: bonds (site, dim) applied in the given order; out = {active_bonds, top4[4],
+ * large_components, winding_x, winding_y} (utils.rs tests :736-781). */
+void orc_graph_observation(const orc_lattice *lat, const uint64_t *bond_sites, const uint64_t *bond_dims,
+                           size_t n_bonds, uint32_t out[9]) {
+    size_t n = lat->n_spins;
+    uint32_t *parent = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
+    uint32_t *counts = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
+    uint8_t *rank = (uint8_t *)calloc(n + 1, 1);
+    bond_metrics m;
+    metrics_begin(&m, lat);
+    for (size_t i = 0; i < n; ++i) parent[i] = (uint32_t)i;
+    for (size_t b = 0; b < n_bonds; ++b) {
+        orc_uf_union(parent, rank, (uint32_t)bond_sites[b],
+                     lat->fwd[bond_sites[b] * lat->n_neighbors + bond_dims[b]]);
+        metrics_record(&m, lat, (size_t)bond_sites[b], (size_t)bond_dims[b]);
+    }
+    uf_flatten_counts(parent, n, counts);
+    graph_slot g;
+    metrics_finish(&m, counts, n, &g);
+    out[0] = g.active_bonds;
+    for (int k = 0; k < 4; ++k) out[1 + k] = g.top4[k];
+    out[5] = g.large_components;
+    out[6] = g.winding_x;
+    out[7] = g.winding_y;
+    out[8] = g.observed;
+    free(parent);
+    free(counts);
+    free(rank);
+}
+
+/* Optional outputs of one cluster call, indexed by slot (FK: temperature slot of the system;
+ * overlap moves: t * n_pairs + g).  csd / top4 are cleared by the caller before the call
+ * (mod.rs:442-455,604-626); snap / blue_snap keep what an earlier call left when a slot writes
+ * nothing (a single-cluster move that finds no seed, overlap.rs:246-248). */
+typedef struct {
+    int observe;         /* ClusterAction::Observe: measure the bond graph, leave the spins */
+    uint64_t *csd;       /* [n_slots][N+1] or NULL */
+    uint32_t *top4;      /* [n_slots][4] or NULL */
+    graph_slot *obs;     /* [n_slots] or NULL */
+    uint32_t *snap;      /* [n_slots][N] or NULL */
+    uint32_t *blue_snap; /* [n_slots][N] or NULL (CMR) */
+    int8_t *spin_snap;   /* [n_slots][2][N], with snap */
+    uint64_t *sid_snap;  /* [n_slots][2], with snap */
+} cluster_out;
+
+/* the per-slot outputs every union-find path shares (overlap.rs:257-291) */
+static void emit_counts(const cluster_out *out, size_t slot, const uint32_t *parent, const uint32_t *counts,
+                        size_t n, int with_snap) {
+    if (!out) return;
+    if (out->csd) orc_uf_histogram(counts, n, out->csd + slot * (n + 1));
+    if (out->top4) orc_top4_sizes(counts, n, out->top4 + slot * 4);
+    if (with_snap && out->snap) memcpy(out->snap + slot * n, parent, sizeof(uint32_t) * n);
+}
+
+static void emit_spins(const cluster_out *out, size_t slot, const int8_t *a, const int8_t *b, uint64_t sa,
+                       uint64_t sb, size_t n) { /* overlap.rs:211-221,411-419,680-688 */
+    if (!out || !out->snap) return;
+    memcpy(out->spin_snap + (slot * 2 + 0) * n, a, n);
+    memcpy(out->spin_snap + (slot * 2 + 1) * n, b, n);
+    out->sid_snap[slot * 2 + 0] = sa;
+    out->sid_snap[slot * 2 + 1] = sb;
+}
+
 /* ========================================================================== */
 /* Realisation state                                                          */
 /* ========================================================================== */
@@ -539,6 +733,88 @@ typedef struct {
     uint32_t power;
 } statistics;
 
+/* GraphObservationAccum / GraphObservationSummary (simulation/mod.rs:17-98, results.rs:22-31) */
+typedef struct {
+    int enabled, present, has_winding;
+    uint64_t *count;      /* [n_temps] observation_count */
+    uint64_t *csd;        /* [n_temps][N+1] cluster_size_counts */
+    uint64_t *top4_sum;   /* [n_temps][4] */
+    uint64_t *bonds;      /* [n_temps] */
+    uint64_t *winding;    /* [n_temps][4]: x, y, either, both */
+    uint64_t *large;      /* [n_temps] */
+    double *top4_frac;    /* [n_temps][4] top_four_component_fractions */
+    double *bond_density; /* [n_temps] */
+    double *large_mean;   /* [n_temps] */
+    double *winding_frac; /* [n_temps][4] */
+} graph_summary;
+
+typedef struct {
+    uint64_t sweep_id;
+    int mode_idx, has_blue;
+    uint32_t *cluster_ids; /* [n_temps][N] */
+    uint32_t *blue_ids;    /* [n_temps][N] */
+    int8_t *spins;         /* [n_temps][2][N] */
+    uint64_t *system_ids;  /* [n_temps][2] */
+} cluster_snapshot;
+
+static void summary_enable(graph_summary *g, size_t n_temps, size_t n) { /* mod.rs:27-36 */
+    if (g->enabled) return;
+    g->enabled = 1;
+    g->count = (uint64_t *)calloc(n_temps + 1, sizeof(uint64_t));
+    g->csd = (uint64_t *)calloc(n_temps * (n + 1) + 1, sizeof(uint64_t));
+    g->top4_sum = (uint64_t *)calloc(4 * n_temps + 1, sizeof(uint64_t));
+    g->bonds = (uint64_t *)calloc(n_temps + 1, sizeof(uint64_t));
+    g->winding = (uint64_t *)calloc(4 * n_temps + 1, sizeof(uint64_t));
+    g->large = (uint64_t *)calloc(n_temps + 1, sizeof(uint64_t));
+    g->top4_frac = (double *)calloc(4 * n_temps + 1, sizeof(double));
+    g->bond_density = (double *)calloc(n_temps + 1, sizeof(double));
+    g->large_mean = (double *)calloc(n_temps + 1, sizeof(double));
+    g->winding_frac = (double *)calloc(4 * n_temps + 1, sizeof(double));
+}
+
+static void summary_push(graph_summary *g, size_t temp, const uint64_t *sizes, size_t n, const graph_slot *slot) {
+    if (!slot->observed) return; /* mod.rs:38-55 */
+    g->count[temp] += 1;
+    for (size_t k = 0; k <= n; ++k) g->csd[temp * (n + 1) + k] += sizes[k];
+    for (int k = 0; k < 4; ++k) g->top4_sum[temp * 4 + k] += slot->top4[k];
+    g->bonds[temp] += slot->active_bonds;
+    g->winding[temp * 4 + 0] += slot->winding_x;
+    g->winding[temp * 4 + 1] += slot->winding_y;
+    g->winding[temp * 4 + 2] += (uint64_t)(slot->winding_x || slot->winding_y);
+    g->winding[temp * 4 + 3] += (uint64_t)(slot->winding_x && slot->winding_y);
+    g->large[temp] += slot->large_components;
+}
+
+static void summary_finish(graph_summary *g, size_t n_temps, size_t n, size_t nn, int has_winding) {
+    if (!g->enabled) return; /* mod.rs:57-97 */
+    g->has_winding = has_winding;
+    for (size_t t = 0; t < n_temps; ++t) g->present |= g->count[t] != 0;
+    for (size_t t = 0; t < n_temps; ++t) {
+        if (g->count[t] == 0) continue;
+        double c = (double)g->count[t];
+        for (int k = 0; k < 4; ++k) {
+            g->top4_frac[t * 4 + k] = (double)g->top4_sum[t * 4 + k] / (c * (double)n);
+            if (has_winding) g->winding_frac[t * 4 + k] = (double)g->winding[t * 4 + k] / c;
+        }
+        g->bond_density[t] = (double)g->bonds[t] / (c * (double)n * (double)nn);
+        g->large_mean[t] = (double)g->large[t] / c;
+    }
+}
+
+static void summary_free(graph_summary *g) {
+    free(g->count);
+    free(g->csd);
+    free(g->top4_sum);
+    free(g->bonds);
+    free(g->winding);
+    free(g->large);
+    free(g->top4_frac);
+    free(g->bond_density);
+    free(g->large_mean);
+    free(g->winding_frac);
+    memset(g, 0, sizeof(*g));
+}
+
 /* SweepResult fields on the path (statistics/results.rs:56-77, overlap.rs:8-39) */
 typedef struct {
     double *moments;      /* [5][n_temps] mags, mags2, mags4, energies, energies2 */
@@ -552,6 +828,16 @@ typedef struct {
     uint64_t *equil_sweeps;
     double *equil_energy; /* [n_equil][n_temps] */
     double *equil_ql;     /* [n_equil][n_temps] */
+    /* ClusterStats (statistics/results.rs:12-20) */
+    uint64_t *fk_csd;      /* [n_temps][N+1] or NULL */
+    uint64_t *overlap_csd; /* [n_modes][n_temps][N+1] or NULL */
+    double *top_sizes;     /* [n_modes][n_temps][4] or NULL */
+    size_t n_modes;
+    /* per-disorder graph observations (results.rs:22-45): fk, houdayer, jorg, cmr_blue */
+    graph_summary observations[4];
+    /* ClusterSnapshot list (results.rs:47-54), realisation 0 only */
+    size_t n_snapshots;
+    cluster_snapshot *snapshots;
 } sweep_result;
 
 struct orc_sim {
@@ -736,14 +1022,19 @@ static int64_t find_seed(size_t n_spins, orc_rng *rng, const int8_t *a, const in
 }
 
 /* ss/clusters/overlap.rs:35-56 (build_tasks), :153-339 (houdayer_step, group
- * size 2) and :348-553 (jorg_step); Wolff variant = find_seed + dfs_cluster
- * (utils.rs:125-149), SW variant = uf_bonds + per-root coin in discovery order.
- * Update action only; observers/CSD/snapshots are out of scope. */
+ * size 2) and :348-553 (jorg_step).  Without outputs the single-cluster variant is find_seed +
+ * dfs_cluster (utils.rs:125-149); the SW variant, the Observe action and every call that collects
+ * sizes or a snapshot take the union-find path (`use_uf`, :179-183,:376-380), whose
+ * single-cluster form draws all bonds first and looks for the seed afterwards. */
 static void overlap_update(const orc_lattice *lat, realization *real, size_t n_replicas,
-                           size_t n_temps, int mode, int cluster_mode) {
+                           size_t n_temps, int mode, int cluster_mode, const cluster_out *out) {
     size_t n = lat->n_spins, nn = lat->n_neighbors;
     size_t n_pairs = n_replicas / 2, group_size = 2, n_groups = n_replicas / group_size;
     int joerg = (mode == ORC_OC_JORG);
+    int wolff = cluster_mode == ORC_CLUSTER_WOLFF;
+    int observe = out && out->observe;
+    int collects = out && (out->csd || out->top4 || out->snap);
+    int use_uf = observe || !wolff || collects;
     uint64_t *systems = (uint64_t *)malloc(sizeof(uint64_t) * (n_temps * n_replicas + 1));
     for (size_t t = 0; t < n_temps; ++t) {
         for (size_t k = 0; k < n_replicas; ++k)
@@ -757,14 +1048,15 @@ static void overlap_update(const orc_lattice *lat, realization *real, size_t n_r
     uint8_t *rank = (uint8_t *)malloc(n + 1);
 
     for (size_t task = 0; task < n_temps * n_groups; ++task) {
-        size_t t = task / n_groups, g = task % n_groups;
+        size_t t = task / n_groups, g = task % n_groups, slot = t * n_pairs + g;
         const uint64_t *grp = systems + t * n_replicas + g * group_size;
         orc_rng *rng = &real->pair_rngs[t * n_pairs + g];
         float temp = real->temperatures[t];
         int8_t *a = real->spins + (size_t)grp[0] * n;
         int8_t *b = real->spins + (size_t)grp[1] * n;
+        emit_spins(out, slot, a, b, grp[0], grp[1], n);
 #define ACTIVE(i) (joerg ? (a[i] != b[i]) : ((int)a[i] + (int)b[i] == 0))
-        if (cluster_mode == ORC_CLUSTER_WOLFF) {
+        if (!use_uf) {
             int64_t seed = find_seed(n, rng, a, b, joerg);
             if (seed < 0) continue;
             memset(in_cluster, 0, n);
@@ -803,6 +1095,9 @@ static void overlap_update(const orc_lattice *lat, realization *real, size_t n_r
                     b[i] = (int8_t)-b[i];
                 }
         } else {
+            bond_metrics metrics;
+            int with_metrics = out && out->obs;
+            if (with_metrics) metrics_begin(&metrics, lat);
             for (size_t i = 0; i < n; ++i) parent[i] = (uint32_t)i;
             memset(rank, 0, n);
             for (size_t i = 0; i < n; ++i)
@@ -818,9 +1113,31 @@ static void overlap_update(const orc_lattice *lat, realization *real, size_t n_r
                                 bond = orc_rng_gen_f32(rng) < 1.0f - expf(-4.0f * inter / temp);
                         }
                     }
-                    if (bond) orc_uf_union(parent, rank, (uint32_t)i, (uint32_t)j);
+                    if (bond) {
+                        orc_uf_union(parent, rank, (uint32_t)i, (uint32_t)j);
+                        if (with_metrics) metrics_record(&metrics, lat, i, d);
+                    }
                 }
+            if (wolff) { /* overlap.rs:245-272,446-472 */
+                if (with_metrics) winding_free(metrics.winding); /* not reported by this branch */
+                int64_t seed = find_seed(n, rng, a, b, joerg);
+                if (seed < 0) continue;
+                uint32_t seed_root = orc_uf_find(parent, (uint32_t)seed);
+                for (size_t i = 0; i < n; ++i)
+                    if (orc_uf_find(parent, (uint32_t)i) == seed_root) {
+                        a[i] = (int8_t)-a[i];
+                        b[i] = (int8_t)-b[i];
+                    }
+                if (collects) {
+                    uf_flatten_counts(parent, n, counts);
+                    emit_counts(out, slot, parent, counts, n, 1);
+                }
+                continue;
+            }
             uf_flatten_counts(parent, n, counts);
+            emit_counts(out, slot, parent, counts, n, 1);
+            if (with_metrics) metrics_finish(&metrics, counts, n, &out->obs[slot]);
+            if (observe) continue;
             memset(rank, 0xFF, n);
             for (size_t i = 0; i < n; ++i) {
                 uint32_t root = parent[i];
@@ -847,7 +1164,8 @@ static void overlap_update(const orc_lattice *lat, realization *real, size_t n_r
  * groups of N consecutive replicas of the shuffled order, active sites = the N spins sum to
  * zero, deterministic bonds between active neighbours, every replica of the group flips. */
 static void houdayer_n_update(const orc_lattice *lat, realization *real, size_t n_replicas, size_t n_temps,
-                              size_t group_size, int cluster_mode) {
+                              size_t group_size, int cluster_mode, const cluster_out *out) {
+    int collects = out && (out->csd || out->top4 || out->snap);
     size_t n = lat->n_spins, nn = lat->n_neighbors;
     size_t n_pairs = n_replicas / 2, n_groups = n_replicas / group_size;
     uint64_t *systems = (uint64_t *)malloc(sizeof(uint64_t) * (n_temps * n_replicas + 1));
@@ -863,16 +1181,38 @@ static void houdayer_n_update(const orc_lattice *lat, realization *real, size_t 
     uint32_t *counts = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
     uint8_t *rank = (uint8_t *)malloc(n + 1);
     for (size_t task = 0; task < n_temps * n_groups; ++task) {
-        size_t t = task / n_groups, g = task % n_groups;
+        size_t t = task / n_groups, g = task % n_groups, slot = t * n_pairs + g;
         const uint64_t *grp = systems + t * n_replicas + g * group_size;
         orc_rng *rng = &real->pair_rngs[t * n_pairs + g];
+        emit_spins(out, slot, real->spins + (size_t)grp[0] * n, real->spins + (size_t)grp[1] * n, grp[0],
+                   grp[1], n); /* the group's first two systems, :211-221 */
         for (size_t i = 0; i < n; ++i) { /* is_active, :199-205 (the spins do not change before the flips) */
             int sum = 0;
             for (size_t k = 0; k < group_size; ++k) sum += real->spins[(size_t)grp[k] * n + i];
             active[i] = sum == 0;
         }
         memset(in_cluster, 0, n);
-        if (cluster_mode == ORC_CLUSTER_WOLFF) {
+        if (cluster_mode == ORC_CLUSTER_WOLFF && collects) { /* union-find form, :231-272 */
+            for (size_t i = 0; i < n; ++i) parent[i] = (uint32_t)i;
+            memset(rank, 0, n);
+            for (size_t i = 0; i < n; ++i)
+                for (size_t d = 0; d < nn; ++d) {
+                    size_t j = lat->fwd[i * nn + d];
+                    if (active[i] && active[j]) orc_uf_union(parent, rank, (uint32_t)i, (uint32_t)j);
+                }
+            int64_t seed = -1;
+            for (int probe = 0; probe < 64; ++probe) {
+                size_t i = (size_t)orc_rng_gen_range_usize(rng, 0, n);
+                if (active[i]) {
+                    seed = (int64_t)i;
+                    break;
+                }
+            }
+            if (seed < 0) continue;
+            uf_flatten_counts(parent, n, counts);
+            for (size_t i = 0; i < n; ++i) in_cluster[i] = parent[i] == parent[seed];
+            emit_counts(out, slot, parent, counts, n, 1);
+        } else if (cluster_mode == ORC_CLUSTER_WOLFF) {
             int64_t seed = -1;
             for (int probe = 0; probe < 64; ++probe) { /* find_seed, utils.rs:107-119 */
                 size_t i = (size_t)orc_rng_gen_range_usize(rng, 0, n);
@@ -905,6 +1245,7 @@ static void houdayer_n_update(const orc_lattice *lat, realization *real, size_t 
                     if (active[i] && active[j]) orc_uf_union(parent, rank, (uint32_t)i, (uint32_t)j);
                 }
             uf_flatten_counts(parent, n, counts);
+            emit_counts(out, slot, parent, counts, n, 1);
             memset(rank, 0xFF, n);
             for (size_t i = 0; i < n; ++i) {
                 uint32_t root = parent[i];
@@ -933,9 +1274,12 @@ static void houdayer_n_update(const orc_lattice *lat, realization *real, size_t 
  * r = exp(-2|J|/T)).  Update action without observers: cluster_mode sw = union-find path
  * (:690-843), wolff = the two-phase depth-first search (:845-965). */
 static void cmr_update(const orc_lattice *lat, realization *real, size_t n_replicas, size_t n_temps,
-                       int cluster_mode) {
+                       int cluster_mode, const cluster_out *out) {
     size_t n = lat->n_spins, nn = lat->n_neighbors;
     size_t n_pairs = n_replicas / 2;
+    int wolff = cluster_mode == ORC_CLUSTER_WOLFF;
+    int observe = out && out->observe;
+    int use_uf = observe || !wolff || (out && (out->csd || out->top4 || out->snap)); /* :640-644 */
     uint64_t *systems = (uint64_t *)malloc(sizeof(uint64_t) * (n_temps * n_replicas + 1));
     for (size_t t = 0; t < n_temps; ++t) { /* build_tasks, :35-56 */
         for (size_t k = 0; k < n_replicas; ++k)
@@ -950,14 +1294,15 @@ static void cmr_update(const orc_lattice *lat, realization *real, size_t n_repli
     uint8_t *flag = (uint8_t *)malloc(n + 1);
 
     for (size_t task = 0; task < n_temps * n_pairs; ++task) {
-        size_t t = task / n_pairs, g = task % n_pairs;
+        size_t t = task / n_pairs, g = task % n_pairs, slot = t * n_pairs + g;
         const uint64_t *grp = systems + t * n_replicas + g * 2;
         orc_rng *rng = &real->pair_rngs[t * n_pairs + g];
         float temp = real->temperatures[t];
         int8_t *a = real->spins + (size_t)grp[0] * n;
         int8_t *b = real->spins + (size_t)grp[1] * n;
+        emit_spins(out, slot, a, b, grp[0], grp[1], n);
 #define SAT(s, i, j, c) ((float)(s)[i] * (float)(s)[j] * (c) > 0.0f)
-        if (cluster_mode == ORC_CLUSTER_WOLFF) {
+        if (!use_uf) {
             size_t seed = (size_t)orc_rng_gen_range_usize(rng, 0, n);
             memset(in_cluster, 0, n);
             size_t top = 0;
@@ -1007,6 +1352,11 @@ static void cmr_update(const orc_lattice *lat, realization *real, size_t n_repli
                     if (k & 2) b[i] = (int8_t)-b[i];
                 }
         } else {
+            /* the single-cluster form of the union-find path draws its seed first (:691-695) */
+            size_t seed = wolff ? (size_t)orc_rng_gen_range_usize(rng, 0, n) : 0;
+            bond_metrics metrics;
+            int with_metrics = out && out->obs;
+            if (with_metrics) metrics_begin(&metrics, lat);
             for (size_t i = 0; i < n; ++i) parent[i] = (uint32_t)i;
             memset(rank, 0, n);
             for (size_t i = 0; i < n; ++i) /* blue bonds, :582-605 */
@@ -1015,21 +1365,36 @@ static void cmr_update(const orc_lattice *lat, realization *real, size_t n_repli
                     float c = real->couplings[i * nn + d];
                     if (!SAT(a, i, j, c) || !SAT(b, i, j, c)) continue;
                     float r = expf(-2.0f * fabsf(c) / temp);
-                    if (orc_rng_gen_f32(rng) < 1.0f - r * r)
+                    if (orc_rng_gen_f32(rng) < 1.0f - r * r) {
                         orc_uf_union(parent, rank, (uint32_t)i, (uint32_t)j);
+                        if (with_metrics) metrics_record(&metrics, lat, i, d);
+                    }
                 }
             uf_flatten_counts(parent, n, counts);
-            memset(flag, 0xFF, n); /* :757-770 */
-            for (size_t i = 0; i < n; ++i) {
-                uint32_t root = parent[i];
-                if (counts[root] > 1 && flag[root] == 0xFF)
-                    flag[root] = (uint8_t)(orc_rng_gen_f32(rng) < 0.5f);
-            }
-            for (size_t i = 0; i < n; ++i)
-                if (flag[parent[i]] == 1) {
-                    a[i] = (int8_t)-a[i];
-                    b[i] = (int8_t)-b[i];
+            emit_counts(out, slot, parent, counts, n, 0); /* sizes are those of the blue clusters, :725-733 */
+            if (out && out->blue_snap) memcpy(out->blue_snap + slot * n, parent, sizeof(uint32_t) * n);
+            if (with_metrics) metrics_finish(&metrics, counts, n, &out->obs[slot]);
+            if (observe) continue; /* :743-745 */
+            if (wolff) { /* :748-755 */
+                uint32_t seed_root = parent[seed];
+                for (size_t i = 0; i < n; ++i)
+                    if (parent[i] == seed_root) {
+                        a[i] = (int8_t)-a[i];
+                        b[i] = (int8_t)-b[i];
+                    }
+            } else {
+                memset(flag, 0xFF, n); /* :757-770 */
+                for (size_t i = 0; i < n; ++i) {
+                    uint32_t root = parent[i];
+                    if (counts[root] > 1 && flag[root] == 0xFF)
+                        flag[root] = (uint8_t)(orc_rng_gen_f32(rng) < 0.5f);
                 }
+                for (size_t i = 0; i < n; ++i)
+                    if (flag[parent[i]] == 1) {
+                        a[i] = (int8_t)-a[i];
+                        b[i] = (int8_t)-b[i];
+                    }
+            }
             for (size_t i = 0; i < n; ++i) /* red bonds extend the blue forest, :777-795 */
                 for (size_t d = 0; d < nn; ++d) {
                     size_t j = lat->fwd[i * nn + d];
@@ -1040,6 +1405,17 @@ static void cmr_update(const orc_lattice *lat, realization *real, size_t n_repli
                         orc_uf_union(parent, rank, (uint32_t)i, (uint32_t)j);
                 }
             uf_flatten_counts(parent, n, counts);
+            if (out && out->snap) memcpy(out->snap + slot * n, parent, sizeof(uint32_t) * n); /* :799-803 */
+            if (wolff) { /* :806-820 */
+                uint32_t seed_root = parent[seed];
+                uint8_t k = gen_range_u8_inclusive(rng, 1, 3);
+                for (size_t i = 0; i < n; ++i)
+                    if (parent[i] == seed_root) {
+                        if (k & 1) a[i] = (int8_t)-a[i];
+                        if (k & 2) b[i] = (int8_t)-b[i];
+                    }
+                continue;
+            }
             memset(flag, 0xFF, n); /* :822-841 */
             for (size_t i = 0; i < n; ++i) {
                 uint32_t root = parent[i];
@@ -1070,8 +1446,11 @@ static void cmr_update(const orc_lattice *lat, realization *real, size_t n_repli
 /* Update action without CSD collection: Wolff takes the DFS fast path (:42-86), SW the
  * union-find path (:102-196).  Slot k carries temperature temperatures[k] and system
  * system_ids[k]; the system's own generator is used (par_over_replicas / rngs[system_id]). */
-static void fk_update(const orc_lattice *lat, realization *real, size_t n_systems, int wolff) {
+static void fk_update(const orc_lattice *lat, realization *real, size_t n_systems, int wolff,
+                      const cluster_out *out) {
     size_t n = lat->n_spins, nn = lat->n_neighbors;
+    int observe = out && out->observe, has_csd = out && out->csd, with_metrics = out && out->obs;
+    uint32_t *counts = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
     uint8_t *in_cluster = (uint8_t *)malloc(n + 1);
     size_t *stack = (size_t *)malloc(sizeof(size_t) * (n + 1));
     uint32_t *parent = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
@@ -1081,7 +1460,7 @@ static void fk_update(const orc_lattice *lat, realization *real, size_t n_system
         int8_t *spin = real->spins + system * n;
         orc_rng *rng = &real->rngs[system];
         float temp = real->temperatures[slot];
-        if (wolff) {
+        if (!observe && wolff && !has_csd) { /* fk.rs:45 */
             size_t seed = (size_t)orc_rng_gen_range_usize(rng, 0, n);
             memset(in_cluster, 0, n);
             size_t top = 0;
@@ -1106,6 +1485,8 @@ static void fk_update(const orc_lattice *lat, realization *real, size_t n_system
             for (size_t i = 0; i < n; ++i)
                 if (in_cluster[i]) spin[i] = (int8_t)-spin[i];
         } else {
+            bond_metrics metrics;
+            if (with_metrics) metrics_begin(&metrics, lat);
             for (size_t i = 0; i < n; ++i) parent[i] = (uint32_t)i;
             memset(rank, 0, n);
             for (size_t i = 0; i < n; ++i) /* activate_bonds, utils.rs:225-241 */
@@ -1113,10 +1494,22 @@ static void fk_update(const orc_lattice *lat, realization *real, size_t n_system
                     size_t j = lat->fwd[i * nn + d];
                     float inter = (float)spin[i] * (float)spin[j] * real->couplings[i * nn + d];
                     if (inter <= 0.0f) continue;
-                    if (orc_rng_gen_f32(rng) < 1.0f - expf(-2.0f * inter / temp))
+                    if (orc_rng_gen_f32(rng) < 1.0f - expf(-2.0f * inter / temp)) {
                         orc_uf_union(parent, rank, (uint32_t)i, (uint32_t)j);
+                        if (with_metrics) metrics_record(&metrics, lat, i, d);
+                    }
                 }
-            for (size_t i = 0; i < n; ++i) parent[i] = orc_uf_find(parent, (uint32_t)i); /* uf_flatten */
+            uf_flatten_counts(parent, n, counts); /* fk.rs:126-138 */
+            if (has_csd) orc_uf_histogram(counts, n, out->csd + slot * (n + 1));
+            if (with_metrics) metrics_finish(&metrics, counts, n, &out->obs[slot]);
+            if (observe) continue; /* fk.rs:140-142 */
+            if (wolff) { /* fk.rs:144-151: the seed is drawn after the bonds */
+                size_t seed = (size_t)orc_rng_gen_range_usize(rng, 0, n);
+                uint32_t seed_root = parent[seed];
+                for (size_t i = 0; i < n; ++i)
+                    if (parent[i] == seed_root) spin[i] = (int8_t)-spin[i];
+                continue;
+            }
             memset(rank, 2, n); /* 2 = undecided (fk.rs:182-192): every cluster draws, singletons too */
             for (size_t i = 0; i < n; ++i) {
                 uint32_t root = parent[i];
@@ -1129,6 +1522,7 @@ static void fk_update(const orc_lattice *lat, realization *real, size_t n_system
     free(stack);
     free(parent);
     free(rank);
+    free(counts);
 }
 
 /* ========================================================================== */
@@ -1237,6 +1631,17 @@ static void result_free(sweep_result *res) {
     free(res->equil_sweeps);
     free(res->equil_energy);
     free(res->equil_ql);
+    free(res->fk_csd);
+    free(res->overlap_csd);
+    free(res->top_sizes);
+    for (int k = 0; k < 4; ++k) summary_free(&res->observations[k]);
+    for (size_t k = 0; k < res->n_snapshots; ++k) {
+        free(res->snapshots[k].cluster_ids);
+        free(res->snapshots[k].blue_ids);
+        free(res->snapshots[k].spins);
+        free(res->snapshots[k].system_ids);
+    }
+    free(res->snapshots);
     memset(res, 0, sizeof(*res));
 }
 
@@ -1244,8 +1649,24 @@ static void result_free(sweep_result *res) {
 static const char *validate_config(const orc_config *cfg) {
     if (cfg->n_sweeps < 1) return "n_sweeps must be >= 1";
     if (cfg->warmup_sweeps > cfg->n_sweeps) return "warmup_sweeps must be <= n_sweeps";
-    if (cfg->overlap_cluster_interval > 0 && cfg->n_overlap_cluster_modes < 1)
-        return "overlap_cluster modes must not be empty";
+    if (cfg->cluster_interval > 0 && cfg->cluster_action == ORC_ACTION_OBSERVE &&
+        cfg->cluster_mode == ORC_CLUSTER_WOLFF)
+        return "cluster_action='observe' requires cluster_mode='sw'";
+    if (cfg->overlap_cluster_interval > 0) {
+        if (cfg->snapshot_interval > 0 && cfg->snapshot_interval % cfg->overlap_cluster_interval != 0)
+            return "snapshot_interval must be a positive multiple of overlap_cluster interval";
+        if (cfg->n_overlap_cluster_modes < 1) return "overlap_cluster modes must not be empty";
+        if (cfg->overlap_cluster_action == ORC_ACTION_OBSERVE) {
+            if (cfg->overlap_cluster_mode == ORC_CLUSTER_WOLFF)
+                return "overlap_cluster_action='observe' requires overlap_cluster_mode='sw'";
+            if (cfg->snapshot_interval > 0)
+                return "snapshot_interval is not supported with overlap_cluster_action='observe'";
+            for (int k = 0; k < cfg->n_overlap_cluster_modes; ++k)
+                if ((cfg->overlap_cluster_modes[k] & 0xFF) == ORC_OC_HOUDAYER &&
+                    (cfg->overlap_cluster_modes[k] >> 8) > 2)
+                    return "overlap_cluster_action='observe' does not support experimental houdN with N > 2";
+        }
+    }
     return NULL;
 }
 
@@ -1253,10 +1674,56 @@ static const char *validate_config(const orc_config *cfg) {
  * sweep -> [energies(+mags)] -> [overlap collect] -> [stats] -> [overlap
  * cluster move] -> [parallel tempering]. */
 static void run_sweep_loop(const orc_lattice *lat, realization *real, size_t n_replicas,
-                           size_t n_temps, const orc_config *cfg, sweep_result *res) {
+                           size_t n_temps, const orc_config *cfg, sweep_result *res,
+                           size_t realization_idx) {
     size_t n = lat->n_spins, nn = lat->n_neighbors;
     size_t n_systems = n_replicas * n_temps, n_pairs = n_replicas / 2;
     size_t n_bonds = n * nn;
+
+    /* mod.rs:205-335: what the cluster calls report besides moving spins */
+    size_t n_modes = cfg->overlap_cluster_interval > 0 ? (size_t)cfg->n_overlap_cluster_modes : 0;
+    size_t n_pair_slots = n_temps * n_pairs;
+    int has_fk = cfg->cluster_interval > 0, has_oc = cfg->overlap_cluster_interval > 0;
+    int observe_fk = has_fk && cfg->cluster_action == ORC_ACTION_OBSERVE;
+    int observe_overlap = has_oc && cfg->overlap_cluster_action == ORC_ACTION_OBSERVE;
+    int collect_fk = has_fk && (cfg->collect_cluster_stats || observe_fk);
+    int collect_overlap = has_oc && (cfg->collect_cluster_stats || observe_overlap) && n_pairs > 0;
+    static const int kind_of_mode[4] = {-1, 1, 2, 3}; /* ORC_OC_* -> houdayer, jorg, cmr_blue */
+    if (observe_fk) summary_enable(&res->observations[0], n_temps, n);
+    if (observe_overlap)
+        for (size_t m = 0; m < n_modes; ++m)
+            summary_enable(&res->observations[kind_of_mode[cfg->overlap_cluster_modes[m] & 0xFF]], n_temps, n);
+    uint64_t *sw_csd_buf = NULL, *overlap_csd_buf = NULL;
+    graph_slot *fk_obs_buf = NULL, *overlap_obs_buf = NULL;
+    uint32_t *top4_buf = NULL;
+    double *top4_accum = NULL;
+    size_t *top4_n = NULL;
+    if (collect_fk) {
+        res->fk_csd = (uint64_t *)calloc(n_temps * (n + 1) + 1, sizeof(uint64_t));
+        sw_csd_buf = (uint64_t *)calloc(n_systems * (n + 1) + 1, sizeof(uint64_t));
+    }
+    if (observe_fk) fk_obs_buf = (graph_slot *)calloc(n_systems + 1, sizeof(graph_slot));
+    if (collect_overlap) {
+        res->n_modes = n_modes;
+        res->overlap_csd = (uint64_t *)calloc(n_modes * n_temps * (n + 1) + 1, sizeof(uint64_t));
+        res->top_sizes = (double *)calloc(n_modes * n_temps * 4 + 1, sizeof(double));
+        overlap_csd_buf = (uint64_t *)calloc(n_pair_slots * (n + 1) + 1, sizeof(uint64_t));
+        top4_buf = (uint32_t *)calloc(n_pair_slots * 4 + 1, sizeof(uint32_t));
+        top4_accum = (double *)calloc(n_modes * n_temps * 4 + 1, sizeof(double));
+        top4_n = (size_t *)calloc(n_modes + 1, sizeof(size_t));
+    }
+    if (observe_overlap) overlap_obs_buf = (graph_slot *)calloc(n_pair_slots + 1, sizeof(graph_slot));
+    /* snapshots: first realisation only (mod.rs:302-335) */
+    uint64_t snapshot_interval = (realization_idx == 0 && has_oc) ? cfg->snapshot_interval : 0;
+    uint32_t *snap_buf = NULL, *blue_snap_buf = NULL;
+    int8_t *spin_snap_buf = NULL;
+    uint64_t *sid_snap_buf = NULL;
+    if (snapshot_interval > 0) {
+        snap_buf = (uint32_t *)calloc(n_pair_slots * n + 1, sizeof(uint32_t));
+        blue_snap_buf = (uint32_t *)calloc(n_pair_slots * n + 1, sizeof(uint32_t));
+        spin_snap_buf = (int8_t *)calloc(n_pair_slots * 2 * n + 1, 1);
+        sid_snap_buf = (uint64_t *)calloc(n_pair_slots * 2 + 1, sizeof(uint64_t));
+    }
 
     /* mod.rs:190-198 */
     orc_lookup *lookup = NULL;
@@ -1322,8 +1789,28 @@ static void run_sweep_loop(const orc_lattice *lat, realization *real, size_t n_r
             orc_gibbs_sweep(lat, real->spins, real->couplings, real->temperatures, real->system_ids,
                             n_systems, real->rngs);
 
-        if (cfg->cluster_interval > 0 && sweep_id % cfg->cluster_interval == 0) /* mod.rs:434-469 */
-            fk_update(lat, real, n_systems, cfg->cluster_mode == ORC_CLUSTER_WOLFF);
+        if (cfg->cluster_interval > 0 && sweep_id % cfg->cluster_interval == 0) { /* mod.rs:434-484 */
+            cluster_out out;
+            memset(&out, 0, sizeof(out));
+            out.observe = observe_fk;
+            if (collect_fk && record) {
+                memset(sw_csd_buf, 0, sizeof(uint64_t) * n_systems * (n + 1));
+                out.csd = sw_csd_buf;
+            }
+            if (observe_fk && record) {
+                memset(fk_obs_buf, 0, sizeof(graph_slot) * n_systems);
+                out.obs = fk_obs_buf;
+            }
+            fk_update(lat, real, n_systems, cfg->cluster_mode == ORC_CLUSTER_WOLFF, &out);
+            if (collect_fk && record)
+                for (size_t slot = 0; slot < n_systems; ++slot)
+                    for (size_t k = 0; k <= n; ++k)
+                        res->fk_csd[(slot % n_temps) * (n + 1) + k] += sw_csd_buf[slot * (n + 1) + k];
+            if (observe_fk && record)
+                for (size_t slot = 0; slot < n_systems; ++slot)
+                    summary_push(&res->observations[0], slot % n_temps, sw_csd_buf + slot * (n + 1), n,
+                                 &fk_obs_buf[slot]);
+        }
 
         int pt_this_sweep = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0; /* :486-488 */
 
@@ -1440,16 +1927,77 @@ static void run_sweep_loop(const orc_lattice *lat, realization *real, size_t n_r
 
         int did_overlap_mutate = 0; /* mod.rs:597-746 */
         if (cfg->overlap_cluster_interval > 0 && sweep_id % cfg->overlap_cluster_interval == 0) {
-            did_overlap_mutate = 1;
-            int mode = cfg->overlap_cluster_modes[overlap_call_count %
-                                                  (size_t)cfg->n_overlap_cluster_modes];
+            did_overlap_mutate = !observe_overlap;
+            size_t mode_idx = overlap_call_count % (size_t)cfg->n_overlap_cluster_modes;
+            int mode = cfg->overlap_cluster_modes[mode_idx];
+            cluster_out out;
+            memset(&out, 0, sizeof(out));
+            out.observe = observe_overlap;
+            if (collect_overlap && record) { /* mod.rs:604-626 */
+                memset(overlap_csd_buf, 0, sizeof(uint64_t) * n_pair_slots * (n + 1));
+                memset(top4_buf, 0, sizeof(uint32_t) * n_pair_slots * 4);
+                out.csd = overlap_csd_buf;
+                out.top4 = top4_buf;
+            }
+            if (observe_overlap && record) {
+                memset(overlap_obs_buf, 0, sizeof(graph_slot) * n_pair_slots);
+                out.obs = overlap_obs_buf;
+            }
+            int take_snapshot = snapshot_interval > 0 && sweep_id % snapshot_interval == 0 && record;
+            int is_cmr = (mode & 0xFF) == ORC_OC_CMR;
+            if (take_snapshot) { /* mod.rs:628-658 */
+                memset(spin_snap_buf, 0, n_pair_slots * 2 * n);
+                memset(sid_snap_buf, 0, sizeof(uint64_t) * n_pair_slots * 2);
+                out.snap = snap_buf;
+                out.spin_snap = spin_snap_buf;
+                out.sid_snap = sid_snap_buf;
+                if (is_cmr) out.blue_snap = blue_snap_buf;
+            }
             /* mode = kind | group_size << 8 (group size 0 or 2: pairs) */
-            if ((mode & 0xFF) == ORC_OC_CMR)
-                cmr_update(lat, real, n_replicas, n_temps, cfg->overlap_cluster_mode);
+            if (is_cmr)
+                cmr_update(lat, real, n_replicas, n_temps, cfg->overlap_cluster_mode, &out);
             else if ((mode & 0xFF) == ORC_OC_HOUDAYER && (mode >> 8) > 2)
-                houdayer_n_update(lat, real, n_replicas, n_temps, (size_t)(mode >> 8), cfg->overlap_cluster_mode);
+                houdayer_n_update(lat, real, n_replicas, n_temps, (size_t)(mode >> 8), cfg->overlap_cluster_mode,
+                                  &out);
             else
-                overlap_update(lat, real, n_replicas, n_temps, mode & 0xFF, cfg->overlap_cluster_mode);
+                overlap_update(lat, real, n_replicas, n_temps, mode & 0xFF, cfg->overlap_cluster_mode, &out);
+            if (take_snapshot) { /* mod.rs:682-714: pair 0 of every temperature */
+                res->snapshots = (cluster_snapshot *)realloc(res->snapshots,
+                                                             sizeof(cluster_snapshot) * (res->n_snapshots + 1));
+                cluster_snapshot *snap = &res->snapshots[res->n_snapshots++];
+                memset(snap, 0, sizeof(*snap));
+                snap->sweep_id = sweep_id;
+                snap->mode_idx = (int)mode_idx;
+                snap->has_blue = is_cmr;
+                snap->cluster_ids = (uint32_t *)calloc(n_temps * n + 1, sizeof(uint32_t));
+                snap->blue_ids = (uint32_t *)calloc(n_temps * n + 1, sizeof(uint32_t));
+                snap->spins = (int8_t *)calloc(n_temps * 2 * n + 1, 1);
+                snap->system_ids = (uint64_t *)calloc(n_temps * 2 + 1, sizeof(uint64_t));
+                for (size_t t = 0; t < n_temps; ++t) {
+                    size_t slot = t * n_pairs;
+                    memcpy(snap->cluster_ids + t * n, snap_buf + slot * n, sizeof(uint32_t) * n);
+                    if (is_cmr) memcpy(snap->blue_ids + t * n, blue_snap_buf + slot * n, sizeof(uint32_t) * n);
+                    memcpy(snap->spins + t * 2 * n, spin_snap_buf + slot * 2 * n, 2 * n);
+                    snap->system_ids[t * 2] = sid_snap_buf[slot * 2];
+                    snap->system_ids[t * 2 + 1] = sid_snap_buf[slot * 2 + 1];
+                }
+            }
+            if (collect_overlap && record) { /* mod.rs:716-735 */
+                for (size_t slot = 0; slot < n_pair_slots; ++slot)
+                    for (size_t k = 0; k <= n; ++k)
+                        res->overlap_csd[(mode_idx * n_temps + slot / n_pairs) * (n + 1) + k] +=
+                            overlap_csd_buf[slot * (n + 1) + k];
+                for (size_t t = 0; t < n_temps; ++t)
+                    for (size_t pr = 0; pr < n_pairs; ++pr)
+                        for (int k = 0; k < 4; ++k)
+                            top4_accum[(mode_idx * n_temps + t) * 4 + k] +=
+                                (double)top4_buf[(t * n_pairs + pr) * 4 + k] / (double)n;
+                top4_n[mode_idx] += 1;
+            }
+            if (record && observe_overlap) /* mod.rs:737-742 */
+                for (size_t slot = 0; slot < n_pair_slots; ++slot)
+                    summary_push(&res->observations[kind_of_mode[mode & 0xFF]], slot / n_pairs,
+                                 overlap_csd_buf + slot * (n + 1), n, &overlap_obs_buf[slot]);
             overlap_call_count += 1;
         }
 
@@ -1483,6 +2031,26 @@ static void run_sweep_loop(const orc_lattice *lat, realization *real, size_t n_r
     stat_average(&energies2, res->moments + 4 * n_temps, n_temps);
     if (n_pairs > 0)
         for (int k = 0; k < 6; ++k) stat_average(&ov[k], res->overlap + k * n_temps, n_temps);
+
+    if (collect_overlap) /* mod.rs:799-823 */
+        for (size_t m = 0; m < n_modes; ++m) {
+            if (top4_n[m] == 0) continue;
+            double denom = (double)(top4_n[m] * n_pairs);
+            for (size_t k = 0; k < n_temps * 4; ++k)
+                res->top_sizes[m * n_temps * 4 + k] = top4_accum[m * n_temps * 4 + k] / denom;
+        }
+    for (int k = 0; k < 4; ++k) summary_finish(&res->observations[k], n_temps, n, nn, lat->has_square_shape);
+    free(sw_csd_buf);
+    free(overlap_csd_buf);
+    free(fk_obs_buf);
+    free(overlap_obs_buf);
+    free(top4_buf);
+    free(top4_accum);
+    free(top4_n);
+    free(snap_buf);
+    free(blue_snap_buf);
+    free(spin_snap_buf);
+    free(sid_snap_buf);
 
     free(mags.aggregate);
     free(mags2.aggregate);
@@ -1588,7 +2156,7 @@ static void *worker_main(void *p) {
     worker_args *args = (worker_args *)p;
     for (size_t r = args->begin; r < args->end; ++r)
         run_sweep_loop(args->sim->lattice, &args->sim->realizations[r], args->sim->n_replicas,
-                       args->sim->n_temps, args->cfg, &args->sim->results[r]);
+                       args->sim->n_temps, args->cfg, &args->sim->results[r], r);
     return NULL;
 }
 
@@ -1685,4 +2253,49 @@ void orc_sim_get_result_histograms(const orc_sim *sim, size_t r, uint64_t *histo
     memcpy(histogram, sim->results[r].histogram, sizeof(uint64_t) * count);
     memcpy(ql_at_q_sum, sim->results[r].ql_at_q_sum, sizeof(double) * count);
     memcpy(ql2_at_q_sum, sim->results[r].ql2_at_q_sum, sizeof(double) * count);
+}
+
+/* cluster size histograms and mean top-4 sizes of one realisation (ClusterStats, results.rs:12-20);
+ * a pointer may be NULL; returns bit 0 = FK histogram present, bit 1 = overlap statistics present */
+int orc_sim_get_cluster_stats(const orc_sim *sim, size_t r, uint64_t *fk_csd, uint64_t *overlap_csd,
+                              double *top_sizes) {
+    const sweep_result *res = &sim->results[r];
+    size_t n = sim->lattice->n_spins, n_temps = sim->n_temps;
+    if (res->fk_csd && fk_csd) memcpy(fk_csd, res->fk_csd, sizeof(uint64_t) * n_temps * (n + 1));
+    if (res->overlap_csd && overlap_csd)
+        memcpy(overlap_csd, res->overlap_csd, sizeof(uint64_t) * res->n_modes * n_temps * (n + 1));
+    if (res->top_sizes && top_sizes) memcpy(top_sizes, res->top_sizes, sizeof(double) * res->n_modes * n_temps * 4);
+    return (res->fk_csd ? 1 : 0) | (res->overlap_csd ? 2 : 0);
+}
+
+/* graph observation summary `kind` (0 fk, 1 houdayer, 2 jorg, 3 cmr_blue) of one realisation;
+ * returns 0 if absent, 1 if present, 3 if present with winding fractions */
+int orc_sim_get_observation(const orc_sim *sim, size_t r, int kind, uint64_t *count, uint64_t *sizes,
+                            double *top4_frac, double *bond_density, double *large_mean, double *winding) {
+    const graph_summary *g = &sim->results[r].observations[kind];
+    size_t n = sim->lattice->n_spins, n_temps = sim->n_temps;
+    if (!g->enabled || !g->present) return 0;
+    memcpy(count, g->count, sizeof(uint64_t) * n_temps);
+    memcpy(sizes, g->csd, sizeof(uint64_t) * n_temps * (n + 1));
+    memcpy(top4_frac, g->top4_frac, sizeof(double) * n_temps * 4);
+    memcpy(bond_density, g->bond_density, sizeof(double) * n_temps);
+    memcpy(large_mean, g->large_mean, sizeof(double) * n_temps);
+    if (g->has_winding) memcpy(winding, g->winding_frac, sizeof(double) * n_temps * 4);
+    return g->has_winding ? 3 : 1;
+}
+
+size_t orc_sim_n_snapshots(const orc_sim *sim) { return sim->results[0].n_snapshots; }
+
+/* snapshot k of realisation 0: returns 1 when blue_ids are present (CMR) */
+int orc_sim_get_snapshot(const orc_sim *sim, size_t k, uint64_t *sweep_id, int32_t *mode_idx,
+                         uint32_t *cluster_ids, uint32_t *blue_ids, int8_t *spins, uint64_t *system_ids) {
+    const cluster_snapshot *snap = &sim->results[0].snapshots[k];
+    size_t n = sim->lattice->n_spins, n_temps = sim->n_temps;
+    *sweep_id = snap->sweep_id;
+    *mode_idx = snap->mode_idx;
+    memcpy(cluster_ids, snap->cluster_ids, sizeof(uint32_t) * n_temps * n);
+    if (snap->has_blue) memcpy(blue_ids, snap->blue_ids, sizeof(uint32_t) * n_temps * n);
+    memcpy(spins, snap->spins, n_temps * 2 * n);
+    memcpy(system_ids, snap->system_ids, sizeof(uint64_t) * n_temps * 2);
+    return snap->has_blue;
 }

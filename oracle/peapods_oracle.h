@@ -127,12 +127,17 @@ void orc_uf_from_bonds(const orc_lattice *lat, const uint64_t *bond_sites, const
                        size_t n_bonds, uint32_t *parent, uint32_t *counts);
 void orc_uf_histogram(const uint32_t *counts, size_t n, uint64_t *hist /* [n+1] */);
 void orc_top4_sizes(const uint32_t *counts, size_t n, uint32_t out[4]);
+/* graph observation of a bond list applied in order (BondMetrics + WindingUf, utils.rs:317-455):
+ * out = {active_bonds, top4[4], large_components, winding_x, winding_y, observed} */
+void orc_graph_observation(const orc_lattice *lat, const uint64_t *bond_sites, const uint64_t *bond_dims,
+                           size_t n_bonds, uint32_t out[9]);
 
 /* ---- full simulation (ss/simulation/{mod.rs,realization.rs}, src/lib.rs) -- */
 enum { ORC_SWEEP_METROPOLIS = 0, ORC_SWEEP_GIBBS = 1 };
 enum { ORC_PT_SINGLE_RANDOM_EDGE = 0, ORC_PT_FULL_LADDER = 1 };
 enum { ORC_OC_NONE = 0, ORC_OC_HOUDAYER = 1, ORC_OC_JORG = 2, ORC_OC_CMR = 3 };
 enum { ORC_CLUSTER_WOLFF = 0, ORC_CLUSTER_SW = 1 };
+enum { ORC_ACTION_UPDATE = 0, ORC_ACTION_OBSERVE = 1 }; /* ss/config.rs:41-59 */
 
 typedef struct {
     uint64_t n_sweeps;
@@ -150,6 +155,10 @@ typedef struct {
     uint64_t autocorrelation_max_lag; /* 0 = none; ring backend of ss/statistics/autocorrelation.rs */
     int32_t equilibration_diagnostic; /* running means of E and q_l at log-spaced checkpoints
                                          (ss/statistics/equilibration.rs) */
+    int32_t collect_cluster_stats;    /* cluster size histograms + top-4 sizes (src/lib.rs:243,266) */
+    int32_t cluster_action;           /* ORC_ACTION_*: FK update */
+    int32_t overlap_cluster_action;   /* ORC_ACTION_*: overlap move */
+    uint64_t snapshot_interval;       /* 0 = none; cluster snapshots of realisation 0 (mod.rs:302-335) */
 } orc_config;
 
 typedef struct orc_sim orc_sim;
@@ -190,6 +199,15 @@ void orc_sim_get_equil(const orc_sim *sim, size_t realization, uint64_t *sweeps,
                        double *link_overlap_avg);
 void orc_sim_get_result_overlap(const orc_sim *sim, size_t realization,
                                 double *out /* [6][n_temps]: q,q2,q4,ql,ql2,ql4 */);
+/* cluster statistics / graph observations / snapshots of the last sample() (results.rs:12-54) */
+int orc_sim_get_cluster_stats(const orc_sim *sim, size_t realization, uint64_t *fk_csd /* [n_temps][N+1] */,
+                              uint64_t *overlap_csd /* [n_modes][n_temps][N+1] */,
+                              double *top_sizes /* [n_modes][n_temps][4] */);
+int orc_sim_get_observation(const orc_sim *sim, size_t realization, int kind, uint64_t *count, uint64_t *sizes,
+                            double *top4_frac, double *bond_density, double *large_mean, double *winding);
+size_t orc_sim_n_snapshots(const orc_sim *sim);
+int orc_sim_get_snapshot(const orc_sim *sim, size_t k, uint64_t *sweep_id, int32_t *mode_idx,
+                         uint32_t *cluster_ids, uint32_t *blue_ids, int8_t *spins, uint64_t *system_ids);
 void orc_sim_get_result_histograms(const orc_sim *sim, size_t realization,
                                    uint64_t *histogram /* [n_temps][N+1] */,
                                    double *ql_at_q_sum, double *ql2_at_q_sum);

@@ -12,7 +12,7 @@ from . import _native as nat
 _SWEEP_MODES = {"metropolis": 0, "gibbs": 1}
 _PT_SCHEDULES = {"single_random_edge": 0, "full_ladder": 1}
 _CLUSTER_MODES = {"wolff": 0, "sw": 1}
-_CLUSTER_ACTIONS = ("update", "observe")
+_CLUSTER_ACTIONS = {"update": 0, "observe": 1}
 _AUTOCORR_BACKENDS = ("ring", "fft")
 _OC_MODES = {"houdayer": 1, "houd2": 1, "jorg": 2, "cmr": 3, "cmr2": 3}
 
@@ -165,10 +165,9 @@ class IsingSimulation:
                 raise ValueError("cluster_update interval must be >= 1")
             if action == "observe" and mode == "wolff":
                 raise ValueError("cluster_action='observe' requires cluster_mode='sw'")
-            if action == "observe" or collect_cluster_stats:
-                raise NotImplementedError("cluster observers are outside the HIP hot path")
             cfg.cluster_interval = int(cluster_update_interval)
             cfg.cluster_mode = _CLUSTER_MODES[mode]
+            cfg.cluster_action = _CLUSTER_ACTIONS[action]
         if overlap_cluster_update_interval is not None:
             modes = _parse_overlap_modes(
                 "houdayer" if overlap_cluster_build_mode is None else overlap_cluster_build_mode
@@ -181,12 +180,17 @@ class IsingSimulation:
                 raise ValueError(f"unknown cluster action '{action}', expected 'update' or 'observe'")
             if overlap_cluster_update_interval < 1:
                 raise ValueError("overlap_cluster interval must be >= 1")
-            if action == "observe":
-                if oc_mode == "wolff":
+            if action == "observe" and oc_mode == "wolff":
+                raise ValueError("overlap_cluster_action='observe' requires overlap_cluster_mode='sw'")
+            if snapshot_interval is not None:  # config.rs:213-219,231-235
+                if snapshot_interval < 1 or snapshot_interval % overlap_cluster_update_interval != 0:
                     raise ValueError(
-                        "overlap_cluster_action='observe' requires overlap_cluster_mode='sw'"
-                    )
-                raise NotImplementedError("cluster observers are outside the HIP hot path")
+                        "snapshot_interval must be a positive multiple of overlap_cluster interval")
+                if action == "observe":
+                    raise ValueError(
+                        "snapshot_interval is not supported with overlap_cluster_action='observe'")
+                cfg.snapshot_interval = int(snapshot_interval)
+            cfg.overlap_cluster_action = _CLUSTER_ACTIONS[action]
             if len(modes) > 4:
                 raise NotImplementedError("at most 4 alternating overlap modes are supported")
             cfg.overlap_cluster_interval = int(overlap_cluster_update_interval)
@@ -200,6 +204,7 @@ class IsingSimulation:
                                           "(use the exact ring backend)")
             cfg.autocorrelation_max_lag = int(autocorrelation_max_lag)
         cfg.equilibration_diagnostic = 1 if equilibration_diagnostic else 0
+        cfg.collect_cluster_stats = 1 if collect_cluster_stats else 0
         cfg.measure_overlap = 1 if measure_overlap else 0
         err = C.create_string_buffer(512)
         code = self._lib.pa_validate_sample_config(C.byref(cfg), self.n_replicas, err, len(err))
@@ -326,7 +331,93 @@ class IsingSimulation:
             out.update(self.autocorrelation_times())
         if cfg.equilibration_diagnostic:
             out.update(self.equilibration_checkpoints())
+        observing = (cfg.cluster_interval and cfg.cluster_action) or \
+                    (cfg.overlap_cluster_interval and cfg.overlap_cluster_action)
+        if cfg.collect_cluster_stats or observing:
+            self._cluster_results(out, int(cfg.n_overlap_cluster_modes))
+        if cfg.snapshot_interval and cfg.overlap_cluster_interval:
+            snaps = self.cluster_snapshots()
+            if snaps:
+                out["cluster_snapshots"] = snaps
         return out
+
+    def _cluster_results(self, out, n_modes):
+        """fk_csd / overlap_csd / top_cluster_sizes and per_disorder["cluster_observations"] of the last
+        sample(): sums (histograms) and realisation-ordered means (top sizes) as in
+        results.rs:181-214,261-267 and src/lib.rs:414-456,492-543."""
+        n_t, n_bins, n_real = self.n_temps, self.n_spins + 1, self.n_realizations
+        modes = max(n_modes, 1)
+        fk = np.zeros((n_real, n_t, n_bins), dtype=np.uint64)
+        ov = np.zeros((n_real, modes, n_t, n_bins), dtype=np.uint64)
+        tops = np.zeros((n_real, modes, n_t, 4), dtype=np.float64)
+        got = 0
+        for r in range(n_real):
+            got = self._lib.pa_sim_get_cluster_stats(self._handle, r, nat.ptr(fk[r]), nat.ptr(ov[r]),
+                                                     nat.ptr(tops[r]))
+            if got < 0:
+                self._check(got)
+        if got & 1:
+            total = np.empty((n_t, n_bins), dtype=np.uint64)
+            self._lib.pa_aggregate_sum_u64(nat.ptr(fk), n_real, fk[0].size, nat.ptr(total))
+            if total.any():  # src/lib.rs:492-505
+                out["fk_csd"] = [total[t].copy() for t in range(n_t)]
+        if got & 2:
+            total = np.empty((modes, n_t, n_bins), dtype=np.uint64)
+            self._lib.pa_aggregate_sum_u64(nat.ptr(ov), n_real, ov[0].size, nat.ptr(total))
+            if total.any():
+                out["overlap_csd"] = [[total[m, t].copy() for t in range(n_t)] for m in range(modes)]
+            mean = np.empty((modes, n_t, 4), dtype=np.float64)
+            self._lib.pa_aggregate_mean(nat.ptr(tops), n_real, tops[0].size, nat.ptr(mean))
+            out["top_cluster_sizes"] = [mean[m].copy() for m in range(modes)]
+        observations = {}
+        for kind, name in enumerate(("fk", "houdayer", "jorg", "cmr_blue")):
+            rows = []
+            for r in range(n_real):
+                count = np.zeros(n_t, dtype=np.uint64)
+                sizes = np.zeros((n_t, n_bins), dtype=np.uint64)
+                top4 = np.zeros((n_t, 4), dtype=np.float64)
+                density = np.zeros(n_t, dtype=np.float64)
+                large = np.zeros(n_t, dtype=np.float64)
+                winding = np.zeros((n_t, 4), dtype=np.float64)
+                got = self._lib.pa_sim_get_observation(
+                    self._handle, r, kind, nat.ptr(count), nat.ptr(sizes), nat.ptr(top4), nat.ptr(density),
+                    nat.ptr(large), nat.ptr(winding))
+                if got < 0:
+                    self._check(got)
+                if not got:
+                    break
+                row = {"observation_count": count, "cluster_size_counts": sizes,
+                       "top_four_component_fractions": top4, "active_bond_density": density,
+                       "large_component_count": large}
+                if got & 2:  # src/lib.rs:84-99
+                    for k, key in enumerate(("winding_x", "winding_y", "winding_either", "winding_both")):
+                        row[key] = winding[:, k].copy()
+                rows.append(row)
+            if len(rows) == n_real:  # a kind is reported when every realisation has it (src/lib.rs:447-453)
+                observations[name] = {f: np.stack([row[f] for row in rows]) for f in rows[0]}
+        if observations:
+            out.setdefault("per_disorder", {})["cluster_observations"] = observations
+
+    def cluster_snapshots(self):
+        """`cluster_snapshots` of the last sample() (src/lib.rs:576-614)."""
+        snaps = []
+        n_t, n = self.n_temps, self.n_spins
+        for k in range(int(self._lib.pa_sim_n_snapshots(self._handle))):
+            sweep_id, mode_idx = C.c_uint64(), C.c_int32()
+            ids = np.zeros((n_t, n), dtype=np.uint32)
+            blue = np.zeros((n_t, n), dtype=np.uint32)
+            spins = np.zeros((n_t, 2, n), dtype=np.int8)
+            sids = np.zeros((n_t, 2), dtype=np.uint64)
+            has_blue = self._lib.pa_sim_get_snapshot(self._handle, k, C.byref(sweep_id), C.byref(mode_idx),
+                                                     nat.ptr(ids), nat.ptr(blue), nat.ptr(spins), nat.ptr(sids))
+            if has_blue < 0:
+                self._check(has_blue)
+            snap = {"sweep_id": int(sweep_id.value), "mode_idx": int(mode_idx.value), "cluster_ids": ids,
+                    "spins": spins, "system_ids": sids}
+            if has_blue:
+                snap["blue_ids"] = blue
+            snaps.append(snap)
+        return snaps
 
     def autocorrelation_times(self):
         """mags2_tau (and overlap2_tau with replica pairs) of the last sample(), averaged over the

@@ -46,6 +46,10 @@ class PaSampleConfig(C.Structure):
         ("cluster_mode", C.c_int32),
         ("equilibration_diagnostic", C.c_int32),
         ("autocorrelation_max_lag", C.c_uint64),
+        ("collect_cluster_stats", C.c_int32),
+        ("cluster_action", C.c_int32),
+        ("overlap_cluster_action", C.c_int32),
+        ("snapshot_interval", C.c_uint64),
     ]
 
 
@@ -84,6 +88,10 @@ SIGNATURES = {
     "pa_sim_get_autocorrelation_tau": (C.c_int, [_vp, _u64, _vp, _vp]),
     "pa_sim_n_equil_checkpoints": (_u64, [_vp]),
     "pa_sim_get_equilibration": (C.c_int, [_vp, _u64, _vp, _vp, _vp]),
+    "pa_sim_get_cluster_stats": (C.c_int, [_vp, _u64, _vp, _vp, _vp]),
+    "pa_sim_get_observation": (C.c_int, [_vp, _u64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pa_sim_n_snapshots": (_u64, [_vp]),
+    "pa_sim_get_snapshot": (C.c_int, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pa_sim_get_result_blocks": (C.c_int, [_vp, _vp]),
     "pa_splitmix64": (_u64, [_u64]),
     "pa_child_seed": (_u64, [_u64, _u64, _u64]),

@@ -104,11 +104,39 @@ struct DevPtrs {
     float *ac_m2, *ac_q2;    // [n_real][ac_stride][n_temps] per-sweep series of <m^2> and <q^2> (f32, as pushed)
     double *eq_sum;          // [n_real][2][n_temps] running sums of the equilibration diagnostic
     double *eq_ckpt;         // [n_real][64][2][n_temps] checkpoint averages
+    // cluster statistics / graph observations / snapshots (kernels_cluster.hip; built on first use)
+    uint64_t *cs_fk_csd;     // [n_real][n_temps][N + 1] FK cluster-size histogram
+    uint64_t *cs_ov_csd;     // [n_real][cs_modes][n_temps][N + 1] overlap-cluster size histograms per build mode
+    uint32_t *cs_top4_raw;   // [n_real][n_temps * n_pairs][4] four largest clusters of the current call
+    double *cs_top4_acc;     // [n_real][cs_modes][n_temps][4] running sums of top4 / N (pair order)
+    uint64_t *obs_acc;       // [n_real][4 kinds][n_temps][kObsWords + N + 1] observation accumulators:
+                             //   count, top4[4], bonds, winding[4] (x, y, either, both), large, then sizes[N + 1]
+    uint32_t *snap_bonds;    // [n_temps][2][6][MW] realisation 0, pair 0: accepted bonds (blue / only; red extension)
+    uint32_t *snap_ids;      // [n_temps][N] cluster ids in the reference's union-find convention (k_uf_replay)
+    uint32_t *snap_blue;     // [n_temps][N] CMR blue-cluster ids
+    int8_t *snap_spins;      // [n_temps][2][N] spins of the pair before the move
+    uint32_t *snap_sids;     // [n_temps][4] systems of the pair, then 1 if the ids are to be rebuilt, then unused
     // general-coupling path only
     const float *Jf;         // [n_real][N][nn] forward couplings as given
     const float *temps;      // [n_temps]
     float *thr_f;            // [n_real][W][N][32] thresholds (T/2) ln(..) of the current sweep
     uint32_t *xw;            // [n_real][W][N][4] bond sign words S_i ^ S_fwd(i,d)
+};
+
+// What a cluster call reports besides moving spins (simulation/mod.rs:217-335).
+enum : uint32_t {
+    kAuxSizes = 1,    // cluster-size histogram (+ four largest clusters for the overlap moves)
+    kAuxObserve = 2,  // ClusterAction::Observe: the bonds are drawn, then nothing moves and no coin is drawn
+    kAuxSnapshot = 4, // realisation 0, pair 0 of every temperature: spins, systems and bonds exported
+    kAuxMetrics = 8,  // graph metrics of a recorded observation into obs_acc (with kAuxSizes)
+};
+constexpr uint32_t kObsWords = 11;
+struct ClusterAux {
+    uint32_t flags;
+    uint32_t mode_idx; // row of cs_ov_csd / cs_top4_acc (round-robin index of the build mode)
+    uint32_t n_modes;  // rows allocated
+    uint32_t kind;     // obs_acc row: 0 fk, 1 houdayer, 2 jorg, 3 cmr_blue
+    uint32_t square;   // 1: canonical 2D hypercubic lattice -> winding is measured (lattice.rs:31-38)
 };
 
 struct PtParams {
@@ -144,11 +172,13 @@ hipError_t launch_measure_stamped(const SimDims &d, const DevPtrs &p, const PtPa
 size_t sweep_lds_bytes(const SimDims &d, bool gibbs);
 // kernels_cluster.hip
 hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, uint32_t group, bool wolff,
-                             hipStream_t stream);
+                             const ClusterAux &aux, hipStream_t stream);
+hipError_t launch_top4_accumulate(const SimDims &d, const DevPtrs &p, const ClusterAux &aux, hipStream_t stream);
+hipError_t launch_uf_replay(const SimDims &d, const DevPtrs &p, bool cmr, hipStream_t stream);
 hipError_t launch_cmr_wolff(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 size_t cmr_wolff_lds_bytes(const SimDims &d);
 size_t cluster_sw_lds_bytes(const SimDims &d);
-hipError_t launch_fk(const SimDims &d, const DevPtrs &p, bool wolff, hipStream_t stream);
+hipError_t launch_fk(const SimDims &d, const DevPtrs &p, bool wolff, const ClusterAux &aux, hipStream_t stream);
 size_t fk_wolff_lds_bytes(const SimDims &d);
 hipError_t configure_cluster_kernels();
 hipError_t launch_exp_selftest(float *out, hipStream_t stream);

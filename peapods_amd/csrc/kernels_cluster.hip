@@ -108,14 +108,14 @@ struct SwLds {
     uint32_t *bits;    // [n_bit_words] accept / coin bits by draw position
     uint32_t *bits2;   // [n_bit_words] second bit of the CMR grey draw
     uint32_t *scratch; // [8]
-    uint32_t *misc;    // [4] changed flag
+    uint32_t *misc;    // [16] 0 changed, 1 seed / root, 2 draws, 3-4 winding x/y, 5 large, 6 bonds, 8-11 top four
 };
 
 __host__ __device__ inline size_t cluster_sw_bit_words(const SimDims &d) {
     return (static_cast<size_t>(d.N) * d.nn + 255) / 256 * 8 + 16;
 }
 __host__ __device__ inline size_t cluster_sw_lds_words(const SimDims &d) {
-    return 2 * static_cast<size_t>(d.N) + 26 * static_cast<size_t>(d.MW) + 1 + 3 * cluster_sw_bit_words(d) + 12 +
+    return 2 * static_cast<size_t>(d.N) + 26 * static_cast<size_t>(d.MW) + 1 + 3 * cluster_sw_bit_words(d) + 24 +
            (d.unit ? 0 : static_cast<size_t>(d.N) * d.nn);
 }
 
@@ -125,7 +125,8 @@ enum { kSwHoudayer = 0, kSwJorg = 1, kSwFk = 2, kSwCmr = 3 };
 // sum to zero on the active sites, all of them flipped).  wolff: single-cluster variant of a
 // deterministic-bond move (find_seed, utils.rs:107-119, then flip the seed's component).
 template <int MODE>
-__global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p, uint32_t group, int wolff) {
+__global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p, uint32_t group, int wolff,
+                                                            ClusterAux aux) {
     constexpr bool JORG = MODE == kSwJorg, FK = MODE == kSwFk, CMR = MODE == kSwCmr;
     constexpr bool STOCHASTIC = JORG || FK || CMR; // bonds are drawn
     constexpr uint32_t N_PHASES = CMR ? 2 : 1;     // CMR: blue clusters, then grey = blue + red bonds
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
         L.bits = q; q += cluster_sw_bit_words(d);
         L.bits2 = q; q += cluster_sw_bit_words(d);
         L.scratch = q; q += 8;
-        L.misc = q; q += 4;
+        L.misc = q; q += 16;
         L.thr = q;
     }
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -169,6 +170,9 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
     uint64_t *rng_state = FK ? nullptr : p.pair_rng + (static_cast<size_t>(real) * d.n_temps * d.n_pairs +
                                                        static_cast<size_t>(t) * d.n_pairs + g) * 4;
     uint32_t *Stile = p.S + static_cast<size_t>(real) * d.W * d.N; // all words (groups above two)
+    // snapshots are those of the first realisation's first group at every temperature (mod.rs:302,683-705)
+    const bool snap_here = !FK && (aux.flags & kAuxSnapshot) && real == 0 && g == 0;
+    const bool observe = (aux.flags & kAuxObserve) != 0, metrics = (aux.flags & kAuxMetrics) != 0;
     const uint32_t n_rounds = (d.N + kSwThreads - 1) / kSwThreads; // site i = r * 256 + tid
     // write the ballot of a predicate over sites r*256 + tid into a bitmap (two words per wave)
     auto put_ballot = [&](uint32_t *bitmap, uint32_t r, bool pred) {
@@ -203,7 +207,16 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
             put_ballot(L.act, r, active);
             put_ballot(L.spa, r, va[q] != 0);
             put_ballot(L.spb, r, vb[q] != 0);
+            if (snap_here && i < d.N) { // the pair's spins before the move (overlap.rs:211-221)
+                p.snap_spins[(static_cast<size_t>(t) * 2 + 0) * d.N + i] = va[q] ? -1 : 1;
+                p.snap_spins[(static_cast<size_t>(t) * 2 + 1) * d.N + i] = vb[q] ? -1 : 1;
+            }
         }
+    }
+    if (snap_here && tid == 0) {
+        p.snap_sids[t * 4 + 0] = p.system_ids[static_cast<size_t>(real) * d.n_sys + sa];
+        p.snap_sids[t * 4 + 1] = p.system_ids[static_cast<size_t>(real) * d.n_sys + sb];
+        p.snap_sids[t * 4 + 2] = 0; // cluster ids are rebuilt only if this call gets as far as writing them
     }
     for (uint32_t m = tid; m < d.MW; m += kSwThreads) {
         L.flip_a[m] = 0;
@@ -309,7 +322,233 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
             x = upup;
         }
     };
+    // the task's generator `at` draws after its position at entry (one lane)
+    auto rng_at = [&](uint32_t at) -> DevRng {
+        uint32_t js[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) js[k] = base_state[k];
+        if (at / 256) jump_state_lds(js, p.jump256 + static_cast<size_t>(at / 256) * (64 * 16 * 8));
+        if ((at / 64) & 3u) jump_state_lds(js, p.jump64 + static_cast<size_t>((at / 64) & 3u) * (64 * 16 * 8));
+        Rng32 r32;
+        r32.load(js);
+        for (uint32_t k = 0; k < (at & 63u); ++k) (void)r32.next_top();
+        uint32_t st[8];
+        r32.store(st);
+        DevRng rng;
+        rng.s0 = (static_cast<uint64_t>(st[1]) << 32) | st[0];
+        rng.s1 = (static_cast<uint64_t>(st[3]) << 32) | st[2];
+        rng.s2 = (static_cast<uint64_t>(st[5]) << 32) | st[4];
+        rng.s3 = (static_cast<uint64_t>(st[7]) << 32) | st[6];
+        return rng;
+    };
+    auto store_rng = [&](const DevRng &rng) {
+        if (FK) {
+            const uint32_t st[8] = {static_cast<uint32_t>(rng.s0), static_cast<uint32_t>(rng.s0 >> 32),
+                                    static_cast<uint32_t>(rng.s1), static_cast<uint32_t>(rng.s1 >> 32),
+                                    static_cast<uint32_t>(rng.s2), static_cast<uint32_t>(rng.s2 >> 32),
+                                    static_cast<uint32_t>(rng.s3), static_cast<uint32_t>(rng.s3 >> 32)};
+            store_cursor(p.cursor, real, d.SP, sa, st);
+        } else {
+            rng_state[0] = rng.s0; rng_state[1] = rng.s1; rng_state[2] = rng.s2; rng_state[3] = rng.s3;
+        }
+    };
+    // rand 0.8.5 gen_range(0..N) on usize: widening multiply + zone rejection
+    auto draw_site = [&](DevRng &rng) -> uint32_t {
+        const uint64_t range = d.N, zone = (range << __clzll(range)) - 1ull;
+        uint64_t v;
+        do v = rng.next(); while (v * range > zone);
+        return static_cast<uint32_t>(__umul64hi(v, range));
+    };
+    // block-wide maximum of a 64-bit key (all threads receive it)
+    auto block_max = [&](unsigned long long key) -> unsigned long long {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned long long other = __shfl_xor(key, off);
+            key = other > key ? other : key;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            L.scratch[2 * (tid >> 6)] = static_cast<uint32_t>(key);
+            L.scratch[2 * (tid >> 6) + 1] = static_cast<uint32_t>(key >> 32);
+        }
+        __syncthreads();
+        unsigned long long best = 0;
+        for (uint32_t w = 0; w < kSwThreads / 64; ++w) {
+            const unsigned long long v = (static_cast<unsigned long long>(L.scratch[2 * w + 1]) << 32) | L.scratch[2 * w];
+            best = v > best ? v : best;
+        }
+        return best;
+    };
+    // Sizes of the components in L.label and, for an observed graph, its metrics (utils.rs:317-369):
+    // histogram rows by atomics (integer sums commute), the four largest clusters by four block-wide
+    // maximum extractions, winding by propagating displacements from every root over the bonds
+    // and testing every bond for a non-zero mismatch (any closed walk with a net displacement shows
+    // up on one of its bonds; the reference's displacement union-find records the same fact).
+    auto report = [&](const uint32_t *links, const uint32_t *links2) {
+        const uint32_t slot_idx = FK ? task : t * d.n_pairs + g;
+        for (uint32_t i = tid; i < d.N; i += kSwThreads) L.aux[i] = 0;
+        if (tid < 16) L.misc[tid] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < d.N; i += kSwThreads) atomicAdd(&L.aux[L.label[i]], 1u);
+        __syncthreads();
+        unsigned long long *row =
+            reinterpret_cast<unsigned long long *>(FK ? p.cs_fk_csd + (static_cast<size_t>(real) * d.n_temps + t) * (d.N + 1)
+                                                      : p.cs_ov_csd + ((static_cast<size_t>(real) * aux.n_modes + aux.mode_idx) * d.n_temps + t) * (d.N + 1));
+        unsigned long long *orow = reinterpret_cast<unsigned long long *>(
+            p.obs_acc + ((static_cast<size_t>(real) * 4 + aux.kind) * d.n_temps + t) * (kObsWords + d.N + 1));
+        uint32_t mine[4] = {0, 0, 0, 0}; // ascending
+        uint32_t n_large = 0;
+        const uint32_t large_from = (d.N + 19) / 20; // ceil(0.05 N)
+        for (uint32_t i = tid; i < d.N; i += kSwThreads) {
+            if (L.label[i] != i) continue;
+            const uint32_t c = L.aux[i];
+            atomicAdd(&row[c], 1ull);
+            if (metrics) atomicAdd(&orow[kObsWords + c], 1ull);
+            n_large += c >= large_from;
+            if (c > mine[0]) {
+                mine[0] = c;
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    if (mine[a] > mine[a + 1]) {
+                        const uint32_t tmp = mine[a];
+                        mine[a] = mine[a + 1];
+                        mine[a + 1] = tmp;
+                    }
+            }
+        }
+        uint32_t top[4];
+        for (int k = 0; k < 4; ++k) { // largest remaining value; ties go to the smallest thread
+            const unsigned long long key = (static_cast<unsigned long long>(mine[3]) << 32) | (0xFFFFFFFFu - tid);
+            const unsigned long long best = block_max(key);
+            top[k] = static_cast<uint32_t>(best >> 32);
+            if (best == key && mine[3] != 0) {
+                mine[3] = mine[2];
+                mine[2] = mine[1];
+                mine[1] = mine[0];
+                mine[0] = 0;
+            }
+        }
+        if (!FK && tid == 0)
+            for (int k = 0; k < 4; ++k)
+                p.cs_top4_raw[(static_cast<size_t>(real) * d.n_temps * d.n_pairs + slot_idx) * 4 + k] = top[k];
+        if (!metrics) {
+            __syncthreads();
+            return;
+        }
+        uint32_t n_bonds = 0;
+        for (uint32_t m = tid; m < d.MW; m += kSwThreads)
+            for (uint32_t x = 0; x < d.nn; ++x)
+                n_bonds += __popc(links[x * d.MW + m] | (links2 ? links2[x * d.MW + m] : 0u));
+        atomicAdd(&L.misc[5], n_large);
+        atomicAdd(&L.misc[6], n_bonds);
+        __syncthreads();
+        if (aux.square) {
+            constexpr uint32_t kUnknown = 0xFFFFFFFFu, kOrigin = 0x80008000u;
+            auto linked = [&](uint32_t dd, uint32_t i) -> bool {
+                return get_bit(links + dd * d.MW, i) || (links2 && get_bit(links2 + dd * d.MW, i));
+            };
+            for (uint32_t i = tid; i < d.N; i += kSwThreads) L.aux[i] = L.label[i] == i ? kOrigin : kUnknown;
+            __syncthreads();
+            for (;;) {
+                if (tid == 0) L.misc[0] = 0;
+                __syncthreads();
+                bool moved = false;
+                for (uint32_t i = tid; i < d.N; i += kSwThreads) {
+                    const uint32_t here = L.aux[i];
+                    if (here == kUnknown) continue;
+                    for (uint32_t dd = 0; dd < 2; ++dd) {
+                        const uint32_t step = dd == 0 ? 0x10000u : 1u;
+                        const uint32_t f = p.nbr_site[i * 12 + 2 * dd], b = p.nbr_site[i * 12 + 2 * dd + 1];
+                        if (linked(dd, i) && L.aux[f] == kUnknown) {
+                            L.aux[f] = here + step;
+                            moved = true;
+                        }
+                        if (linked(dd, b) && L.aux[b] == kUnknown) {
+                            L.aux[b] = here - step;
+                            moved = true;
+                        }
+                    }
+                }
+                if (moved) L.misc[0] = 1;
+                __syncthreads();
+                const bool again = L.misc[0] != 0;
+                __syncthreads();
+                if (!again) break;
+            }
+            bool wx = false, wy = false;
+            for (uint32_t i = tid; i < d.N; i += kSwThreads)
+                for (uint32_t dd = 0; dd < 2; ++dd)
+                    if (linked(dd, i)) {
+                        const uint32_t diff = L.aux[i] + (dd == 0 ? 0x10000u : 1u) - L.aux[p.nbr_site[i * 12 + 2 * dd]];
+                        // the halves cannot borrow from each other: |displacement| < 2^15
+                        wx = wx || ((diff + 0x8000u) >> 16) != 0;
+                        wy = wy || (diff & 0xFFFFu) != 0;
+                    }
+            if (wx) L.misc[3] = 1;
+            if (wy) L.misc[4] = 1;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            atomicAdd(&orow[0], 1ull);
+            for (int k = 0; k < 4; ++k) atomicAdd(&orow[1 + k], static_cast<unsigned long long>(top[k]));
+            atomicAdd(&orow[5], static_cast<unsigned long long>(L.misc[6]));
+            const uint32_t wx = L.misc[3], wy = L.misc[4];
+            atomicAdd(&orow[6], static_cast<unsigned long long>(wx));
+            atomicAdd(&orow[7], static_cast<unsigned long long>(wy));
+            atomicAdd(&orow[8], static_cast<unsigned long long>(wx | wy));
+            atomicAdd(&orow[9], static_cast<unsigned long long>(wx & wy));
+            atomicAdd(&orow[10], static_cast<unsigned long long>(L.misc[5]));
+        }
+        __syncthreads();
+    };
+    // accepted bonds of a snapshot, for the reference-order union-find replay (k_uf_replay)
+    auto export_bonds = [&](uint32_t which, const uint32_t *links) {
+        uint32_t *out = p.snap_bonds + (static_cast<size_t>(t) * 2 + which) * 6 * d.MW;
+        for (uint32_t x = 0; x < d.nn; ++x)
+            for (uint32_t m = tid; m < d.MW; m += kSwThreads) out[x * d.MW + m] = links[x * d.MW + m];
+    };
+    // one flip step: decide(i, fa, fb) per site; both systems' bitmaps and the accumulated flips follow
+    auto flip_step = [&](auto decide) {
+        for (uint32_t r = 0; r < n_rounds; ++r) {
+            const uint32_t i = r * kSwThreads + tid;
+            bool fa = false, fb = false;
+            if (i < d.N) decide(i, fa, fb);
+            const unsigned long long va = __ballot(fa), vb = __ballot(fb);
+            const uint32_t word = (r * kSwThreads + (tid & ~63u)) >> 5;
+            if (lane == 0 && word < d.MW) {
+                L.flip_a[word] ^= static_cast<uint32_t>(va);
+                L.flip_b[word] ^= static_cast<uint32_t>(vb);
+                L.spa[word] ^= static_cast<uint32_t>(va);
+                L.spb[word] ^= static_cast<uint32_t>(vb);
+            }
+            if (lane == 32 && word + 1 < d.MW) {
+                L.flip_a[word + 1] ^= static_cast<uint32_t>(va >> 32);
+                L.flip_b[word + 1] ^= static_cast<uint32_t>(vb >> 32);
+                L.spa[word + 1] ^= static_cast<uint32_t>(va >> 32);
+                L.spb[word + 1] ^= static_cast<uint32_t>(vb >> 32);
+            }
+        }
+    };
     uint32_t pos = 0; // draws of the generator consumed so far
+    bool rng_stored = false; // a single-cluster form has already written the generator back
+    if (CMR && wolff) { // the single-cluster form of the union-find path draws its seed first (overlap.rs:691-695)
+        if (tid == 0) {
+            DevRng rng = rng_at(0);
+            const DevRng before = rng;
+            L.misc[1] = draw_site(rng);
+            uint32_t used = 0; // gen_range consumed `used` draws (rejections are rare but possible)
+            DevRng walk = before;
+            while (walk.s0 != rng.s0 || walk.s1 != rng.s1 || walk.s2 != rng.s2 || walk.s3 != rng.s3) {
+                (void)walk.next();
+                ++used;
+            }
+            L.misc[2] = used;
+        }
+        __syncthreads();
+        pos = L.misc[2];
+    }
+    const uint32_t cmr_seed = (CMR && wolff) ? L.misc[1] : 0u;
+    __syncthreads();
     for (uint32_t phase = 0; phase < N_PHASES; ++phase) {
         // ---- B: eligible forward bonds.  Houdayer: both ends active (overlap.rs:228-231).
         // Joerg: both ends active and s_a(i) s_a(j) J > 0 (:417-429).  FK: s_i s_j J > 0
@@ -435,32 +674,88 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
         for (uint32_t i = tid; i < d.N; i += kSwThreads) L.label[i] = L.aux[i];
         __syncthreads();
 
-        if (MODE == kSwHoudayer && wolff) {
-            // single-cluster variant: up to 64 probes for an active seed (utils.rs:107-119), flip its component
+        // ---- what the call reports (mod.rs:442-455,604-626): sizes of this phase's clusters -- for
+        // CMR the blue ones (overlap.rs:725-742) -- and the accepted bonds of a snapshot
+        const uint32_t *links2 = (CMR && phase == 1) ? L.blue : nullptr;
+        const bool seed_first = wolff && (MODE == kSwHoudayer || JORG); // reports only once a seed is found
+        const bool reports = (aux.flags & (kAuxSizes | kAuxMetrics)) != 0 && phase == 0;
+        if (reports && !seed_first) report(links, links2);
+        if (snap_here) {
+            export_bonds(phase, links);
+            if (!seed_first && tid == 0) p.snap_sids[t * 4 + 2] = 1;
+        }
+        if (observe) break; // the graph is measured, nothing moves (fk.rs:140-142, overlap.rs:292-294,743-745)
+
+        if (wolff && seed_first) {
+            // single-cluster form of a pair move on the union-find path: bonds first, then up to 64
+            // probes for an active seed (utils.rs:107-119), flip its component (overlap.rs:245-272,446-472)
             if (tid == 0) {
-                DevRng rng;
-                rng.s0 = (static_cast<uint64_t>(base_state[1]) << 32) | base_state[0];
-                rng.s1 = (static_cast<uint64_t>(base_state[3]) << 32) | base_state[2];
-                rng.s2 = (static_cast<uint64_t>(base_state[5]) << 32) | base_state[4];
-                rng.s3 = (static_cast<uint64_t>(base_state[7]) << 32) | base_state[6];
+                DevRng rng = rng_at(pos);
                 uint32_t root = 0xFFFFFFFFu;
-                const uint64_t range = d.N, zone = (range << __clzll(range)) - 1ull;
                 for (int probe = 0; probe < 64 && root == 0xFFFFFFFFu; ++probe) {
-                    uint64_t v;
-                    do v = rng.next(); while (v * range > zone);
-                    const uint32_t i = static_cast<uint32_t>(__umul64hi(v, range));
+                    const uint32_t i = draw_site(rng);
                     if (get_bit(L.act, i)) root = L.label[i];
                 }
                 L.misc[1] = root;
-                rng_state[0] = rng.s0; rng_state[1] = rng.s1; rng_state[2] = rng.s2; rng_state[3] = rng.s3;
+                store_rng(rng);
+            }
+            __syncthreads();
+            const uint32_t root = L.misc[1];
+            __syncthreads();
+            if (root == 0xFFFFFFFFu) return; // no seed: nothing flips and nothing is reported
+            for (uint32_t i = tid; i < d.N; i += kSwThreads)
+                if (L.label[i] == root) {
+                    if (MODE == kSwHoudayer && group > 2) {
+                        for (uint32_t k = 0; k < group; ++k)
+                            atomicXor(&Stile[static_cast<size_t>(members[k] >> 5) * d.N + i], 1u << (members[k] & 31u));
+                    } else {
+                        atomicXor(&Sa[i], 1u << ba);
+                        atomicXor(&Sb[i], 1u << bb);
+                    }
+                }
+            if (reports) report(links, links2);
+            if (snap_here && tid == 0) p.snap_sids[t * 4 + 2] = 1;
+            return;
+        }
+        if (wolff && FK) { // fk.rs:144-151: the seed is drawn after the bonds
+            if (tid == 0) {
+                DevRng rng = rng_at(pos);
+                L.misc[1] = L.label[draw_site(rng)];
+                store_rng(rng);
             }
             __syncthreads();
             const uint32_t root = L.misc[1];
             for (uint32_t i = tid; i < d.N; i += kSwThreads)
-                if (root != 0xFFFFFFFFu && L.label[i] == root)
-                    for (uint32_t k = 0; k < group; ++k)
-                        atomicXor(&Stile[static_cast<size_t>(members[k] >> 5) * d.N + i], 1u << (members[k] & 31u));
+                if (L.label[i] == root) atomicXor(&Sa[i], 1u << ba);
             return;
+        }
+        if (wolff && CMR) { // overlap.rs:748-755 (blue: both systems), :806-820 (grey: k in 1..=3)
+            const uint32_t root = L.label[cmr_seed];
+            uint32_t k = 3;
+            if (phase == 1) {
+                if (tid == 0) {
+                    DevRng rng = rng_at(pos);
+                    for (;;) { // rand 0.8.5 u8 gen_range(1..=3): u32 draw, zone = u32::MAX - (2^32 - 3) % 3
+                        const uint32_t v = static_cast<uint32_t>(rng.next() >> 32);
+                        const uint64_t m = static_cast<uint64_t>(v) * 3u;
+                        if (static_cast<uint32_t>(m) <= 0xFFFFFFFFu - ((0xFFFFFFFFu - 3u + 1u) % 3u)) {
+                            L.misc[7] = 1u + static_cast<uint32_t>(m >> 32);
+                            break;
+                        }
+                    }
+                    store_rng(rng);
+                }
+                __syncthreads();
+                k = L.misc[7];
+                rng_stored = true;
+            }
+            flip_step([&](uint32_t i, bool &fa, bool &fb) {
+                const bool in = L.label[i] == root;
+                fa = in && (k & 1u);
+                fb = in && (k & 2u);
+            });
+            __syncthreads();
+            continue;
         }
         // ---- G: clusters that draw -- more than one site for the overlap moves (overlap.rs:312-318,
         // :757-762, :822-828), every cluster for FK (fk.rs:182-192) -- ranked by their smallest site
@@ -482,42 +777,24 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
         __syncthreads();
         const uint32_t rel = pos - (pos / 256) * 256;
         // ---- I: flips (both systems for a coin; bit 0 / bit 1 of k for the two systems of a grey cluster)
-        for (uint32_t r = 0; r < n_rounds; ++r) {
-            const uint32_t i = r * kSwThreads + tid;
-            bool fa = false, fb = false;
-            if (i < d.N) {
-                const uint32_t root = L.label[i];
-                if (FK || L.aux[root]) {
-                    const uint32_t q = rel + L.wbase[root >> 5] + __popc(L.roots[root >> 5] & ((1u << (root & 31u)) - 1u));
-                    const uint32_t b0 = (L.bits[q >> 5] >> (q & 31u)) & 1u;
-                    if (grey) {
-                        fa = b0 != 0;
-                        fb = ((L.bits2[q >> 5] >> (q & 31u)) & 1u) != 0;
-                    } else {
-                        fa = fb = b0 != 0;
-                    }
+        flip_step([&](uint32_t i, bool &fa, bool &fb) {
+            const uint32_t root = L.label[i];
+            if (FK || L.aux[root]) {
+                const uint32_t q = rel + L.wbase[root >> 5] + __popc(L.roots[root >> 5] & ((1u << (root & 31u)) - 1u));
+                const uint32_t b0 = (L.bits[q >> 5] >> (q & 31u)) & 1u;
+                if (grey) {
+                    fa = b0 != 0;
+                    fb = ((L.bits2[q >> 5] >> (q & 31u)) & 1u) != 0;
+                } else {
+                    fa = fb = b0 != 0;
                 }
             }
-            const unsigned long long va = __ballot(fa), vb = __ballot(fb);
-            const uint32_t word = (r * kSwThreads + (tid & ~63u)) >> 5;
-            if (lane == 0 && word < d.MW) {
-                L.flip_a[word] ^= static_cast<uint32_t>(va);
-                L.flip_b[word] ^= static_cast<uint32_t>(vb);
-                L.spa[word] ^= static_cast<uint32_t>(va);
-                L.spb[word] ^= static_cast<uint32_t>(vb);
-            }
-            if (lane == 32 && word + 1 < d.MW) {
-                L.flip_a[word + 1] ^= static_cast<uint32_t>(va >> 32);
-                L.flip_b[word + 1] ^= static_cast<uint32_t>(vb >> 32);
-                L.spa[word + 1] ^= static_cast<uint32_t>(va >> 32);
-                L.spb[word + 1] ^= static_cast<uint32_t>(vb >> 32);
-            }
-        }
+        });
         pos += n_clusters;
         __syncthreads();
     }
     // ---- the generator ends `pos` draws after where it started
-    if (tid == 0) {
+    if (tid == 0 && !rng_stored) {
         uint32_t js[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) js[k] = base_state[k];
@@ -544,6 +821,68 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
         }
         if (get_bit(L.flip_a, i)) atomicXor(&Sa[i], 1u << ba);
         if (!FK && get_bit(L.flip_b, i)) atomicXor(&Sb[i], 1u << bb);
+    }
+}
+
+// k_top4_accumulate: top4_accum[mode][t][k] += top4 / N over the pairs of a call, in pair order
+// (simulation/mod.rs:725-735) -- one thread per (temperature, rank), so every f64 sum sees its
+// terms in the reference's order.
+__global__ void k_top4_accumulate(SimDims d, DevPtrs p, ClusterAux aux) {
+    const uint32_t real = blockIdx.x;
+    for (uint32_t tk = threadIdx.x; tk < d.n_temps * 4; tk += blockDim.x) {
+        const uint32_t t = tk / 4, k = tk % 4;
+        double *acc = p.cs_top4_acc + ((static_cast<size_t>(real) * aux.n_modes + aux.mode_idx) * d.n_temps + t) * 4 + k;
+        double sum = *acc;
+        for (uint32_t pr = 0; pr < d.n_pairs; ++pr)
+            sum += static_cast<double>(p.cs_top4_raw[(static_cast<size_t>(real) * d.n_temps * d.n_pairs + t * d.n_pairs + pr) * 4 + k]) /
+                   static_cast<double>(d.N);
+        *acc = sum;
+    }
+}
+
+// k_uf_replay: cluster ids of a snapshot in the reference's union-find convention.  The parallel
+// components above name a cluster by its smallest site; the reference's ids are the roots its
+// union-by-rank / path-halving forest ends with (utils.rs:68-91,222-238), which depend on the order
+// of the unions.  One lane per temperature replays that order over the exported bonds.
+__global__ __launch_bounds__(64) void k_uf_replay(SimDims d, DevPtrs p, int cmr) {
+    extern __shared__ uint32_t lds[];
+    uint32_t *parent = lds;                                        // [N]
+    uint8_t *rank = reinterpret_cast<uint8_t *>(lds + d.N);        // [N]
+    const uint32_t t = blockIdx.x, tid = threadIdx.x;
+    if (p.snap_sids[t * 4 + 2] == 0) return; // nothing new was written for this slot: the ids stay
+    for (uint32_t i = tid; i < d.N; i += 64) {
+        parent[i] = i;
+        rank[i] = 0;
+    }
+    __syncthreads();
+    auto find = [&](uint32_t x) -> uint32_t {
+        while (parent[x] != x) {
+            parent[x] = parent[parent[x]];
+            x = parent[x];
+        }
+        return x;
+    };
+    for (int which = 0; which < (cmr ? 2 : 1); ++which) {
+        const uint32_t *bonds = p.snap_bonds + (static_cast<size_t>(t) * 2 + which) * 6 * d.MW;
+        if (tid == 0) {
+            for (uint32_t i = 0; i < d.N; ++i)
+                for (uint32_t dd = 0; dd < d.nn; ++dd) {
+                    if (!((bonds[dd * d.MW + (i >> 5)] >> (i & 31u)) & 1u)) continue;
+                    const uint32_t rx = find(i), ry = find(p.nbr_site[i * 12 + 2 * dd]);
+                    if (rx == ry) continue;
+                    if (rank[rx] < rank[ry]) {
+                        parent[rx] = ry;
+                    } else {
+                        parent[ry] = rx;
+                        if (rank[rx] == rank[ry]) rank[rx] += 1;
+                    }
+                }
+            for (uint32_t i = 0; i < d.N; ++i) parent[i] = find(i); // uf_flatten, utils.rs:289-293
+        }
+        __syncthreads();
+        uint32_t *out = (cmr && which == 0) ? p.snap_blue : p.snap_ids;
+        for (uint32_t i = tid; i < d.N; i += 64) out[static_cast<size_t>(t) * d.N + i] = parent[i];
+        __syncthreads();
     }
 }
 
@@ -791,7 +1130,8 @@ hipError_t configure_cluster_kernels() {
                            reinterpret_cast<const void *>(k_cluster_sw<kSwFk>),
                            reinterpret_cast<const void *>(k_cluster_sw<kSwCmr>),
                            reinterpret_cast<const void *>(k_fk_wolff),
-                           reinterpret_cast<const void *>(k_cmr_wolff)}) {
+                           reinterpret_cast<const void *>(k_cmr_wolff),
+                           reinterpret_cast<const void *>(k_uf_replay)}) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
@@ -799,27 +1139,41 @@ hipError_t configure_cluster_kernels() {
 }
 
 hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, uint32_t group, bool wolff,
-                             hipStream_t stream) {
+                             const ClusterAux &aux, hipStream_t stream) {
     hipLaunchKernelGGL(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
     const dim3 grid(d.n_real * d.n_temps * (d.n_replicas / group)), block(kSwThreads);
     const size_t lds = cluster_sw_lds_bytes(d);
+    const int single = wolff ? 1 : 0;
     if (oc_mode == 2) // PA_OC_JORG
-        hipLaunchKernelGGL(k_cluster_sw<kSwJorg>, grid, block, lds, stream, d, p, 2u, 0);
+        hipLaunchKernelGGL(k_cluster_sw<kSwJorg>, grid, block, lds, stream, d, p, 2u, single, aux);
     else if (oc_mode == 3) // PA_OC_CMR
-        hipLaunchKernelGGL(k_cluster_sw<kSwCmr>, grid, block, lds, stream, d, p, 2u, 0);
+        hipLaunchKernelGGL(k_cluster_sw<kSwCmr>, grid, block, lds, stream, d, p, 2u, single, aux);
     else
-        hipLaunchKernelGGL(k_cluster_sw<kSwHoudayer>, grid, block, lds, stream, d, p, group, wolff ? 1 : 0);
+        hipLaunchKernelGGL(k_cluster_sw<kSwHoudayer>, grid, block, lds, stream, d, p, group, single, aux);
+    return hipGetLastError();
+}
+
+hipError_t launch_top4_accumulate(const SimDims &d, const DevPtrs &p, const ClusterAux &aux, hipStream_t stream) {
+    hipLaunchKernelGGL(k_top4_accumulate, dim3(d.n_real), dim3(128), 0, stream, d, p, aux);
+    return hipGetLastError();
+}
+
+hipError_t launch_uf_replay(const SimDims &d, const DevPtrs &p, bool cmr, hipStream_t stream) {
+    const size_t lds = static_cast<size_t>(d.N) * 5 + 16;
+    hipLaunchKernelGGL(k_uf_replay, dim3(d.n_temps), dim3(64), lds, stream, d, p, cmr ? 1 : 0);
     return hipGetLastError();
 }
 
 size_t fk_wolff_lds_bytes(const SimDims &d) { return fk_wolff_lds_words(d) * 4; }
 
-hipError_t launch_fk(const SimDims &d, const DevPtrs &p, bool wolff, hipStream_t stream) {
-    if (wolff)
+// The depth-first single-cluster kernel serves calls that report nothing; a call that collects
+// sizes takes the union-find path, which draws every bond first and the seed afterwards (fk.rs:45).
+hipError_t launch_fk(const SimDims &d, const DevPtrs &p, bool wolff, const ClusterAux &aux, hipStream_t stream) {
+    if (wolff && aux.flags == 0)
         hipLaunchKernelGGL(k_fk_wolff, dim3(d.n_real), dim3(1024), fk_wolff_lds_bytes(d), stream, d, p);
     else
         hipLaunchKernelGGL(k_cluster_sw<kSwFk>, dim3(d.n_real * d.n_sys), dim3(kSwThreads),
-                           cluster_sw_lds_bytes(d), stream, d, p, 1u, 0);
+                           cluster_sw_lds_bytes(d), stream, d, p, 1u, wolff ? 1 : 0, aux);
     return hipGetLastError();
 }
 

@@ -76,6 +76,24 @@ struct pa_sim {
     uint32_t *jump256 = nullptr, *jorg_thr = nullptr, *fk_thr = nullptr, *cmr_thr = nullptr; // cluster kernels
     int32_t *nz_bonds = nullptr;
     float *dbeta = nullptr;
+    // cluster statistics / observations / snapshots of the last sample()
+    bool square = false;              // canonical 2D hypercubic lattice (lattice.rs:31-38): winding is defined
+    uint32_t cs_modes = 0;            // rows allocated in cs_ov_csd / cs_top4_acc
+    bool cs_ready = false, snap_ready = false;
+    bool cs_fk = false, cs_overlap = false; // what the last sample() collected
+    bool obs_kind[4] = {false, false, false, false};
+    uint32_t cs_n_modes = 0;
+    uint64_t top4_calls[4] = {0, 0, 0, 0};
+    struct Snapshot {
+        uint64_t sweep_id;
+        int32_t mode_idx;
+        bool has_blue;
+        std::vector<uint32_t> ids, blue;
+        std::vector<int8_t> spins;
+        std::vector<uint64_t> sids;
+    };
+    std::vector<Snapshot> snapshots;
+    std::vector<uint32_t> snap_ids_host, snap_blue_host; // ids persist from call to call (overlap.rs:246-248)
     // bookkeeping of the last sample()
     uint64_t n_recorded = 0;
     bool overlap_collected = false;
@@ -347,6 +365,21 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     return q;
 }
 
+// the cluster-statistics arrays of the sub-ensemble starting at realisation r0
+void offset_cluster_stats(DevPtrs &q, const DevPtrs &p, const SimDims &d, uint32_t modes, uint32_t r0) {
+    const size_t bins = static_cast<size_t>(d.n_temps) * (d.N + 1);
+    q.cs_fk_csd = p.cs_fk_csd + bins * r0;
+    q.cs_ov_csd = p.cs_ov_csd + bins * modes * r0;
+    q.cs_top4_raw = p.cs_top4_raw + static_cast<size_t>(4) * d.n_temps * std::max(d.n_pairs, 1u) * r0;
+    q.cs_top4_acc = p.cs_top4_acc + static_cast<size_t>(4) * d.n_temps * modes * r0;
+    q.obs_acc = p.obs_acc + static_cast<size_t>(4) * d.n_temps * (kObsWords + d.N + 1) * r0;
+    q.snap_bonds = p.snap_bonds;
+    q.snap_ids = p.snap_ids;
+    q.snap_blue = p.snap_blue;
+    q.snap_spins = p.snap_spins;
+    q.snap_sids = p.snap_sids;
+}
+
 int make_groups(pa_sim *sim) {
     uint32_t n_groups = 2; // two interleaved groups overlap a little (5 %); three or more collapse
     if (const char *env = std::getenv("PEAPODS_STREAMS")) {
@@ -547,6 +580,55 @@ int ensure_autocorr(pa_sim *sim, uint64_t n_samples) {
     return PA_OK;
 }
 
+// Accumulators of the cluster statistics (ClusterStats, GraphObservationAccum, snapshots), allocated by
+// the first sample() that asks for them and cleared by every such sample().
+int ensure_cluster_stats(pa_sim *sim, uint32_t modes, bool snapshots) {
+    const SimDims &d = sim->d;
+    modes = std::max(modes, 1u);
+    const size_t bins = static_cast<size_t>(d.n_real) * d.n_temps * (d.N + 1);
+    const size_t pairs = std::max(d.n_pairs, 1u);
+    if (!sim->cs_ready || modes > sim->cs_modes) {
+        if (sim->cs_ready) {
+            (void)hipFree(sim->p.cs_ov_csd);
+            (void)hipFree(sim->p.cs_top4_acc);
+        } else {
+            PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&sim->p.cs_fk_csd), sizeof(uint64_t) * bins));
+            PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&sim->p.cs_top4_raw),
+                                  sizeof(uint32_t) * 4 * d.n_real * d.n_temps * pairs));
+            PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&sim->p.obs_acc),
+                                  sizeof(uint64_t) * 4 * d.n_real * d.n_temps * (kObsWords + d.N + 1)));
+        }
+        PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&sim->p.cs_ov_csd), sizeof(uint64_t) * bins * modes));
+        PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&sim->p.cs_top4_acc),
+                              sizeof(double) * 4 * d.n_real * d.n_temps * modes));
+        sim->cs_modes = modes;
+        sim->cs_ready = true;
+    }
+    if (snapshots && !sim->snap_ready) {
+        PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&sim->p.snap_bonds), sizeof(uint32_t) * d.n_temps * 2 * 6 * d.MW));
+        PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&sim->p.snap_ids), sizeof(uint32_t) * d.n_temps * d.N));
+        PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&sim->p.snap_blue), sizeof(uint32_t) * d.n_temps * d.N));
+        PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&sim->p.snap_spins), static_cast<size_t>(d.n_temps) * 2 * d.N));
+        PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&sim->p.snap_sids), sizeof(uint32_t) * d.n_temps * 4));
+        sim->snap_ready = true;
+    }
+    PA_HIP(sim, hipMemsetAsync(sim->p.cs_fk_csd, 0, sizeof(uint64_t) * bins, sim->stream));
+    PA_HIP(sim, hipMemsetAsync(sim->p.cs_ov_csd, 0, sizeof(uint64_t) * bins * sim->cs_modes, sim->stream));
+    PA_HIP(sim, hipMemsetAsync(sim->p.cs_top4_acc, 0, sizeof(double) * 4 * d.n_real * d.n_temps * sim->cs_modes, sim->stream));
+    PA_HIP(sim, hipMemsetAsync(sim->p.obs_acc, 0, sizeof(uint64_t) * 4 * d.n_real * d.n_temps * (kObsWords + d.N + 1),
+                               sim->stream));
+    if (snapshots) { // the buffers of a run start empty (mod.rs:311-334)
+        PA_HIP(sim, hipMemsetAsync(sim->p.snap_ids, 0, sizeof(uint32_t) * d.n_temps * d.N, sim->stream));
+        PA_HIP(sim, hipMemsetAsync(sim->p.snap_blue, 0, sizeof(uint32_t) * d.n_temps * d.N, sim->stream));
+    }
+    uint32_t r0 = 0;
+    for (auto &g : sim->groups) {
+        offset_cluster_stats(g.p, sim->p, d, sim->cs_modes, r0);
+        r0 += g.d.n_real;
+    }
+    return PA_OK;
+}
+
 std::string validate_text(const pa_sample_config *cfg, uint64_t n_replicas, int *code) {
     *code = PA_ERR_INVALID;
     // spin-sim/src/config.rs:180-247 (message texts are the reference's)
@@ -565,6 +647,21 @@ std::string validate_text(const pa_sample_config *cfg, uint64_t n_replicas, int 
     }
     if (cfg->cluster_interval > 0 && cfg->cluster_mode != PA_CLUSTER_WOLFF && cfg->cluster_mode != PA_CLUSTER_SW)
         return "unknown cluster_mode, expected 'wolff' or 'sw'";
+    if (cfg->cluster_interval > 0 && cfg->cluster_action == PA_ACTION_OBSERVE && cfg->cluster_mode == PA_CLUSTER_WOLFF)
+        return "cluster_action='observe' requires cluster_mode='sw'";
+    if (cfg->overlap_cluster_interval > 0) {
+        if (cfg->snapshot_interval > 0 && cfg->snapshot_interval % cfg->overlap_cluster_interval != 0)
+            return "snapshot_interval must be a positive multiple of overlap_cluster interval";
+        if (cfg->overlap_cluster_action == PA_ACTION_OBSERVE) {
+            if (cfg->overlap_cluster_mode == PA_CLUSTER_WOLFF)
+                return "overlap_cluster_action='observe' requires overlap_cluster_mode='sw'";
+            if (cfg->snapshot_interval > 0)
+                return "snapshot_interval is not supported with overlap_cluster_action='observe'";
+            for (int k = 0; k < cfg->n_overlap_cluster_modes && k < 4; ++k)
+                if ((cfg->overlap_cluster_modes[k] & 0xFF) == PA_OC_HOUDAYER && (cfg->overlap_cluster_modes[k] >> 8) > 2)
+                    return "overlap_cluster_action='observe' does not support experimental houdN with N > 2";
+        }
+    }
     *code = PA_ERR_UNSUPPORTED;
     if (cfg->overlap_cluster_interval > 0) {
         for (int k = 0; k < cfg->n_overlap_cluster_modes && k < 4; ++k) {
@@ -627,6 +724,30 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     sim->ac_samples = 0;
     if (autocorr && n_meas > 0 && (rc = ensure_autocorr(sim, n_meas))) return rc;
     if ((rc = zero_accumulators(sim))) return rc;
+    // what the cluster calls report besides moving spins (mod.rs:216-335)
+    const bool has_oc = cfg->overlap_cluster_interval > 0;
+    const uint32_t n_modes = has_oc ? static_cast<uint32_t>(cfg->n_overlap_cluster_modes) : 0u;
+    const bool observe_fk = fk && cfg->cluster_action == PA_ACTION_OBSERVE;
+    const bool observe_overlap = has_oc && cfg->overlap_cluster_action == PA_ACTION_OBSERVE;
+    const bool collect_fk = fk && (cfg->collect_cluster_stats || observe_fk);
+    const bool collect_overlap = has_oc && (cfg->collect_cluster_stats || observe_overlap) && d.n_pairs > 0;
+    const uint64_t snapshot_interval = has_oc ? cfg->snapshot_interval : 0;
+    sim->cs_fk = collect_fk;
+    sim->cs_overlap = collect_overlap;
+    sim->cs_n_modes = n_modes;
+    sim->snapshots.clear();
+    for (int k = 0; k < 4; ++k) sim->obs_kind[k] = false, sim->top4_calls[k] = 0;
+    sim->obs_kind[0] = observe_fk;
+    for (uint32_t m = 0; observe_overlap && m < n_modes; ++m) sim->obs_kind[cfg->overlap_cluster_modes[m] & 0xFF] = true;
+    if (collect_fk || collect_overlap || snapshot_interval > 0) {
+        if (d.big) return fail(sim, PA_ERR_UNSUPPORTED, "cluster statistics are not built for lattices above 12000 sites");
+        if ((rc = ensure_cluster_sw(sim))) return rc;
+        if ((rc = ensure_cluster_stats(sim, n_modes, snapshot_interval > 0))) return rc;
+        if (snapshot_interval > 0) {
+            sim->snap_ids_host.assign(static_cast<size_t>(d.n_temps) * d.N, 0u);
+            sim->snap_blue_host.assign(static_cast<size_t>(d.n_temps) * d.N, 0u);
+        }
+    }
     const bool want_overlap = d.n_pairs > 0 && cfg->measure_overlap;
     sim->n_recorded = 0;
     sim->overlap_collected = want_overlap;
@@ -692,8 +813,13 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         if (equil && equil_next < sim->equil_sweeps.size() && sweep_id + 1 == sim->equil_sweeps[equil_next])
             equil_ckpt = static_cast<uint32_t>(++equil_next);
         for (auto &g : sim->groups) {
-            if (fk_this) { // clusters::fk_update (:439-469), then the energies
-                PA_HIP(sim, launch_fk(g.d, g.p, cfg->cluster_mode == PA_CLUSTER_WOLFF, g.stream));
+            if (fk_this) { // clusters::fk_update (:439-484), then the energies
+                ClusterAux aux{};
+                if (collect_fk && record) aux.flags |= kAuxSizes;
+                if (observe_fk) aux.flags |= kAuxObserve | (record ? kAuxMetrics : 0u);
+                aux.n_modes = sim->cs_modes;
+                aux.square = sim->square ? 1u : 0u;
+                PA_HIP(sim, launch_fk(g.d, g.p, cfg->cluster_mode == PA_CLUSTER_WOLFF, aux, g.stream));
                 if (record || pt_this || equil) PA_HIP(sim, launch_sweep(g.d, g.p, true, false, false, g.stream));
             }
             if (((record && want_overlap) || equil) && d.n_pairs) PA_HIP(sim, launch_overlap(g.d, g.p, g.stream)); // :527-529
@@ -713,30 +839,92 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                 pt.equil = 0; // the tempering launch below must not accumulate the diagnostic again
                 if (g.d.N * g.d.W * 12 + 4096 > 160 * 1024)
                     return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the overlap-cluster kernel");
-                const int oc_mode = cfg->overlap_cluster_modes[overlap_call_count %
-                                                               static_cast<uint64_t>(cfg->n_overlap_cluster_modes)];
+                const uint64_t mode_idx = overlap_call_count % static_cast<uint64_t>(cfg->n_overlap_cluster_modes);
+                const int oc_mode = cfg->overlap_cluster_modes[mode_idx];
                 const int oc_kind = oc_mode & 0xFF;
                 const uint32_t oc_group = (oc_mode >> 8) > 2 ? static_cast<uint32_t>(oc_mode >> 8) : 2u;
+                const bool first_group = &g == &sim->groups.front();
+                // mod.rs:604-658: sizes / metrics on recorded calls, snapshots of the first realisation
+                const bool take_snapshot = snapshot_interval > 0 && sweep_id % snapshot_interval == 0 && record;
+                ClusterAux aux{};
+                if (collect_overlap && record) aux.flags |= kAuxSizes;
+                if (observe_overlap) aux.flags |= kAuxObserve | (record ? kAuxMetrics : 0u);
+                aux.mode_idx = static_cast<uint32_t>(mode_idx);
+                aux.n_modes = sim->cs_modes;
+                aux.kind = static_cast<uint32_t>(oc_kind);
+                aux.square = sim->square ? 1u : 0u;
+                if (aux.flags & kAuxSizes)
+                    PA_HIP(sim, hipMemsetAsync(g.p.cs_top4_raw, 0, sizeof(uint32_t) * 4 * g.d.n_real * d.n_temps * d.n_pairs,
+                                               g.stream));
                 // union-find variants; groups above two and lattices with more than three forward
-                // directions also for the single-cluster Houdayer move (same components, same seed rule)
-                if (oc_sw || oc_group > 2 || (oc_kind == PA_OC_HOUDAYER && d.nn > 3))
-                    PA_HIP(sim, launch_cluster_sw(g.d, g.p, oc_kind, oc_group, !oc_sw, g.stream));
-                else if (oc_mode == PA_OC_CMR)
+                // directions also for the single-cluster Houdayer move (same components, same seed rule).
+                // Every call that reports sizes or takes a snapshot is on the union-find path too
+                // (`use_uf`, overlap.rs:179-183,376-380,640-644) -- a snapshot only for the first realisation.
+                const bool uf_all = oc_sw || oc_group > 2 || (oc_kind == PA_OC_HOUDAYER && d.nn > 3) || aux.flags != 0;
+                const bool dfs_same = oc_kind == PA_OC_HOUDAYER; // deterministic bonds: both paths consume the same draws
+                if (uf_all || (take_snapshot && first_group && dfs_same)) {
+                    ClusterAux a2 = aux;
+                    if (take_snapshot && first_group) a2.flags |= kAuxSnapshot;
+                    PA_HIP(sim, launch_cluster_sw(g.d, g.p, oc_kind, oc_group, !oc_sw, a2, g.stream));
+                } else if (take_snapshot && first_group) {
+                    // the first realisation alone takes the union-find path, the others the search
+                    SimDims d0 = g.d, d1 = g.d;
+                    d0.n_real = 1;
+                    d1.n_real = g.d.n_real - 1;
+                    ClusterAux a2 = aux;
+                    a2.flags |= kAuxSnapshot;
+                    PA_HIP(sim, launch_cluster_sw(d0, g.p, oc_kind, oc_group, true, a2, g.stream));
+                    if (d1.n_real > 0) {
+                        DevPtrs p1 = offset_ptrs(g.p, g.d, 1);
+                        if (oc_kind == PA_OC_CMR)
+                            PA_HIP(sim, launch_cmr_wolff(d1, p1, g.stream));
+                        else
+                            PA_HIP(sim, launch_jorg(d1, p1, g.stream));
+                    }
+                } else if (oc_kind == PA_OC_CMR)
                     PA_HIP(sim, launch_cmr_wolff(g.d, g.p, g.stream)); // :845-965
-                else if (oc_mode == PA_OC_JORG)
+                else if (oc_kind == PA_OC_JORG)
                     PA_HIP(sim, launch_jorg(g.d, g.p, g.stream)); // :601-602,660-680
                 else
                     PA_HIP(sim, launch_houdayer(g.d, g.p, g.stream));
+                if (aux.flags & kAuxSizes) PA_HIP(sim, launch_top4_accumulate(g.d, g.p, aux, g.stream)); // :725-735
+                if (take_snapshot && first_group) { // :682-714
+                    PA_HIP(sim, launch_uf_replay(g.d, g.p, oc_kind == PA_OC_CMR, g.stream));
+                    PA_HIP(sim, hipStreamSynchronize(g.stream));
+                    pa_sim::Snapshot snap;
+                    snap.sweep_id = sweep_id;
+                    snap.mode_idx = static_cast<int32_t>(mode_idx);
+                    snap.has_blue = oc_kind == PA_OC_CMR;
+                    const size_t cells = static_cast<size_t>(d.n_temps) * d.N;
+                    snap.ids.resize(cells);
+                    snap.spins.resize(2 * cells);
+                    std::vector<uint32_t> sids(static_cast<size_t>(d.n_temps) * 4);
+                    PA_HIP(sim, hipMemcpy(snap.ids.data(), sim->p.snap_ids, sizeof(uint32_t) * cells, hipMemcpyDeviceToHost));
+                    PA_HIP(sim, hipMemcpy(snap.spins.data(), sim->p.snap_spins, 2 * cells, hipMemcpyDeviceToHost));
+                    PA_HIP(sim, hipMemcpy(sids.data(), sim->p.snap_sids, sizeof(uint32_t) * sids.size(), hipMemcpyDeviceToHost));
+                    if (snap.has_blue) {
+                        snap.blue.resize(cells);
+                        PA_HIP(sim, hipMemcpy(snap.blue.data(), sim->p.snap_blue, sizeof(uint32_t) * cells, hipMemcpyDeviceToHost));
+                    }
+                    for (uint32_t t = 0; t < d.n_temps; ++t) {
+                        snap.sids.push_back(sids[t * 4]);
+                        snap.sids.push_back(sids[t * 4 + 1]);
+                    }
+                    sim->snapshots.push_back(std::move(snap));
+                }
                 if (pt_this) { // energies are recomputed after a mutating move (:749-756)
-                    PA_HIP(sim, launch_sweep(g.d, g.p, true, false, false, g.stream));
+                    if (!observe_overlap) PA_HIP(sim, launch_sweep(g.d, g.p, true, false, false, g.stream));
                     PA_HIP(sim, launch_measure(g.d, g.p, pt, false, false, false, true, g.stream));
                 }
             }
         }
         if (pt_this) sim->swaps_pending = true;
         if (record) sim->n_recorded += 1;
-        if (cfg->overlap_cluster_interval > 0 && sweep_id % cfg->overlap_cluster_interval == 0)
+        if (cfg->overlap_cluster_interval > 0 && sweep_id % cfg->overlap_cluster_interval == 0) {
+            if (collect_overlap && record) // :734
+                sim->top4_calls[overlap_call_count % static_cast<uint64_t>(cfg->n_overlap_cluster_modes)] += 1;
             overlap_call_count += 1; // :744
+        }
         if (pt_this && cfg->pt_schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
     }
     sim->ac_samples = autocorr ? sim->n_recorded : 0;
@@ -896,6 +1084,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
                                     desc->neighbor_offsets ? desc->n_neighbors : desc->n_dims,
                                     desc->neighbor_offsets);
     const LatticeTables &lat = sim->lat;
+    sim->square = desc->neighbor_offsets == nullptr && desc->n_dims == 2; // Lattice::new, lattice.rs:31-38
     if (lat.n_neighbors > 6) {
         sim->error = "more than 6 forward directions are not built on the HIP path yet";
         return bail(PA_ERR_UNSUPPORTED);
@@ -1636,6 +1825,85 @@ int pa_sim_get_autocorrelation_tau(pa_sim *sim, uint64_t realization, double *ma
         autocorrelation_tau(series.data(), sim->ac_samples, d.n_temps, sim->ac_lag, overlap2_tau);
     }
     return PA_OK;
+}
+
+int pa_sim_get_cluster_stats(pa_sim *sim, uint64_t realization, uint64_t *fk_csd, uint64_t *overlap_csd,
+                             double *top_sizes) {
+    PA_CHECK_REAL(sim, realization);
+    const SimDims &d = sim->d;
+    if (!sim->cs_fk && !sim->cs_overlap)
+        return fail(sim, PA_ERR_INVALID, "the last sample() did not collect cluster statistics");
+    PA_HIP(sim, hipSetDevice(sim->device));
+    const size_t bins = static_cast<size_t>(d.n_temps) * (d.N + 1);
+    if (sim->cs_fk && fk_csd)
+        PA_HIP(sim, hipMemcpy(fk_csd, sim->p.cs_fk_csd + bins * realization, sizeof(uint64_t) * bins, hipMemcpyDeviceToHost));
+    if (sim->cs_overlap) {
+        const uint32_t modes = sim->cs_n_modes;
+        if (overlap_csd)
+            PA_HIP(sim, hipMemcpy(overlap_csd, sim->p.cs_ov_csd + bins * sim->cs_modes * realization,
+                                  sizeof(uint64_t) * bins * modes, hipMemcpyDeviceToHost));
+        if (top_sizes) { // mod.rs:799-823: sums over the recorded calls of a mode / (calls * n_pairs)
+            std::vector<double> acc;
+            int rc = download(sim, acc, sim->p.cs_top4_acc + static_cast<size_t>(4) * d.n_temps * sim->cs_modes * realization,
+                              static_cast<size_t>(4) * d.n_temps * modes);
+            if (rc) return rc;
+            for (uint32_t m = 0; m < modes; ++m) {
+                const double denom = static_cast<double>(sim->top4_calls[m] * d.n_pairs);
+                for (size_t k = 0; k < static_cast<size_t>(4) * d.n_temps; ++k)
+                    top_sizes[m * 4 * d.n_temps + k] = sim->top4_calls[m] ? acc[m * 4 * d.n_temps + k] / denom : 0.0;
+            }
+        }
+    }
+    return (sim->cs_fk ? 1 : 0) | (sim->cs_overlap ? 2 : 0);
+}
+
+int pa_sim_get_observation(pa_sim *sim, uint64_t realization, int32_t kind, uint64_t *count, uint64_t *sizes,
+                           double *top4_frac, double *bond_density, double *large_mean, double *winding) {
+    PA_CHECK_REAL(sim, realization);
+    const SimDims &d = sim->d;
+    if (kind < 0 || kind > 3) return fail(sim, PA_ERR_INVALID, "observation kind out of range");
+    if (!sim->obs_kind[kind]) return 0;
+    PA_HIP(sim, hipSetDevice(sim->device));
+    const size_t row = kObsWords + d.N + 1;
+    std::vector<uint64_t> acc;
+    int rc = download(sim, acc, sim->p.obs_acc + (static_cast<size_t>(realization) * 4 + kind) * d.n_temps * row,
+                      static_cast<size_t>(d.n_temps) * row);
+    if (rc) return rc;
+    bool any = false;
+    for (uint32_t t = 0; t < d.n_temps; ++t) any = any || acc[t * row] != 0;
+    if (!any) return 0; // GraphObservationAccum::finish, mod.rs:63-65
+    for (uint32_t t = 0; t < d.n_temps; ++t) { // mod.rs:67-97
+        const uint64_t *a = &acc[t * row];
+        count[t] = a[0];
+        std::memcpy(sizes + static_cast<size_t>(t) * (d.N + 1), a + kObsWords, sizeof(uint64_t) * (d.N + 1));
+        for (int k = 0; k < 4; ++k) top4_frac[t * 4 + k] = winding[t * 4 + k] = 0.0;
+        bond_density[t] = large_mean[t] = 0.0;
+        if (a[0] == 0) continue;
+        const double c = static_cast<double>(a[0]);
+        for (int k = 0; k < 4; ++k) {
+            top4_frac[t * 4 + k] = static_cast<double>(a[1 + k]) / (c * static_cast<double>(d.N));
+            if (sim->square) winding[t * 4 + k] = static_cast<double>(a[6 + k]) / c;
+        }
+        bond_density[t] = static_cast<double>(a[5]) / (c * static_cast<double>(d.N) * static_cast<double>(d.nn));
+        large_mean[t] = static_cast<double>(a[10]) / c;
+    }
+    return sim->square ? 3 : 1;
+}
+
+uint64_t pa_sim_n_snapshots(const pa_sim *sim) { return sim->snapshots.size(); }
+
+int pa_sim_get_snapshot(pa_sim *sim, uint64_t index, uint64_t *sweep_id, int32_t *mode_idx, uint32_t *cluster_ids,
+                        uint32_t *blue_ids, int8_t *spins, uint64_t *system_ids) {
+    if (!sim) return PA_ERR_INVALID;
+    if (index >= sim->snapshots.size()) return fail(sim, PA_ERR_INVALID, "snapshot index out of range");
+    const pa_sim::Snapshot &snap = sim->snapshots[index];
+    *sweep_id = snap.sweep_id;
+    *mode_idx = snap.mode_idx;
+    std::memcpy(cluster_ids, snap.ids.data(), sizeof(uint32_t) * snap.ids.size());
+    if (snap.has_blue && blue_ids) std::memcpy(blue_ids, snap.blue.data(), sizeof(uint32_t) * snap.blue.size());
+    std::memcpy(spins, snap.spins.data(), snap.spins.size());
+    std::memcpy(system_ids, snap.sids.data(), sizeof(uint64_t) * snap.sids.size());
+    return snap.has_blue ? 1 : 0;
 }
 
 uint64_t pa_sim_n_equil_checkpoints(const pa_sim *sim) { return sim->equil_sweeps.size(); }

@@ -169,6 +169,18 @@ class Ising:
                     "per_sample_ql2_at_q_sum"):
             if key in result:
                 setattr(self, key, result[key])
+        if "fk_csd" in result:  # spin_models.py:309-317: mean cluster size <s^2>/<s> per temperature
+            self.fk_csd = result["fk_csd"]
+            mean_size = np.empty(self.n_temps)
+            for t, hist in enumerate(self.fk_csd):
+                sizes = np.arange(len(hist))
+                weighted = sizes * hist
+                n_sites = weighted.sum()
+                mean_size[t] = (sizes * weighted).sum() / n_sites if n_sites > 0 else 0.0
+            self.mean_cluster_size = mean_size
+        for key in ("top_cluster_sizes", "cluster_snapshots"):  # spin_models.py:319-333
+            if key in result:
+                setattr(self, key, result[key])
         for key in ("mags2_tau", "overlap2_tau"):  # spin_models.py:325-328
             if key in result:
                 setattr(self, key, result[key])

@@ -702,9 +702,8 @@ def test_unbuilt_overlap_modes_are_refused_not_emulated():
     couplings = bimodal((4, 4), 2, 1, 2)
     sim = IsingSimulation([4, 4], couplings, np.array([1.0, 2.0], np.float32), 2, None, 1)
     before = sim.get_spins().copy()
-    with pytest.raises(NotImplementedError):
-        sim.sample(2, "metropolis", overlap_cluster_update_interval=1, overlap_cluster_action="observe",
-                   overlap_cluster_mode="sw")
+    with pytest.raises(NotImplementedError):  # the exact ring accumulator is the one built
+        sim.sample(8, "metropolis", autocorrelation_max_lag=2, autocorrelation_backend="fft")
     with pytest.raises(ValueError, match="n_replicas >= max group_size"):
         sim.sample(2, "metropolis", overlap_cluster_update_interval=1, overlap_cluster_build_mode="houd4")
     np.testing.assert_array_equal(sim.get_spins(), before)

@@ -299,3 +299,65 @@ def test_2d_ferromagnet_binder_curves_cross_at_the_exact_tc(oracle):
         binder = 1 - res["mags4"] / (3 * res["mags2"] ** 2)
         at_tc.append(float(np.interp(tc, temps, binder)))
     assert max(at_tc) - min(at_tc) < 0.05, at_tc
+
+
+# ---- graph observers (reference spin-sim/src/clusters/utils.rs:736-781, simulation/mod.rs:949-1177) ----
+def _observe(oracle, lattice, bonds):
+    lib = oracle.load()
+    sites = np.array([b[0] for b in bonds], dtype=np.uint64)
+    dims = np.array([b[1] for b in bonds], dtype=np.uint64)
+    out = np.zeros(9, dtype=np.uint32)
+    lib.orc_graph_observation(lattice.handle, oracle._ptr(sites), oracle._ptr(dims), len(bonds), oracle._ptr(out))
+    return {"active_bonds": int(out[0]), "top4": out[1:5].tolist(), "large": int(out[5]),
+            "winding": (bool(out[6]), bool(out[7])), "observed": bool(out[8])}
+
+
+def test_winding_distinguishes_seams_and_noncontractible_cycles(oracle):
+    lat = oracle.Lattice([4, 4])
+    index = lambda row, col: 4 * row + col  # noqa: E731
+    assert _observe(oracle, lat, [(index(0, 3), 1)])["winding"] == (False, False)
+    assert _observe(oracle, lat, [(index(1, c), 1) for c in range(4)])["winding"] == (False, True)
+    both = [(index(0, c), 1) for c in range(4)] + [(index(r, 0), 0) for r in range(4)]
+    assert _observe(oracle, lat, both)["winding"] == (True, True)
+
+
+def test_bond_metrics_reuse_component_counts(oracle):
+    got = _observe(oracle, oracle.Lattice([4, 4]), [(0, 0), (0, 1), (3, 1), (10, 0), (10, 1)])
+    assert got["active_bonds"] == 5 and got["top4"] == [4, 3, 1, 1] and got["observed"]
+    # a lattice built from explicit offsets has no canonical square shape: winding is not tracked
+    lat = oracle.Lattice([4, 4], offsets=[[1, 0], [0, 1]])
+    assert _observe(oracle, lat, [(4 * 1 + c, 1) for c in range(4)])["winding"] == (False, False)
+
+
+def test_cluster_histograms_appear_only_when_collected(oracle):
+    J = np.ones((4, 4, 2), dtype=np.float32)
+    temps = np.array([2.0], dtype=np.float32)
+    kw = dict(warmup_ratio=0.0, cluster_update_interval=1, cluster_mode="sw")
+    plain = oracle.OracleSimulation([4, 4], J, temps, 1, None, 42).sample(1, "metropolis", **kw)
+    assert "fk_csd" not in plain
+    stats = oracle.OracleSimulation([4, 4], J, temps, 1, None, 42).sample(1, "metropolis", collect_cluster_stats=True, **kw)
+    assert len(stats["fk_csd"]) == 1 and stats["fk_csd"][0].sum() > 0
+    assert int((np.arange(17) * stats["fk_csd"][0]).sum()) == 16
+    kw = dict(warmup_ratio=0.0, overlap_cluster_update_interval=1, overlap_cluster_mode="sw")
+    plain = oracle.OracleSimulation([4, 4], J, temps, 2, None, 42).sample(1, "metropolis", **kw)
+    assert "overlap_csd" not in plain and "top_cluster_sizes" not in plain
+    stats = oracle.OracleSimulation([4, 4], J, temps, 2, None, 42).sample(1, "metropolis", collect_cluster_stats=True, **kw)
+    assert len(stats["overlap_csd"]) == 1 and stats["overlap_csd"][0][0].sum() > 0
+
+
+def test_observe_records_without_changing_spins(oracle):
+    J = np.ones((4, 4, 2), dtype=np.float32)
+    for n_rep, temp, seed, kw, kind in (
+            (1, 2.0, 19, dict(cluster_update_interval=1, cluster_mode="sw", cluster_action="observe"), "fk"),
+            (2, 1.5, 23, dict(overlap_cluster_update_interval=1, overlap_cluster_build_mode="cmr",
+                              overlap_cluster_mode="sw", overlap_cluster_action="observe"), "cmr_blue")):
+        temps = np.array([temp], dtype=np.float32)
+        baseline = oracle.OracleSimulation([4, 4], J, temps, n_rep, None, seed)
+        observed = oracle.OracleSimulation([4, 4], J, temps, n_rep, None, seed)
+        baseline.sample(1, "metropolis", warmup_ratio=0.0)
+        result = observed.sample(1, "metropolis", warmup_ratio=0.0, **kw)
+        np.testing.assert_array_equal(observed.get_spins(), baseline.get_spins())
+        np.testing.assert_array_equal(observed.get_system_ids(), baseline.get_system_ids())
+        summary = result["per_disorder"]["cluster_observations"][kind]
+        assert summary["observation_count"].tolist() == [[1]]
+        assert int((np.arange(17) * summary["cluster_size_counts"][0, 0]).sum()) == 16

@@ -193,6 +193,12 @@ __device__ __forceinline__ uint32_t coherent_load(const uint32_t *ptr) {
 __device__ __forceinline__ void coherent_store(uint32_t *ptr, uint32_t v) {
     __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Waits until the L2 has acknowledged every global store / atomic this wave has issued (s_waitcnt
+// vmcnt(0); expcnt and lgkmcnt left alone).  A workgroup barrier does not imply it: its fence is
+// workgroup-scope, which needs no vmcnt wait on one CU, so a store issued just before the barrier
+// can still be in flight when another wave -- or, after a progress flag, another workgroup -- reads
+// the location through the L2.
+__device__ __forceinline__ void drain_global_stores() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
 
 // expf as glibc computes it (sysdeps/ieee754/flt-32/e_expf.c, glibc >= 2.27): x N / ln2 = k + r with

@@ -1559,7 +1559,8 @@ __global__ __launch_bounds__(1024) void k_sweep_big(SimDims d, DevPtrs p, int gi
                                         : accept_mask(s, nb, r.jm, lv.x, lv.y)) & valid_bits;
             coherent_store(Sg + r.site, s ^ acc);
         }
-        __syncthreads(); // drains the stores (vmcnt 0) before the next level reads them
+        drain_global_stores(); // the next level reads these words through the L2
+        __syncthreads();
     }
 }
 
@@ -1629,7 +1630,8 @@ __global__ __launch_bounds__(256) void k_sweep_pipe(SimDims d, DevPtrs p, int gi
                                         : accept_mask(s, nb, r.jm, lv.x, lv.y)) & valid_bits;
             coherent_store(Snew + r.site, s ^ acc);
         }
-        __syncthreads(); // every wave's stores have completed (vmcnt 0) before the counter moves
+        drain_global_stores(); // every wave's stores are in the L2 before the counter moves
+        __syncthreads();
         if (tid == 0)
             __hip_atomic_store(&progress[k], base + level + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

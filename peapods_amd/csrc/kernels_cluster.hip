@@ -124,7 +124,9 @@ enum { kSwHoudayer = 0, kSwJorg = 1, kSwFk = 2, kSwCmr = 3 };
 // group: replicas per task (2 except for the experimental "houdN" moves: N replicas whose spins
 // sum to zero on the active sites, all of them flipped).  wolff: single-cluster variant of a
 // deterministic-bond move (find_seed, utils.rs:107-119, then flip the seed's component).
-template <int MODE>
+// EXTRAS = false is the lean build of the plain moves (no reporting; single-cluster form only for the
+// deterministic Houdayer bonds): the reporting code costs ~100 VGPRs and a third of the occupancy.
+template <int MODE, bool EXTRAS>
 __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p, uint32_t group, int wolff,
                                                             ClusterAux aux) {
     constexpr bool JORG = MODE == kSwJorg, FK = MODE == kSwFk, CMR = MODE == kSwCmr;
@@ -171,8 +173,8 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
                                                        static_cast<size_t>(t) * d.n_pairs + g) * 4;
     uint32_t *Stile = p.S + static_cast<size_t>(real) * d.W * d.N; // all words (groups above two)
     // snapshots are those of the first realisation's first group at every temperature (mod.rs:302,683-705)
-    const bool snap_here = !FK && (aux.flags & kAuxSnapshot) && real == 0 && g == 0;
-    const bool observe = (aux.flags & kAuxObserve) != 0, metrics = (aux.flags & kAuxMetrics) != 0;
+    const bool snap_here = EXTRAS && !FK && (aux.flags & kAuxSnapshot) && real == 0 && g == 0;
+    const bool observe = EXTRAS && (aux.flags & kAuxObserve) != 0, metrics = EXTRAS && (aux.flags & kAuxMetrics) != 0;
     const uint32_t n_rounds = (d.N + kSwThreads - 1) / kSwThreads; // site i = r * 256 + tid
     // write the ballot of a predicate over sites r*256 + tid into a bitmap (two words per wave)
     auto put_ballot = [&](uint32_t *bitmap, uint32_t r, bool pred) {
@@ -531,7 +533,7 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
     };
     uint32_t pos = 0; // draws of the generator consumed so far
     bool rng_stored = false; // a single-cluster form has already written the generator back
-    if (CMR && wolff) { // the single-cluster form of the union-find path draws its seed first (overlap.rs:691-695)
+    if (EXTRAS && CMR && wolff) { // the single-cluster form of the union-find path draws its seed first (overlap.rs:691-695)
         if (tid == 0) {
             DevRng rng = rng_at(0);
             const DevRng before = rng;
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
         __syncthreads();
         pos = L.misc[2];
     }
-    const uint32_t cmr_seed = (CMR && wolff) ? L.misc[1] : 0u;
+    const uint32_t cmr_seed = (EXTRAS && CMR && wolff) ? L.misc[1] : 0u;
     __syncthreads();
     for (uint32_t phase = 0; phase < N_PHASES; ++phase) {
         // ---- B: eligible forward bonds.  Houdayer: both ends active (overlap.rs:228-231).
@@ -677,8 +679,8 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
         // ---- what the call reports (mod.rs:442-455,604-626): sizes of this phase's clusters -- for
         // CMR the blue ones (overlap.rs:725-742) -- and the accepted bonds of a snapshot
         const uint32_t *links2 = (CMR && phase == 1) ? L.blue : nullptr;
-        const bool seed_first = wolff && (MODE == kSwHoudayer || JORG); // reports only once a seed is found
-        const bool reports = (aux.flags & (kAuxSizes | kAuxMetrics)) != 0 && phase == 0;
+        const bool seed_first = wolff && (MODE == kSwHoudayer || (EXTRAS && JORG)); // reports only once a seed is found
+        const bool reports = EXTRAS && (aux.flags & (kAuxSizes | kAuxMetrics)) != 0 && phase == 0;
         if (reports && !seed_first) report(links, links2);
         if (snap_here) {
             export_bonds(phase, links);
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
             if (snap_here && tid == 0) p.snap_sids[t * 4 + 2] = 1;
             return;
         }
-        if (wolff && FK) { // fk.rs:144-151: the seed is drawn after the bonds
+        if (EXTRAS && wolff && FK) { // fk.rs:144-151: the seed is drawn after the bonds
             if (tid == 0) {
                 DevRng rng = rng_at(pos);
                 L.misc[1] = L.label[draw_site(rng)];
@@ -729,7 +731,7 @@ __global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p,
                 if (L.label[i] == root) atomicXor(&Sa[i], 1u << ba);
             return;
         }
-        if (wolff && CMR) { // overlap.rs:748-755 (blue: both systems), :806-820 (grey: k in 1..=3)
+        if (EXTRAS && wolff && CMR) { // overlap.rs:748-755 (blue: both systems), :806-820 (grey: k in 1..=3)
             const uint32_t root = L.label[cmr_seed];
             uint32_t k = 3;
             if (phase == 1) {
@@ -1125,10 +1127,14 @@ hipError_t launch_exp_selftest(float *out, hipStream_t stream) {
 size_t cluster_sw_lds_bytes(const SimDims &d) { return cluster_sw_lds_words(d) * 4; }
 
 hipError_t configure_cluster_kernels() {
-    for (const void *fn : {reinterpret_cast<const void *>(k_cluster_sw<kSwHoudayer>),
-                           reinterpret_cast<const void *>(k_cluster_sw<kSwJorg>),
-                           reinterpret_cast<const void *>(k_cluster_sw<kSwFk>),
-                           reinterpret_cast<const void *>(k_cluster_sw<kSwCmr>),
+    for (const void *fn : {reinterpret_cast<const void *>(k_cluster_sw<kSwHoudayer, false>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwJorg, false>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwFk, false>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwCmr, false>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwHoudayer, true>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwJorg, true>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwFk, true>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwCmr, true>),
                            reinterpret_cast<const void *>(k_fk_wolff),
                            reinterpret_cast<const void *>(k_cmr_wolff),
                            reinterpret_cast<const void *>(k_uf_replay)}) {
@@ -1144,12 +1150,23 @@ hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, ui
     const dim3 grid(d.n_real * d.n_temps * (d.n_replicas / group)), block(kSwThreads);
     const size_t lds = cluster_sw_lds_bytes(d);
     const int single = wolff ? 1 : 0;
-    if (oc_mode == 2) // PA_OC_JORG
-        hipLaunchKernelGGL(k_cluster_sw<kSwJorg>, grid, block, lds, stream, d, p, 2u, single, aux);
-    else if (oc_mode == 3) // PA_OC_CMR
-        hipLaunchKernelGGL(k_cluster_sw<kSwCmr>, grid, block, lds, stream, d, p, 2u, single, aux);
-    else
-        hipLaunchKernelGGL(k_cluster_sw<kSwHoudayer>, grid, block, lds, stream, d, p, group, single, aux);
+    const bool extras = aux.flags != 0 || (wolff && oc_mode != 1); // PA_OC_HOUDAYER = 1 has its single-cluster form in both builds
+    if (oc_mode == 2) { // PA_OC_JORG
+        if (extras)
+            hipLaunchKernelGGL((k_cluster_sw<kSwJorg, true>), grid, block, lds, stream, d, p, 2u, single, aux);
+        else
+            hipLaunchKernelGGL((k_cluster_sw<kSwJorg, false>), grid, block, lds, stream, d, p, 2u, single, aux);
+    } else if (oc_mode == 3) { // PA_OC_CMR
+        if (extras)
+            hipLaunchKernelGGL((k_cluster_sw<kSwCmr, true>), grid, block, lds, stream, d, p, 2u, single, aux);
+        else
+            hipLaunchKernelGGL((k_cluster_sw<kSwCmr, false>), grid, block, lds, stream, d, p, 2u, single, aux);
+    } else {
+        if (extras)
+            hipLaunchKernelGGL((k_cluster_sw<kSwHoudayer, true>), grid, block, lds, stream, d, p, group, single, aux);
+        else
+            hipLaunchKernelGGL((k_cluster_sw<kSwHoudayer, false>), grid, block, lds, stream, d, p, group, single, aux);
+    }
     return hipGetLastError();
 }
 
@@ -1171,9 +1188,12 @@ size_t fk_wolff_lds_bytes(const SimDims &d) { return fk_wolff_lds_words(d) * 4; 
 hipError_t launch_fk(const SimDims &d, const DevPtrs &p, bool wolff, const ClusterAux &aux, hipStream_t stream) {
     if (wolff && aux.flags == 0)
         hipLaunchKernelGGL(k_fk_wolff, dim3(d.n_real), dim3(1024), fk_wolff_lds_bytes(d), stream, d, p);
-    else
-        hipLaunchKernelGGL(k_cluster_sw<kSwFk>, dim3(d.n_real * d.n_sys), dim3(kSwThreads),
+    else if (aux.flags != 0 || wolff)
+        hipLaunchKernelGGL((k_cluster_sw<kSwFk, true>), dim3(d.n_real * d.n_sys), dim3(kSwThreads),
                            cluster_sw_lds_bytes(d), stream, d, p, 1u, wolff ? 1 : 0, aux);
+    else
+        hipLaunchKernelGGL((k_cluster_sw<kSwFk, false>), dim3(d.n_real * d.n_sys), dim3(kSwThreads),
+                           cluster_sw_lds_bytes(d), stream, d, p, 1u, 0, aux);
     return hipGetLastError();
 }
 

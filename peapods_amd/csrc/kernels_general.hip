@@ -252,6 +252,7 @@ __global__ __launch_bounds__(kSweepFThreads) void k_sweep_f(SimDims d, DevPtrs p
             run(cur);
             cur = nxt;
         }
+        if (BIG) drain_global_stores(); // the flips of this level are in the L2 before the next level loads
         __syncthreads();
     }
     if (!BIG)

@@ -34,6 +34,12 @@ for mode in ("houdayer", "jorg"):
     for inner in ("wolff", "sw"):
         run(f"{mode}/{inner}", overlap_cluster_update_interval=1, overlap_cluster_build_mode=mode,
             overlap_cluster_mode=inner)
+for mode in ("houdayer", "jorg", "cmr"):  # the same moves while collecting sizes + top-four (recorded sweeps)
+    for inner in ("wolff", "sw"):
+        run(f"{mode}/{inner} + statistics", overlap_cluster_update_interval=1, overlap_cluster_build_mode=mode,
+            overlap_cluster_mode=inner, collect_cluster_stats=True)
+run("houdayer/sw observed", overlap_cluster_update_interval=1, overlap_cluster_build_mode="houdayer",
+    overlap_cluster_mode="sw", overlap_cluster_action="observe")
 print(json.dumps({"us_per_step": out}, indent=1))
 
 # ---- FK cluster updates on a ferromagnet (16^3, 32 temperatures around T_c, 2 replicas, 16 chains)
@@ -44,4 +50,6 @@ out = {}
 run("fm no cluster update")
 run("fm fk/sw", cluster_update_interval=1, cluster_mode="sw")
 run("fm fk/wolff", cluster_update_interval=1, cluster_mode="wolff")
+run("fm fk/sw + statistics", cluster_update_interval=1, cluster_mode="sw", collect_cluster_stats=True)
+run("fm fk/wolff + statistics", cluster_update_interval=1, cluster_mode="wolff", collect_cluster_stats=True)
 print(json.dumps({"fk_us_per_step": out}, indent=1))

@@ -45,6 +45,8 @@ struct SimDims {
     uint32_t unit;       // 1: every coupling is -1, 0 or +1 and every T/2 > 0 (cluster moves use integer thresholds)
     uint32_t general;    // 1: arbitrary f32 couplings / temperatures -> the reference's logarithmic rule
                          //    (kernels_general.hip); Esum then holds raw f32 bits of the energy sum
+    uint32_t pipe_lds;   // 1: the slabs of the pipelined sweep keep their spins in the LDS (k_sweep_slab)
+    uint32_t plane;      // sites of one hyperplane of the slowest dimension (halo window of a slab)
 };
 
 struct DevPtrs {
@@ -67,6 +69,9 @@ struct DevPtrs {
     const uint32_t *pass_start; // [n_passes + 1]
     const uint32_t *seg;     // [n_levels][pipe_K + 1] schedule positions where each slab's part of a level starts
     uint32_t *progress;      // [n_real * W][pipe_K] levels completed by each slab workgroup (epoch-based, monotone)
+    const uint32_t *halo_sites; // [pipe_K][2 * plane] k_sweep_slab: outside neighbours whose NEW value a slab needs,
+                             //   ordered by the level that first reads them
+    const uint32_t *halo_start; // [pipe_K][n_levels + 2] halo_sites[k][start[l] .. start[l + 1]) are needed at level l
     const uint32_t *jump;    // [B][64][16][8] nibble tables of T^(b*BS)
     int32_t *Esum;           // [n_real][n_sys] by slot: sum_{i,d} J s s (exact integer)
     int32_t *Msum;           // [n_real][n_sys] by slot: sum_i s_i
@@ -170,6 +175,7 @@ hipError_t launch_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt
 hipError_t launch_measure_stamped(const SimDims &d, const DevPtrs &p, const PtParams &pt,
                                   unsigned long long *stamps, hipStream_t stream);
 size_t sweep_lds_bytes(const SimDims &d, bool gibbs);
+size_t sweep_slab_lds_bytes(const SimDims &d);
 // kernels_cluster.hip
 hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, uint32_t group, bool wolff,
                              const ClusterAux &aux, hipStream_t stream);

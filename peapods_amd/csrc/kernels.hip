@@ -1637,6 +1637,184 @@ __global__ __launch_bounds__(256) void k_sweep_pipe(SimDims d, DevPtrs p, int gi
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_sweep_slab: the pipelined sweep with every slab's spins resident in the LDS.
+//
+// k_sweep_pipe pays three dependent L2 round trips per level (progress flag, neighbour words,
+// store + drain).  Here a slab of whole hyperplanes (own = N / pipe_K sites) is loaded once, swept in
+// place level by level like the on-chip kernel (neighbours inside the slab come from the LDS), and
+// written back once.  Only two things cross workgroups, both off the common path:
+//   * a slab's boundary sites -- the ones another slab reads as NEW values -- are stored to S_next
+//     as soon as they are decided, and the slab's progress counter moves once they are in the L2;
+//   * a slab's lower halo plane holds NEW values of the slab below (for the last slab also the
+//     first plane of slab 0 through the periodic wrap).  They are fetched in batches: one look at the
+//     predecessor's counter tells how many levels may be run, every halo site those levels read is
+//     fetched at once (halo_sites is ordered by the level that first needs a site), and no further
+//     global access happens until that allowance is used up.  A slab that falls behind its
+//     predecessor by a few levels therefore runs at on-chip speed.
+// The upper halo plane (and slab 0's lower one) carries OLD values and is loaded with the slab.
+// Site records and acceptance planes do not depend on the spins and are prefetched a level ahead.
+// Host-checked: every outside neighbour lies in one of the two halo planes, is either always newer
+// or always older than the slab's sites that read it, and level(j) + m <= level(i) across m slabs.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sweep_slab(SimDims d, DevPtrs p, int gibbs, uint32_t epoch,
+                                                    uint32_t n_tw_pad) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t tw = blockIdx.x % n_tw_pad, k = blockIdx.x / n_tw_pad;
+    if (tw >= d.n_real * d.W) return;
+    const uint32_t real = tw / d.W, w = tw % d.W;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t K = d.pipe_K, P = d.plane, own = d.N / K;
+    const uint32_t a = k * own;                              // first site of the slab
+    const uint32_t lo0 = (a + d.N - P) % d.N, hi0 = (a + own) % d.N; // halo planes below / above
+    const uint32_t *Sold = p.S + static_cast<size_t>(tw) * d.N;
+    uint32_t *Snew = p.S_next + static_cast<size_t>(tw) * d.N;
+    const uint2 *planes = p.planes + static_cast<size_t>(tw) * d.N;
+    const uint32_t *planes_hi = p.planes_hi + static_cast<size_t>(tw) * d.N;
+    const uint4 *rec = p.rec + static_cast<size_t>(real) * (d.N + 1) * 2;
+    uint32_t *progress = p.progress + static_cast<size_t>(tw) * K;
+    const uint32_t *halo = p.halo_sites + static_cast<size_t>(k) * 2 * P;
+    const uint32_t *halo_start = p.halo_start + static_cast<size_t>(k) * (d.n_levels + 2);
+    const uint32_t live = d.n_sys - w * 32;
+    const uint32_t valid_bits = live >= 32 ? 0xFFFFFFFFu : ((1u << live) - 1u);
+    const uint32_t base = epoch * (d.n_levels + 1);
+    __shared__ uint32_t allowance; // levels <= allowance may run: the predecessor has completed that many levels
+    __shared__ uint32_t gave_up;
+    // LDS location of site j: own range, then the lower halo plane, then the upper one
+    auto loc = [&](uint32_t j) -> uint32_t {
+        uint32_t r = j - a;
+        if (r < own) return r;
+        r = j - lo0;
+        if (r < P) return own + r;
+        return own + P + (j - hi0);
+    };
+    for (uint32_t i = tid; i < own; i += 256) lds[i] = Sold[a + i];
+    for (uint32_t i = tid; i < P; i += 256) {
+        lds[own + i] = Sold[lo0 + i];
+        lds[own + P + i] = Sold[hi0 + i];
+    }
+    if (tid == 0) {
+        allowance = k == 0 ? d.n_levels : 0u;
+        gave_up = 0;
+    }
+    // the slab's levels: first to last with a non-empty segment
+    uint32_t first = d.n_levels, last = 0;
+    for (uint32_t l = tid; l < d.n_levels; l += 256)
+        if (p.seg[l * (K + 1) + k + 1] > p.seg[l * (K + 1) + k]) {
+            first = min(first, l);
+            last = max(last, l);
+        }
+    __shared__ uint32_t range[2];
+    if (tid == 0) {
+        range[0] = d.n_levels;
+        range[1] = 0;
+    }
+    __syncthreads();
+    atomicMin(&range[0], first);
+    atomicMax(&range[1], last);
+    __syncthreads();
+    first = range[0];
+    last = range[1];
+    if (first > last) { // a slab without sites: nothing to do, nobody waits for less than everything
+        if (tid == 0) __hip_atomic_store(&progress[k], base + d.n_levels, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    uint32_t fetched = halo_start[0]; // halo entries below this cursor are in the LDS
+    // record + acceptance planes of this thread's site at a level (prefetched; independent of the spins)
+    struct Work {
+        uint4 r0, r1;
+        uint2 lv;
+        uint32_t hi;
+        bool live;
+    };
+    auto fetch_rec = [&](uint32_t level, Work &wk) {
+        wk.live = false;
+        if (level > last) return;
+        const uint32_t pos = p.seg[level * (K + 1) + k] + tid;
+        if (pos >= p.seg[level * (K + 1) + k + 1]) return;
+        wk.live = true;
+        wk.r0 = rec[2 * pos];
+        wk.r1 = rec[2 * pos + 1];
+    };
+    auto fetch_planes = [&](Work &wk) {
+        if (!wk.live) return;
+        const uint32_t site = BigRec(wk.r0, wk.r1).site;
+        wk.lv = planes[site];
+        wk.hi = gibbs ? planes_hi[site] : 0u;
+    };
+    Work cur, nxt;
+    fetch_rec(first, cur);
+    fetch_planes(cur);
+    fetch_rec(first + 1, nxt);
+    for (uint32_t level = first; level <= last; ++level) {
+        // ---- allowance: levels <= level must have been completed below (and their halo values fetched)
+        if (k > 0 && allowance < level) {
+            if (tid == 0) {
+                uint32_t spins = 0, seen;
+                for (;;) { // the predecessor's count of completed levels (earlier epochs read as negative)
+                    seen = __hip_atomic_load(&progress[k - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
+                    if (static_cast<int32_t>(seen) >= static_cast<int32_t>(level)) break; // levels < level done
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 26)) { // never reached unless a predecessor died: leave
+                        gave_up = 1;
+                        break;
+                    }
+                }
+                allowance = min(seen, d.n_levels);
+            }
+            __syncthreads();
+            if (gave_up) return;
+            // every halo site first read at a level <= allowance: decided, stored and drained by its owner
+            const uint32_t upto = halo_start[allowance + 1];
+            for (uint32_t e = fetched + tid; e < upto; e += 256) {
+                const uint32_t j = halo[e];
+                lds[loc(j)] = coherent_load(Snew + j);
+            }
+            fetched = upto;
+            __syncthreads();
+        }
+        fetch_planes(nxt);
+        Work ahead;
+        fetch_rec(level + 2, ahead);
+        // ---- this level's sites (one per thread; longer segments loop)
+        const uint32_t begin = p.seg[level * (K + 1) + k], end = p.seg[level * (K + 1) + k + 1];
+        bool exported = false;
+        for (uint32_t pos = begin + tid; pos < end; pos += 256) {
+            Work wk;
+            if (pos == begin + tid) {
+                wk = cur;
+            } else { // second and later rounds of a long segment are not prefetched
+                wk.r0 = rec[2 * pos];
+                wk.r1 = rec[2 * pos + 1];
+                wk.live = true;
+                fetch_planes(wk);
+            }
+            const BigRec r(wk.r0, wk.r1);
+            uint32_t nb[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) nb[q] = lds[loc(r.nb[q])];
+            const uint32_t at = r.site - a;
+            const uint32_t sv = lds[at];
+            const uint32_t acc = (gibbs ? accept_mask_gibbs(sv, nb, r.jm, d.nn, wk.lv.x, wk.lv.y, wk.hi)
+                                        : accept_mask(sv, nb, r.jm, wk.lv.x, wk.lv.y)) & valid_bits;
+            lds[at] = sv ^ acc;
+            // sites another slab reads as new values: the top plane, and slab 0's first plane (periodic wrap)
+            if (at >= own - P || (k == 0 && at < P)) {
+                coherent_store(Snew + r.site, sv ^ acc);
+                exported = true;
+            }
+        }
+        if (exported) drain_global_stores(); // in the L2 before the counter moves
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(&progress[k], base + (level == last ? d.n_levels : level + 1), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        cur = nxt;
+        nxt = ahead;
+    }
+    for (uint32_t i = tid; i < own; i += 256) Snew[a + i] = lds[i];
+}
+
 // chunk = 4096 schedule positions per workgroup; counts go to cnt[real][n_sys][3] (u32 atomics)
 __global__ __launch_bounds__(256) void k_energy_big(SimDims d, DevPtrs p, uint32_t n_chunks) {
     __shared__ uint32_t scratch[5 * 48];
@@ -1792,7 +1970,9 @@ hipError_t configure_kernels(const SimDims &) {
                                            static_cast<int>(kLdsPerCu));
         if (e != hipSuccess) return e;
     }
-    return hipSuccess;
+    // k_sweep_slab also has a few static LDS words: leave room for them
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_slab), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(kLdsPerCu) - 1024);
 }
 
 hipError_t launch_rng(const SimDims &d, const DevPtrs &p, bool gibbs, hipStream_t stream) {
@@ -1859,11 +2039,19 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
     return hipGetLastError();
 }
 
+size_t sweep_slab_lds_bytes(const SimDims &d) {
+    return d.pipe_K ? (static_cast<size_t>(d.N) / d.pipe_K + 2 * static_cast<size_t>(d.plane)) * 4 : 0;
+}
+
 hipError_t launch_sweep_pipe(const SimDims &d, const DevPtrs &p, bool gibbs, uint32_t epoch,
                              hipStream_t stream) {
     const uint32_t n_tw_pad = (d.n_real * d.W + 7u) & ~7u;
-    hipLaunchKernelGGL(k_sweep_pipe, dim3(n_tw_pad * d.pipe_K), dim3(256), 0, stream, d, p,
-                       gibbs ? 1 : 0, epoch, n_tw_pad);
+    if (d.pipe_lds)
+        hipLaunchKernelGGL(k_sweep_slab, dim3(n_tw_pad * d.pipe_K), dim3(256), sweep_slab_lds_bytes(d), stream, d, p,
+                           gibbs ? 1 : 0, epoch, n_tw_pad);
+    else
+        hipLaunchKernelGGL(k_sweep_pipe, dim3(n_tw_pad * d.pipe_K), dim3(256), 0, stream, d, p,
+                           gibbs ? 1 : 0, epoch, n_tw_pad);
     return hipGetLastError();
 }
 

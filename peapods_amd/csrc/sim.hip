@@ -68,6 +68,8 @@ struct pa_sim {
     float *jorg_p = nullptr;
     uint32_t *thr_gibbs = nullptr; // built by the first Gibbs sample (ensure_gibbs)
     uint32_t *seg = nullptr;       // slab segments of the pipelined large-lattice sweep
+    uint32_t *halo_sites = nullptr, *halo_start = nullptr; // k_sweep_slab tables
+    std::vector<uint32_t> halo_sites_host, halo_start_host;
     uint32_t pipe_epoch = 1;       // bumped by every k_sweep_pipe launch (progress counters are monotone)
     std::vector<uint64_t> equil_sweeps; // checkpoints of the last sample() with the equilibration diagnostic
     uint64_t ac_lag = 0, ac_samples = 0, ac_capacity = 0; // autocorrelation series of the last sample()
@@ -1189,6 +1191,8 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     // m >= 1 slabs below satisfies level(j) + m <= level(i).
     d.n_levels = n_levels;
     d.pipe_K = 0;
+    d.pipe_lds = 0;
+    d.plane = 0;
     std::vector<uint32_t> seg;
     if (d.big && !d.general) {
         uint32_t widest = 1;
@@ -1214,7 +1218,86 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
                     }
             return true;
         };
-        while (K > 1 && !admissible(K)) --K;
+        // LDS-resident slabs (k_sweep_slab): whole hyperplanes of the slowest dimension, as thick as the LDS
+        // and one site per thread and level allow (fewer, thicker slabs = a shorter pipeline).  Every outside
+        // neighbour of a slab must lie in the plane just below or just above it, and be read only as a NEW
+        // value (below, and the first plane through the periodic wrap of the last slab) or only as an OLD one.
+        const uint32_t plane = d.N / lat.shape[0];
+        d.plane = plane;
+        d.pipe_lds = 0;
+        std::vector<uint32_t> halo_sites, halo_start;
+        auto build_halo = [&](uint32_t slabs) -> bool {
+            if (slabs < 2 || lat.shape[0] % slabs != 0 || !admissible(slabs)) return false;
+            const uint32_t own = d.N / slabs;
+            if ((static_cast<size_t>(own) + 2 * plane) * 4 > 150 * 1024) return false;
+            halo_sites.assign(static_cast<size_t>(slabs) * 2 * plane, 0u);
+            halo_start.assign(static_cast<size_t>(slabs) * (n_levels + 2), 0u);
+            const uint32_t unset = 0xFFFFFFFFu;
+            for (uint32_t k = 0; k < slabs; ++k) {
+                const uint32_t a = k * own, lo0 = (a + d.N - plane) % d.N, hi0 = (a + own) % d.N;
+                if (lo0 == hi0) return false; // the two halo planes must be distinct
+                std::vector<uint32_t> need_lo(plane, unset), need_hi(plane, unset);
+                std::vector<uint8_t> old_lo(plane, 0), old_hi(plane, 0);
+                for (uint32_t i = a; i < a + own; ++i)
+                    for (uint32_t q = 0; q < d.nn; ++q)
+                        for (uint32_t j : {lat.fwd[i * d.nn + q], lat.bwd[i * d.nn + q]}) {
+                            if (j >= a && j < a + own) continue;
+                            const uint32_t rl = (j + d.N - lo0) % d.N, rh = (j + d.N - hi0) % d.N;
+                            if (rl < plane) {
+                                if (j < i) need_lo[rl] = std::min(need_lo[rl], level[i]);
+                                else old_lo[rl] = 1;
+                            } else if (rh < plane) {
+                                if (j < i) need_hi[rh] = std::min(need_hi[rh], level[i]);
+                                else old_hi[rh] = 1;
+                            } else {
+                                return false;
+                            }
+                        }
+                std::vector<std::pair<uint32_t, uint32_t>> wanted; // (level that first reads it, site)
+                for (uint32_t r = 0; r < plane; ++r) {
+                    if ((need_lo[r] != unset && old_lo[r]) || (need_hi[r] != unset && old_hi[r])) return false;
+                    if (need_lo[r] != unset) wanted.emplace_back(need_lo[r], lo0 + r);
+                    if (need_hi[r] != unset) wanted.emplace_back(need_hi[r], hi0 + r);
+                }
+                if (k == 0 && !wanted.empty()) return false; // the first slab waits for nobody
+                std::sort(wanted.begin(), wanted.end());
+                uint32_t *start = &halo_start[static_cast<size_t>(k) * (n_levels + 2)];
+                size_t e = 0;
+                for (uint32_t l = 0; l <= n_levels + 1; ++l) {
+                    while (e < wanted.size() && wanted[e].first < l) ++e;
+                    start[l] = static_cast<uint32_t>(e);
+                }
+                for (size_t x = 0; x < wanted.size(); ++x)
+                    halo_sites[static_cast<size_t>(k) * 2 * plane + x] = wanted[x].second;
+            }
+            return true;
+        };
+        if (!std::getenv("PEAPODS_NO_SLAB_LDS") && lat.shape[0] >= 4) {
+            uint32_t best = 0;
+            for (uint32_t slabs = 2; slabs <= lat.shape[0] / 2 && !best; ++slabs) { // fewest slabs first
+                if (lat.shape[0] % slabs != 0) continue;
+                uint32_t longest = 0; // sites of one slab at one level
+                const uint32_t own = d.N / slabs;
+                for (uint32_t l = 0; l < n_levels; ++l) {
+                    std::vector<uint32_t> count(slabs, 0u);
+                    for (uint32_t pos = level_start[l]; pos < level_start[l + 1]; ++pos) count[order[pos] / own] += 1;
+                    for (uint32_t c : count) longest = std::max(longest, c);
+                }
+                if (longest <= 256 && build_halo(slabs)) best = slabs;
+            }
+            if (const char *env = std::getenv("PEAPODS_SLAB_K")) {
+                const long v = std::strtol(env, nullptr, 10);
+                best = (v >= 2 && build_halo(static_cast<uint32_t>(v))) ? static_cast<uint32_t>(v) : 0u;
+            }
+            if (best) {
+                build_halo(best);
+                K = best;
+                d.pipe_lds = 1;
+                sim->halo_sites_host = halo_sites;
+                sim->halo_start_host = halo_start;
+            }
+        }
+        while (!d.pipe_lds && K > 1 && !admissible(K)) --K;
         if (K > 1) {
             d.pipe_K = K;
             const uint32_t slab = (d.N + K - 1) / K;
@@ -1340,6 +1423,10 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         p.S_next = p.S; // these paths sweep in place
     else
         ok(bufs.alloc(&p.S_next, tile_words * d.n_real));
+    if (d.pipe_lds) {
+        ok(bufs.alloc(&sim->halo_sites, sim->halo_sites_host.size()));
+        ok(bufs.alloc(&sim->halo_start, sim->halo_start_host.size()));
+    }
     if (d.pipe_K) {
         ok(bufs.alloc(&sim->seg, seg.size()));
         ok(bufs.alloc(&p.progress, static_cast<size_t>(d.n_real) * d.W * d.pipe_K));
@@ -1401,6 +1488,12 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     p.nbr_wide = sim->nbr_wide;
     p.jorg_p = sim->jorg_p;
     p.seg = sim->seg;
+    p.halo_sites = sim->halo_sites;
+    p.halo_start = sim->halo_start;
+    if (d.pipe_lds) {
+        if ((rc = upload(sim, sim->halo_sites, sim->halo_sites_host))) return bail(rc);
+        if ((rc = upload(sim, sim->halo_start, sim->halo_start_host))) return bail(rc);
+    }
     if (d.pipe_K) {
         if ((rc = upload(sim, sim->seg, seg))) return bail(rc);
         if (hipMemsetAsync(p.progress, 0, sizeof(uint32_t) * d.n_real * d.W * d.pipe_K, sim->stream) != hipSuccess) {

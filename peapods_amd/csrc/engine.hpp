@@ -47,6 +47,8 @@ struct SimDims {
                          //    (kernels_general.hip); Esum then holds raw f32 bits of the energy sum
     uint32_t pipe_lds;   // 1: the slabs of the pipelined sweep keep their spins in the LDS (k_sweep_slab)
     uint32_t plane;      // sites of one hyperplane of the slowest dimension (halo window of a slab)
+    uint32_t planes_stride; // entries of planes / planes_hi per (realisation, word): N, or the padded
+                         //    schedule length when the slab kernel reads them in schedule order
 };
 
 struct DevPtrs {
@@ -72,6 +74,13 @@ struct DevPtrs {
     const uint32_t *halo_sites; // [pipe_K][2 * plane] k_sweep_slab: outside neighbours whose NEW value a slab needs,
                              //   ordered by the level that first reads them
     const uint32_t *halo_start; // [pipe_K][n_levels + 2] halo_sites[k][start[l] .. start[l + 1]) are needed at level l
+    const uint2 *slab_seg;   // [n_levels][pipe_K] (first padded schedule position, sites) of a slab at a level;
+                             //   positions are padded so that every segment starts at a multiple of 4
+    const uint32_t *pos_of;  // [N] site -> padded schedule position (k_rng files the acceptance planes there)
+    uint32_t *slab_scratch;  // [workgroups][4] dummy store target of sweep waves without sites at a level
+    uint32_t *slab_error;    // [1] set when a slab gave up waiting for its predecessor
+    const uint4 *recS;       // [n_real][planes_stride] by padded position: 8 x u16 = LDS word of the site and of
+                             //   f0,b0,f1,b1,f2,b2, then jmeta
     const uint32_t *jump;    // [B][64][16][8] nibble tables of T^(b*BS)
     int32_t *Esum;           // [n_real][n_sys] by slot: sum_{i,d} J s s (exact integer)
     int32_t *Msum;           // [n_real][n_sys] by slot: sum_i s_i
@@ -176,6 +185,7 @@ hipError_t launch_measure_stamped(const SimDims &d, const DevPtrs &p, const PtPa
                                   unsigned long long *stamps, hipStream_t stream);
 size_t sweep_lds_bytes(const SimDims &d, bool gibbs);
 size_t sweep_slab_lds_bytes(const SimDims &d);
+size_t sweep_slab_lds_bytes_for(uint32_t own_sites, uint32_t plane_sites, uint32_t n_levels);
 // kernels_cluster.hip
 hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, uint32_t group, bool wolff,
                              const ClusterAux &aux, hipStream_t stream);

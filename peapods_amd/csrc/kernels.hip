@@ -134,8 +134,10 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
 
     const uint32_t begin = block * d.BS;
     const uint32_t len = min(d.BS, d.N - begin); // uniform over the workgroup
-    uint2 *planes = p.planes + static_cast<size_t>(tw_ok ? tw : 0) * d.N;
+    uint2 *planes = p.planes + static_cast<size_t>(tw_ok ? tw : 0) * d.planes_stride;
     const uint32_t *mpar = p.mpar + static_cast<size_t>(real) * d.MW;
+    // where a site's acceptance planes go: by site, or (k_sweep_slab) at its padded schedule position
+    auto filed = [&](uint32_t site) -> uint32_t { return d.pipe_lds ? p.pos_of[site] : site; };
 
     if (GIBBS) {
         uint32_t ce[7] = {0, 0, 0, 0, 0, 0, 0}, co[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -147,7 +149,7 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
                 co[j] = p.thr_gibbs[(7 + j) * d.n_temps + t];
             }
         }
-        uint32_t *planes_hi = p.planes_hi + static_cast<size_t>(tw_ok ? tw : 0) * d.N;
+        uint32_t *planes_hi = p.planes_hi + static_cast<size_t>(tw_ok ? tw : 0) * d.planes_stride;
         for (uint32_t j0 = 0; j0 < len; j0 += 32) {
             uint32_t keep0 = 0, keep1 = 0, keep2 = 0;
             const uint32_t chunk = min(32u, len - j0);
@@ -171,8 +173,9 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
                 }
             }
             if (tw_ok && bit < chunk) {
-                planes[begin + j0 + bit] = make_uint2(keep0, keep1);
-                planes_hi[begin + j0 + bit] = keep2;
+                const uint32_t at = filed(begin + j0 + bit);
+                planes[at] = make_uint2(keep0, keep1);
+                planes_hi[at] = keep2;
             }
         }
         if (active && block == d.B - 1) {
@@ -222,7 +225,7 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
                 }
             }
         }
-        if (tw_ok && bit < chunk) planes[begin + j0 + bit] = make_uint2(keep0, keep1);
+        if (tw_ok && bit < chunk) planes[filed(begin + j0 + bit)] = make_uint2(keep0, keep1);
     }
     // The last block ends exactly N draws after the cursor: that is the next cursor.
     if (active && block == d.B - 1) {
@@ -1641,178 +1644,217 @@ __global__ __launch_bounds__(256) void k_sweep_pipe(SimDims d, DevPtrs p, int gi
 // k_sweep_slab: the pipelined sweep with every slab's spins resident in the LDS.
 //
 // k_sweep_pipe pays three dependent L2 round trips per level (progress flag, neighbour words,
-// store + drain).  Here a slab of whole hyperplanes (own = N / pipe_K sites) is loaded once, swept in
-// place level by level like the on-chip kernel (neighbours inside the slab come from the LDS), and
-// written back once.  Only two things cross workgroups, both off the common path:
-//   * a slab's boundary sites -- the ones another slab reads as NEW values -- are stored to S_next
-//     as soon as they are decided, and the slab's progress counter moves once they are in the L2;
-//   * a slab's lower halo plane holds NEW values of the slab below (for the last slab also the
-//     first plane of slab 0 through the periodic wrap).  They are fetched in batches: one look at the
-//     predecessor's counter tells how many levels may be run, every halo site those levels read is
-//     fetched at once (halo_sites is ordered by the level that first needs a site), and no further
-//     global access happens until that allowance is used up.  A slab that falls behind its
-//     predecessor by a few levels therefore runs at on-chip speed.
+// store + drain).  Here a slab of whole hyperplanes (own = N / pipe_K sites) is loaded once and
+// swept in place level by level like the on-chip kernel: neighbours inside the slab come from the
+// LDS, and a level costs one workgroup barrier.  What crosses workgroups is kept off that path:
+//   * inputs that do not depend on the spins -- the site records (LDS word of the site and of its
+//     six neighbours, coupling metadata) and the acceptance planes k_rng filed in schedule order --
+//     are streamed by a fifth wave with LDS-DMA loads into a ring kSlabDepth levels deep; the
+//     four sweep waves never wait for memory;
+//   * every site is stored to S_next as it is decided (one store instruction per wave and level,
+//     so that `s_waitcnt vmcnt(2)` means "the stores of two levels ago are in the L2": stores of a
+//     wave retire in order), and the slab's progress counter follows two levels behind;
+//   * the lower halo plane holds NEW values of the slab below (for the last slab also the first
+//     plane of slab 0, through the periodic wrap).  They are fetched in batches: one look at the
+//     predecessor's counter tells how many levels may be run, every halo site those levels read
+//     is fetched at once (halo_sites is ordered by the level that first needs a site), and no
+//     further global access happens until that allowance is used up.
 // The upper halo plane (and slab 0's lower one) carries OLD values and is loaded with the slab.
-// Site records and acceptance planes do not depend on the spins and are prefetched a level ahead.
 // Host-checked: every outside neighbour lies in one of the two halo planes, is either always newer
 // or always older than the slab's sites that read it, and level(j) + m <= level(i) across m slabs.
+// Barriers are raw s_barrier + lgkmcnt(0): a __syncthreads() would drain the DMA ring (its fence
+// waits vmcnt(0) while an LDS-DMA is pending).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sweep_slab(SimDims d, DevPtrs p, int gibbs, uint32_t epoch,
-                                                    uint32_t n_tw_pad) {
+constexpr uint32_t kSlabDepth = 8;     // levels of records and planes resident in the ring
+constexpr uint32_t kSlabThreads = 320; // four sweep waves + the loader wave
+
+__device__ __forceinline__ void slab_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// LDS read the compiler does not see (an ordinary read would make it wait for every pending DMA)
+__device__ __forceinline__ uint32_t lds_peek(const uint32_t *ptr) {
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                 : "=v"(v)
+                 : "v"(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ptr)))
+                 : "memory");
+    return v;
+}
+
+template <bool GIBBS>
+__global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs p, uint32_t epoch, uint32_t n_tw_pad) {
+    typedef __attribute__((address_space(1))) const void GlobalPtr;
+    typedef __attribute__((address_space(3))) void LdsPtr;
+    constexpr uint32_t D = kSlabDepth;
+    constexpr uint32_t G = GIBBS ? 7 : 6; // DMA instructions per level: 4 records, 2 planes (+ 1 third plane)
     extern __shared__ uint32_t lds[];
-    const uint32_t tw = blockIdx.x % n_tw_pad, k = blockIdx.x / n_tw_pad;
+    // (block-uniform values made scalar so that table reads indexed by them are scalar loads)
+    const uint32_t tw = __builtin_amdgcn_readfirstlane(blockIdx.x % n_tw_pad);
+    const uint32_t k = __builtin_amdgcn_readfirstlane(blockIdx.x / n_tw_pad);
     if (tw >= d.n_real * d.W) return;
-    const uint32_t real = tw / d.W, w = tw % d.W;
+    const uint32_t real = __builtin_amdgcn_readfirstlane(tw / d.W), w = __builtin_amdgcn_readfirstlane(tw % d.W);
     const uint32_t tid = threadIdx.x;
-    const uint32_t K = d.pipe_K, P = d.plane, own = d.N / K;
-    const uint32_t a = k * own;                              // first site of the slab
-    const uint32_t lo0 = (a + d.N - P) % d.N, hi0 = (a + own) % d.N; // halo planes below / above
+    const uint32_t K = d.pipe_K, P = d.plane, own = __builtin_amdgcn_readfirstlane(d.N / K);
+    const uint32_t a = k * own;                                       // first site of the slab
+    const uint32_t lo0 = __builtin_amdgcn_readfirstlane((a + d.N - P) % d.N);
+    const uint32_t hi0 = __builtin_amdgcn_readfirstlane((a + own) % d.N); // halo planes below / above
     const uint32_t *Sold = p.S + static_cast<size_t>(tw) * d.N;
     uint32_t *Snew = p.S_next + static_cast<size_t>(tw) * d.N;
-    const uint2 *planes = p.planes + static_cast<size_t>(tw) * d.N;
-    const uint32_t *planes_hi = p.planes_hi + static_cast<size_t>(tw) * d.N;
-    const uint4 *rec = p.rec + static_cast<size_t>(real) * (d.N + 1) * 2;
+    const uint2 *planes = p.planes + static_cast<size_t>(tw) * d.planes_stride;
+    const uint32_t *planes_hi = GIBBS ? p.planes_hi + static_cast<size_t>(tw) * d.planes_stride : nullptr;
+    const uint4 *recS = p.recS + static_cast<size_t>(real) * d.planes_stride;
     uint32_t *progress = p.progress + static_cast<size_t>(tw) * K;
     const uint32_t *halo = p.halo_sites + static_cast<size_t>(k) * 2 * P;
     const uint32_t *halo_start = p.halo_start + static_cast<size_t>(k) * (d.n_levels + 2);
     const uint32_t live = d.n_sys - w * 32;
     const uint32_t valid_bits = live >= 32 ? 0xFFFFFFFFu : ((1u << live) - 1u);
     const uint32_t base = epoch * (d.n_levels + 1);
-    __shared__ uint32_t allowance; // levels <= allowance may run: the predecessor has completed that many levels
-    __shared__ uint32_t gave_up;
-    // LDS location of site j: own range, then the lower halo plane, then the upper one
-    auto loc = [&](uint32_t j) -> uint32_t {
-        uint32_t r = j - a;
-        if (r < own) return r;
-        r = j - lo0;
-        if (r < P) return own + r;
-        return own + P + (j - hi0);
+    // one LDS array: spins (own, lower halo, upper halo), the three rings, control words
+    uint32_t *ring_rec = lds + own + 2 * P;           // [D][256][4]
+    uint32_t *ring_pl = ring_rec + D * 256 * 4;       // [D][256][2]
+    uint32_t *ring_hi = ring_pl + D * 256 * 2;        // [D][256] (heat bath)
+    uint32_t *ctl = ring_hi + (GIBBS ? D * 256 : 0);  // 0 allowance, 1 gave up, 2 first level, 3 last level, 4 new allowance
+    uint32_t *segs = ctl + 8;                         // [n_levels][2] (first padded position, sites) of this slab
+    auto loc = [&](uint32_t j) -> uint32_t { // LDS word of an outside site (halo fetches)
+        const uint32_t r = j - lo0;
+        return r < P ? own + r : own + P + (j - hi0);
     };
-    for (uint32_t i = tid; i < own; i += 256) lds[i] = Sold[a + i];
-    for (uint32_t i = tid; i < P; i += 256) {
+    for (uint32_t i = tid; i < own; i += kSlabThreads) lds[i] = Sold[a + i];
+    for (uint32_t i = tid; i < P; i += kSlabThreads) {
         lds[own + i] = Sold[lo0 + i];
         lds[own + P + i] = Sold[hi0 + i];
     }
-    if (tid == 0) {
-        allowance = k == 0 ? d.n_levels : 0u;
-        gave_up = 0;
+    for (uint32_t l = tid; l < d.n_levels; l += kSlabThreads) { // the per-level table reads become LDS reads
+        const uint2 sg = p.slab_seg[l * K + k];
+        segs[2 * l] = sg.x;
+        segs[2 * l + 1] = sg.y;
     }
-    // the slab's levels: first to last with a non-empty segment
-    uint32_t first = d.n_levels, last = 0;
-    for (uint32_t l = tid; l < d.n_levels; l += 256)
-        if (p.seg[l * (K + 1) + k + 1] > p.seg[l * (K + 1) + k]) {
-            first = min(first, l);
-            last = max(last, l);
+    if (tid == 0) {
+        ctl[0] = k == 0 ? d.n_levels : 0u; // levels <= allowance may run: the predecessor has completed that many
+        ctl[1] = 0;
+        ctl[2] = d.n_levels;
+        ctl[3] = 0;
+    }
+    __syncthreads();
+    { // the slab's levels: first to last with a non-empty segment
+        uint32_t first = d.n_levels, last = 0;
+        for (uint32_t l = tid; l < d.n_levels; l += kSlabThreads)
+            if (p.slab_seg[l * K + k].y != 0) {
+                first = min(first, l);
+                last = max(last, l);
+            }
+        if (first <= last) {
+            atomicMin(&ctl[2], first);
+            atomicMax(&ctl[3], last);
         }
-    __shared__ uint32_t range[2];
-    if (tid == 0) {
-        range[0] = d.n_levels;
-        range[1] = 0;
     }
     __syncthreads();
-    atomicMin(&range[0], first);
-    atomicMax(&range[1], last);
-    __syncthreads();
-    first = range[0];
-    last = range[1];
+    // (made scalar: the per-level table reads below must be scalar loads -- a vector load would put the
+    // sweep waves' stores and the loader's DMA pieces behind a vmcnt(0))
+    const uint32_t first = __builtin_amdgcn_readfirstlane(ctl[2]), last = __builtin_amdgcn_readfirstlane(ctl[3]);
     if (first > last) { // a slab without sites: nothing to do, nobody waits for less than everything
         if (tid == 0) __hip_atomic_store(&progress[k], base + d.n_levels, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
+    __syncthreads(); // the last ordinary barrier: from here on DMA loads stay in flight across barriers
+
+    if (tid >= 256) {
+        // ================= loader wave: records and planes of level L -> ring slot (L - first) % D
+        const uint32_t lane = tid - 256;
+        auto issue = [&](uint32_t L) {
+            const uint32_t slot = (L - first) % D;
+            const uint32_t begin = L <= last ? lds_peek(&segs[2 * L]) : 0u; // past the end: harmless, never read
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q)
+                __builtin_amdgcn_global_load_lds((GlobalPtr *)(recS + begin + q * 64 + lane),
+                                                 (LdsPtr *)(ring_rec + (slot * 256 + q * 64) * 4), 16, 0, 0);
+#pragma unroll
+            for (uint32_t q = 0; q < 2; ++q)
+                __builtin_amdgcn_global_load_lds((GlobalPtr *)(planes + begin + q * 128 + 2 * lane),
+                                                 (LdsPtr *)(ring_pl + (slot * 256 + q * 128) * 2), 16, 0, 0);
+            if (GIBBS)
+                __builtin_amdgcn_global_load_lds((GlobalPtr *)(planes_hi + begin + 4 * lane),
+                                                 (LdsPtr *)(ring_hi + slot * 256), 16, 0, 0);
+        };
+        for (uint32_t L = first; L < first + D - 1; ++L) issue(L);
+        for (uint32_t level = first; level <= last; ++level) {
+            // the pieces of `level` have landed once only the D - 2 younger groups are outstanding
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (((D - 2) * G) & 0xF) | ((((D - 2) * G) >> 4) << 14));
+            slab_barrier(); // X(level)
+            if (k > 0 && lds_peek(&ctl[0]) < level) { // the sweep waves refill their allowance: same barriers
+                slab_barrier();
+                if (lds_peek(&ctl[1])) return;
+                slab_barrier();
+            }
+            issue(level + D - 1); // into the slot read during level - 1 (those reads retired before X(level))
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70); // nothing of this wave may still be writing the LDS at exit
+        slab_barrier();                     // matches the sweep waves' final barrier
+        return;
+    }
+
+    // ================= sweep waves
+    uint32_t *scratch = p.slab_scratch + (static_cast<size_t>(blockIdx.x) * 4 + (tid >> 6)); // idle waves store here
     uint32_t fetched = halo_start[0]; // halo entries below this cursor are in the LDS
-    // record + acceptance planes of this thread's site at a level (prefetched; independent of the spins)
-    struct Work {
-        uint4 r0, r1;
-        uint2 lv;
-        uint32_t hi;
-        bool live;
-    };
-    auto fetch_rec = [&](uint32_t level, Work &wk) {
-        wk.live = false;
-        if (level > last) return;
-        const uint32_t pos = p.seg[level * (K + 1) + k] + tid;
-        if (pos >= p.seg[level * (K + 1) + k + 1]) return;
-        wk.live = true;
-        wk.r0 = rec[2 * pos];
-        wk.r1 = rec[2 * pos + 1];
-    };
-    auto fetch_planes = [&](Work &wk) {
-        if (!wk.live) return;
-        const uint32_t site = BigRec(wk.r0, wk.r1).site;
-        wk.lv = planes[site];
-        wk.hi = gibbs ? planes_hi[site] : 0u;
-    };
-    Work cur, nxt;
-    fetch_rec(first, cur);
-    fetch_planes(cur);
-    fetch_rec(first + 1, nxt);
     for (uint32_t level = first; level <= last; ++level) {
-        // ---- allowance: levels <= level must have been completed below (and their halo values fetched)
-        if (k > 0 && allowance < level) {
+        slab_barrier(); // X(level): the ring slot of this level is ready, last level's spins are visible
+        // every wave left level - 1 with at most two stores in flight: levels <= level - 3 are in the L2
+        if (tid == 0 && level >= 2)
+            __hip_atomic_store(&progress[k], base + level - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k > 0 && ctl[0] < level) { // (ctl[0] changes only between the second barrier below and the next X)
+            // ---- allowance used up: wait for the predecessor, then fetch every halo site the allowed levels read
             if (tid == 0) {
                 uint32_t spins = 0, seen;
                 for (;;) { // the predecessor's count of completed levels (earlier epochs read as negative)
                     seen = __hip_atomic_load(&progress[k - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
                     if (static_cast<int32_t>(seen) >= static_cast<int32_t>(level)) break; // levels < level done
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 26)) { // never reached unless a predecessor died: leave
-                        gave_up = 1;
+                    if (++spins > (1u << 24)) { // never reached unless a predecessor died: leave
+                        ctl[1] = 1;
+                        seen = d.n_levels;
                         break;
                     }
                 }
-                allowance = min(seen, d.n_levels);
+                ctl[4] = min(seen, d.n_levels); // the new allowance; ctl[0] itself moves after the second barrier
             }
-            __syncthreads();
-            if (gave_up) return;
-            // every halo site first read at a level <= allowance: decided, stored and drained by its owner
-            const uint32_t upto = halo_start[allowance + 1];
+            slab_barrier();
+            if (ctl[1]) {
+                if (tid == 0) atomicExch(p.slab_error, 1u);
+                return;
+            }
+            const uint32_t allowed = ctl[4];
+            const uint32_t upto = halo_start[allowed + 1]; // first read at a level <= allowance: decided and in the L2
             for (uint32_t e = fetched + tid; e < upto; e += 256) {
                 const uint32_t j = halo[e];
                 lds[loc(j)] = coherent_load(Snew + j);
             }
             fetched = upto;
-            __syncthreads();
+            drain_global_stores(); // back to "only stores in flight" for the counted wait below
+            slab_barrier();
+            if (tid == 0) ctl[0] = allowed;
         }
-        fetch_planes(nxt);
-        Work ahead;
-        fetch_rec(level + 2, ahead);
-        // ---- this level's sites (one per thread; longer segments loop)
-        const uint32_t begin = p.seg[level * (K + 1) + k], end = p.seg[level * (K + 1) + k + 1];
-        bool exported = false;
-        for (uint32_t pos = begin + tid; pos < end; pos += 256) {
-            Work wk;
-            if (pos == begin + tid) {
-                wk = cur;
-            } else { // second and later rounds of a long segment are not prefetched
-                wk.r0 = rec[2 * pos];
-                wk.r1 = rec[2 * pos + 1];
-                wk.live = true;
-                fetch_planes(wk);
-            }
-            const BigRec r(wk.r0, wk.r1);
-            uint32_t nb[6];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) nb[q] = lds[loc(r.nb[q])];
-            const uint32_t at = r.site - a;
+        const uint32_t slot = (level - first) % D;
+        const uint32_t count = segs[2 * level + 1];
+        if (tid < count) {
+            const uint4 r = *reinterpret_cast<const uint4 *>(ring_rec + (slot * 256 + tid) * 4);
+            const uint2 lv = *reinterpret_cast<const uint2 *>(ring_pl + (slot * 256 + tid) * 2);
+            const uint32_t at = r.x & 0xFFFFu;
+            uint32_t nb[6] = {lds[r.x >> 16],     lds[r.y & 0xFFFFu], lds[r.y >> 16],
+                              lds[r.z & 0xFFFFu], lds[r.z >> 16],     lds[r.w & 0xFFFFu]};
+            const uint32_t jm = r.w >> 16;
             const uint32_t sv = lds[at];
-            const uint32_t acc = (gibbs ? accept_mask_gibbs(sv, nb, r.jm, d.nn, wk.lv.x, wk.lv.y, wk.hi)
-                                        : accept_mask(sv, nb, r.jm, wk.lv.x, wk.lv.y)) & valid_bits;
+            const uint32_t acc = (GIBBS ? accept_mask_gibbs(sv, nb, jm, d.nn, lv.x, lv.y, ring_hi[slot * 256 + tid])
+                                        : accept_mask(sv, nb, jm, lv.x, lv.y)) & valid_bits;
             lds[at] = sv ^ acc;
-            // sites another slab reads as new values: the top plane, and slab 0's first plane (periodic wrap)
-            if (at >= own - P || (k == 0 && at < P)) {
-                coherent_store(Snew + r.site, sv ^ acc);
-                exported = true;
-            }
+            coherent_store(Snew + a + at, sv ^ acc);
+        } else if ((tid & 63u) == 0 && (tid & ~63u) >= count) {
+            coherent_store(scratch, level); // a wave without sites still issues its one store of the level
         }
-        if (exported) drain_global_stores(); // in the L2 before the counter moves
-        __syncthreads();
-        if (tid == 0)
-            __hip_atomic_store(&progress[k], base + (level == last ? d.n_levels : level + 1), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        cur = nxt;
-        nxt = ahead;
+        // one store per wave and level, retired in order: at most two outstanding <=> level - 2 and older are done
+        __builtin_amdgcn_s_waitcnt(0x0F70 | 2u);
     }
-    for (uint32_t i = tid; i < own; i += 256) Snew[a + i] = lds[i];
+    drain_global_stores();
+    slab_barrier();
+    if (tid == 0)
+        __hip_atomic_store(&progress[k], base + d.n_levels, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // chunk = 4096 schedule positions per workgroup; counts go to cnt[real][n_sys][3] (u32 atomics)
@@ -1970,9 +2012,11 @@ hipError_t configure_kernels(const SimDims &) {
                                            static_cast<int>(kLdsPerCu));
         if (e != hipSuccess) return e;
     }
-    // k_sweep_slab also has a few static LDS words: leave room for them
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_slab), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               static_cast<int>(kLdsPerCu) - 1024);
+    for (const void *fn : {reinterpret_cast<const void *>(k_sweep_slab<false>), reinterpret_cast<const void *>(k_sweep_slab<true>)}) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsPerCu));
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_rng(const SimDims &d, const DevPtrs &p, bool gibbs, hipStream_t stream) {
@@ -2039,16 +2083,23 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
     return hipGetLastError();
 }
 
+// spins of the slab and its two halo planes, then the record / plane rings (sized for the heat bath) and control words
+size_t sweep_slab_lds_bytes_for(uint32_t own_sites, uint32_t plane_sites, uint32_t n_levels) {
+    return (static_cast<size_t>(own_sites) + 2 * static_cast<size_t>(plane_sites) + kSlabDepth * 256 * 7 + 8 + 2 * n_levels) * 4;
+}
 size_t sweep_slab_lds_bytes(const SimDims &d) {
-    return d.pipe_K ? (static_cast<size_t>(d.N) / d.pipe_K + 2 * static_cast<size_t>(d.plane)) * 4 : 0;
+    return d.pipe_K ? sweep_slab_lds_bytes_for(d.N / d.pipe_K, d.plane, d.n_levels) : 0;
 }
 
 hipError_t launch_sweep_pipe(const SimDims &d, const DevPtrs &p, bool gibbs, uint32_t epoch,
                              hipStream_t stream) {
     const uint32_t n_tw_pad = (d.n_real * d.W + 7u) & ~7u;
-    if (d.pipe_lds)
-        hipLaunchKernelGGL(k_sweep_slab, dim3(n_tw_pad * d.pipe_K), dim3(256), sweep_slab_lds_bytes(d), stream, d, p,
-                           gibbs ? 1 : 0, epoch, n_tw_pad);
+    if (d.pipe_lds && gibbs)
+        hipLaunchKernelGGL(k_sweep_slab<true>, dim3(n_tw_pad * d.pipe_K), dim3(kSlabThreads), sweep_slab_lds_bytes(d),
+                           stream, d, p, epoch, n_tw_pad);
+    else if (d.pipe_lds)
+        hipLaunchKernelGGL(k_sweep_slab<false>, dim3(n_tw_pad * d.pipe_K), dim3(kSlabThreads), sweep_slab_lds_bytes(d),
+                           stream, d, p, epoch, n_tw_pad);
     else
         hipLaunchKernelGGL(k_sweep_pipe, dim3(n_tw_pad * d.pipe_K), dim3(256), 0, stream, d, p,
                            gibbs ? 1 : 0, epoch, n_tw_pad);

@@ -69,6 +69,9 @@ struct pa_sim {
     uint32_t *thr_gibbs = nullptr; // built by the first Gibbs sample (ensure_gibbs)
     uint32_t *seg = nullptr;       // slab segments of the pipelined large-lattice sweep
     uint32_t *halo_sites = nullptr, *halo_start = nullptr; // k_sweep_slab tables
+    uint2 *slab_seg = nullptr;
+    uint32_t *pos_of = nullptr;
+    uint4 *recS = nullptr;
     std::vector<uint32_t> halo_sites_host, halo_start_host;
     uint32_t pipe_epoch = 1;       // bumped by every k_sweep_pipe launch (progress counters are monotone)
     std::vector<uint64_t> equil_sweeps; // checkpoints of the last sample() with the equilibration diagnostic
@@ -330,13 +333,14 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
         q.thr_f += tile_words * 32 * r0;
         q.xw += tile_words * (d.nn <= 3 ? 4 : 8) * r0;
     } else {
-        q.planes += tile_words * r0;
+        q.planes += static_cast<size_t>(d.planes_stride) * d.W * r0;
     }
     q.cursor += static_cast<size_t>(8) * d.SP * r0;
     q.system_ids += static_cast<size_t>(d.n_sys) * r0;
     q.slot_of += static_cast<size_t>(d.n_sys) * r0;
     q.mpar += static_cast<size_t>(d.MW) * r0;
     q.rec += (static_cast<size_t>(d.N) + 1) * (d.big ? 2 : 1) * r0;
+    if (d.pipe_lds) q.recS += static_cast<size_t>(d.planes_stride) * r0;
     if (d.pipe_K) q.progress += static_cast<size_t>(d.W) * d.pipe_K * r0;
 
     q.big_counts += static_cast<size_t>(4) * d.n_sys * r0;
@@ -452,13 +456,13 @@ int ensure_gibbs(pa_sim *sim) {
             if (2 * j + 1 <= 2 * off - 1) thr[(7 + j) * d.n_temps + t] = table[t * width + 2 * off - 1 - 2 * j]; // 2z' - 1 - 2j
         }
     PA_HIP(sim, sim->buffers.alloc(&sim->thr_gibbs, thr.size()));
-    PA_HIP(sim, sim->buffers.alloc(&sim->p.planes_hi, static_cast<size_t>(d.N) * d.W * d.n_real));
+    PA_HIP(sim, sim->buffers.alloc(&sim->p.planes_hi, static_cast<size_t>(d.planes_stride) * d.W * d.n_real));
     if (int rc = upload(sim, sim->thr_gibbs, thr)) return rc;
     sim->p.thr_gibbs = sim->thr_gibbs;
     uint32_t r0 = 0;
     for (auto &g : sim->groups) {
         g.p.thr_gibbs = sim->thr_gibbs;
-        g.p.planes_hi = sim->p.planes_hi + static_cast<size_t>(d.N) * d.W * r0;
+        g.p.planes_hi = sim->p.planes_hi + static_cast<size_t>(d.planes_stride) * d.W * r0;
         r0 += g.d.n_real;
     }
     return PA_OK;
@@ -1229,7 +1233,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         auto build_halo = [&](uint32_t slabs) -> bool {
             if (slabs < 2 || lat.shape[0] % slabs != 0 || !admissible(slabs)) return false;
             const uint32_t own = d.N / slabs;
-            if ((static_cast<size_t>(own) + 2 * plane) * 4 > 150 * 1024) return false;
+            if (sweep_slab_lds_bytes_for(own, plane, n_levels) > 160 * 1024) return false;
             halo_sites.assign(static_cast<size_t>(slabs) * 2 * plane, 0u);
             halo_start.assign(static_cast<size_t>(slabs) * (n_levels + 2), 0u);
             const uint32_t unset = 0xFFFFFFFFu;
@@ -1371,6 +1375,49 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     }
     d.dense_nn = all_nonzero ? d.nn : 0;
 
+    // ---- k_sweep_slab streams its inputs in schedule order: per (level, slab) segment, padded to
+    // start at a multiple of four entries (16-byte aligned pieces for the LDS-DMA loads)
+    d.planes_stride = d.N;
+    std::vector<uint2> slab_seg;
+    std::vector<uint32_t> pos_of;
+    std::vector<uint4> recS;
+    if (d.pipe_lds) {
+        const uint32_t K = d.pipe_K, own = d.N / K, P = d.plane;
+        slab_seg.assign(static_cast<size_t>(n_levels) * K, make_uint2(0u, 0u));
+        pos_of.assign(d.N, 0u);
+        std::vector<uint32_t> padded_of_pos(d.N, 0u);
+        uint32_t cursor = 0;
+        for (uint32_t l = 0; l < n_levels; ++l)
+            for (uint32_t k = 0; k < K; ++k) {
+                const uint32_t b = seg[static_cast<size_t>(l) * (K + 1) + k], e = seg[static_cast<size_t>(l) * (K + 1) + k + 1];
+                cursor = (cursor + 3u) & ~3u;
+                slab_seg[static_cast<size_t>(l) * K + k] = make_uint2(cursor, e - b);
+                for (uint32_t pos = b; pos < e; ++pos) {
+                    padded_of_pos[pos] = cursor + (pos - b);
+                    pos_of[order[pos]] = cursor + (pos - b);
+                }
+                cursor += e - b;
+            }
+        d.planes_stride = ((cursor + 3u) & ~3u) + 512; // room for the loader's fixed-size pieces past the last segment
+        recS.assign(static_cast<size_t>(d.n_real) * d.planes_stride, make_uint4(0u, 0u, 0u, 0u));
+        for (uint32_t real = 0; real < d.n_real; ++real)
+            for (uint32_t pos = 0; pos < d.N; ++pos) {
+                const uint4 r0 = rec[static_cast<size_t>(real) * rec_stride + 2 * pos];
+                const uint4 r1 = rec[static_cast<size_t>(real) * rec_stride + 2 * pos + 1];
+                const uint32_t site = r0.x, k = site / own, a = k * own;
+                const uint32_t lo0 = (a + d.N - P) % d.N, hi0 = (a + own) % d.N;
+                auto loc = [&](uint32_t j) -> uint32_t { // LDS word: own range, lower halo plane, upper halo plane
+                    if (j >= a && j < a + own) return j - a;
+                    const uint32_t rl = (j + d.N - lo0) % d.N;
+                    if (rl < P) return own + rl;
+                    return own + P + (j + d.N - hi0) % d.N;
+                };
+                const uint32_t f[8] = {loc(site), loc(r0.y), loc(r0.z), loc(r0.w), loc(r1.x), loc(r1.y), loc(r1.z), r1.w};
+                recS[static_cast<size_t>(real) * d.planes_stride + padded_of_pos[pos]] =
+                    make_uint4(f[0] | (f[1] << 16), f[2] | (f[3] << 16), f[4] | (f[5] << 16), f[6] | (f[7] << 16));
+            }
+    }
+
     // ---- jump tables T^(b*BS), b = 0..B-1
     std::vector<uint32_t> jump(static_cast<size_t>(d.B) * 64 * 16 * 8);
     {
@@ -1426,15 +1473,20 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     if (d.pipe_lds) {
         ok(bufs.alloc(&sim->halo_sites, sim->halo_sites_host.size()));
         ok(bufs.alloc(&sim->halo_start, sim->halo_start_host.size()));
+        ok(bufs.alloc(&sim->slab_seg, slab_seg.size()));
+        ok(bufs.alloc(&sim->pos_of, pos_of.size()));
+        ok(bufs.alloc(&sim->recS, recS.size()));
     }
     if (d.pipe_K) {
         ok(bufs.alloc(&sim->seg, seg.size()));
         ok(bufs.alloc(&p.progress, static_cast<size_t>(d.n_real) * d.W * d.pipe_K));
+        ok(bufs.alloc(&p.slab_scratch, static_cast<size_t>((d.n_real * d.W + 7u) & ~7u) * d.pipe_K * 4));
+        ok(bufs.alloc(&p.slab_error, 4));
     }
     ok(bufs.alloc(&p.swap_epoch, static_cast<size_t>(d.n_real)));
 
     ok(bufs.alloc(&p.applied_epoch, static_cast<size_t>(d.n_real) * d.W));
-    ok(bufs.alloc(&p.planes, d.general ? 1 : tile_words * d.n_real));
+    ok(bufs.alloc(&p.planes, d.general ? 1 : static_cast<size_t>(d.planes_stride) * d.W * d.n_real));
     if (d.general) {
         ok(bufs.alloc(&sim->Jf, n_coup * d.n_real));
         ok(bufs.alloc(&sim->temps_dev, static_cast<size_t>(d.n_temps)));
@@ -1490,13 +1542,20 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     p.seg = sim->seg;
     p.halo_sites = sim->halo_sites;
     p.halo_start = sim->halo_start;
+    p.slab_seg = sim->slab_seg;
+    p.pos_of = sim->pos_of;
+    p.recS = sim->recS;
     if (d.pipe_lds) {
         if ((rc = upload(sim, sim->halo_sites, sim->halo_sites_host))) return bail(rc);
         if ((rc = upload(sim, sim->halo_start, sim->halo_start_host))) return bail(rc);
+        if ((rc = upload(sim, sim->slab_seg, slab_seg))) return bail(rc);
+        if ((rc = upload(sim, sim->pos_of, pos_of))) return bail(rc);
+        if ((rc = upload(sim, sim->recS, recS))) return bail(rc);
     }
     if (d.pipe_K) {
         if ((rc = upload(sim, sim->seg, seg))) return bail(rc);
-        if (hipMemsetAsync(p.progress, 0, sizeof(uint32_t) * d.n_real * d.W * d.pipe_K, sim->stream) != hipSuccess) {
+        if (hipMemsetAsync(p.progress, 0, sizeof(uint32_t) * d.n_real * d.W * d.pipe_K, sim->stream) != hipSuccess ||
+            hipMemsetAsync(p.slab_error, 0, sizeof(uint32_t) * 4, sim->stream) != hipSuccess) {
             sim->error = "hipMemsetAsync failed";
             return bail(PA_ERR_DEVICE);
         }
@@ -1563,6 +1622,11 @@ void pa_sim_request_interrupt(pa_sim *sim) { sim->interrupt.store(true); }
 int pa_sim_synchronize(pa_sim *sim) {
     PA_HIP(sim, hipSetDevice(sim->device));
     PA_HIP(sim, hipStreamSynchronize(sim->stream));
+    if (sim->d.pipe_lds) { // a slab workgroup that gave up waiting leaves the state unusable: say so
+        uint32_t gave_up = 0;
+        PA_HIP(sim, hipMemcpy(&gave_up, sim->p.slab_error, sizeof(gave_up), hipMemcpyDeviceToHost));
+        if (gave_up) return fail(sim, PA_ERR_DEVICE, "a slab of the pipelined sweep gave up waiting for its predecessor");
+    }
     return PA_OK;
 }
 

@@ -80,7 +80,10 @@ struct DevPtrs {
     uint32_t *slab_scratch;  // [workgroups][4] dummy store target of sweep waves without sites at a level
     uint32_t *slab_error;    // [1] set when a slab gave up waiting for its predecessor
     const uint4 *recS;       // [n_real][planes_stride] by padded position: 8 x u16 = LDS word of the site and of
-                             //   f0,b0,f1,b1,f2,b2, then jmeta
+                             //   f0,b0,f1,b1,f2,b2 (for a new value of another slab: the value word of its staged exchange record), then jmeta
+    const uint32_t *xportS;  // [planes_stride] by padded position: 1 + exchange record the site's new value goes to, or 0
+    uint4 *xchg;             // [n_real * W][pipe_K][2 * plane] exchange records {value, tag, value ^ tag, ~tag} in the
+                             //   order of the reading slab's staged entries; tag = epoch base + level + 1
     const uint32_t *jump;    // [B][64][16][8] nibble tables of T^(b*BS)
     int32_t *Esum;           // [n_real][n_sys] by slot: sum_{i,d} J s s (exact integer)
     int32_t *Msum;           // [n_real][n_sys] by slot: sum_i s_i
@@ -152,6 +155,14 @@ struct ClusterAux {
     uint32_t kind;     // obs_acc row: 0 fk, 1 houdayer, 2 jorg, 3 cmr_blue
     uint32_t square;   // 1: canonical 2D hypercubic lattice -> winding is measured (lattice.rs:31-38)
 };
+
+// k_sweep_slab: ring depths and the LDS word where the staged exchange records begin (the host writes the
+// word of a staged neighbour's value into the site records)
+constexpr uint32_t kSlabDepth = 5; // levels of records / planes / export targets resident in the ring
+constexpr uint32_t kSlabStage = 4; // levels of staged exchange records, 128 records of 4 words each
+__host__ __device__ inline uint32_t slab_stage_word(uint32_t own_sites, uint32_t plane_sites) {
+    return own_sites + 2 * plane_sites + kSlabDepth * 256 * 7;
+}
 
 struct PtParams {
     int32_t schedule;     // PA_PT_*

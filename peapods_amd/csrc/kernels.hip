@@ -1647,26 +1647,29 @@ __global__ __launch_bounds__(256) void k_sweep_pipe(SimDims d, DevPtrs p, int gi
 // store + drain).  Here a slab of whole hyperplanes (own = N / pipe_K sites) is loaded once and
 // swept in place level by level like the on-chip kernel: neighbours inside the slab come from the
 // LDS, and a level costs one workgroup barrier.  What crosses workgroups is kept off that path:
-//   * inputs that do not depend on the spins -- the site records (LDS word of the site and of its
-//     six neighbours, coupling metadata) and the acceptance planes k_rng filed in schedule order --
-//     are streamed by a fifth wave with LDS-DMA loads into a ring kSlabDepth levels deep; the
-//     four sweep waves never wait for memory;
-//   * every site is stored to S_next as it is decided (one store instruction per wave and level,
-//     so that `s_waitcnt vmcnt(2)` means "the stores of two levels ago are in the L2": stores of a
-//     wave retire in order), and the slab's progress counter follows two levels behind;
-//   * the lower halo plane holds NEW values of the slab below (for the last slab also the first
-//     plane of slab 0, through the periodic wrap).  They are fetched in batches: one look at the
-//     predecessor's counter tells how many levels may be run, every halo site those levels read
-//     is fetched at once (halo_sites is ordered by the level that first needs a site), and no
-//     further global access happens until that allowance is used up.
+//   * inputs that do not depend on the spins -- the 16-byte site records (LDS word of the site and of
+//     its six neighbours, coupling metadata), the acceptance planes k_rng filed in schedule order
+//     and the export targets -- are streamed by a fifth wave with LDS-DMA loads into a ring
+//     kSlabDepth levels deep; the four sweep waves never wait for them;
+//   * a site whose new value another slab reads (the top plane; slab 0's first plane, through the
+//     periodic wrap) also writes an EXCHANGE RECORD {value, tag, value ^ tag, ~tag}, tag = epoch
+//     base + level + 1, at the position the reading slab will look for it.  A record is valid iff
+//     its tag belongs to this sweep and the two check words agree, so value and "ready" travel in
+//     one 16-byte access: no progress counter, no store drain, one round trip;
+//   * the reading slab's sixth wave fetches the records of level l + 3 speculatively with LDS-DMA while
+//     level l runs (into a staging ring; the site record of a reader holds the LDS word its staged
+//     neighbour will occupy).  One level before use the records are validated; if the
+//     producer was not that far ahead yet, the level's group is re-read until it is (bounded).
+//     A slab therefore settles a few levels behind its predecessor and then runs at on-chip speed.
 // The upper halo plane (and slab 0's lower one) carries OLD values and is loaded with the slab.
 // Host-checked: every outside neighbour lies in one of the two halo planes, is either always newer
-// or always older than the slab's sites that read it, and level(j) + m <= level(i) across m slabs.
-// Barriers are raw s_barrier + lgkmcnt(0): a __syncthreads() would drain the DMA ring (its fence
-// waits vmcnt(0) while an LDS-DMA is pending).
+// or always older than the slab's sites that read it, a new value is read at exactly one level, and
+// level(j) + m <= level(i) across m slabs.  Barriers are raw s_barrier + lgkmcnt(0): a
+// __syncthreads() would drain the DMA rings (its fence waits vmcnt(0) while an LDS-DMA is pending).
+// Counted vmcnt waits rely on vector-memory operations of a wave retiring in issue order.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kSlabDepth = 8;     // levels of records and planes resident in the ring
-constexpr uint32_t kSlabThreads = 320; // four sweep waves + the loader wave
+// (kSlabDepth, kSlabStage: engine.hpp -- the host writes LDS word indices of staged records into the site records)
+constexpr uint32_t kSlabThreads = 384; // four sweep waves, the loader wave (inputs), the fetcher wave (exchange records)
 
 __device__ __forceinline__ void slab_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // LDS read the compiler does not see (an ordinary read would make it wait for every pending DMA)
@@ -1678,13 +1681,25 @@ __device__ __forceinline__ uint32_t lds_peek(const uint32_t *ptr) {
                  : "memory");
     return v;
 }
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); // a 128-bit register operand for inline asm
+__device__ __forceinline__ uint4 lds_peek4(const uint32_t *ptr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                 : "=v"(v)
+                 : "v"(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ptr)))
+                 : "memory");
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ bool exchange_valid(const uint4 r, uint32_t base, uint32_t n_levels) {
+    return (r.y - base - 1u) < n_levels && r.z == (r.x ^ r.y) && r.w == ~r.y;
+}
 
 template <bool GIBBS>
 __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs p, uint32_t epoch, uint32_t n_tw_pad) {
     typedef __attribute__((address_space(1))) const void GlobalPtr;
     typedef __attribute__((address_space(3))) void LdsPtr;
-    constexpr uint32_t D = kSlabDepth;
-    constexpr uint32_t G = GIBBS ? 7 : 6; // DMA instructions per level: 4 records, 2 planes (+ 1 third plane)
+    constexpr uint32_t D = kSlabDepth, R = kSlabStage;
+    constexpr uint32_t G = GIBBS ? 8 : 7; // loader DMA instructions per level: 4 records, 2 planes, 1 export targets (+ 1 third plane)
     extern __shared__ uint32_t lds[];
     // (block-uniform values made scalar so that table reads indexed by them are scalar loads)
     const uint32_t tw = __builtin_amdgcn_readfirstlane(blockIdx.x % n_tw_pad);
@@ -1701,24 +1716,23 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
     const uint2 *planes = p.planes + static_cast<size_t>(tw) * d.planes_stride;
     const uint32_t *planes_hi = GIBBS ? p.planes_hi + static_cast<size_t>(tw) * d.planes_stride : nullptr;
     const uint4 *recS = p.recS + static_cast<size_t>(real) * d.planes_stride;
-    uint32_t *progress = p.progress + static_cast<size_t>(tw) * K;
-    const uint32_t *halo = p.halo_sites + static_cast<size_t>(k) * 2 * P;
-    const uint32_t *halo_start = p.halo_start + static_cast<size_t>(k) * (d.n_levels + 2);
+    uint4 *xchg = p.xchg + static_cast<size_t>(tw) * K * 2 * P;       // this word's exchange records, by reading slab
+    const uint4 *xin = xchg + static_cast<size_t>(k) * 2 * P;         // the records this slab reads
+    const uint32_t *halo_start_g = p.halo_start + static_cast<size_t>(k) * (d.n_levels + 2);
     const uint32_t live = d.n_sys - w * 32;
     const uint32_t valid_bits = live >= 32 ? 0xFFFFFFFFu : ((1u << live) - 1u);
     const uint32_t base = epoch * (d.n_levels + 1);
-    // one LDS array: spins (own, lower halo, upper halo), the three rings, control words
-    uint32_t *ring_rec = lds + own + 2 * P;           // [D][256][4]
-    uint32_t *ring_pl = ring_rec + D * 256 * 4;       // [D][256][2]
-    uint32_t *ring_hi = ring_pl + D * 256 * 2;        // [D][256] (heat bath)
-    uint32_t *ctl = ring_hi + (GIBBS ? D * 256 : 0);  // 0 allowance, 1 gave up, 2 first level, 3 last level, 4 new allowance
-    uint32_t *segs = ctl + 8;                         // [n_levels][2] (first padded position, sites) of this slab
-    auto loc = [&](uint32_t j) -> uint32_t { // LDS word of an outside site (halo fetches)
-        const uint32_t r = j - lo0;
-        return r < P ? own + r : own + P + (j - hi0);
-    };
+    // one LDS array: spins (own, lower halo, upper halo), the rings, the staged records, control words
+    uint32_t *ring_rec = lds + own + 2 * P;          // [D][256][4]
+    uint32_t *ring_pl = ring_rec + D * 256 * 4;      // [D][256][2]
+    uint32_t *ring_x = ring_pl + D * 256 * 2;        // [D][256] export targets
+    uint32_t *stage = ring_x + D * 256;              // [R][128][4] exchange records of the levels ahead (= slab_stage_word())
+    uint32_t *ctl = stage + R * 128 * 4;             // 1 gave up, 2 first level, 3 last level, 8 + s: group in stage slot s incomplete
+    uint32_t *segs = ctl + 16;                       // [n_levels][2] (first padded position, sites) of this slab
+    uint32_t *halo_start = segs + 2 * d.n_levels;    // [n_levels + 2] first staged entry of every level (copy of the table)
+    uint32_t *ring_hi = halo_start + d.n_levels + 2; // [D][256] third acceptance plane (heat bath)
     for (uint32_t i = tid; i < own; i += kSlabThreads) lds[i] = Sold[a + i];
-    for (uint32_t i = tid; i < P; i += kSlabThreads) {
+    for (uint32_t i = tid; i < P; i += kSlabThreads) { // (only the planes read as OLD values are ever used)
         lds[own + i] = Sold[lo0 + i];
         lds[own + P + i] = Sold[hi0 + i];
     }
@@ -1727,17 +1741,14 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
         segs[2 * l] = sg.x;
         segs[2 * l + 1] = sg.y;
     }
-    if (tid == 0) {
-        ctl[0] = k == 0 ? d.n_levels : 0u; // levels <= allowance may run: the predecessor has completed that many
-        ctl[1] = 0;
-        ctl[2] = d.n_levels;
-        ctl[3] = 0;
-    }
+    for (uint32_t l = tid; l < d.n_levels + 2; l += kSlabThreads) halo_start[l] = halo_start_g[l];
+    if (tid < 16) ctl[tid] = 0;
+    if (tid == 0) ctl[2] = d.n_levels;
     __syncthreads();
     { // the slab's levels: first to last with a non-empty segment
         uint32_t first = d.n_levels, last = 0;
         for (uint32_t l = tid; l < d.n_levels; l += kSlabThreads)
-            if (p.slab_seg[l * K + k].y != 0) {
+            if (segs[2 * l + 1] != 0) {
                 first = min(first, l);
                 last = max(last, l);
             }
@@ -1747,17 +1758,14 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
         }
     }
     __syncthreads();
-    // (made scalar: the per-level table reads below must be scalar loads -- a vector load would put the
-    // sweep waves' stores and the loader's DMA pieces behind a vmcnt(0))
+    // (made scalar: loop bounds and everything derived from them stay in SGPRs)
     const uint32_t first = __builtin_amdgcn_readfirstlane(ctl[2]), last = __builtin_amdgcn_readfirstlane(ctl[3]);
-    if (first > last) { // a slab without sites: nothing to do, nobody waits for less than everything
-        if (tid == 0) __hip_atomic_store(&progress[k], base + d.n_levels, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
+    if (first > last) return; // a slab without sites
+    const bool reads_others = __builtin_amdgcn_readfirstlane(halo_start[d.n_levels + 1]) != 0; // slab 0 stages nothing
     __syncthreads(); // the last ordinary barrier: from here on DMA loads stay in flight across barriers
 
-    if (tid >= 256) {
-        // ================= loader wave: records and planes of level L -> ring slot (L - first) % D
+    if (tid >= 256 && tid < 320) {
+        // ================= loader wave: inputs of level L -> ring slot (L - first) % D
         const uint32_t lane = tid - 256;
         auto issue = [&](uint32_t L) {
             const uint32_t slot = (L - first) % D;
@@ -1770,91 +1778,133 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
             for (uint32_t q = 0; q < 2; ++q)
                 __builtin_amdgcn_global_load_lds((GlobalPtr *)(planes + begin + q * 128 + 2 * lane),
                                                  (LdsPtr *)(ring_pl + (slot * 256 + q * 128) * 2), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((GlobalPtr *)(p.xportS + begin + 4 * lane), (LdsPtr *)(ring_x + slot * 256), 16, 0, 0);
             if (GIBBS)
                 __builtin_amdgcn_global_load_lds((GlobalPtr *)(planes_hi + begin + 4 * lane),
                                                  (LdsPtr *)(ring_hi + slot * 256), 16, 0, 0);
         };
         for (uint32_t L = first; L < first + D - 1; ++L) issue(L);
+        slab_barrier(); // matches the sweep waves' barrier after their first exchange fetches
         for (uint32_t level = first; level <= last; ++level) {
             // the pieces of `level` have landed once only the D - 2 younger groups are outstanding
             __builtin_amdgcn_s_waitcnt(0x0F70 | (((D - 2) * G) & 0xF) | ((((D - 2) * G) >> 4) << 14));
             slab_barrier(); // X(level)
-            if (k > 0 && lds_peek(&ctl[0]) < level) { // the sweep waves refill their allowance: same barriers
+            if (reads_others && lds_peek(&ctl[8 + level % R])) { // the sweep waves re-read the level's group: same barriers
                 slab_barrier();
                 if (lds_peek(&ctl[1])) return;
-                slab_barrier();
             }
             issue(level + D - 1); // into the slot read during level - 1 (those reads retired before X(level))
         }
         __builtin_amdgcn_s_waitcnt(0x0F70); // nothing of this wave may still be writing the LDS at exit
-        slab_barrier();                     // matches the sweep waves' final barrier
+        return;
+    }
+
+    if (tid >= 320) {
+        // ================= fetcher wave: exchange records first read at level L -> staging slot L % R (128 entries)
+        if (!reads_others) { // nothing to stage: only keep the barriers company
+            slab_barrier();
+            for (uint32_t level = first; level <= last; ++level) slab_barrier();
+            return;
+        }
+        const uint32_t lane = tid - 320;
+        auto stage_fetch = [&](uint32_t L) {
+            const uint32_t e0 = L <= last ? lds_peek(&halo_start[L]) : 0u;
+            // (aux 16 = sc1: agent scope, past the CU's L1 -- the records are written while this kernel runs)
+#pragma unroll
+            for (uint32_t q = 0; q < 2; ++q)
+                __builtin_amdgcn_global_load_lds((GlobalPtr *)(xin + e0 + q * 64 + lane),
+                                                 (LdsPtr *)(stage + ((L % R) * 128 + q * 64) * 4), 16, 0, 16);
+        };
+        stage_fetch(first);
+        stage_fetch(first + 1);
+        stage_fetch(first + 2);
+        __builtin_amdgcn_s_waitcnt(0x0F70); // the first groups are simply waited for
+        slab_barrier();
+        for (uint32_t level = first; level <= last; ++level) {
+            // the group of level + 1 (fetched two levels ago) has landed once only the group of level + 2 is outstanding
+            __builtin_amdgcn_s_waitcnt(0x0F70 | 2u);
+            slab_barrier(); // X(level)
+            if (lds_peek(&ctl[8 + level % R])) { // the sweep waves re-read the level's group: same barrier
+                slab_barrier();
+                if (lds_peek(&ctl[1])) return;
+            }
+            stage_fetch(level + 3);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         return;
     }
 
     // ================= sweep waves
-    uint32_t *scratch = p.slab_scratch + (static_cast<size_t>(blockIdx.x) * 4 + (tid >> 6)); // idle waves store here
-    uint32_t fetched = halo_start[0]; // halo entries below this cursor are in the LDS
+    slab_barrier(); // the fetcher's first three groups are in the staging ring
+    if (reads_others && tid < 128) { // validate them
+        for (uint32_t L = first; L < first + 3 && L <= last; ++L) {
+            const uint32_t n_h = halo_start[L + 1] - halo_start[L];
+            if (tid < n_h && !exchange_valid(*reinterpret_cast<const uint4 *>(stage + ((L % R) * 128 + tid) * 4), base, d.n_levels))
+                ctl[8 + L % R] = 1;
+        }
+    }
     for (uint32_t level = first; level <= last; ++level) {
-        slab_barrier(); // X(level): the ring slot of this level is ready, last level's spins are visible
-        // every wave left level - 1 with at most two stores in flight: levels <= level - 3 are in the L2
-        if (tid == 0 && level >= 2)
-            __hip_atomic_store(&progress[k], base + level - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (k > 0 && ctl[0] < level) { // (ctl[0] changes only between the second barrier below and the next X)
-            // ---- allowance used up: wait for the predecessor, then fetch every halo site the allowed levels read
-            if (tid == 0) {
-                uint32_t spins = 0, seen;
-                for (;;) { // the predecessor's count of completed levels (earlier epochs read as negative)
-                    seen = __hip_atomic_load(&progress[k - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
-                    if (static_cast<int32_t>(seen) >= static_cast<int32_t>(level)) break; // levels < level done
+        slab_barrier(); // X(level): the ring slot of this level is ready, last level's spins and flags are visible
+        const uint32_t sslot = level % R;
+        if (reads_others && ctl[8 + sslot]) {
+            // ---- the producer was not far enough ahead when this level's records were fetched: read them again
+            const uint32_t e0 = halo_start[level], n_h = halo_start[level + 1] - e0;
+            if (tid < n_h) {
+                uint32_t spins = 0;
+                for (;;) {
+                    u32x4 raw;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(raw) : "v"(xin + e0 + tid) : "memory");
+                    const uint4 r = make_uint4(raw.x, raw.y, raw.z, raw.w);
+                    if (exchange_valid(r, base, d.n_levels)) {
+                        *reinterpret_cast<uint4 *>(stage + (sslot * 128 + tid) * 4) = r;
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 24)) { // never reached unless a predecessor died: leave
+                    if (++spins > (1u << 22)) { // never reached unless the producer died: leave
                         ctl[1] = 1;
-                        seen = d.n_levels;
                         break;
                     }
                 }
-                ctl[4] = min(seen, d.n_levels); // the new allowance; ctl[0] itself moves after the second barrier
             }
             slab_barrier();
             if (ctl[1]) {
                 if (tid == 0) atomicExch(p.slab_error, 1u);
                 return;
             }
-            const uint32_t allowed = ctl[4];
-            const uint32_t upto = halo_start[allowed + 1]; // first read at a level <= allowance: decided and in the L2
-            for (uint32_t e = fetched + tid; e < upto; e += 256) {
-                const uint32_t j = halo[e];
-                lds[loc(j)] = coherent_load(Snew + j);
-            }
-            fetched = upto;
-            drain_global_stores(); // back to "only stores in flight" for the counted wait below
-            slab_barrier();
-            if (tid == 0) ctl[0] = allowed;
         }
+        // the flag of level - 1 is free for the group of level + R - 1 (every wave read it before passing X(level))
+        if (tid == 0) ctl[8 + (level + R - 1) % R] = 0;
+        // ---- this level's sites
         const uint32_t slot = (level - first) % D;
         const uint32_t count = segs[2 * level + 1];
         if (tid < count) {
             const uint4 r = *reinterpret_cast<const uint4 *>(ring_rec + (slot * 256 + tid) * 4);
             const uint2 lv = *reinterpret_cast<const uint2 *>(ring_pl + (slot * 256 + tid) * 2);
+            const uint32_t target = ring_x[slot * 256 + tid];
             const uint32_t at = r.x & 0xFFFFu;
+            // (a neighbour in another slab is the value word of its staged exchange record: the host wrote that LDS word)
             uint32_t nb[6] = {lds[r.x >> 16],     lds[r.y & 0xFFFFu], lds[r.y >> 16],
                               lds[r.z & 0xFFFFu], lds[r.z >> 16],     lds[r.w & 0xFFFFu]};
             const uint32_t jm = r.w >> 16;
             const uint32_t sv = lds[at];
             const uint32_t acc = (GIBBS ? accept_mask_gibbs(sv, nb, jm, d.nn, lv.x, lv.y, ring_hi[slot * 256 + tid])
                                         : accept_mask(sv, nb, jm, lv.x, lv.y)) & valid_bits;
-            lds[at] = sv ^ acc;
-            coherent_store(Snew + a + at, sv ^ acc);
-        } else if ((tid & 63u) == 0 && (tid & ~63u) >= count) {
-            coherent_store(scratch, level); // a wave without sites still issues its one store of the level
+            const uint32_t value = sv ^ acc;
+            lds[at] = value;
+            coherent_store(Snew + a + at, value);
+            if (target) { // another slab reads this site: value and "ready" in one 16-byte record
+                const uint32_t tag = base + level + 1;
+                const u32x4 record = {value, tag, value ^ tag, ~tag};
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(xchg + (target - 1)), "v"(record) : "memory");
+            }
         }
-        // one store per wave and level, retired in order: at most two outstanding <=> level - 2 and older are done
-        __builtin_amdgcn_s_waitcnt(0x0F70 | 2u);
+        // ---- validate the group of level + 1 (landed before X(level): the fetcher waited for it)
+        if (reads_others && level + 1 <= last && level + 1 >= first + 3) { // (the first three were validated before the loop)
+            const uint32_t L = level + 1, n_h = halo_start[L + 1] - halo_start[L];
+            if (tid < n_h && !exchange_valid(*reinterpret_cast<const uint4 *>(stage + ((L % R) * 128 + tid) * 4), base, d.n_levels))
+                ctl[8 + L % R] = 1;
+        }
     }
-    drain_global_stores();
-    slab_barrier();
-    if (tid == 0)
-        __hip_atomic_store(&progress[k], base + d.n_levels, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // chunk = 4096 schedule positions per workgroup; counts go to cnt[real][n_sys][3] (u32 atomics)
@@ -2084,8 +2134,11 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
 }
 
 // spins of the slab and its two halo planes, then the record / plane rings (sized for the heat bath) and control words
+// spins of the slab and its two halo planes, the input rings (sized for the heat bath), the staged exchange records,
+// control words and the slab's segment table
 size_t sweep_slab_lds_bytes_for(uint32_t own_sites, uint32_t plane_sites, uint32_t n_levels) {
-    return (static_cast<size_t>(own_sites) + 2 * static_cast<size_t>(plane_sites) + kSlabDepth * 256 * 7 + 8 + 2 * n_levels) * 4;
+    return (static_cast<size_t>(own_sites) + 2 * static_cast<size_t>(plane_sites) + kSlabDepth * 256 * 9 + kSlabStage * 128 * 4 + 16 +
+            3 * n_levels + 2) * 4;
 }
 size_t sweep_slab_lds_bytes(const SimDims &d) {
     return d.pipe_K ? sweep_slab_lds_bytes_for(d.N / d.pipe_K, d.plane, d.n_levels) : 0;

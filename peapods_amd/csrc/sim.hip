@@ -72,6 +72,7 @@ struct pa_sim {
     uint2 *slab_seg = nullptr;
     uint32_t *pos_of = nullptr;
     uint4 *recS = nullptr;
+    uint32_t *xportS = nullptr;
     std::vector<uint32_t> halo_sites_host, halo_start_host;
     uint32_t pipe_epoch = 1;       // bumped by every k_sweep_pipe launch (progress counters are monotone)
     std::vector<uint64_t> equil_sweeps; // checkpoints of the last sample() with the equilibration diagnostic
@@ -342,6 +343,7 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     q.rec += (static_cast<size_t>(d.N) + 1) * (d.big ? 2 : 1) * r0;
     if (d.pipe_lds) q.recS += static_cast<size_t>(d.planes_stride) * r0;
     if (d.pipe_K) q.progress += static_cast<size_t>(d.W) * d.pipe_K * r0;
+    if (d.pipe_lds) q.xchg += static_cast<size_t>(d.W) * d.pipe_K * 2 * d.plane * r0;
 
     q.big_counts += static_cast<size_t>(4) * d.n_sys * r0;
     q.Esum += static_cast<size_t>(d.n_sys) * r0;
@@ -1234,13 +1236,14 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
             if (slabs < 2 || lat.shape[0] % slabs != 0 || !admissible(slabs)) return false;
             const uint32_t own = d.N / slabs;
             if (sweep_slab_lds_bytes_for(own, plane, n_levels) > 160 * 1024) return false;
+            if (sweep_slab_lds_bytes_for(own, plane, n_levels) / 4 > 65536 || own < 2 * plane) return false; // 16-bit LDS words; a site feeds one slab
             halo_sites.assign(static_cast<size_t>(slabs) * 2 * plane, 0u);
             halo_start.assign(static_cast<size_t>(slabs) * (n_levels + 2), 0u);
             const uint32_t unset = 0xFFFFFFFFu;
             for (uint32_t k = 0; k < slabs; ++k) {
                 const uint32_t a = k * own, lo0 = (a + d.N - plane) % d.N, hi0 = (a + own) % d.N;
                 if (lo0 == hi0) return false; // the two halo planes must be distinct
-                std::vector<uint32_t> need_lo(plane, unset), need_hi(plane, unset);
+                std::vector<uint32_t> need_lo(plane, unset), need_hi(plane, unset), last_lo(plane, 0), last_hi(plane, 0);
                 std::vector<uint8_t> old_lo(plane, 0), old_hi(plane, 0);
                 for (uint32_t i = a; i < a + own; ++i)
                     for (uint32_t q = 0; q < d.nn; ++q)
@@ -1248,10 +1251,10 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
                             if (j >= a && j < a + own) continue;
                             const uint32_t rl = (j + d.N - lo0) % d.N, rh = (j + d.N - hi0) % d.N;
                             if (rl < plane) {
-                                if (j < i) need_lo[rl] = std::min(need_lo[rl], level[i]);
+                                if (j < i) need_lo[rl] = std::min(need_lo[rl], level[i]), last_lo[rl] = std::max(last_lo[rl], level[i]);
                                 else old_lo[rl] = 1;
                             } else if (rh < plane) {
-                                if (j < i) need_hi[rh] = std::min(need_hi[rh], level[i]);
+                                if (j < i) need_hi[rh] = std::min(need_hi[rh], level[i]), last_hi[rh] = std::max(last_hi[rh], level[i]);
                                 else old_hi[rh] = 1;
                             } else {
                                 return false;
@@ -1260,6 +1263,9 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
                 std::vector<std::pair<uint32_t, uint32_t>> wanted; // (level that first reads it, site)
                 for (uint32_t r = 0; r < plane; ++r) {
                     if ((need_lo[r] != unset && old_lo[r]) || (need_hi[r] != unset && old_hi[r])) return false;
+                    // a new value is staged for exactly one level: every reader of it must sit on that level
+                    if ((need_lo[r] != unset && last_lo[r] != need_lo[r]) || (need_hi[r] != unset && last_hi[r] != need_hi[r]))
+                        return false;
                     if (need_lo[r] != unset) wanted.emplace_back(need_lo[r], lo0 + r);
                     if (need_hi[r] != unset) wanted.emplace_back(need_hi[r], hi0 + r);
                 }
@@ -1270,6 +1276,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
                 for (uint32_t l = 0; l <= n_levels + 1; ++l) {
                     while (e < wanted.size() && wanted[e].first < l) ++e;
                     start[l] = static_cast<uint32_t>(e);
+                    if (l > 0 && start[l] - start[l - 1] > 128) return false; // staged entries of one level
                 }
                 for (size_t x = 0; x < wanted.size(); ++x)
                     halo_sites[static_cast<size_t>(k) * 2 * plane + x] = wanted[x].second;
@@ -1381,6 +1388,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     std::vector<uint2> slab_seg;
     std::vector<uint32_t> pos_of;
     std::vector<uint4> recS;
+    std::vector<uint32_t> xportS;
     if (d.pipe_lds) {
         const uint32_t K = d.pipe_K, own = d.N / K, P = d.plane;
         slab_seg.assign(static_cast<size_t>(n_levels) * K, make_uint2(0u, 0u));
@@ -1416,6 +1424,43 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
                 recS[static_cast<size_t>(real) * d.planes_stride + padded_of_pos[pos]] =
                     make_uint4(f[0] | (f[1] << 16), f[2] | (f[3] << 16), f[4] | (f[5] << 16), f[6] | (f[7] << 16));
             }
+        // New values from another slab are not read from a halo plane but from the staging ring the
+        // exchange records land in: neighbour field = 0x8000 | entry index within the level's group.
+        // xportS: where a site's exchange record goes (1 + record index; 0 = not read by another slab).
+        xportS.assign(d.planes_stride, 0u);
+        for (uint32_t k = 0; k < K; ++k) {
+            const uint32_t a = k * own;
+            const uint32_t *start = &sim->halo_start_host[static_cast<size_t>(k) * (n_levels + 2)];
+            const uint32_t n_entries = start[n_levels + 1];
+            std::vector<uint32_t> entry_of(d.N, 0xFFFFFFFFu);
+            for (uint32_t e = 0; e < n_entries; ++e) {
+                const uint32_t j = sim->halo_sites_host[static_cast<size_t>(k) * 2 * P + e];
+                entry_of[j] = e;
+                uint32_t &target = xportS[pos_of[j]];
+                if (target != 0) { // (excluded by own >= 2 planes; kept as a hard check)
+                    sim->error = "internal: a site would feed two slabs";
+                    return bail(PA_ERR_UNSUPPORTED);
+                }
+                target = 1 + k * 2 * P + e;
+            }
+            for (uint32_t i = a; i < a + own; ++i) {
+                uint32_t nbs[6];
+                for (uint32_t q = 0; q < 3; ++q) {
+                    nbs[2 * q] = q < d.nn ? lat.fwd[i * d.nn + q] : i;
+                    nbs[2 * q + 1] = q < d.nn ? lat.bwd[i * d.nn + q] : i;
+                }
+                for (uint32_t real = 0; real < d.n_real; ++real) {
+                    uint4 &r = recS[static_cast<size_t>(real) * d.planes_stride + pos_of[i]];
+                    uint32_t f[8] = {r.x & 0xFFFFu, r.x >> 16, r.y & 0xFFFFu, r.y >> 16, r.z & 0xFFFFu, r.z >> 16, r.w & 0xFFFFu, r.w >> 16};
+                    for (uint32_t q = 0; q < 6; ++q) {
+                        const uint32_t j = nbs[q];
+                        if (j < i && (j < a || j >= a + own) && entry_of[j] != 0xFFFFFFFFu)
+                            f[1 + q] = slab_stage_word(own, P) + ((level[i] % kSlabStage) * 128 + (entry_of[j] - start[level[i]])) * 4;
+                    }
+                    r = make_uint4(f[0] | (f[1] << 16), f[2] | (f[3] << 16), f[4] | (f[5] << 16), f[6] | (f[7] << 16));
+                }
+            }
+        }
     }
 
     // ---- jump tables T^(b*BS), b = 0..B-1
@@ -1476,11 +1521,13 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         ok(bufs.alloc(&sim->slab_seg, slab_seg.size()));
         ok(bufs.alloc(&sim->pos_of, pos_of.size()));
         ok(bufs.alloc(&sim->recS, recS.size()));
+        ok(bufs.alloc(&sim->xportS, xportS.size()));
+        ok(bufs.alloc(&p.xchg, static_cast<size_t>(d.n_real) * d.W * d.pipe_K * 2 * d.plane + 256));
     }
     if (d.pipe_K) {
         ok(bufs.alloc(&sim->seg, seg.size()));
         ok(bufs.alloc(&p.progress, static_cast<size_t>(d.n_real) * d.W * d.pipe_K));
-        ok(bufs.alloc(&p.slab_scratch, static_cast<size_t>((d.n_real * d.W + 7u) & ~7u) * d.pipe_K * 4));
+        ok(bufs.alloc(&p.slab_scratch, static_cast<size_t>((d.n_real * d.W + 7u) & ~7u) * d.pipe_K * 4 * 64 * 4));
         ok(bufs.alloc(&p.slab_error, 4));
     }
     ok(bufs.alloc(&p.swap_epoch, static_cast<size_t>(d.n_real)));
@@ -1545,12 +1592,19 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     p.slab_seg = sim->slab_seg;
     p.pos_of = sim->pos_of;
     p.recS = sim->recS;
+    p.xportS = sim->xportS;
     if (d.pipe_lds) {
         if ((rc = upload(sim, sim->halo_sites, sim->halo_sites_host))) return bail(rc);
         if ((rc = upload(sim, sim->halo_start, sim->halo_start_host))) return bail(rc);
         if ((rc = upload(sim, sim->slab_seg, slab_seg))) return bail(rc);
         if ((rc = upload(sim, sim->pos_of, pos_of))) return bail(rc);
         if ((rc = upload(sim, sim->recS, recS))) return bail(rc);
+        if ((rc = upload(sim, sim->xportS, xportS))) return bail(rc);
+        if (hipMemsetAsync(p.xchg, 0, sizeof(uint4) * (static_cast<size_t>(d.n_real) * d.W * d.pipe_K * 2 * d.plane + 256),
+                           sim->stream) != hipSuccess) {
+            sim->error = "hipMemsetAsync failed";
+            return bail(PA_ERR_DEVICE);
+        }
     }
     if (d.pipe_K) {
         if ((rc = upload(sim, sim->seg, seg))) return bail(rc);

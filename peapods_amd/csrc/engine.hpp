@@ -47,6 +47,7 @@ struct SimDims {
                          //    (kernels_general.hip); Esum then holds raw f32 bits of the energy sum
     uint32_t pipe_lds;   // 1: the slabs of the pipelined sweep keep their spins in the LDS (k_sweep_slab)
     uint32_t plane;      // sites of one hyperplane of the slowest dimension (halo window of a slab)
+    uint32_t slab_lead;  // k_sweep_slab: levels a slab starts behind the slab it reads from (tuning knob PEAPODS_SLAB_LEAD)
     uint32_t planes_stride; // entries of planes / planes_hi per (realisation, word): N, or the padded
                          //    schedule length when the slab kernel reads them in schedule order
 };
@@ -158,8 +159,9 @@ struct ClusterAux {
 
 // k_sweep_slab: ring depths and the LDS word where the staged exchange records begin (the host writes the
 // word of a staged neighbour's value into the site records)
-constexpr uint32_t kSlabDepth = 5; // levels of records / planes / export targets resident in the ring
-constexpr uint32_t kSlabStage = 4; // levels of staged exchange records, 128 records of 4 words each
+constexpr uint32_t kSlabDepth = 6; // levels of records / planes / export targets resident in the ring
+constexpr uint32_t kSlabAhead = 3; // exchange records are fetched this many levels ahead of their use (5: slower)
+constexpr uint32_t kSlabStage = kSlabAhead + 1; // levels of staged exchange records, 128 records of 4 words each
 __host__ __device__ inline uint32_t slab_stage_word(uint32_t own_sites, uint32_t plane_sites) {
     return own_sites + 2 * plane_sites + kSlabDepth * 256 * 7;
 }

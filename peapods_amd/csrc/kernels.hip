@@ -1658,7 +1658,7 @@ __global__ __launch_bounds__(256) void k_sweep_pipe(SimDims d, DevPtrs p, int gi
 //     one 16-byte access: no progress counter, no store drain, one round trip;
 //   * the reading slab's sixth wave fetches the records of level l + 3 speculatively with LDS-DMA while
 //     level l runs (into a staging ring; the site record of a reader holds the LDS word its staged
-//     neighbour will occupy).  One level before use the records are validated; if the
+//     neighbour will occupy).  The same wave validates a group one level before its use; if the
 //     producer was not that far ahead yet, the level's group is re-read until it is (bounded).
 //     A slab therefore settles a few levels behind its predecessor and then runs at on-chip speed.
 // The upper halo plane (and slab 0's lower one) carries OLD values and is loaded with the slab.
@@ -1784,10 +1784,13 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
                                                  (LdsPtr *)(ring_hi + slot * 256), 16, 0, 0);
         };
         for (uint32_t L = first; L < first + D - 1; ++L) issue(L);
-        slab_barrier(); // matches the sweep waves' barrier after their first exchange fetches
+        slab_barrier(); // matches the sweep waves' barrier after the fetcher's first groups
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (((D - 2) * G) & 0xF) | ((((D - 2) * G) >> 4) << 14)); // the first level's pieces
+        slab_barrier(); // the sweep waves pick the first level up
         for (uint32_t level = first; level <= last; ++level) {
-            // the pieces of `level` have landed once only the D - 2 younger groups are outstanding
-            __builtin_amdgcn_s_waitcnt(0x0F70 | (((D - 2) * G) & 0xF) | ((((D - 2) * G) >> 4) << 14));
+            // the pieces of `level + 1` have landed once only the D - 3 younger groups are outstanding: the sweep
+            // waves pick up the records of the next level at the end of this one
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (((D - 3) * G) & 0xF) | ((((D - 3) * G) >> 4) << 14));
             slab_barrier(); // X(level)
             if (reads_others && lds_peek(&ctl[8 + level % R])) { // the sweep waves re-read the level's group: same barriers
                 slab_barrier();
@@ -1803,6 +1806,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
         // ================= fetcher wave: exchange records first read at level L -> staging slot L % R (128 entries)
         if (!reads_others) { // nothing to stage: only keep the barriers company
             slab_barrier();
+            slab_barrier();
             for (uint32_t level = first; level <= last; ++level) slab_barrier();
             return;
         }
@@ -1815,38 +1819,93 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
                 __builtin_amdgcn_global_load_lds((GlobalPtr *)(xin + e0 + q * 64 + lane),
                                                  (LdsPtr *)(stage + ((L % R) * 128 + q * 64) * 4), 16, 0, 16);
         };
-        stage_fetch(first);
-        stage_fetch(first + 1);
-        stage_fetch(first + 2);
+        // is the landed group of level L complete?  -> ctl[8 + L % R] (read by every wave after X(L)); this wave
+        // reads what its own DMA wrote, ordered by its own counted wait
+        auto validate = [&](uint32_t L) {
+            const uint32_t n_h = L <= last ? lds_peek(&halo_start[L + 1]) - lds_peek(&halo_start[L]) : 0u;
+            bool bad = false;
+#pragma unroll
+            for (uint32_t q = 0; q < 2; ++q)
+                if (q * 64 + lane < n_h)
+                    bad = bad || !exchange_valid(lds_peek4(stage + ((L % R) * 128 + q * 64 + lane) * 4), base, d.n_levels);
+            const uint32_t any = __ballot(bad) != 0ull ? 1u : 0u;
+            if (lane == 0)
+                asm volatile("ds_write_b32 %0, %1" ::"v"(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&ctl[8 + L % R]))), "v"(any)
+                             : "memory");
+        };
+        // Optional head start for the slab(s) read from (tuning knob, off by default: the slab finds its distance by
+        // itself through a few re-reads, and starting further back only adds to the pipeline's length): wait until
+        // the group of a level `lead` ahead exists, then begin.
+        if (d.slab_lead) {
+            const uint32_t lead = d.slab_lead;
+            uint32_t L = min(first + lead, last);
+            while (L > first && lds_peek(&halo_start[L + 1]) == lds_peek(&halo_start[L])) --L; // a level that reads something
+            const uint32_t e0 = lds_peek(&halo_start[L]), n_h = lds_peek(&halo_start[L + 1]) - e0;
+            for (uint32_t spins = 0; spins < (1u << 20); ++spins) { // bounded: afterwards the ordinary re-read path takes over
+                bool missing = false;
+                for (uint32_t q = 0; q < 2; ++q)
+                    if (q * 64 + lane < n_h) {
+                        u32x4 raw;
+                        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(raw) : "v"(xin + e0 + q * 64 + lane) : "memory");
+                        missing = missing || !exchange_valid(make_uint4(raw.x, raw.y, raw.z, raw.w), base, d.n_levels);
+                    }
+                if (__ballot(missing) == 0ull) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        for (uint32_t L = first; L < first + kSlabAhead; ++L) stage_fetch(L);
         __builtin_amdgcn_s_waitcnt(0x0F70); // the first groups are simply waited for
+        validate(first);
         slab_barrier();
+        slab_barrier(); // the sweep waves pick the first level up
         for (uint32_t level = first; level <= last; ++level) {
-            // the group of level + 1 (fetched two levels ago) has landed once only the group of level + 2 is outstanding
-            __builtin_amdgcn_s_waitcnt(0x0F70 | 2u);
+            // the group of level + 1 has landed once only the kSlabAhead - 2 younger groups (two pieces each) are outstanding:
+            // a fetch has that many levels to come back through this CU's memory queue, behind the loader's pieces
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (2u * (kSlabAhead - 2)));
+            validate(level + 1);
             slab_barrier(); // X(level)
             if (lds_peek(&ctl[8 + level % R])) { // the sweep waves re-read the level's group: same barrier
                 slab_barrier();
                 if (lds_peek(&ctl[1])) return;
             }
-            stage_fetch(level + 3);
+            stage_fetch(level + kSlabAhead);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);
         return;
     }
 
     // ================= sweep waves
-    slab_barrier(); // the fetcher's first three groups are in the staging ring
-    if (reads_others && tid < 128) { // validate them
-        for (uint32_t L = first; L < first + 3 && L <= last; ++L) {
-            const uint32_t n_h = halo_start[L + 1] - halo_start[L];
-            if (tid < n_h && !exchange_valid(*reinterpret_cast<const uint4 *>(stage + ((L % R) * 128 + tid) * 4), base, d.n_levels))
-                ctl[8 + L % R] = 1;
+    slab_barrier(); // the fetcher's first groups are in the staging ring, the first one validated
+    // Everything a level needs besides the neighbours' spins is picked up during the level before
+    // (its ring slot has landed by then, its flag is set before the previous barrier): the dependent
+    // chain of a level is barrier -> neighbour words -> accept -> write.
+    struct Inputs {
+        uint4 r;
+        uint2 lv;
+        uint32_t target, hi, count, redo;
+    };
+    auto pick_up = [&](uint32_t L) -> Inputs {
+        Inputs in;
+        in.count = L <= last ? segs[2 * L + 1] : 0u;
+        in.redo = (reads_others && L <= last) ? ctl[8 + L % R] : 0u;
+        const uint32_t slot = (L - first) % D;
+        in.r = make_uint4(0u, 0u, 0u, 0u);
+        in.lv = make_uint2(0u, 0u);
+        in.target = in.hi = 0;
+        if (tid < in.count) {
+            in.r = *reinterpret_cast<const uint4 *>(ring_rec + (slot * 256 + tid) * 4);
+            in.lv = *reinterpret_cast<const uint2 *>(ring_pl + (slot * 256 + tid) * 2);
+            in.target = ring_x[slot * 256 + tid];
+            if (GIBBS) in.hi = ring_hi[slot * 256 + tid];
         }
-    }
+        return in;
+    };
+    slab_barrier(); // the loader's pieces of the first level and the first flag are in place
+    Inputs cur = pick_up(first);
     for (uint32_t level = first; level <= last; ++level) {
-        slab_barrier(); // X(level): the ring slot of this level is ready, last level's spins and flags are visible
+        slab_barrier(); // X(level): last level's spins are visible; the pieces of level + 1 have landed
         const uint32_t sslot = level % R;
-        if (reads_others && ctl[8 + sslot]) {
+        if (__builtin_amdgcn_readfirstlane(cur.redo)) {
             // ---- the producer was not far enough ahead when this level's records were fetched: read them again
             const uint32_t e0 = halo_start[level], n_h = halo_start[level + 1] - e0;
             if (tid < n_h) {
@@ -1872,38 +1931,27 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
                 return;
             }
         }
-        // the flag of level - 1 is free for the group of level + R - 1 (every wave read it before passing X(level))
-        if (tid == 0) ctl[8 + (level + R - 1) % R] = 0;
         // ---- this level's sites
-        const uint32_t slot = (level - first) % D;
-        const uint32_t count = segs[2 * level + 1];
-        if (tid < count) {
-            const uint4 r = *reinterpret_cast<const uint4 *>(ring_rec + (slot * 256 + tid) * 4);
-            const uint2 lv = *reinterpret_cast<const uint2 *>(ring_pl + (slot * 256 + tid) * 2);
-            const uint32_t target = ring_x[slot * 256 + tid];
+        if (tid < cur.count) {
+            const uint4 r = cur.r;
             const uint32_t at = r.x & 0xFFFFu;
             // (a neighbour in another slab is the value word of its staged exchange record: the host wrote that LDS word)
             uint32_t nb[6] = {lds[r.x >> 16],     lds[r.y & 0xFFFFu], lds[r.y >> 16],
                               lds[r.z & 0xFFFFu], lds[r.z >> 16],     lds[r.w & 0xFFFFu]};
             const uint32_t jm = r.w >> 16;
             const uint32_t sv = lds[at];
-            const uint32_t acc = (GIBBS ? accept_mask_gibbs(sv, nb, jm, d.nn, lv.x, lv.y, ring_hi[slot * 256 + tid])
-                                        : accept_mask(sv, nb, jm, lv.x, lv.y)) & valid_bits;
+            const uint32_t acc = (GIBBS ? accept_mask_gibbs(sv, nb, jm, d.nn, cur.lv.x, cur.lv.y, cur.hi)
+                                        : accept_mask(sv, nb, jm, cur.lv.x, cur.lv.y)) & valid_bits;
             const uint32_t value = sv ^ acc;
             lds[at] = value;
             coherent_store(Snew + a + at, value);
-            if (target) { // another slab reads this site: value and "ready" in one 16-byte record
+            if (cur.target) { // another slab reads this site: value and "ready" in one 16-byte record
                 const uint32_t tag = base + level + 1;
                 const u32x4 record = {value, tag, value ^ tag, ~tag};
-                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(xchg + (target - 1)), "v"(record) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(xchg + (cur.target - 1)), "v"(record) : "memory");
             }
         }
-        // ---- validate the group of level + 1 (landed before X(level): the fetcher waited for it)
-        if (reads_others && level + 1 <= last && level + 1 >= first + 3) { // (the first three were validated before the loop)
-            const uint32_t L = level + 1, n_h = halo_start[L + 1] - halo_start[L];
-            if (tid < n_h && !exchange_valid(*reinterpret_cast<const uint4 *>(stage + ((L % R) * 128 + tid) * 4), base, d.n_levels))
-                ctl[8 + L % R] = 1;
-        }
+        cur = pick_up(level + 1);
     }
 }
 
@@ -2137,7 +2185,7 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
 // spins of the slab and its two halo planes, the input rings (sized for the heat bath), the staged exchange records,
 // control words and the slab's segment table
 size_t sweep_slab_lds_bytes_for(uint32_t own_sites, uint32_t plane_sites, uint32_t n_levels) {
-    return (static_cast<size_t>(own_sites) + 2 * static_cast<size_t>(plane_sites) + kSlabDepth * 256 * 9 + kSlabStage * 128 * 4 + 16 +
+    return (static_cast<size_t>(own_sites) + 2 * static_cast<size_t>(plane_sites) + kSlabDepth * 256 * 8 + kSlabStage * 128 * 4 + 16 +
             3 * n_levels + 2) * 4;
 }
 size_t sweep_slab_lds_bytes(const SimDims &d) {

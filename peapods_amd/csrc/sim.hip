@@ -1196,6 +1196,11 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     // consecutive site indices are admissible when every smaller neighbour j of a site i that lies
     // m >= 1 slabs below satisfies level(j) + m <= level(i).
     d.n_levels = n_levels;
+    d.slab_lead = 0; // (measured at 64^3: 0..4 levels make no difference, every further level costs 7 us per sweep)
+    if (const char *env = std::getenv("PEAPODS_SLAB_LEAD")) {
+        const long v = std::strtol(env, nullptr, 10);
+        if (v >= 0 && v <= 64) d.slab_lead = static_cast<uint32_t>(v);
+    }
     d.pipe_K = 0;
     d.pipe_lds = 0;
     d.plane = 0;

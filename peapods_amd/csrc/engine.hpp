@@ -72,14 +72,12 @@ struct DevPtrs {
     const uint32_t *pass_start; // [n_passes + 1]
     const uint32_t *seg;     // [n_levels][pipe_K + 1] schedule positions where each slab's part of a level starts
     uint32_t *progress;      // [n_real * W][pipe_K] levels completed by each slab workgroup (epoch-based, monotone)
-    const uint32_t *halo_sites; // [pipe_K][2 * plane] k_sweep_slab: outside neighbours whose NEW value a slab needs,
-                             //   ordered by the level that first reads them
-    const uint32_t *halo_start; // [pipe_K][n_levels + 2] halo_sites[k][start[l] .. start[l + 1]) are needed at level l
+    const uint32_t *halo_start; // [pipe_K][n_levels + 2] k_sweep_slab: the exchange records a slab first reads at level l are
+                             //   entries start[l] .. start[l + 1] of its region of xchg (ordered by that level)
     const uint2 *slab_seg;   // [n_levels][pipe_K] (first padded schedule position, sites) of a slab at a level;
                              //   positions are padded so that every segment starts at a multiple of 4
     const uint32_t *pos_of;  // [N] site -> padded schedule position (k_rng files the acceptance planes there)
-    uint32_t *slab_scratch;  // [workgroups][4] dummy store target of sweep waves without sites at a level
-    uint32_t *slab_error;    // [1] set when a slab gave up waiting for its predecessor
+    uint32_t *slab_error;    // [1] set when a slab gave up waiting for an exchange record
     const uint4 *recS;       // [n_real][planes_stride] by padded position: 8 x u16 = LDS word of the site and of
                              //   f0,b0,f1,b1,f2,b2 (for a new value of another slab: the value word of its staged exchange record), then jmeta
     const uint32_t *xportS;  // [planes_stride] by padded position: 1 + exchange record the site's new value goes to, or 0

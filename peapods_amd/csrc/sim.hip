@@ -68,7 +68,7 @@ struct pa_sim {
     float *jorg_p = nullptr;
     uint32_t *thr_gibbs = nullptr; // built by the first Gibbs sample (ensure_gibbs)
     uint32_t *seg = nullptr;       // slab segments of the pipelined large-lattice sweep
-    uint32_t *halo_sites = nullptr, *halo_start = nullptr; // k_sweep_slab tables
+    uint32_t *halo_start = nullptr; // k_sweep_slab tables (halo_sites_host: which site each staged entry is, host only)
     uint2 *slab_seg = nullptr;
     uint32_t *pos_of = nullptr;
     uint4 *recS = nullptr;
@@ -1521,7 +1521,6 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     else
         ok(bufs.alloc(&p.S_next, tile_words * d.n_real));
     if (d.pipe_lds) {
-        ok(bufs.alloc(&sim->halo_sites, sim->halo_sites_host.size()));
         ok(bufs.alloc(&sim->halo_start, sim->halo_start_host.size()));
         ok(bufs.alloc(&sim->slab_seg, slab_seg.size()));
         ok(bufs.alloc(&sim->pos_of, pos_of.size()));
@@ -1532,7 +1531,6 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     if (d.pipe_K) {
         ok(bufs.alloc(&sim->seg, seg.size()));
         ok(bufs.alloc(&p.progress, static_cast<size_t>(d.n_real) * d.W * d.pipe_K));
-        ok(bufs.alloc(&p.slab_scratch, static_cast<size_t>((d.n_real * d.W + 7u) & ~7u) * d.pipe_K * 4 * 64 * 4));
         ok(bufs.alloc(&p.slab_error, 4));
     }
     ok(bufs.alloc(&p.swap_epoch, static_cast<size_t>(d.n_real)));
@@ -1592,14 +1590,12 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     p.nbr_wide = sim->nbr_wide;
     p.jorg_p = sim->jorg_p;
     p.seg = sim->seg;
-    p.halo_sites = sim->halo_sites;
     p.halo_start = sim->halo_start;
     p.slab_seg = sim->slab_seg;
     p.pos_of = sim->pos_of;
     p.recS = sim->recS;
     p.xportS = sim->xportS;
     if (d.pipe_lds) {
-        if ((rc = upload(sim, sim->halo_sites, sim->halo_sites_host))) return bail(rc);
         if ((rc = upload(sim, sim->halo_start, sim->halo_start_host))) return bail(rc);
         if ((rc = upload(sim, sim->slab_seg, slab_seg))) return bail(rc);
         if ((rc = upload(sim, sim->pos_of, pos_of))) return bail(rc);

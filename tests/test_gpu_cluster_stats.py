@@ -198,3 +198,46 @@ def test_options_are_checked_like_the_reference():
     model.sample(8, cluster_update_interval=1, collect_cluster_stats=True, overlap_cluster_update_interval=1,
                  overlap_cluster_mode="sw", warmup_ratio=0)
     assert model.mean_cluster_size.shape == (2,) and len(model.top_cluster_sizes) == 1
+
+
+N_RANDOM = int(__import__("os").environ.get("PEAPODS_RANDOM_STATS_CASES", "48"))  # raise for a longer hunt
+
+
+@pytest.mark.parametrize("case_seed", range(N_RANDOM))
+def test_random_configuration_with_cluster_reporting(oracle, case_seed):
+    """The random configurations of test_gpu_random_configs.py with the reporting options layered on top:
+    size statistics, observation instead of update, snapshots -- whatever the reference allows together."""
+    from test_gpu_random_configs import random_case
+
+    rng = np.random.default_rng(9000 + case_seed)
+    shape, offsets, couplings, temps, n_rep, sweep_mode, opts = random_case(rng)
+    # make sure at least one kind of cluster call is present
+    if "cluster_update_interval" not in opts and ("overlap_cluster_update_interval" not in opts):
+        if n_rep >= 2 and rng.random() < 0.5:
+            opts["overlap_cluster_update_interval"] = 1
+            opts["overlap_cluster_build_mode"] = str(rng.choice(["houdayer", "jorg", "cmr"]))
+            opts["overlap_cluster_mode"] = str(rng.choice(["wolff", "sw"]))
+        else:
+            opts["cluster_update_interval"] = 1
+            opts["cluster_mode"] = str(rng.choice(["wolff", "sw"]))
+    opts["warmup_ratio"] = float(rng.choice([0.0, 0.25, 0.5]))
+    roll = rng.random()
+    if roll < 0.45:
+        opts["collect_cluster_stats"] = True
+    elif roll < 0.75:
+        if "cluster_update_interval" in opts:
+            opts["cluster_mode"] = "sw"
+            opts["cluster_action"] = "observe"
+        if "overlap_cluster_update_interval" in opts:
+            opts["overlap_cluster_mode"] = "sw"
+            opts["overlap_cluster_action"] = "observe"
+            opts["overlap_cluster_build_mode"] = opts["overlap_cluster_build_mode"].replace("houd4", "houdayer")
+    if "overlap_cluster_update_interval" in opts and opts.get("overlap_cluster_action") != "observe" and rng.random() < 0.5:
+        opts["snapshot_interval"] = opts["overlap_cluster_update_interval"] * int(rng.choice([1, 2]))
+    seed = int(rng.integers(0, 2**40))
+    gpu, cpu = make_pair(oracle, shape, couplings, temps, n_rep, seed, offsets)
+    for n_sweeps in (int(rng.integers(2, 10)), int(rng.integers(1, 8))):  # the second call continues the chains
+        a = gpu.sample(n_sweeps, sweep_mode, **opts)
+        b = cpu.sample(n_sweeps, sweep_mode, **opts)
+        assert_same(a, b, f"shape={shape} offsets={offsets} n_temps={len(temps)} n_rep={n_rep} {sweep_mode} {opts}")
+        assert_state_equal(gpu, cpu, check_energy=False)

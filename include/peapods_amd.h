@@ -61,6 +61,7 @@ enum { PA_PT_SINGLE_RANDOM_EDGE = 0, PA_PT_FULL_LADDER = 1 };
 enum { PA_OC_HOUDAYER = 1, PA_OC_JORG = 2, PA_OC_CMR = 3 };
 enum { PA_CLUSTER_WOLFF = 0, PA_CLUSTER_SW = 1 };
 enum { PA_ACTION_UPDATE = 0, PA_ACTION_OBSERVE = 1 }; /* ClusterAction, ss/config.rs:41-59 */
+enum { PA_AUTOCORR_RING = 0, PA_AUTOCORR_FFT = 1 };   /* AutocorrelationBackend, ss/config.rs */
 /* rows of pa_sim_get_observation (per_disorder["cluster_observations"], src/lib.rs:416-445) */
 enum { PA_OBS_FK = 0, PA_OBS_HOUDAYER = 1, PA_OBS_JORG = 2, PA_OBS_CMR_BLUE = 3 };
 
@@ -114,6 +115,9 @@ typedef struct {
                                      the reference, single-cluster moves then take their union-find form. */
     int32_t cluster_action;         /* PA_ACTION_*: FK update or observation (ss/config.rs:41-59) */
     int32_t overlap_cluster_action; /* PA_ACTION_* for the overlap move */
+    int32_t autocorrelation_backend; /* PA_AUTOCORR_*: exact ring sums, or the lagged products by an FFT of the
+                                     retained series (ss/statistics/autocorrelation.rs:126-163; equal up to
+                                     rounding -- the transform is a radix-2 one, not rustfft's) */
     uint64_t snapshot_interval;     /* 0 = none; cluster ids, spins and systems of the first realisation's
                                      first pair at every temperature, every k sweeps (mod.rs:302-335,628-714) */
 } pa_sample_config;
@@ -248,6 +252,12 @@ void pa_aggregate_sum_u64(const uint64_t *per_realization, uint64_t n_realizatio
                           uint64_t *out);
 void pa_aggregate_sum_f64(const double *per_realization, uint64_t n_realizations, uint64_t len,
                           double *out);
+/* Integrated autocorrelation time per column of a per-sweep series [n_samples][n_cols] (f32, as pushed):
+ * AutocorrAccum::push/finish + sokal_tau (ss/statistics/autocorrelation.rs:70-208), in f64 on the host.
+ * backend = PA_AUTOCORR_RING (the exact lagged sums) or PA_AUTOCORR_FFT (:126-163).  This is what
+ * pa_sim_get_autocorrelation_tau applies to the series the device wrote; exported for tests. */
+void pa_autocorrelation_tau(const float *series, uint64_t n_samples, uint64_t n_cols, uint64_t max_lag,
+                            double *tau_out, int32_t backend);
 /* Number of visible HIP devices (0 when there is none / the runtime is unusable). */
 int pa_device_count(void);
 const char *pa_version(void);

@@ -13,7 +13,7 @@ _SWEEP_MODES = {"metropolis": 0, "gibbs": 1}
 _PT_SCHEDULES = {"single_random_edge": 0, "full_ladder": 1}
 _CLUSTER_MODES = {"wolff": 0, "sw": 1}
 _CLUSTER_ACTIONS = {"update": 0, "observe": 1}
-_AUTOCORR_BACKENDS = ("ring", "fft")
+_AUTOCORR_BACKENDS = {"ring": 0, "fft": 1}
 _OC_MODES = {"houdayer": 1, "houd2": 1, "jorg": 2, "cmr": 3, "cmr2": 3}
 
 
@@ -199,10 +199,8 @@ class IsingSimulation:
             cfg.n_overlap_cluster_modes = len(modes)
             cfg.overlap_cluster_mode = _CLUSTER_MODES[oc_mode]
         if autocorrelation_max_lag is not None:
-            if backend == "fft":
-                raise NotImplementedError("the FFT autocorrelation backend is not built on the HIP path "
-                                          "(use the exact ring backend)")
             cfg.autocorrelation_max_lag = int(autocorrelation_max_lag)
+            cfg.autocorrelation_backend = _AUTOCORR_BACKENDS[backend]
         cfg.equilibration_diagnostic = 1 if equilibration_diagnostic else 0
         cfg.collect_cluster_stats = 1 if collect_cluster_stats else 0
         cfg.measure_overlap = 1 if measure_overlap else 0

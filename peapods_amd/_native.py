@@ -49,6 +49,7 @@ class PaSampleConfig(C.Structure):
         ("collect_cluster_stats", C.c_int32),
         ("cluster_action", C.c_int32),
         ("overlap_cluster_action", C.c_int32),
+        ("autocorrelation_backend", C.c_int32),
         ("snapshot_interval", C.c_uint64),
     ]
 
@@ -101,6 +102,7 @@ SIGNATURES = {
     "pa_build_metropolis_table": (C.c_int, [_vp, _u64, _vp, _u64, _u64, _vp]),
     "pa_build_gibbs_table": (C.c_int, [_vp, _u64, _vp, _u64, _u64, _vp]),
     "pa_build_sweep_levels": (_u64, [_u32, _vp, _u32, _vp, _vp]),
+    "pa_autocorrelation_tau": (None, [_vp, _u64, _u64, _u64, _vp, _i32]),
     "pa_aggregate_mean": (None, [_vp, _u64, _u64, _vp]),
     "pa_aggregate_sum_u64": (None, [_vp, _u64, _u64, _vp]),
     "pa_aggregate_sum_f64": (None, [_vp, _u64, _u64, _vp]),

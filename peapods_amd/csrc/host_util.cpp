@@ -270,8 +270,41 @@ bool build_gibbs_table(const float *couplings, uint64_t n_couplings, const float
     return true;
 }
 
-void autocorrelation_tau(const float *series, size_t n_samples, size_t n_cols, size_t max_lag, double *tau_out) {
+namespace {
+
+// in-place iterative radix-2 FFT of re/im (length a power of two); inverse = conjugate twiddles, unscaled
+void fft_radix2(std::vector<double> &re, std::vector<double> &im, bool inverse) {
+    const size_t n = re.size();
+    for (size_t i = 1, j = 0; i < n; ++i) { // bit reversal
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) {
+            std::swap(re[i], re[j]);
+            std::swap(im[i], im[j]);
+        }
+    }
+    const double pi = 3.14159265358979323846;
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const double angle = (inverse ? 2.0 : -2.0) * pi / static_cast<double>(len);
+        for (size_t start = 0; start < n; start += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const double wr = std::cos(angle * static_cast<double>(k)), wi = std::sin(angle * static_cast<double>(k));
+                const size_t a = start + k, b = a + len / 2;
+                const double xr = re[b] * wr - im[b] * wi, xi = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - xr;
+                im[b] = im[a] - xi;
+                re[a] += xr;
+                im[a] += xi;
+            }
+    }
+}
+
+} // namespace
+
+void autocorrelation_tau(const float *series, size_t n_samples, size_t n_cols, size_t max_lag, double *tau_out, bool fft) {
     std::vector<double> sum_prod(max_lag + 1), gamma(max_lag + 1);
+    std::vector<double> re, im;
     for (size_t t = 0; t < n_cols; ++t) {
         double sum_o = 0.0, sum_o2 = 0.0;
         std::fill(sum_prod.begin(), sum_prod.end(), 0.0);
@@ -280,9 +313,27 @@ void autocorrelation_tau(const float *series, size_t n_samples, size_t n_cols, s
             const double o = static_cast<double>(series[i * n_cols + t]);
             sum_o += o;
             sum_o2 += o * o;
+            if (fft) continue;
             const size_t n_back = std::min(i, max_lag);
             for (size_t delta = 0; delta <= n_back; ++delta)
                 sum_prod[delta] += o * static_cast<double>(series[(i - delta) * n_cols + t]);
+        }
+        if (fft && n_samples > 0) {
+            // finish_fft (autocorrelation.rs:126-163): zero-pad to a power of two >= 2 n, power spectrum, inverse
+            // transform / fft_len = the lagged products.  Equal to the ring sums up to rounding (the reference's
+            // own test allows 1e-10 between its two backends); the transform here is a plain radix-2 one, not rustfft's.
+            size_t fft_len = 1;
+            while (fft_len < 2 * n_samples) fft_len <<= 1;
+            re.assign(fft_len, 0.0);
+            im.assign(fft_len, 0.0);
+            for (size_t i = 0; i < n_samples; ++i) re[i] = static_cast<double>(series[i * n_cols + t]);
+            fft_radix2(re, im, false);
+            for (size_t i = 0; i < fft_len; ++i) {
+                re[i] = re[i] * re[i] + im[i] * im[i];
+                im[i] = 0.0;
+            }
+            fft_radix2(re, im, true);
+            for (size_t delta = 0; delta <= max_lag && delta < fft_len; ++delta) sum_prod[delta] = re[delta] / static_cast<double>(fft_len);
         }
         for (size_t delta = 0; delta <= max_lag; ++delta) gamma[delta] = delta == 0 ? 1.0 : 0.0;
         if (n_samples > 0) {

@@ -86,7 +86,8 @@ bool build_gibbs_table(const float *couplings, uint64_t n_couplings, const float
 // Integrated autocorrelation time of every column of series[n_samples][n_cols] (f32 values as
 // pushed): AutocorrAccum ring backend + normalize_products + sokal_tau
 // (ss/statistics/autocorrelation.rs:70-124,165-208) with the same f64 operation order.
-void autocorrelation_tau(const float *series, size_t n_samples, size_t n_cols, size_t max_lag, double *tau_out);
+void autocorrelation_tau(const float *series, size_t n_samples, size_t n_cols, size_t max_lag, double *tau_out,
+                         bool fft = false);
 
 // level[i] = 1 + max(level[j]) over neighbours j < i (0 if none).  Returns level count.
 uint32_t build_levels(const LatticeTables &lat, std::vector<uint32_t> &level);

@@ -77,6 +77,7 @@ struct pa_sim {
     uint32_t pipe_epoch = 1;       // bumped by every k_sweep_pipe launch (progress counters are monotone)
     std::vector<uint64_t> equil_sweeps; // checkpoints of the last sample() with the equilibration diagnostic
     uint64_t ac_lag = 0, ac_samples = 0, ac_capacity = 0; // autocorrelation series of the last sample()
+    bool ac_fft = false;                                  // evaluate them with the FFT backend
     float *Jf = nullptr, *temps_dev = nullptr; // general-coupling path
     uint32_t *jump64 = nullptr;
     uint32_t *jump256 = nullptr, *jorg_thr = nullptr, *fk_thr = nullptr, *cmr_thr = nullptr; // cluster kernels
@@ -646,6 +647,10 @@ std::string validate_text(const pa_sample_config *cfg, uint64_t n_replicas, int 
         return "unknown sweep_mode, expected 'metropolis' or 'gibbs'";
     if (cfg->pt_schedule != PA_PT_SINGLE_RANDOM_EDGE && cfg->pt_schedule != PA_PT_FULL_LADDER)
         return "unknown pt_schedule, expected 'single_random_edge' or 'full_ladder'";
+    if (cfg->autocorrelation_backend != PA_AUTOCORR_RING && cfg->autocorrelation_backend != PA_AUTOCORR_FFT)
+        return "unknown autocorrelation_backend, expected 'ring' or 'fft'";
+    if (cfg->autocorrelation_backend == PA_AUTOCORR_FFT && cfg->autocorrelation_max_lag == 0)
+        return "autocorrelation_backend='fft' requires autocorrelation_max_lag";
     if (cfg->overlap_cluster_interval > 0) {
         if (cfg->n_overlap_cluster_modes < 1) return "overlap_cluster modes must not be empty";
         // simulation/mod.rs:207-214
@@ -730,6 +735,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     const bool autocorr = cfg->autocorrelation_max_lag > 0;
     sim->ac_lag = autocorr ? std::max<uint64_t>(1, std::min<uint64_t>(cfg->autocorrelation_max_lag, n_meas / 4)) : 0;
     sim->ac_samples = 0;
+    sim->ac_fft = cfg->autocorrelation_backend == PA_AUTOCORR_FFT;
     if (autocorr && n_meas > 0 && (rc = ensure_autocorr(sim, n_meas))) return rc;
     if ((rc = zero_accumulators(sim))) return rc;
     // what the cluster calls report besides moving spins (mod.rs:216-335)
@@ -1025,6 +1031,11 @@ uint64_t pa_build_sweep_levels(uint32_t n_dims, const uint64_t *shape, uint32_t 
     const uint32_t n_levels = build_levels(lat, level);
     std::memcpy(level_out, level.data(), level.size() * sizeof(uint32_t));
     return n_levels;
+}
+
+void pa_autocorrelation_tau(const float *series, uint64_t n_samples, uint64_t n_cols, uint64_t max_lag, double *tau_out,
+                            int32_t backend) {
+    autocorrelation_tau(series, n_samples, n_cols, max_lag, tau_out, backend == PA_AUTOCORR_FFT);
 }
 
 void pa_aggregate_mean(const double *per_realization, uint64_t n_realizations, uint64_t len,
@@ -2031,10 +2042,10 @@ int pa_sim_get_autocorrelation_tau(pa_sim *sim, uint64_t realization, double *ma
     const size_t base = static_cast<size_t>(realization) * sim->ac_capacity * d.n_temps;
     int rc = download(sim, series, sim->p.ac_m2 + base, n);
     if (rc) return rc;
-    autocorrelation_tau(series.data(), sim->ac_samples, d.n_temps, sim->ac_lag, mags2_tau);
+    autocorrelation_tau(series.data(), sim->ac_samples, d.n_temps, sim->ac_lag, mags2_tau, sim->ac_fft);
     if (d.n_pairs) {
         if ((rc = download(sim, series, sim->p.ac_q2 + base, n))) return rc;
-        autocorrelation_tau(series.data(), sim->ac_samples, d.n_temps, sim->ac_lag, overlap2_tau);
+        autocorrelation_tau(series.data(), sim->ac_samples, d.n_temps, sim->ac_lag, overlap2_tau, sim->ac_fft);
     }
     return PA_OK;
 }

@@ -696,14 +696,39 @@ def test_gaussian_glass_overlap_histogram_protocol():
     assert sweeps[-1] == 12000 and abs(delta[-1, 0]) < 0.15
 
 
+def test_fft_autocorrelation_backend_agrees_with_the_ring(oracle):
+    # reference tests/test_sampling_interfaces.py:159-194 and autocorrelation.rs:345-372: the two backends agree
+    # to 1e-9; the ring result is the exact one (and is compared bit for bit with the oracle elsewhere)
+    from peapods_amd import Ising
+
+    kw = dict(lattice_shape=(4, 4), couplings="bimodal", temperatures=np.array([1.0, 2.0], dtype=np.float32),
+              n_replicas=2, seed=37)
+    default = Ising(**kw).sample(64, autocorrelation_max_lag=8, warmup_ratio=0)
+    ring = Ising(**kw).sample(64, autocorrelation_max_lag=8, autocorrelation_backend="ring", warmup_ratio=0)
+    fft = Ising(**kw).sample(64, autocorrelation_max_lag=8, autocorrelation_backend="fft", warmup_ratio=0)
+    np.testing.assert_array_equal(default["mags2_tau"], ring["mags2_tau"])
+    np.testing.assert_allclose(fft["mags2_tau"], default["mags2_tau"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(fft["overlap2_tau"], default["overlap2_tau"], rtol=0, atol=1e-9)
+    for key in default:  # everything else is untouched by the choice of backend
+        if not key.endswith("_tau") and key != "per_disorder" and key != "overlap_histogram":
+            np.testing.assert_array_equal(fft[key], default[key], err_msg=key)
+    # a longer series on a larger lattice, several realisations
+    big = dict(lattice_shape=(6, 6, 6), couplings="bimodal", temperatures=np.linspace(0.9, 2.0, 5).astype(np.float32),
+               n_replicas=2, n_disorder=3, seed=5)
+    a = Ising(**big).sample(700, autocorrelation_max_lag=60, warmup_ratio=0.25, pt_interval=1)
+    b = Ising(**big).sample(700, autocorrelation_max_lag=60, autocorrelation_backend="fft", warmup_ratio=0.25, pt_interval=1)
+    np.testing.assert_allclose(b["mags2_tau"], a["mags2_tau"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(b["overlap2_tau"], a["overlap2_tau"], rtol=0, atol=1e-9)
+
+
 def test_unbuilt_overlap_modes_are_refused_not_emulated():
     from peapods_amd import IsingSimulation
 
     couplings = bimodal((4, 4), 2, 1, 2)
     sim = IsingSimulation([4, 4], couplings, np.array([1.0, 2.0], np.float32), 2, None, 1)
     before = sim.get_spins().copy()
-    with pytest.raises(NotImplementedError):  # the exact ring accumulator is the one built
-        sim.sample(8, "metropolis", autocorrelation_max_lag=2, autocorrelation_backend="fft")
+    with pytest.raises(ValueError, match="requires autocorrelation_max_lag"):
+        sim.sample(8, "metropolis", autocorrelation_backend="fft")
     with pytest.raises(ValueError, match="n_replicas >= max group_size"):
         sim.sample(2, "metropolis", overlap_cluster_update_interval=1, overlap_cluster_build_mode="houd4")
     np.testing.assert_array_equal(sim.get_spins(), before)

@@ -225,3 +225,26 @@ def test_shard_ranges_cover_the_ensemble():
         assert edges[0][0] == 0 and edges[-1][1] == n_total
         for (a0, a1), (b0, b1) in zip(edges, edges[1:]):
             assert a1 == b0 and a0 <= a1
+
+
+def test_fft_autocorrelation_matches_the_ring_sums():
+    """host_util.cpp autocorrelation_tau: the FFT backend (zero-padded radix-2 transform) against the exact ring
+    sums on a deterministic AR(1)-like series, as the reference checks its own two backends
+    (spin-sim/src/statistics/autocorrelation.rs:345-372)."""
+    lib = nat.lib()
+    rng = np.random.default_rng(3)
+    n, cols, lag = 300, 3, 40
+    x = np.zeros((n, cols), dtype=np.float32)
+    for i in range(1, n):
+        x[i] = 0.8 * x[i - 1] + rng.standard_normal(cols).astype(np.float32)
+    ring = np.zeros(cols)
+    fft = np.zeros(cols)
+    lib.pa_autocorrelation_tau(nat.ptr(x), n, cols, lag, nat.ptr(ring), 0)
+    lib.pa_autocorrelation_tau(nat.ptr(x), n, cols, lag, nat.ptr(fft), 1)
+    np.testing.assert_allclose(fft, ring, rtol=0, atol=1e-10)
+    assert np.all(ring > 1.0)  # a correlated series
+    const = np.full((8, 1), 3.5, dtype=np.float32)  # degenerate: variance 0 -> gamma = delta, tau = 0.5
+    out = np.zeros(1)
+    for backend in (0, 1):
+        lib.pa_autocorrelation_tau(nat.ptr(const), 8, 1, 4, nat.ptr(out), backend)
+        assert out[0] == 0.5

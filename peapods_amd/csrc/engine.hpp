@@ -106,6 +106,7 @@ struct DevPtrs {
     uint32_t *big_counts;     // [n_real][n_sys][4] u32 scratch counters of the large-lattice kernels
     const uint16_t *nbr_site; // [N][12] neighbours by site: f0, b0, f1, b1, ... f5, b5 (self when unused)
     const uint32_t *jsite;    // [n_real][N] by site: neg[0..11] | nz[12..23] for bonds f0,b0,...,f5,b5
+    const uint4 *fwd_big;     // [N] large lattices: forward neighbours f0, f1, f2 of every site (self when unused), by site
     const uint32_t *nbr_wide; // [N][16] in schedule order: site, f0, b0, ..., f5, b5, 0, 0, 0 (general path)
     const float *jorg_p;      // [n_temps] 1 - exp(-4 / T) by the host libm (Joerg bond probability)
     uint16_t *dfs_stack;      // [n_real][n_temps * n_pairs][N] scratch of k_jorg

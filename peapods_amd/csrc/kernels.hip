@@ -1962,25 +1962,27 @@ __global__ __launch_bounds__(256) void k_energy_big(SimDims d, DevPtrs p, uint32
     const uint32_t w = (blockIdx.x / n_chunks) % d.W, real = blockIdx.x / (n_chunks * d.W);
     const uint32_t tid = threadIdx.x;
     const uint32_t *Sg = p.S + (static_cast<size_t>(real) * d.W + w) * d.N;
-    const uint4 *rec = p.rec + static_cast<size_t>(real) * (d.N + 1) * 2;
+    const uint32_t *jsite = p.jsite + static_cast<size_t>(real) * d.N;
     uint32_t c[3][8];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) c[s][j] = 0;
     uint32_t qa[16], qb[16], qc[16];
+    // sites in index order (the sums do not care): the site's word, its coupling bits and its forward
+    // neighbours' indices are coalesced streams, and on a hypercubic lattice so are the neighbour words
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const uint32_t pos = chunk * 4096 + k * 256 + tid;
+        const uint32_t site = chunk * 4096 + k * 256 + tid;
         qa[k] = qb[k] = qc[k] = 0;
-        if (pos < d.N) {
-            const BigRec r(rec[2 * pos], rec[2 * pos + 1]);
-            const uint32_t jm = r.jm;
-            const uint32_t s = Sg[r.site];
-            const uint32_t f0 = Sg[r.nb[0]], f1 = Sg[r.nb[2]], f2 = Sg[r.nb[4]];
-            const uint32_t u0 = (s ^ f0 ^ (0u - ((jm >> 0) & 1u))) & (0u - ((jm >> 6) & 1u));
-            const uint32_t u1 = (s ^ f1 ^ (0u - ((jm >> 2) & 1u))) & (0u - ((jm >> 8) & 1u));
-            const uint32_t u2 = (s ^ f2 ^ (0u - ((jm >> 4) & 1u))) & (0u - ((jm >> 10) & 1u));
+        if (site < d.N) {
+            const uint4 fw = p.fwd_big[site];
+            const uint32_t jm = jsite[site]; // neg[0..11] | nz[12..23] for f0,b0,f1,b1,f2,b2,..
+            const uint32_t s = Sg[site];
+            const uint32_t f0 = Sg[fw.x], f1 = Sg[fw.y], f2 = Sg[fw.z];
+            const uint32_t u0 = (s ^ f0 ^ (0u - ((jm >> 0) & 1u))) & (0u - ((jm >> 12) & 1u));
+            const uint32_t u1 = (s ^ f1 ^ (0u - ((jm >> 2) & 1u))) & (0u - ((jm >> 14) & 1u));
+            const uint32_t u2 = (s ^ f2 ^ (0u - ((jm >> 4) & 1u))) & (0u - ((jm >> 16) & 1u));
             qa[k] = u0 ^ u1 ^ u2;
             qb[k] = maj3(u0, u1, u2);
             qc[k] = s;
@@ -2009,7 +2011,6 @@ __global__ __launch_bounds__(256) void k_overlap_big(SimDims d, DevPtrs p, uint3
     const uint32_t *A = S0 + static_cast<size_t>(w) * d.N;
     const uint32_t *B0 = wa < d.W ? S0 + static_cast<size_t>(wa) * d.N : nullptr;
     const uint32_t *B1 = wb < d.W ? S0 + static_cast<size_t>(wb) * d.N : nullptr;
-    const uint4 *rec = p.rec + static_cast<size_t>(real) * (d.N + 1) * 2;
     auto shifted = [&](uint32_t site) {
         const uint32_t b0 = B0 ? B0[site] : 0u, b1 = B1 ? B1[site] : 0u;
         return r ? ((b0 >> r) | (b1 << (32 - r))) : b0;
@@ -2022,16 +2023,14 @@ __global__ __launch_bounds__(256) void k_overlap_big(SimDims d, DevPtrs p, uint3
     uint32_t qa[16], qb[16], qc[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const uint32_t pos = chunk * 4096 + k * 256 + tid;
+        const uint32_t site = chunk * 4096 + k * 256 + tid; // index order, as in k_energy_big
         qa[k] = qb[k] = qc[k] = 0;
-        if (pos < d.N) {
-            const BigRec sr(rec[2 * pos], rec[2 * pos + 1]);
-            const uint32_t y = A[sr.site] ^ shifted(sr.site);
+        if (site < d.N) {
+            const uint4 fw = p.fwd_big[site];
+            const uint32_t fwd[3] = {fw.x, fw.y, fw.z};
+            const uint32_t y = A[site] ^ shifted(site);
             uint32_t z[3] = {0, 0, 0};
-            for (uint32_t dir = 0; dir < d.nn; ++dir) {
-                const uint32_t nbr = sr.nb[2 * dir];
-                z[dir] = y ^ A[nbr] ^ shifted(nbr);
-            }
+            for (uint32_t dir = 0; dir < d.nn; ++dir) z[dir] = y ^ A[fwd[dir]] ^ shifted(fwd[dir]);
             qa[k] = y;
             qb[k] = z[0] ^ z[1] ^ z[2];
             qc[k] = maj3(z[0], z[1], z[2]);

@@ -65,6 +65,7 @@ struct pa_sim {
     uint4 *rec = nullptr;
     uint16_t *nbr_site = nullptr;
     uint32_t *jsite = nullptr, *nbr_wide = nullptr;
+    uint4 *fwd_big = nullptr;
     float *jorg_p = nullptr;
     uint32_t *thr_gibbs = nullptr; // built by the first Gibbs sample (ensure_gibbs)
     uint32_t *seg = nullptr;       // slab segments of the pipelined large-lattice sweep
@@ -1581,6 +1582,13 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     ok(bufs.alloc(&p.pair_rng, static_cast<size_t>(d.n_real) * d.n_temps * d.n_pairs * 4));
     ok(bufs.alloc(&sim->nbr_site, nbr_site.size()));
     ok(bufs.alloc(&sim->jsite, jsite.size()));
+    std::vector<uint4> fwd_big;
+    if (d.big) { // forward neighbours by site for the energy / overlap kernels of the large path
+        fwd_big.resize(d.N);
+        for (uint32_t i = 0; i < d.N; ++i)
+            fwd_big[i] = make_uint4(lat.fwd[i * d.nn], d.nn > 1 ? lat.fwd[i * d.nn + 1] : i, d.nn > 2 ? lat.fwd[i * d.nn + 2] : i, 0u);
+        ok(bufs.alloc(&sim->fwd_big, fwd_big.size()));
+    }
     ok(bufs.alloc(&sim->nbr_wide, nbr_wide.size()));
     ok(bufs.alloc(&sim->jorg_p, jorg_p.size()));
     ok(bufs.alloc(&p.dfs_stack, d.big ? 1 : static_cast<size_t>(d.n_real) * std::max(d.n_temps * d.n_pairs, d.n_sys) * d.N));
@@ -1598,6 +1606,8 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     p.dbeta = sim->dbeta;
     p.nbr_site = sim->nbr_site;
     p.jsite = sim->jsite;
+    p.fwd_big = sim->fwd_big;
+    if (d.big && (rc = upload(sim, sim->fwd_big, fwd_big))) return bail(rc);
     p.nbr_wide = sim->nbr_wide;
     p.jorg_p = sim->jorg_p;
     p.seg = sim->seg;

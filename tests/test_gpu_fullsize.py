@@ -170,3 +170,30 @@ def test_general_couplings_on_the_large_lattice_path(oracle):
         np.testing.assert_array_equal(gpu.get_spins(0), cpu.get_spins(0))
         np.testing.assert_array_equal(gpu.get_system_ids(0), cpu.get_system_ids(0))
         np.testing.assert_array_equal(gpu.get_energies(0), cpu.get_energies(0))
+
+
+@pytest.mark.parametrize("knob", ["PEAPODS_NO_SLAB_LDS", "PEAPODS_PIPE_K"])
+def test_fallback_sweeps_of_the_large_path_match_oracle(oracle, monkeypatch, knob):
+    """The LDS-resident slab kernel is the default on large lattices; the global-memory pipeline it replaced
+    (k_sweep_pipe, for lattices whose slabs do not fit) and the single-workgroup sweep (k_sweep_big, when no
+    slab cut is admissible) stay as fallbacks and must stay exact."""
+    from peapods_amd import IsingSimulation
+
+    monkeypatch.setenv("PEAPODS_NO_SLAB_LDS", "1")
+    if knob == "PEAPODS_PIPE_K":
+        monkeypatch.setenv("PEAPODS_PIPE_K", "1")  # one slab = no pipeline
+    shape = (24, 24, 24)
+    rng = np.random.default_rng(9)
+    couplings = (2 * rng.integers(0, 2, size=(2,) + shape + (3,)) - 1).astype(np.float32)
+    temps = np.linspace(0.8, 1.6, 5).astype(np.float32)
+    gpu = IsingSimulation(list(shape), couplings, temps, 2, None, 13)
+    cpu = oracle.OracleSimulation(list(shape), couplings, temps, 2, None, 13)
+    for mode in ("metropolis", "gibbs"):
+        kw = dict(pt_interval=1, pt_schedule="full_ladder", warmup_ratio=0.25)
+        a = gpu.sample(5, mode, **kw)
+        b = cpu.sample(5, mode, n_threads=8, **kw)
+        np.testing.assert_array_equal(a["energies"], b["energies"])
+        np.testing.assert_array_equal(a["overlap2"], b["overlap2"])
+        for r in range(2):
+            np.testing.assert_array_equal(gpu.get_spins(r), cpu.get_spins(r))
+            np.testing.assert_array_equal(gpu.get_system_ids(r), cpu.get_system_ids(r))

@@ -126,9 +126,12 @@ enum { kSwHoudayer = 0, kSwJorg = 1, kSwFk = 2, kSwCmr = 3 };
 // deterministic-bond move (find_seed, utils.rs:107-119, then flip the seed's component).
 // EXTRAS = false is the lean build of the plain moves (no reporting; single-cluster form only for the
 // deterministic Houdayer bonds): the reporting code costs ~100 VGPRs and a third of the occupancy.
+// The lean Houdayer build (no bond draws) is capped at 128 VGPRs: four workgroups per CU instead of three, 461 ->
+// 400 us per call on 6144 pairs.  The moves that draw bonds lose more to the spills than they gain (Joerg 792 -> 853 us,
+// FK 312 -> 363 us), and the reporting builds need their registers.
 template <int MODE, bool EXTRAS>
-__global__ __launch_bounds__(kSwThreads) void k_cluster_sw(SimDims d, DevPtrs p, uint32_t group, int wolff,
-                                                            ClusterAux aux) {
+__global__ __launch_bounds__(kSwThreads, (!EXTRAS && MODE == kSwHoudayer) ? 4 : 1) void k_cluster_sw(
+    SimDims d, DevPtrs p, uint32_t group, int wolff, ClusterAux aux) {
     constexpr bool JORG = MODE == kSwJorg, FK = MODE == kSwFk, CMR = MODE == kSwCmr;
     constexpr bool STOCHASTIC = JORG || FK || CMR; // bonds are drawn
     constexpr uint32_t N_PHASES = CMR ? 2 : 1;     // CMR: blue clusters, then grey = blue + red bonds

@@ -204,6 +204,8 @@ hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, ui
 hipError_t launch_top4_accumulate(const SimDims &d, const DevPtrs &p, const ClusterAux &aux, hipStream_t stream);
 hipError_t launch_uf_replay(const SimDims &d, const DevPtrs &p, bool cmr, hipStream_t stream);
 hipError_t launch_cmr_wolff(const SimDims &d, const DevPtrs &p, hipStream_t stream);
+hipError_t launch_jorg_wave(const SimDims &d, const DevPtrs &p, hipStream_t stream);
+size_t wolff_wave_lds_bytes(const SimDims &d);
 size_t cmr_wolff_lds_bytes(const SimDims &d);
 size_t cluster_sw_lds_bytes(const SimDims &d);
 hipError_t launch_fk(const SimDims &d, const DevPtrs &p, bool wolff, const ClusterAux &aux, hipStream_t stream);

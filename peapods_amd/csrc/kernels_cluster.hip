@@ -892,6 +892,179 @@ __global__ __launch_bounds__(64) void k_uf_replay(SimDims d, DevPtrs p, int cmr)
 }
 
 // ---------------------------------------------------------------------------
+// k_wolff_wave: the single-cluster moves whose bonds are drawn in the order a depth-first search
+// meets them (Joerg, overlap.rs:510-545; FK, fk.rs:45-86), one WAVE per pair / system.  The search
+// has to be replayed draw for draw, so it stays sequential per task -- but its steps need not be
+// slow: the neighbour table, the coupling bits, the task's spin / activity / membership bitmaps
+// and its stack all live in the LDS, lanes 0..11 test the twelve neighbour slots of the popped
+// site at once (one ballot = the eligible bonds, in the reference's order f0, b0, f1, b1, ...),
+// and only the accept draws walk through them one by one, the generator held uniformly by the
+// wave.  A site costs a few LDS round trips instead of several global ones per neighbour
+// (k_jorg / k_fk_wolff, one lane per task with stacks in global memory, remain for lattices
+// whose tables do not fit: Joerg 2.1 ms -> 0.2 ms per call on 6144 pairs of 12^3).
+// ---------------------------------------------------------------------------
+// tasks (waves) per workgroup share the lattice tables: as many as the LDS holds, up to 16 -- a wave alone issues an
+// instruction every five cycles or so, so the throughput is the number of waves a CU can keep resident
+__host__ __device__ inline size_t wolff_wave_lds_words(const SimDims &d, uint32_t tasks) {
+    return static_cast<size_t>(d.N) * 6 + d.N + tasks * (3 * static_cast<size_t>(d.MW) + (d.N + 1) / 2) + 16;
+}
+__host__ inline uint32_t wolff_wave_tasks(const SimDims &d) {
+    uint32_t tasks = 16;
+    while (tasks > 1 && wolff_wave_lds_words(d, tasks) * 4 > 160 * 1024) tasks /= 2;
+    return tasks;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
+    const uint32_t kWaveTasks = blockDim.x / 64;
+    constexpr bool FK = MODE == kSwFk;
+    extern __shared__ uint32_t lds[];
+    uint16_t *nbr = reinterpret_cast<uint16_t *>(lds); // [N][12] neighbours by site: f0, b0, f1, b1, ...
+    uint32_t *jbits = lds + static_cast<size_t>(d.N) * 6; // [N] neg[0..11] | nz[12..23] of the twelve bond slots
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t per_task = 3 * d.MW + (d.N + 1) / 2;
+    uint32_t *mine = jbits + d.N + wave * per_task;
+    uint32_t *act = mine, *spa = mine + d.MW, *member = mine + 2 * d.MW;
+    uint16_t *stack = reinterpret_cast<uint16_t *>(mine + 3 * d.MW);
+    const uint32_t n_tasks = FK ? d.n_sys : d.n_temps * d.n_pairs;
+    const uint32_t blocks_per_real = (n_tasks + kWaveTasks - 1) / kWaveTasks;
+    const uint32_t real = blockIdx.x / blocks_per_real;
+    const uint32_t task = __builtin_amdgcn_readfirstlane((blockIdx.x % blocks_per_real) * kWaveTasks + wave);
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(p.nbr_site);
+        for (uint32_t i = tid; i < d.N * 6; i += blockDim.x) lds[i] = src[i];
+        const uint32_t *js = p.jsite + static_cast<size_t>(real) * d.N;
+        for (uint32_t i = tid; i < d.N; i += blockDim.x) jbits[i] = js[i];
+    }
+    __syncthreads();
+    if (task >= n_tasks) return; // (no workgroup barrier below)
+    const uint32_t t = FK ? task % d.n_temps : task / d.n_pairs;
+    const uint32_t g = FK ? 0u : task % d.n_pairs;
+    const uint32_t *members = p.pair_slots + (static_cast<size_t>(real) * d.n_temps + t) * d.n_replicas + g * 2;
+    const uint32_t sa = FK ? task : members[0], sb = FK ? task : members[1];
+    uint32_t *Sa = p.S + (static_cast<size_t>(real) * d.W + (sa >> 5)) * d.N;
+    uint32_t *Sb = p.S + (static_cast<size_t>(real) * d.W + (sb >> 5)) * d.N;
+    const uint32_t ba = sa & 31u, bb = sb & 31u;
+    // ---- the task's bitmaps: active sites (Joerg: the pair's spins differ), spins of the first system, cluster
+    for (uint32_t i0 = 0; i0 < d.N; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const uint32_t va = i < d.N ? (Sa[i] >> ba) & 1u : 0u, vb = i < d.N ? (Sb[i] >> bb) & 1u : 0u;
+        const unsigned long long ma = __ballot(FK ? i < d.N : (va ^ vb) != 0), ms = __ballot(va != 0);
+        const uint32_t word = i0 >> 5;
+        if (lane == 0) {
+            act[word] = static_cast<uint32_t>(ma);
+            spa[word] = static_cast<uint32_t>(ms);
+            member[word] = 0;
+        }
+        if (lane == 32 && word + 1 < d.MW) {
+            act[word + 1] = static_cast<uint32_t>(ma >> 32);
+            spa[word + 1] = static_cast<uint32_t>(ms >> 32);
+            member[word + 1] = 0;
+        }
+    }
+    auto bit = [&](const uint32_t *bitmap, uint32_t i) -> uint32_t { return (bitmap[i >> 5] >> (i & 31u)) & 1u; };
+    // ---- the task's generator, held identically by every lane
+    DevRng rng;
+    uint64_t *pair_state = FK ? nullptr : p.pair_rng + (static_cast<size_t>(real) * d.n_temps * d.n_pairs + task) * 4;
+    if (FK) {
+        uint32_t st[8];
+        load_cursor(p.cursor, real, d.SP, sa, st);
+        rng.s0 = (static_cast<uint64_t>(st[1]) << 32) | st[0];
+        rng.s1 = (static_cast<uint64_t>(st[3]) << 32) | st[2];
+        rng.s2 = (static_cast<uint64_t>(st[5]) << 32) | st[4];
+        rng.s3 = (static_cast<uint64_t>(st[7]) << 32) | st[6];
+    } else {
+        rng.s0 = pair_state[0]; rng.s1 = pair_state[1]; rng.s2 = pair_state[2]; rng.s3 = pair_state[3];
+    }
+    auto draw_site = [&]() -> uint32_t { // rand 0.8.5 gen_range(0..N) on usize: widening multiply + zone rejection
+        const uint64_t range = d.N, zone = (range << __clzll(range)) - 1ull;
+        uint64_t v;
+        do v = rng.next(); while (v * range > zone);
+        return static_cast<uint32_t>(__umul64hi(v, range));
+    };
+    // ---- seed: FK any site (fk.rs:54); Joerg up to 64 probes for an active one (utils.rs:107-119)
+    uint32_t seed = 0xFFFFFFFFu;
+    if (FK) {
+        seed = draw_site();
+    } else {
+        for (int probe = 0; probe < 64 && seed == 0xFFFFFFFFu; ++probe) {
+            const uint32_t i = draw_site();
+            if (bit(act, i)) seed = i;
+        }
+    }
+    if (seed != 0xFFFFFFFFu) {
+        const uint32_t threshold = FK ? p.fk_thr[t] : p.jorg_thr[t]; // draw < ceil(p 2^24)  <=>  gen::<f32>() < p
+        const float temp = d.unit ? 0.0f : p.temps[t];
+        if (lane == 0) {
+            member[seed >> 5] |= 1u << (seed & 31u);
+            stack[0] = static_cast<uint16_t>(seed);
+        }
+        uint32_t top = 1;
+        uint32_t next = seed; // the entry on top of the stack, kept in a register: most pops never read the LDS
+        bool next_known = true;
+        while (top > 0) { // dfs_cluster, utils.rs:125-149
+            --top;
+            const uint32_t site = next_known ? next : __builtin_amdgcn_readfirstlane(stack[top]);
+            next_known = false;
+            const uint32_t jm = jbits[site];
+            // lanes 0..11: is the bond of slot `lane` eligible?  (not yet in the cluster, active, s s J > 0)
+            uint32_t nb = site;
+            bool eligible = false;
+            if (lane < 2 * d.nn) {
+                nb = nbr[site * 12 + lane];
+                eligible = ((jm >> (12 + lane)) & 1u) && !bit(member, nb) && bit(act, nb) &&
+                           ((bit(spa, site) ^ bit(spa, nb) ^ ((jm >> lane) & 1u)) == 0);
+            }
+            uint32_t todo = static_cast<uint32_t>(__ballot(eligible));
+            while (todo) {
+                const uint32_t q = __ffs(todo) - 1;
+                todo &= todo - 1;
+                const uint32_t target = __builtin_amdgcn_readlane(nb, q);
+                const uint32_t draw = static_cast<uint32_t>(rng.next() >> 40);
+                uint32_t limit = threshold;
+                if (!d.unit) { // this bond's own probability; the coupling belongs to the bond's forward end
+                    const uint32_t owner = (q & 1u) ? target : site;
+                    const float j_abs = fabsf(p.Jf[(static_cast<size_t>(real) * d.N + owner) * d.nn + (q >> 1)]);
+                    limit = FK ? fk_threshold(j_abs, temp) : jorg_threshold(j_abs, temp);
+                }
+                if (draw < limit) {
+                    if (lane == 0) {
+                        member[target >> 5] |= 1u << (target & 31u);
+                        stack[top] = static_cast<uint16_t>(target);
+                    }
+                    ++top;
+                    next = target;
+                    next_known = true;
+                    // another slot of this site leading to the same neighbour now finds it in the cluster
+                    todo &= ~static_cast<uint32_t>(__ballot(nb == target));
+                }
+            }
+        }
+        // ---- flip the cluster (the pair's / system's bit columns; other tasks own other bits of these words)
+        for (uint32_t m = lane; m < d.MW; m += 64) {
+            uint32_t bits = member[m];
+            while (bits) {
+                const uint32_t site = m * 32 + (__ffs(bits) - 1);
+                bits &= bits - 1;
+                atomicXor(&Sa[site], 1u << ba);
+                if (!FK) atomicXor(&Sb[site], 1u << bb);
+            }
+        }
+    }
+    if (lane == 0) {
+        if (FK) {
+            const uint32_t st[8] = {static_cast<uint32_t>(rng.s0), static_cast<uint32_t>(rng.s0 >> 32),
+                                    static_cast<uint32_t>(rng.s1), static_cast<uint32_t>(rng.s1 >> 32),
+                                    static_cast<uint32_t>(rng.s2), static_cast<uint32_t>(rng.s2 >> 32),
+                                    static_cast<uint32_t>(rng.s3), static_cast<uint32_t>(rng.s3 >> 32)};
+            store_cursor(p.cursor, real, d.SP, sa, st);
+        } else {
+            pair_state[0] = rng.s0; pair_state[1] = rng.s1; pair_state[2] = rng.s2; pair_state[3] = rng.s3;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_fk_wolff: FK single-cluster update (fk.rs:42-86): seed = gen_range(0..N) of the system's
 // generator, then dfs_cluster (utils.rs:125-149) with bonds drawn in the order the search meets
 // them, so the search is replayed draw for draw: one lane per system, the tile in LDS, stacks in
@@ -1139,6 +1312,8 @@ hipError_t configure_cluster_kernels() {
                            reinterpret_cast<const void *>(k_cluster_sw<kSwFk, true>),
                            reinterpret_cast<const void *>(k_cluster_sw<kSwCmr, true>),
                            reinterpret_cast<const void *>(k_fk_wolff),
+                           reinterpret_cast<const void *>(k_wolff_wave<kSwJorg>),
+                           reinterpret_cast<const void *>(k_wolff_wave<kSwFk>),
                            reinterpret_cast<const void *>(k_cmr_wolff),
                            reinterpret_cast<const void *>(k_uf_replay)}) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1173,6 +1348,17 @@ hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, ui
     return hipGetLastError();
 }
 
+size_t wolff_wave_lds_bytes(const SimDims &d) { return wolff_wave_lds_words(d, wolff_wave_tasks(d)) * 4; }
+
+// Joerg single-cluster move, one wave per pair (after the pairing shuffle)
+hipError_t launch_jorg_wave(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
+    hipLaunchKernelGGL(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
+    const uint32_t n_tasks = d.n_temps * d.n_pairs, per_block = wolff_wave_tasks(d);
+    hipLaunchKernelGGL(k_wolff_wave<kSwJorg>, dim3(d.n_real * ((n_tasks + per_block - 1) / per_block)), dim3(64 * per_block),
+                       wolff_wave_lds_bytes(d), stream, d, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_top4_accumulate(const SimDims &d, const DevPtrs &p, const ClusterAux &aux, hipStream_t stream) {
     hipLaunchKernelGGL(k_top4_accumulate, dim3(d.n_real), dim3(128), 0, stream, d, p, aux);
     return hipGetLastError();
@@ -1189,7 +1375,10 @@ size_t fk_wolff_lds_bytes(const SimDims &d) { return fk_wolff_lds_words(d) * 4; 
 // The depth-first single-cluster kernel serves calls that report nothing; a call that collects
 // sizes takes the union-find path, which draws every bond first and the seed afterwards (fk.rs:45).
 hipError_t launch_fk(const SimDims &d, const DevPtrs &p, bool wolff, const ClusterAux &aux, hipStream_t stream) {
-    if (wolff && aux.flags == 0)
+    if (wolff && aux.flags == 0 && wolff_wave_lds_bytes(d) <= 160 * 1024 && d.N <= 65535)
+        hipLaunchKernelGGL(k_wolff_wave<kSwFk>, dim3(d.n_real * ((d.n_sys + wolff_wave_tasks(d) - 1) / wolff_wave_tasks(d))),
+                           dim3(64 * wolff_wave_tasks(d)), wolff_wave_lds_bytes(d), stream, d, p);
+    else if (wolff && aux.flags == 0)
         hipLaunchKernelGGL(k_fk_wolff, dim3(d.n_real), dim3(1024), fk_wolff_lds_bytes(d), stream, d, p);
     else if (aux.flags != 0 || wolff)
         hipLaunchKernelGGL((k_cluster_sw<kSwFk, true>), dim3(d.n_real * d.n_sys), dim3(kSwThreads),

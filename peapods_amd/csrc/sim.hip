@@ -728,7 +728,12 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     const bool fk = cfg->cluster_interval > 0;
     if (fk && cfg->cluster_mode == PA_CLUSTER_WOLFF && (d.big || fk_wolff_lds_bytes(d) > 160 * 1024))
         return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the FK cluster kernel");
-    if ((oc_sw || fk || oc_cmr) && (rc = ensure_cluster_sw(sim))) return rc;
+    // Joerg single-cluster moves run one wave per pair when the lattice tables fit the LDS (k_wolff_wave)
+    bool jorg_wave = false;
+    for (int k = 0; cfg->overlap_cluster_interval > 0 && !oc_sw && k < cfg->n_overlap_cluster_modes && k < 4; ++k)
+        jorg_wave = jorg_wave || (cfg->overlap_cluster_modes[k] & 0xFF) == PA_OC_JORG;
+    jorg_wave = jorg_wave && !d.big && d.N <= 65535 && wolff_wave_lds_bytes(d) <= 160 * 1024 && cluster_sw_lds_bytes(d) <= 160 * 1024;
+    if ((oc_sw || fk || oc_cmr || jorg_wave) && (rc = ensure_cluster_sw(sim))) return rc;
     if (needs_exp && (rc = ensure_device_exp(sim))) return rc;
     if (cfg->equilibration_diagnostic && (rc = ensure_equil(sim))) return rc;
     // autocorrelation (mod.rs:342-345): max_lag capped at a quarter of the measurement sweeps, at least 1
@@ -893,11 +898,15 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                         DevPtrs p1 = offset_ptrs(g.p, g.d, 1);
                         if (oc_kind == PA_OC_CMR)
                             PA_HIP(sim, launch_cmr_wolff(d1, p1, g.stream));
+                        else if (jorg_wave)
+                            PA_HIP(sim, launch_jorg_wave(d1, p1, g.stream));
                         else
                             PA_HIP(sim, launch_jorg(d1, p1, g.stream));
                     }
                 } else if (oc_kind == PA_OC_CMR)
                     PA_HIP(sim, launch_cmr_wolff(g.d, g.p, g.stream)); // :845-965
+                else if (oc_kind == PA_OC_JORG && jorg_wave)
+                    PA_HIP(sim, launch_jorg_wave(g.d, g.p, g.stream)); // one wave per pair, tables in the LDS
                 else if (oc_kind == PA_OC_JORG)
                     PA_HIP(sim, launch_jorg(g.d, g.p, g.stream)); // :601-602,660-680
                 else

@@ -205,6 +205,7 @@ hipError_t launch_top4_accumulate(const SimDims &d, const DevPtrs &p, const Clus
 hipError_t launch_uf_replay(const SimDims &d, const DevPtrs &p, bool cmr, hipStream_t stream);
 hipError_t launch_cmr_wolff(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 hipError_t launch_jorg_wave(const SimDims &d, const DevPtrs &p, hipStream_t stream);
+hipError_t launch_cmr_wave(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 size_t wolff_wave_lds_bytes(const SimDims &d);
 size_t cmr_wolff_lds_bytes(const SimDims &d);
 size_t cluster_sw_lds_bytes(const SimDims &d);

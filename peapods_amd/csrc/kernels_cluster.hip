@@ -906,7 +906,7 @@ __global__ __launch_bounds__(64) void k_uf_replay(SimDims d, DevPtrs p, int cmr)
 // tasks (waves) per workgroup share the lattice tables: as many as the LDS holds, up to 16 -- a wave alone issues an
 // instruction every five cycles or so, so the throughput is the number of waves a CU can keep resident
 __host__ __device__ inline size_t wolff_wave_lds_words(const SimDims &d, uint32_t tasks) {
-    return static_cast<size_t>(d.N) * 6 + d.N + tasks * (3 * static_cast<size_t>(d.MW) + (d.N + 1) / 2) + 16;
+    return static_cast<size_t>(d.N) * 6 + d.N + tasks * (5 * static_cast<size_t>(d.MW) + (d.N + 1) / 2) + 16;
 }
 __host__ inline uint32_t wolff_wave_tasks(const SimDims &d) {
     uint32_t tasks = 16;
@@ -917,15 +917,16 @@ __host__ inline uint32_t wolff_wave_tasks(const SimDims &d) {
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
     const uint32_t kWaveTasks = blockDim.x / 64;
-    constexpr bool FK = MODE == kSwFk;
+    constexpr bool FK = MODE == kSwFk, CMR = MODE == kSwCmr;
     extern __shared__ uint32_t lds[];
     uint16_t *nbr = reinterpret_cast<uint16_t *>(lds); // [N][12] neighbours by site: f0, b0, f1, b1, ...
     uint32_t *jbits = lds + static_cast<size_t>(d.N) * 6; // [N] neg[0..11] | nz[12..23] of the twelve bond slots
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t per_task = 3 * d.MW + (d.N + 1) / 2;
+    const uint32_t per_task = 5 * d.MW + (d.N + 1) / 2;
     uint32_t *mine = jbits + d.N + wave * per_task;
     uint32_t *act = mine, *spa = mine + d.MW, *member = mine + 2 * d.MW;
-    uint16_t *stack = reinterpret_cast<uint16_t *>(mine + 3 * d.MW);
+    uint32_t *spb = mine + 3 * d.MW, *blue = mine + 4 * d.MW; // CMR: spins of the second system, the blue cluster
+    uint16_t *stack = reinterpret_cast<uint16_t *>(mine + 5 * d.MW);
     const uint32_t n_tasks = FK ? d.n_sys : d.n_temps * d.n_pairs;
     const uint32_t blocks_per_real = (n_tasks + kWaveTasks - 1) / kWaveTasks;
     const uint32_t real = blockIdx.x / blocks_per_real;
@@ -949,16 +950,19 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
     for (uint32_t i0 = 0; i0 < d.N; i0 += 64) {
         const uint32_t i = i0 + lane;
         const uint32_t va = i < d.N ? (Sa[i] >> ba) & 1u : 0u, vb = i < d.N ? (Sb[i] >> bb) & 1u : 0u;
-        const unsigned long long ma = __ballot(FK ? i < d.N : (va ^ vb) != 0), ms = __ballot(va != 0);
+        const unsigned long long ma = __ballot((FK || CMR) ? i < d.N : (va ^ vb) != 0), ms = __ballot(va != 0);
+        const unsigned long long mb = __ballot(vb != 0);
         const uint32_t word = i0 >> 5;
         if (lane == 0) {
             act[word] = static_cast<uint32_t>(ma);
             spa[word] = static_cast<uint32_t>(ms);
+            spb[word] = static_cast<uint32_t>(mb);
             member[word] = 0;
         }
         if (lane == 32 && word + 1 < d.MW) {
             act[word + 1] = static_cast<uint32_t>(ma >> 32);
             spa[word + 1] = static_cast<uint32_t>(ms >> 32);
+            spb[word + 1] = static_cast<uint32_t>(mb >> 32);
             member[word + 1] = 0;
         }
     }
@@ -984,7 +988,7 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
     };
     // ---- seed: FK any site (fk.rs:54); Joerg up to 64 probes for an active one (utils.rs:107-119)
     uint32_t seed = 0xFFFFFFFFu;
-    if (FK) {
+    if (FK || CMR) { // (CMR: overlap.rs:847)
         seed = draw_site();
     } else {
         for (int probe = 0; probe < 64 && seed == 0xFFFFFFFFu; ++probe) {
@@ -993,61 +997,105 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
         }
     }
     if (seed != 0xFFFFFFFFu) {
-        const uint32_t threshold = FK ? p.fk_thr[t] : p.jorg_thr[t]; // draw < ceil(p 2^24)  <=>  gen::<f32>() < p
         const float temp = d.unit ? 0.0f : p.temps[t];
+        uint32_t top = 0;
+        uint32_t next = 0; // the entry on top of the stack, kept in a register: most pops never read the LDS
+        bool next_known = false;
+        // depth-first search from whatever is on the stack (dfs_cluster, utils.rs:125-149).  phase 0: Joerg / FK
+        // bonds, or CMR's blue bonds (both systems satisfied, 1 - r^2); phase 1: CMR's red bonds (exactly one
+        // system satisfied, 1 - r), which a flip of both systems on the blue cluster leaves as they are
+        auto search = [&](uint32_t phase) {
+            const uint32_t threshold = FK ? p.fk_thr[t] : (CMR ? (phase == 0 ? p.cmr_thr[t] : p.fk_thr[t]) : p.jorg_thr[t]);
+            while (top > 0) {
+                --top;
+                const uint32_t site = next_known ? next : __builtin_amdgcn_readfirstlane(stack[top]);
+                next_known = false;
+                const uint32_t jm = jbits[site];
+                // lanes 0..11: is the bond of slot `lane` eligible?
+                uint32_t nb = site;
+                bool eligible = false;
+                if (lane < 2 * d.nn) {
+                    nb = nbr[site * 12 + lane];
+                    const bool a_sat = (bit(spa, site) ^ bit(spa, nb) ^ ((jm >> lane) & 1u)) == 0;
+                    bool wanted = a_sat && bit(act, nb);
+                    if (CMR) {
+                        const bool b_sat = (bit(spb, site) ^ bit(spb, nb) ^ ((jm >> lane) & 1u)) == 0;
+                        wanted = phase == 0 ? (a_sat && b_sat) : (a_sat != b_sat);
+                    }
+                    eligible = ((jm >> (12 + lane)) & 1u) && !bit(member, nb) && wanted;
+                }
+                uint32_t todo = static_cast<uint32_t>(__ballot(eligible));
+                while (todo) {
+                    const uint32_t q = __ffs(todo) - 1;
+                    todo &= todo - 1;
+                    const uint32_t target = __builtin_amdgcn_readlane(nb, q);
+                    const uint32_t draw = static_cast<uint32_t>(rng.next() >> 40);
+                    uint32_t limit = threshold; // draw < ceil(p 2^24)  <=>  gen::<f32>() < p
+                    if (!d.unit) { // this bond's own probability; the coupling belongs to the bond's forward end
+                        const uint32_t owner = (q & 1u) ? target : site;
+                        const float j_abs = fabsf(p.Jf[(static_cast<size_t>(real) * d.N + owner) * d.nn + (q >> 1)]);
+                        limit = FK ? fk_threshold(j_abs, temp)
+                                   : (CMR ? (phase == 0 ? cmr_blue_threshold(j_abs, temp) : fk_threshold(j_abs, temp))
+                                          : jorg_threshold(j_abs, temp));
+                    }
+                    if (draw < limit) {
+                        if (lane == 0) {
+                            member[target >> 5] |= 1u << (target & 31u);
+                            stack[top] = static_cast<uint16_t>(target);
+                        }
+                        ++top;
+                        next = target;
+                        next_known = true;
+                        // another slot of this site leading to the same neighbour now finds it in the cluster
+                        todo &= ~static_cast<uint32_t>(__ballot(nb == target));
+                    }
+                }
+            }
+        };
         if (lane == 0) {
             member[seed >> 5] |= 1u << (seed & 31u);
             stack[0] = static_cast<uint16_t>(seed);
         }
-        uint32_t top = 1;
-        uint32_t next = seed; // the entry on top of the stack, kept in a register: most pops never read the LDS
-        bool next_known = true;
-        while (top > 0) { // dfs_cluster, utils.rs:125-149
-            --top;
-            const uint32_t site = next_known ? next : __builtin_amdgcn_readfirstlane(stack[top]);
-            next_known = false;
-            const uint32_t jm = jbits[site];
-            // lanes 0..11: is the bond of slot `lane` eligible?  (not yet in the cluster, active, s s J > 0)
-            uint32_t nb = site;
-            bool eligible = false;
-            if (lane < 2 * d.nn) {
-                nb = nbr[site * 12 + lane];
-                eligible = ((jm >> (12 + lane)) & 1u) && !bit(member, nb) && bit(act, nb) &&
-                           ((bit(spa, site) ^ bit(spa, nb) ^ ((jm >> lane) & 1u)) == 0);
+        top = 1;
+        next = seed;
+        next_known = true;
+        search(0);
+        uint32_t k = 3; // which system(s) the final cluster flips: both, except for CMR's grey cluster
+        if (CMR) {
+            // the blue cluster has flipped in both systems (overlap.rs:889-895); the search goes on from every blue
+            // site, pushed in ascending order (:897-902), over the red bonds; k in 1..=3 then picks the systems
+            for (uint32_t m = lane; m < d.MW; m += 64) blue[m] = member[m];
+            for (uint32_t i0 = 0; i0 < d.N; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                const bool in = i < d.N && bit(member, i);
+                const unsigned long long votes = __ballot(in);
+                if (in) stack[top + __popcll(votes & ((1ull << lane) - 1ull))] = static_cast<uint16_t>(i);
+                top += static_cast<uint32_t>(__popcll(votes));
             }
-            uint32_t todo = static_cast<uint32_t>(__ballot(eligible));
-            while (todo) {
-                const uint32_t q = __ffs(todo) - 1;
-                todo &= todo - 1;
-                const uint32_t target = __builtin_amdgcn_readlane(nb, q);
-                const uint32_t draw = static_cast<uint32_t>(rng.next() >> 40);
-                uint32_t limit = threshold;
-                if (!d.unit) { // this bond's own probability; the coupling belongs to the bond's forward end
-                    const uint32_t owner = (q & 1u) ? target : site;
-                    const float j_abs = fabsf(p.Jf[(static_cast<size_t>(real) * d.N + owner) * d.nn + (q >> 1)]);
-                    limit = FK ? fk_threshold(j_abs, temp) : jorg_threshold(j_abs, temp);
-                }
-                if (draw < limit) {
-                    if (lane == 0) {
-                        member[target >> 5] |= 1u << (target & 31u);
-                        stack[top] = static_cast<uint16_t>(target);
-                    }
-                    ++top;
-                    next = target;
-                    next_known = true;
-                    // another slot of this site leading to the same neighbour now finds it in the cluster
-                    todo &= ~static_cast<uint32_t>(__ballot(nb == target));
+            next_known = false;
+            search(1);
+            for (;;) { // rand 0.8.5 u8 gen_range(1..=3): u32 draw, zone = u32::MAX - (2^32 - 3) % 3
+                const uint32_t v = static_cast<uint32_t>(rng.next() >> 32);
+                const uint64_t m = static_cast<uint64_t>(v) * 3u;
+                if (static_cast<uint32_t>(m) <= 0xFFFFFFFFu - ((0xFFFFFFFFu - 3u + 1u) % 3u)) {
+                    k = 1u + static_cast<uint32_t>(m >> 32);
+                    break;
                 }
             }
         }
         // ---- flip the cluster (the pair's / system's bit columns; other tasks own other bits of these words)
         for (uint32_t m = lane; m < d.MW; m += 64) {
-            uint32_t bits = member[m];
-            while (bits) {
-                const uint32_t site = m * 32 + (__ffs(bits) - 1);
-                bits &= bits - 1;
+            const uint32_t grey = member[m], was_blue = CMR ? blue[m] : 0u;
+            uint32_t flip_a = ((k & 1u) ? grey : 0u) ^ was_blue, flip_b = ((k & 2u) ? grey : 0u) ^ was_blue;
+            while (flip_a) {
+                const uint32_t site = m * 32 + (__ffs(flip_a) - 1);
+                flip_a &= flip_a - 1;
                 atomicXor(&Sa[site], 1u << ba);
-                if (!FK) atomicXor(&Sb[site], 1u << bb);
+            }
+            while (!FK && flip_b) {
+                const uint32_t site = m * 32 + (__ffs(flip_b) - 1);
+                flip_b &= flip_b - 1;
+                atomicXor(&Sb[site], 1u << bb);
             }
         }
     }
@@ -1314,6 +1362,7 @@ hipError_t configure_cluster_kernels() {
                            reinterpret_cast<const void *>(k_fk_wolff),
                            reinterpret_cast<const void *>(k_wolff_wave<kSwJorg>),
                            reinterpret_cast<const void *>(k_wolff_wave<kSwFk>),
+                           reinterpret_cast<const void *>(k_wolff_wave<kSwCmr>),
                            reinterpret_cast<const void *>(k_cmr_wolff),
                            reinterpret_cast<const void *>(k_uf_replay)}) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1355,6 +1404,14 @@ hipError_t launch_jorg_wave(const SimDims &d, const DevPtrs &p, hipStream_t stre
     hipLaunchKernelGGL(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
     const uint32_t n_tasks = d.n_temps * d.n_pairs, per_block = wolff_wave_tasks(d);
     hipLaunchKernelGGL(k_wolff_wave<kSwJorg>, dim3(d.n_real * ((n_tasks + per_block - 1) / per_block)), dim3(64 * per_block),
+                       wolff_wave_lds_bytes(d), stream, d, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_cmr_wave(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
+    hipLaunchKernelGGL(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
+    const uint32_t n_tasks = d.n_temps * d.n_pairs, per_block = wolff_wave_tasks(d);
+    hipLaunchKernelGGL(k_wolff_wave<kSwCmr>, dim3(d.n_real * ((n_tasks + per_block - 1) / per_block)), dim3(64 * per_block),
                        wolff_wave_lds_bytes(d), stream, d, p);
     return hipGetLastError();
 }

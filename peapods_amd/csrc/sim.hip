@@ -732,7 +732,8 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     bool jorg_wave = false;
     for (int k = 0; cfg->overlap_cluster_interval > 0 && !oc_sw && k < cfg->n_overlap_cluster_modes && k < 4; ++k)
         jorg_wave = jorg_wave || (cfg->overlap_cluster_modes[k] & 0xFF) == PA_OC_JORG;
-    jorg_wave = jorg_wave && !d.big && d.N <= 65535 && wolff_wave_lds_bytes(d) <= 160 * 1024 && cluster_sw_lds_bytes(d) <= 160 * 1024;
+    const bool wave_ok = !d.big && d.N <= 65535 && wolff_wave_lds_bytes(d) <= 160 * 1024 && cluster_sw_lds_bytes(d) <= 160 * 1024;
+    jorg_wave = jorg_wave && wave_ok;
     if ((oc_sw || fk || oc_cmr || jorg_wave) && (rc = ensure_cluster_sw(sim))) return rc;
     if (needs_exp && (rc = ensure_device_exp(sim))) return rc;
     if (cfg->equilibration_diagnostic && (rc = ensure_equil(sim))) return rc;
@@ -896,15 +897,19 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                     PA_HIP(sim, launch_cluster_sw(d0, g.p, oc_kind, oc_group, true, a2, g.stream));
                     if (d1.n_real > 0) {
                         DevPtrs p1 = offset_ptrs(g.p, g.d, 1);
-                        if (oc_kind == PA_OC_CMR)
+                        if (oc_kind == PA_OC_CMR && wave_ok)
+                            PA_HIP(sim, launch_cmr_wave(d1, p1, g.stream));
+                        else if (oc_kind == PA_OC_CMR)
                             PA_HIP(sim, launch_cmr_wolff(d1, p1, g.stream));
                         else if (jorg_wave)
                             PA_HIP(sim, launch_jorg_wave(d1, p1, g.stream));
                         else
                             PA_HIP(sim, launch_jorg(d1, p1, g.stream));
                     }
-                } else if (oc_kind == PA_OC_CMR)
-                    PA_HIP(sim, launch_cmr_wolff(g.d, g.p, g.stream)); // :845-965
+                } else if (oc_kind == PA_OC_CMR && wave_ok)
+                    PA_HIP(sim, launch_cmr_wave(g.d, g.p, g.stream)); // :845-965, one wave per pair
+                else if (oc_kind == PA_OC_CMR)
+                    PA_HIP(sim, launch_cmr_wolff(g.d, g.p, g.stream));
                 else if (oc_kind == PA_OC_JORG && jorg_wave)
                     PA_HIP(sim, launch_jorg_wave(g.d, g.p, g.stream)); // one wave per pair, tables in the LDS
                 else if (oc_kind == PA_OC_JORG)

@@ -30,7 +30,7 @@ def run(label, **kw):
 
 
 run("no move")
-for mode in ("houdayer", "jorg"):
+for mode in ("houdayer", "jorg", "cmr"):
     for inner in ("wolff", "sw"):
         run(f"{mode}/{inner}", overlap_cluster_update_interval=1, overlap_cluster_build_mode=mode,
             overlap_cluster_mode=inner)

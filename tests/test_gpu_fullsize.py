@@ -197,3 +197,30 @@ def test_fallback_sweeps_of_the_large_path_match_oracle(oracle, monkeypatch, kno
         for r in range(2):
             np.testing.assert_array_equal(gpu.get_spins(r), cpu.get_spins(r))
             np.testing.assert_array_equal(gpu.get_system_ids(r), cpu.get_system_ids(r))
+
+
+@pytest.mark.parametrize("build,inner", [("houdayer", "wolff"), ("jorg", "wolff"), ("jorg", "sw"), ("cmr", "wolff"),
+                                         ("cmr+houdayer", "sw")])
+def test_config4_overlap_moves_at_full_size(oracle, build, inner):
+    """BASELINE configs[4]: 12^3 +-J with the overlap-cluster moves at the ensemble shape of the benchmark
+    (24 temperatures x 4 replicas), a few realisations against the oracle."""
+    from peapods_amd import IsingSimulation
+
+    shape = (12, 12, 12)
+    rng = np.random.default_rng(44)
+    couplings = (2 * rng.integers(0, 2, size=(3,) + shape + (3,)) - 1).astype(np.float32)
+    temps = np.linspace(0.8, 1.4, 24).astype(np.float32)
+    gpu = IsingSimulation(list(shape), couplings, temps, 4, None, 17)
+    cpu = oracle.OracleSimulation(list(shape), couplings, temps, 4, None, 17)
+    kw = dict(pt_interval=1, warmup_ratio=0.25, overlap_cluster_update_interval=1, overlap_cluster_build_mode=build,
+              overlap_cluster_mode=inner)
+    a = gpu.sample(10, "metropolis", **kw)
+    b = cpu.sample(10, "metropolis", n_threads=8, **kw)
+    for key in ("energies", "energies2", "mags2", "overlap2", "overlap4", "link_overlap2"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    np.testing.assert_array_equal(a["per_sample_overlap_histogram"], b["per_sample_overlap_histogram"])
+    for r in range(3):
+        np.testing.assert_array_equal(gpu.get_spins(r), cpu.get_spins(r))
+        np.testing.assert_array_equal(gpu.get_system_ids(r), cpu.get_system_ids(r))
+        for s in (0, 17, 95):
+            np.testing.assert_array_equal(gpu.get_rng_state(r, s), cpu.get_rng_state(r, s))

@@ -113,6 +113,7 @@ struct DevPtrs {
     uint64_t *pair_rng;      // [n_real][n_temps * n_pairs][4] xoshiro state of the overlap-move generators
     // "sw" inner variant of the overlap-cluster moves (kernels_cluster.hip; built on first use)
     uint32_t *pair_slots;    // [n_real][n_temps][n_replicas] slots in the shuffled order of each temperature
+    uint32_t *slot_bits;     // [n_real][SP][MW] spins of every slot as a bitmap over the sites (k_slot_bitmaps, per call)
     const uint32_t *jump256; // [n_jump256][64][16][8] nibble tables of T^(256 b)
     const uint32_t *jump64;  // [4][64][16][8] nibble tables of T^(64 s)
     const uint32_t *jorg_thr;// [n_temps] ceil((1 - exp(-4/T)) 2^24): draw < thr <=> gen::<f32>() < p

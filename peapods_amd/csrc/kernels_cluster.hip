@@ -66,6 +66,33 @@ __global__ void k_pairing(SimDims d, DevPtrs p) {
     st[0] = rng.s0; st[1] = rng.s1; st[2] = rng.s2; st[3] = rng.s3;
 }
 
+// k_slot_bitmaps: slot_bits[real][slot][MW] = the spins of one system as a bitmap over the sites (1 <=> -1).
+// The cluster workgroups each need the bit columns of two (or `group`) systems; reading them out of the
+// slot-sliced tile costs a full word per site and system (32x the bits needed, 50-60 us per call on 6144 pairs),
+// so the tile is transposed once per call: 64 sites x 32 slots per wave by 32 ballots.
+__global__ __launch_bounds__(256) void k_slot_bitmaps(SimDims d, DevPtrs p) {
+    const uint32_t n_chunks = (d.N + 255) / 256;
+    const uint32_t chunk = blockIdx.x % n_chunks, w = (blockIdx.x / n_chunks) % d.W, real = blockIdx.x / (n_chunks * d.W);
+    const uint32_t lane = threadIdx.x & 63u, i0 = chunk * 256 + (threadIdx.x & ~63u), i = i0 + lane;
+    if (i0 >= d.N) return;
+    const uint32_t v = i < d.N ? p.S[(static_cast<size_t>(real) * d.W + w) * d.N + i] : 0u;
+    uint32_t keep_lo = 0, keep_hi = 0; // lane k (< 32) ends up with the two words of slot k
+#pragma unroll
+    for (uint32_t k = 0; k < 32; ++k) {
+        const unsigned long long votes = __ballot((v >> k) & 1u);
+        if (lane == k) {
+            keep_lo = static_cast<uint32_t>(votes);
+            keep_hi = static_cast<uint32_t>(votes >> 32);
+        }
+    }
+    if (lane < 32) {
+        uint32_t *row = p.slot_bits + (static_cast<size_t>(real) * d.SP + w * 32 + lane) * d.MW;
+        const uint32_t word = i0 >> 5;
+        row[word] = keep_lo;
+        if (word + 1 < d.MW) row[word + 1] = keep_hi;
+    }
+}
+
 constexpr uint32_t kSwThreads = 256;
 
 // Exclusive prefix sum of v over the workgroup's threads (tid order); returns the exclusive
@@ -188,33 +215,37 @@ __global__ __launch_bounds__(kSwThreads, (!EXTRAS && MODE == kSwHoudayer) ? 4 : 
     };
     auto get_bit = [&](const uint32_t *bitmap, uint32_t i) -> uint32_t { return (bitmap[i >> 5] >> (i & 31u)) & 1u; };
 
-    // ---- A: active sites and the systems' spins (loads of 8 rounds are issued before their ballots)
-    for (uint32_t r0 = 0; r0 < n_rounds; r0 += 8) {
-        uint32_t va[8], vb[8], minus[8];
+    // ---- A: active sites and the systems' spins, from the per-slot bitmaps (k_slot_bitmaps)
+    {
+        const uint32_t *bits = p.slot_bits + static_cast<size_t>(real) * d.SP * d.MW;
+        const uint32_t tail = (d.N & 31u) ? ((1u << (d.N & 31u)) - 1u) : 0xFFFFFFFFu;
+        for (uint32_t m = tid; m < d.MW; m += kSwThreads) {
+            const uint32_t live = m + 1 == d.MW ? tail : 0xFFFFFFFFu;
+            const uint32_t wa = bits[static_cast<size_t>(sa) * d.MW + m], wb = bits[static_cast<size_t>(sb) * d.MW + m];
+            uint32_t active = (FK || CMR) ? live : (wa ^ wb);
+            if (MODE == kSwHoudayer && group > 2) { // the group's spins sum to zero (overlap.rs:199-205): group / 2 are -1
+                uint32_t c[6] = {0, 0, 0, 0, 0, 0}; // bit-sliced count of the members' -1 spins per site
+                for (uint32_t k = 0; k < group; ++k) {
+                    uint32_t carry = bits[static_cast<size_t>(members[k]) * d.MW + m];
 #pragma unroll
-        for (uint32_t q = 0; q < 8; ++q) {
-            const uint32_t i = (r0 + q) * kSwThreads + tid;
-            va[q] = vb[q] = minus[q] = 0;
-            if (r0 + q < n_rounds && i < d.N) {
-                va[q] = (Sa[i] >> ba) & 1u;
-                vb[q] = (Sb[i] >> bb) & 1u;
-                if (MODE == kSwHoudayer && group > 2) // the group's spins sum to zero (overlap.rs:199-205)
-                    for (uint32_t k = 0; k < group; ++k)
-                        minus[q] += (Stile[static_cast<size_t>(members[k] >> 5) * d.N + i] >> (members[k] & 31u)) & 1u;
+                    for (int bq = 0; bq < 6; ++bq) {
+                        const uint32_t t2 = c[bq] & carry;
+                        c[bq] ^= carry;
+                        carry = t2;
+                    }
+                }
+                active = live;
+#pragma unroll
+                for (int bq = 0; bq < 6; ++bq) active &= ((group / 2) >> bq) & 1u ? c[bq] : ~c[bq];
             }
+            L.act[m] = active;
+            L.spa[m] = wa;
+            L.spb[m] = wb;
         }
-#pragma unroll
-        for (uint32_t q = 0; q < 8; ++q) {
-            const uint32_t r = r0 + q, i = r * kSwThreads + tid;
-            if (r >= n_rounds) break;
-            bool active = (FK || CMR) ? i < d.N : (va[q] ^ vb[q]) != 0;
-            if (MODE == kSwHoudayer && group > 2) active = i < d.N && 2 * minus[q] == group;
-            put_ballot(L.act, r, active);
-            put_ballot(L.spa, r, va[q] != 0);
-            put_ballot(L.spb, r, vb[q] != 0);
-            if (snap_here && i < d.N) { // the pair's spins before the move (overlap.rs:211-221)
-                p.snap_spins[(static_cast<size_t>(t) * 2 + 0) * d.N + i] = va[q] ? -1 : 1;
-                p.snap_spins[(static_cast<size_t>(t) * 2 + 1) * d.N + i] = vb[q] ? -1 : 1;
+        if (snap_here) { // the pair's spins before the move (overlap.rs:211-221)
+            for (uint32_t i = tid; i < d.N; i += kSwThreads) {
+                p.snap_spins[(static_cast<size_t>(t) * 2 + 0) * d.N + i] = ((bits[static_cast<size_t>(sa) * d.MW + (i >> 5)] >> (i & 31u)) & 1u) ? -1 : 1;
+                p.snap_spins[(static_cast<size_t>(t) * 2 + 1) * d.N + i] = ((bits[static_cast<size_t>(sb) * d.MW + (i >> 5)] >> (i & 31u)) & 1u) ? -1 : 1;
             }
         }
     }
@@ -1374,6 +1405,7 @@ hipError_t configure_cluster_kernels() {
 hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, uint32_t group, bool wolff,
                              const ClusterAux &aux, hipStream_t stream) {
     hipLaunchKernelGGL(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
+    hipLaunchKernelGGL(k_slot_bitmaps, dim3(d.n_real * d.W * ((d.N + 255) / 256)), dim3(256), 0, stream, d, p);
     const dim3 grid(d.n_real * d.n_temps * (d.n_replicas / group)), block(kSwThreads);
     const size_t lds = cluster_sw_lds_bytes(d);
     const int single = wolff ? 1 : 0;
@@ -1432,12 +1464,17 @@ size_t fk_wolff_lds_bytes(const SimDims &d) { return fk_wolff_lds_words(d) * 4; 
 // The depth-first single-cluster kernel serves calls that report nothing; a call that collects
 // sizes takes the union-find path, which draws every bond first and the seed afterwards (fk.rs:45).
 hipError_t launch_fk(const SimDims &d, const DevPtrs &p, bool wolff, const ClusterAux &aux, hipStream_t stream) {
-    if (wolff && aux.flags == 0 && wolff_wave_lds_bytes(d) <= 160 * 1024 && d.N <= 65535)
-        hipLaunchKernelGGL(k_wolff_wave<kSwFk>, dim3(d.n_real * ((d.n_sys + wolff_wave_tasks(d) - 1) / wolff_wave_tasks(d))),
-                           dim3(64 * wolff_wave_tasks(d)), wolff_wave_lds_bytes(d), stream, d, p);
-    else if (wolff && aux.flags == 0)
-        hipLaunchKernelGGL(k_fk_wolff, dim3(d.n_real), dim3(1024), fk_wolff_lds_bytes(d), stream, d, p);
-    else if (aux.flags != 0 || wolff)
+    if (wolff && aux.flags == 0) { // depth-first single-cluster form: one wave per system if the tables fit the LDS
+        if (wolff_wave_lds_bytes(d) <= 160 * 1024 && d.N <= 65535)
+            hipLaunchKernelGGL(k_wolff_wave<kSwFk>, dim3(d.n_real * ((d.n_sys + wolff_wave_tasks(d) - 1) / wolff_wave_tasks(d))),
+                               dim3(64 * wolff_wave_tasks(d)), wolff_wave_lds_bytes(d), stream, d, p);
+        else
+            hipLaunchKernelGGL(k_fk_wolff, dim3(d.n_real), dim3(1024), fk_wolff_lds_bytes(d), stream, d, p);
+        return hipGetLastError();
+    }
+    // union-find forms (they read the per-slot bitmaps)
+    hipLaunchKernelGGL(k_slot_bitmaps, dim3(d.n_real * d.W * ((d.N + 255) / 256)), dim3(256), 0, stream, d, p);
+    if (aux.flags != 0 || wolff)
         hipLaunchKernelGGL((k_cluster_sw<kSwFk, true>), dim3(d.n_real * d.n_sys), dim3(kSwThreads),
                            cluster_sw_lds_bytes(d), stream, d, p, 1u, wolff ? 1 : 0, aux);
     else

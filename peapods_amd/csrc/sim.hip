@@ -372,6 +372,7 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
         q.eq_ckpt += static_cast<size_t>(64) * 2 * d.n_temps * r0;
     }
     q.dfs_stack += static_cast<size_t>(std::max(d.n_temps * d.n_pairs, d.n_sys)) * d.N * r0;
+    if (q.slot_bits) q.slot_bits += static_cast<size_t>(d.SP) * d.MW * r0;
     return q;
 }
 
@@ -528,6 +529,7 @@ int ensure_cluster_sw(pa_sim *sim) {
     PA_HIP(sim, sim->buffers.alloc(&sim->cmr_thr, thr_cmr.size()));
     const size_t slots_per_real = static_cast<size_t>(d.n_temps) * d.n_replicas;
     PA_HIP(sim, sim->buffers.alloc(&sim->p.pair_slots, slots_per_real * d.n_real));
+    PA_HIP(sim, sim->buffers.alloc(&sim->p.slot_bits, static_cast<size_t>(d.n_real) * d.SP * d.MW));
     int rc;
     if ((rc = upload(sim, sim->jump256, jump)) || (rc = upload(sim, sim->jump64, jump_fine)) ||
         (rc = upload(sim, sim->jorg_thr, thr)) ||
@@ -547,6 +549,7 @@ int ensure_cluster_sw(pa_sim *sim) {
         g.p.fk_thr = sim->fk_thr;
         g.p.cmr_thr = sim->cmr_thr;
         g.p.pair_slots = sim->p.pair_slots + slots_per_real * r0;
+        g.p.slot_bits = sim->p.slot_bits + static_cast<size_t>(d.SP) * d.MW * r0;
         r0 += g.d.n_real;
     }
     return PA_OK;

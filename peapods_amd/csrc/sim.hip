@@ -1151,6 +1151,9 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     // sites per RNG block (tuning knob PEAPODS_RNG_BLOCK): 128 gives twice the waves of 256 for 7 % more
     // jump-ahead work and is 7 % faster per step on the bench workload (64, 96, 160, 256, 512 measured)
     uint32_t target_block = 128;
+    // a jump table (32 KB) is staged once per workgroup: with few systems sharing it (small ensembles on large
+    // lattices) the staging traffic dominates and longer blocks win (64^3 x 64 systems: 43 -> 32 us per sweep)
+    if (static_cast<uint64_t>(d.n_real) * d.W * 32 < 4096) target_block = 256;
     if (const char *env = std::getenv("PEAPODS_RNG_BLOCK")) {
         const long v = std::strtol(env, nullptr, 10);
         if (v >= 16 && v <= 65536) target_block = static_cast<uint32_t>(v);

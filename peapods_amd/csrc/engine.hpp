@@ -114,8 +114,10 @@ struct DevPtrs {
     // "sw" inner variant of the overlap-cluster moves (kernels_cluster.hip; built on first use)
     uint32_t *pair_slots;    // [n_real][n_temps][n_replicas] slots in the shuffled order of each temperature
     uint32_t *slot_bits;     // [n_real][SP][MW] spins of every slot as a bitmap over the sites (k_slot_bitmaps, per call)
-    const uint32_t *jump256; // [n_jump256][64][16][8] nibble tables of T^(256 b)
-    const uint32_t *jump64;  // [4][64][16][8] nibble tables of T^(64 s)
+    const uint32_t *jump_unit; // [cluster_stream_units][64][16][8] nibble tables of T^(64 u)
+    uint8_t *stream_bits;    // [n_real][n_sys][cluster_stream_units * 64] classified draws of the cluster generators (unit couplings)
+    uint32_t *stream_raw;    // same shape: the 24-bit draws themselves (other couplings)
+    uint32_t *stream_error;  // [1] set if a task ever needed draws beyond its stream (checked by pa_sim_synchronize)
     const uint32_t *jorg_thr;// [n_temps] ceil((1 - exp(-4/T)) 2^24): draw < thr <=> gen::<f32>() < p
     const uint32_t *cmr_thr; // [n_temps] CMR blue bonds: 1 - r^2, r = exp(-2/T) (red bonds use fk_thr = 1 - r)
     const uint32_t *fk_thr;  // [n_temps] the same for the FK bond probability 1 - exp(-2/T)
@@ -155,7 +157,12 @@ struct ClusterAux {
     uint32_t n_modes;  // rows allocated
     uint32_t kind;     // obs_acc row: 0 fk, 1 houdayer, 2 jorg, 3 cmr_blue
     uint32_t square;   // 1: canonical 2D hypercubic lattice -> winding is measured (lattice.rs:31-38)
+    uint32_t stream_units; // units of 64 draws k_pair_stream made for this call (set by the launcher)
 };
+
+// Room in a cluster generator's pre-drawn stream, in units of 64 draws: every forward bond, two draws per
+// site (CMR: blue and grey clusters) and the seed draw of a single-cluster form.
+__host__ __device__ inline uint32_t cluster_stream_units(const SimDims &d) { return (d.N * d.nn + 2u * d.N + 64u + 63u) / 64u + 1u; }
 
 // k_sweep_slab: ring depths and the LDS word where the staged exchange records begin (the host writes the
 // word of a staged neighbour's value into the site records)

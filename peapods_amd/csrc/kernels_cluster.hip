@@ -66,6 +66,80 @@ __global__ void k_pairing(SimDims d, DevPtrs p) {
     st[0] = rng.s0; st[1] = rng.s1; st[2] = rng.s2; st[3] = rng.s3;
 }
 
+// k_pair_stream: the draws every cluster task may consume, made before the cluster kernel runs.
+// A task's bond and cluster draws are consecutive outputs of ITS generator (the pair's, or for FK
+// the system's), at positions the cluster kernel knows only after counting eligible bonds -- but
+// every task of a call uses the same positions 0 .. N z' + N at most, and entering a stream at
+// position 64 u needs the same matrix T^(64 u) for every task.  So: one workgroup per (u, 256
+// tasks) stages that 32 KB table in the LDS once, each lane jumps its task's state and steps 64
+// times.  (Inside the cluster kernel the same jumps were gathers from L2-resident tables, two per
+// 64 draws and lane: 60 % of the Joerg move's time.)  Unit couplings: one byte per position --
+// bit 0 draw < first threshold of the move (FK 1 - e^(-2/T), Joerg 1 - e^(-4/T), CMR blue 1 - r^2),
+// bit 1 draw < 1 - e^(-2/T) (CMR red), bits 2-3 the two top bits of the draw (bit 3 clear <=> coin
+// "< 0.5"; both = rand's u8 gen_range(0..=3)).  Other couplings: the 24-bit draw itself.
+// ---------------------------------------------------------------------------
+template <bool RAW>
+__global__ __launch_bounds__(256) void k_pair_stream(SimDims d, DevPtrs p, uint32_t n_units, const uint32_t *first_thr, int fk) {
+    extern __shared__ uint32_t tab[]; // [64][16][8] nibble tables of T^(64 u)
+    const uint32_t u = blockIdx.x % n_units, chunk = blockIdx.x / n_units;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per_real = fk ? d.n_sys : d.n_temps * d.n_pairs;
+    const uint32_t task = chunk * 256 + tid, n_tasks = d.n_real * per_real;
+    if (u > 0) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.jump_unit + static_cast<size_t>(u) * (64 * 16 * 8));
+        uint4 *dst = reinterpret_cast<uint4 *>(tab);
+        for (uint32_t i = tid; i < 64 * 16 * 2; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (task >= n_tasks) return;
+    const uint32_t real = task / per_real, local = task % per_real;
+    const uint32_t t = fk ? local % d.n_temps : local / d.n_pairs;
+    uint32_t st[8];
+    if (fk) {
+        load_cursor(p.cursor, real, d.SP, local, st);
+    } else {
+        const uint64_t *state = p.pair_rng + static_cast<size_t>(task) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            st[2 * k] = static_cast<uint32_t>(state[k]);
+            st[2 * k + 1] = static_cast<uint32_t>(state[k] >> 32);
+        }
+    }
+    if (u > 0) jump_state_lds(st, tab);
+    Rng32 rng;
+    rng.load(st);
+    const size_t stride = static_cast<size_t>(cluster_stream_units(d)) * 64; // positions a task's stream has room for
+    if (RAW) {
+        uint32_t *out = p.stream_raw + static_cast<size_t>(task) * stride + u * 64;
+        for (uint32_t j = 0; j < 64; j += 4) {
+            uint4 v;
+            v.x = rng.next_top() >> 8;
+            v.y = rng.next_top() >> 8;
+            v.z = rng.next_top() >> 8;
+            v.w = rng.next_top() >> 8;
+            *reinterpret_cast<uint4 *>(out + j) = v;
+        }
+    } else {
+        const uint32_t first = first_thr ? first_thr[t] : 0u;
+        const uint32_t second = p.fk_thr[t];
+        uint8_t *out = p.stream_bits + static_cast<size_t>(task) * stride + u * 64;
+        for (uint32_t j = 0; j < 64; j += 16) {
+            uint32_t w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                w[q] = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t top = rng.next_top(), draw = top >> 8;
+                    const uint32_t code = (draw < first ? 1u : 0u) | (draw < second ? 2u : 0u) | ((top >> 30) << 2);
+                    w[q] |= code << (8 * b);
+                }
+            }
+            *reinterpret_cast<uint4 *>(out + j) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+}
+
 // k_slot_bitmaps: slot_bits[real][slot][MW] = the spins of one system as a bitmap over the sites (1 <=> -1).
 // The cluster workgroups each need the bit columns of two (or `group`) systems; reading them out of the
 // slot-sliced tile costs a full word per site and system (32x the bits needed, 50-60 us per call on 6144 pairs),
@@ -157,7 +231,7 @@ enum { kSwHoudayer = 0, kSwJorg = 1, kSwFk = 2, kSwCmr = 3 };
 // 400 us per call on 6144 pairs.  The moves that draw bonds lose more to the spills than they gain (Joerg 792 -> 853 us,
 // FK 312 -> 363 us), and the reporting builds need their registers.
 template <int MODE, bool EXTRAS>
-__global__ __launch_bounds__(kSwThreads, (!EXTRAS && MODE == kSwHoudayer) ? 4 : 1) void k_cluster_sw(
+__global__ __launch_bounds__(kSwThreads, (!EXTRAS && MODE == kSwHoudayer) ? 4 : 2) void k_cluster_sw(
     SimDims d, DevPtrs p, uint32_t group, int wolff, ClusterAux aux) {
     constexpr bool JORG = MODE == kSwJorg, FK = MODE == kSwFk, CMR = MODE == kSwCmr;
     constexpr bool STOCHASTIC = JORG || FK || CMR; // bonds are drawn
@@ -297,52 +371,51 @@ __global__ __launch_bounds__(kSwThreads, (!EXTRAS && MODE == kSwHoudayer) ? 4 : 
             base_state[2 * k + 1] = static_cast<uint32_t>(rng_state[k] >> 32);
         }
     }
-    // Bits of the draws at stream positions [start, start + count): bit = draw < threshold (and,
-    // with two_bits, the top two bits of the draw: rand's u8 gen_range(0..=3), overlap.rs:827).
-    // Position q lands at bit q - 256 * (start / 256) of bits / bits2.  Two stages of jump-ahead:
-    // the states at the 256-draw block boundaries (T^(256 b), one lane per block, kept in LDS),
-    // then one lane per 64 draws (T^(64 s) from its block's state).
-    auto block_states = [&](uint32_t first_block, uint32_t last_block) {
-        for (uint32_t b = first_block + tid; b <= last_block; b += kSwThreads) {
-            uint32_t st[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) st[k] = base_state[k];
-            if (b > 0) jump_state_lds(st, p.jump256 + static_cast<size_t>(b) * (64 * 16 * 8));
-#pragma unroll
-            for (int k = 0; k < 8; ++k) L.blk[(b - first_block) * 8 + k] = st[k];
-        }
-        __syncthreads();
-    };
-    auto draw_bits = [&](uint32_t start, uint32_t count, uint32_t threshold, bool two_bits, const uint32_t *thr_by_rank) {
+    // Bits of the draws at stream positions [start, start + count), read from the task's pre-drawn stream
+    // (k_pair_stream): kind 0 / 1 = below the move's first / second threshold, 2 = coin (draw < 1/2), 3 = the two top
+    // bits of the draw (rand's u8 gen_range(0..=3), overlap.rs:827); with thr_by_rank (couplings that are not
+    // unit: every bond has its own probability) the raw draw is compared with the threshold of the bond of rank
+    // q - start.  Position q lands at bit q - 256 * (start / 256) of bits / bits2.
+    const size_t stream_stride = static_cast<size_t>(cluster_stream_units(d)) * 64;
+    const size_t stream_task = FK ? static_cast<size_t>(real) * d.n_sys + task
+                                  : (static_cast<size_t>(real) * d.n_temps + t) * d.n_pairs + g;
+    auto draw_bits = [&](uint32_t start, uint32_t count, uint32_t kind, const uint32_t *thr_by_rank) {
         if (count == 0) return;
-        const uint32_t first_block = start / 256, last_pos = start + count - 1;
-        block_states(first_block, last_pos / 256);
-        for (uint32_t unit = first_block * 4 + tid; unit <= last_pos / 64; unit += kSwThreads) {
-            uint32_t st[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) st[k] = L.blk[(unit / 4 - first_block) * 8 + k];
-            if (unit & 3u) jump_state_lds(st, p.jump64 + static_cast<size_t>(unit & 3u) * (64 * 16 * 8));
-            Rng32 rng;
-            rng.load(st);
-            for (uint32_t half_unit = 0; half_unit < 2; ++half_unit) {
-                uint32_t acc = 0, acc2 = 0;
-                for (uint32_t k = 0; k < 32; ++k) {
-                    const uint32_t top = rng.next_top();
-                    if (two_bits) {
-                        acc |= ((top >> 30) & 1u) << k;
-                        acc2 |= (top >> 31) << k;
+        const uint32_t base_q = (start / 256) * 256, end = start + count;
+        if (end > aux.stream_units * 64u) { // only after > 64 rejections of a seed draw (p < 2^-50 each): refuse, never guess
+            if (tid == 0) atomicOr(p.stream_error, 1u);
+            return;
+        }
+        const uint8_t *codes = p.stream_bits + stream_task * stream_stride;
+        const uint32_t *raw = p.stream_raw + stream_task * stream_stride;
+        for (uint32_t q0 = base_q; q0 < end; q0 += kSwThreads) {
+            const uint32_t q = q0 + tid;
+            const bool live = q >= start && q < end;
+            bool b0 = false, b1 = false;
+            if (live) {
+                if (!d.unit) {
+                    const uint32_t draw = raw[q];
+                    if (kind == 3) {
+                        b0 = (draw >> 22) & 1u;
+                        b1 = (draw >> 23) & 1u;
                     } else {
-                        uint32_t limit = threshold;
-                        if (thr_by_rank) { // the bond of rank q - start owns this draw
-                            const uint32_t q = unit * 64 + half_unit * 32 + k;
-                            limit = (q >= start && q - start < count) ? thr_by_rank[q - start] : 0u;
-                        }
-                        acc |= ((top >> 8) < limit ? 1u : 0u) << k;
+                        b0 = draw < (kind == 2 ? (1u << 23) : thr_by_rank[q - start]);
                     }
+                } else {
+                    const uint32_t code = codes[q];
+                    b0 = kind == 3 ? (code >> 2) & 1u : (kind == 2 ? !((code >> 3) & 1u) : (code >> kind) & 1u);
+                    b1 = (code >> 3) & 1u;
                 }
-                const uint32_t wd = (unit - first_block * 4) * 2 + half_unit;
-                L.bits[wd] = acc;
-                if (two_bits) L.bits2[wd] = acc2;
+            }
+            const unsigned long long v0 = __ballot(b0), v1 = __ballot(b1);
+            const uint32_t wd = (q0 - base_q + (tid & ~63u)) >> 5;
+            if (lane == 0) {
+                L.bits[wd] = static_cast<uint32_t>(v0);
+                L.bits2[wd] = static_cast<uint32_t>(v1);
+            }
+            if (lane == 32) {
+                L.bits[wd + 1] = static_cast<uint32_t>(v0 >> 32);
+                L.bits2[wd + 1] = static_cast<uint32_t>(v1 >> 32);
             }
         }
     };
@@ -363,8 +436,7 @@ __global__ __launch_bounds__(kSwThreads, (!EXTRAS && MODE == kSwHoudayer) ? 4 : 
         uint32_t js[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) js[k] = base_state[k];
-        if (at / 256) jump_state_lds(js, p.jump256 + static_cast<size_t>(at / 256) * (64 * 16 * 8));
-        if ((at / 64) & 3u) jump_state_lds(js, p.jump64 + static_cast<size_t>((at / 64) & 3u) * (64 * 16 * 8));
+        if (at / 64) jump_state_lds(js, p.jump_unit + static_cast<size_t>(at / 64) * (64 * 16 * 8));
         Rng32 r32;
         r32.load(js);
         for (uint32_t k = 0; k < (at & 63u); ++k) (void)r32.next_top();
@@ -642,8 +714,7 @@ __global__ __launch_bounds__(kSwThreads, (!EXTRAS && MODE == kSwHoudayer) ? 4 : 
                 for (uint32_t x = 0; x < d.nn; ++x) c += __popc(L.bond[x * d.MW + m]);
                 return c;
             });
-            // draw < ceil(p 2^24)  <=>  gen::<f32>() < p
-            const uint32_t threshold = FK ? p.fk_thr[t] : (CMR ? (phase == 0 ? p.cmr_thr[t] : p.fk_thr[t]) : p.jorg_thr[t]);
+            // draw < ceil(p 2^24)  <=>  gen::<f32>() < p (unit couplings: classified by k_pair_stream)
             if (!d.unit) { // every bond has its own probability: thresholds by draw rank
                 const float temp = p.temps[t];
                 for (uint32_t i = tid; i < d.N; i += kSwThreads)
@@ -656,7 +727,7 @@ __global__ __launch_bounds__(kSwThreads, (!EXTRAS && MODE == kSwHoudayer) ? 4 : 
                         }
                 __syncthreads();
             }
-            draw_bits(pos, n_eligible, threshold, false, d.unit ? nullptr : L.thr);
+            draw_bits(pos, n_eligible, (CMR && phase == 1) ? 1u : 0u, d.unit ? nullptr : L.thr);
             __syncthreads();
             const uint32_t rel = pos - (pos / 256) * 256;
             uint32_t *accepted = (CMR && phase == 0) ? L.blue : L.acc;
@@ -809,7 +880,7 @@ __global__ __launch_bounds__(kSwThreads, (!EXTRAS && MODE == kSwHoudayer) ? 4 : 
         // ---- H: the cluster draws continue the stream after the bond draws: a coin
         // gen::<f32>() < 0.5, or for the grey clusters of CMR gen_range(0..=3) = the top two bits
         const bool grey = CMR && phase == 1;
-        draw_bits(pos, n_clusters, 1u << 23, grey, nullptr);
+        draw_bits(pos, n_clusters, grey ? 3u : 2u, nullptr);
         __syncthreads();
         const uint32_t rel = pos - (pos / 256) * 256;
         // ---- I: flips (both systems for a coin; bit 0 / bit 1 of k for the two systems of a grey cluster)
@@ -834,8 +905,7 @@ __global__ __launch_bounds__(kSwThreads, (!EXTRAS && MODE == kSwHoudayer) ? 4 : 
         uint32_t js[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) js[k] = base_state[k];
-        if (pos / 256) jump_state_lds(js, p.jump256 + static_cast<size_t>(pos / 256) * (64 * 16 * 8));
-        if ((pos / 64) & 3u) jump_state_lds(js, p.jump64 + static_cast<size_t>((pos / 64) & 3u) * (64 * 16 * 8));
+        if (pos / 64) jump_state_lds(js, p.jump_unit + static_cast<size_t>(pos / 64) * (64 * 16 * 8));
         Rng32 rng;
         rng.load(js);
         for (uint32_t k = 0; k < (pos & 63u); ++k) (void)rng.next_top();
@@ -1403,9 +1473,20 @@ hipError_t configure_cluster_kernels() {
 }
 
 hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, uint32_t group, bool wolff,
-                             const ClusterAux &aux, hipStream_t stream) {
+                             const ClusterAux &aux_in, hipStream_t stream) {
     hipLaunchKernelGGL(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
     hipLaunchKernelGGL(k_slot_bitmaps, dim3(d.n_real * d.W * ((d.N + 255) / 256)), dim3(256), 0, stream, d, p);
+    ClusterAux aux = aux_in;
+    { // the generators' draws: bonds (stochastic moves) + one per cluster (twice for CMR) + the seed
+        const uint32_t draws = (oc_mode == 1 ? 0u : d.N * d.nn) + (oc_mode == 3 ? 2u : 1u) * d.N + 64u;
+        aux.stream_units = std::min(cluster_stream_units(d), (draws + 63u) / 64u + 1u);
+        const uint32_t *first = oc_mode == 2 ? p.jorg_thr : (oc_mode == 3 ? p.cmr_thr : nullptr);
+        const dim3 sgrid(aux.stream_units * ((d.n_real * d.n_temps * d.n_pairs + 255u) / 256u));
+        if (d.unit)
+            hipLaunchKernelGGL(k_pair_stream<false>, sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, first, 0);
+        else
+            hipLaunchKernelGGL(k_pair_stream<true>, sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, first, 0);
+    }
     const dim3 grid(d.n_real * d.n_temps * (d.n_replicas / group)), block(kSwThreads);
     const size_t lds = cluster_sw_lds_bytes(d);
     const int single = wolff ? 1 : 0;
@@ -1463,7 +1544,8 @@ size_t fk_wolff_lds_bytes(const SimDims &d) { return fk_wolff_lds_words(d) * 4; 
 
 // The depth-first single-cluster kernel serves calls that report nothing; a call that collects
 // sizes takes the union-find path, which draws every bond first and the seed afterwards (fk.rs:45).
-hipError_t launch_fk(const SimDims &d, const DevPtrs &p, bool wolff, const ClusterAux &aux, hipStream_t stream) {
+hipError_t launch_fk(const SimDims &d, const DevPtrs &p, bool wolff, const ClusterAux &aux_in, hipStream_t stream) {
+    ClusterAux aux = aux_in;
     if (wolff && aux.flags == 0) { // depth-first single-cluster form: one wave per system if the tables fit the LDS
         if (wolff_wave_lds_bytes(d) <= 160 * 1024 && d.N <= 65535)
             hipLaunchKernelGGL(k_wolff_wave<kSwFk>, dim3(d.n_real * ((d.n_sys + wolff_wave_tasks(d) - 1) / wolff_wave_tasks(d))),
@@ -1472,8 +1554,16 @@ hipError_t launch_fk(const SimDims &d, const DevPtrs &p, bool wolff, const Clust
             hipLaunchKernelGGL(k_fk_wolff, dim3(d.n_real), dim3(1024), fk_wolff_lds_bytes(d), stream, d, p);
         return hipGetLastError();
     }
-    // union-find forms (they read the per-slot bitmaps)
+    // union-find forms (they read the per-slot bitmaps and the systems' pre-drawn streams)
     hipLaunchKernelGGL(k_slot_bitmaps, dim3(d.n_real * d.W * ((d.N + 255) / 256)), dim3(256), 0, stream, d, p);
+    {
+        aux.stream_units = std::min(cluster_stream_units(d), (d.N * d.nn + d.N + 64u + 63u) / 64u + 1u);
+        const dim3 sgrid(aux.stream_units * ((d.n_real * d.n_sys + 255u) / 256u));
+        if (d.unit)
+            hipLaunchKernelGGL(k_pair_stream<false>, sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, p.fk_thr, 1);
+        else
+            hipLaunchKernelGGL(k_pair_stream<true>, sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, p.fk_thr, 1);
+    }
     if (aux.flags != 0 || wolff)
         hipLaunchKernelGGL((k_cluster_sw<kSwFk, true>), dim3(d.n_real * d.n_sys), dim3(kSwThreads),
                            cluster_sw_lds_bytes(d), stream, d, p, 1u, wolff ? 1 : 0, aux);

@@ -80,8 +80,8 @@ struct pa_sim {
     uint64_t ac_lag = 0, ac_samples = 0, ac_capacity = 0; // autocorrelation series of the last sample()
     bool ac_fft = false;                                  // evaluate them with the FFT backend
     float *Jf = nullptr, *temps_dev = nullptr; // general-coupling path
-    uint32_t *jump64 = nullptr;
-    uint32_t *jump256 = nullptr, *jorg_thr = nullptr, *fk_thr = nullptr, *cmr_thr = nullptr; // cluster kernels
+    uint32_t *jump_unit = nullptr;
+    uint32_t *jorg_thr = nullptr, *fk_thr = nullptr, *cmr_thr = nullptr; // cluster kernels
     int32_t *nz_bonds = nullptr;
     float *dbeta = nullptr;
     // cluster statistics / observations / snapshots of the last sample()
@@ -373,6 +373,9 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     }
     q.dfs_stack += static_cast<size_t>(std::max(d.n_temps * d.n_pairs, d.n_sys)) * d.N * r0;
     if (q.slot_bits) q.slot_bits += static_cast<size_t>(d.SP) * d.MW * r0;
+    const size_t stream_per_real = static_cast<size_t>(d.n_sys) * cluster_stream_units(d) * 64;
+    if (q.stream_bits) q.stream_bits += stream_per_real * r0;
+    if (q.stream_raw) q.stream_raw += stream_per_real * r0;
     return q;
 }
 
@@ -481,31 +484,22 @@ int flush_swaps(pa_sim *sim) {
     return PA_OK;
 }
 
-// The "sw" inner variant of the overlap moves draws the pair generators' streams in blocks of 256
-// by jump-ahead: tables T^(256 b) for every block a move can reach, integer bond thresholds and the
-// pairing scratch are built by the first call that asks for them.
+// The union-find cluster moves read their generators' draws from streams made by jump-ahead in units
+// of 64 draws (k_pair_stream): tables T^(64 u) for every unit a move can reach, the stream buffers,
+// integer bond thresholds and the pairing scratch are built by the first call that asks for them.
 int ensure_cluster_sw(pa_sim *sim) {
-    if (sim->jump256) return PA_OK;
+    if (sim->jump_unit) return PA_OK;
     const SimDims &d = sim->d;
     if (d.big || cluster_sw_lds_bytes(d) > 160 * 1024)
         return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the overlap-cluster kernel");
-    const uint32_t n_tab = (d.N * d.nn + d.N) / 256 + 2;
-    std::vector<uint32_t> jump(static_cast<size_t>(n_tab) * 64 * 16 * 8);
-    {
-        JumpMatrix step = JumpMatrix::steps(256);
-        JumpMatrix acc = JumpMatrix::identity();
-        for (uint32_t b = 0; b < n_tab; ++b) {
-            acc.nibble_table(&jump[static_cast<size_t>(b) * 64 * 16 * 8]);
-            if (b + 1 < n_tab) acc = step.compose(acc);
-        }
-    }
-    std::vector<uint32_t> jump_fine(static_cast<size_t>(4) * 64 * 16 * 8);
+    const uint32_t n_units = cluster_stream_units(d);
+    std::vector<uint32_t> jump_unit(static_cast<size_t>(n_units) * 64 * 16 * 8);
     {
         JumpMatrix step = JumpMatrix::steps(64);
         JumpMatrix acc = JumpMatrix::identity();
-        for (uint32_t b = 0; b < 4; ++b) {
-            acc.nibble_table(&jump_fine[static_cast<size_t>(b) * 64 * 16 * 8]);
-            if (b + 1 < 4) acc = step.compose(acc);
+        for (uint32_t b = 0; b < n_units; ++b) {
+            acc.nibble_table(&jump_unit[static_cast<size_t>(b) * 64 * 16 * 8]);
+            if (b + 1 < n_units) acc = step.compose(acc);
         }
     }
     // gen::<f32>() < p on the 2^24 grid as an integer threshold; p by the host's expf for a
@@ -522,8 +516,14 @@ int ensure_cluster_sw(pa_sim *sim) {
         const float r = expf(-2.0f * 1.0f / sim->temps[t]);
         thr_cmr[t] = as_threshold(1.0f - r * r);
     }
-    PA_HIP(sim, sim->buffers.alloc(&sim->jump256, jump.size()));
-    PA_HIP(sim, sim->buffers.alloc(&sim->jump64, jump_fine.size()));
+    PA_HIP(sim, sim->buffers.alloc(&sim->jump_unit, jump_unit.size()));
+    const size_t stream_per_real = static_cast<size_t>(d.n_sys) * n_units * 64;
+    PA_HIP(sim, sim->buffers.alloc(&sim->p.stream_error, 1));
+    PA_HIP(sim, hipMemsetAsync(sim->p.stream_error, 0, sizeof(uint32_t), sim->stream));
+    if (d.unit)
+        PA_HIP(sim, sim->buffers.alloc(&sim->p.stream_bits, stream_per_real * d.n_real));
+    else
+        PA_HIP(sim, sim->buffers.alloc(&sim->p.stream_raw, stream_per_real * d.n_real));
     PA_HIP(sim, sim->buffers.alloc(&sim->jorg_thr, thr.size()));
     PA_HIP(sim, sim->buffers.alloc(&sim->fk_thr, thr_fk.size()));
     PA_HIP(sim, sim->buffers.alloc(&sim->cmr_thr, thr_cmr.size()));
@@ -531,20 +531,21 @@ int ensure_cluster_sw(pa_sim *sim) {
     PA_HIP(sim, sim->buffers.alloc(&sim->p.pair_slots, slots_per_real * d.n_real));
     PA_HIP(sim, sim->buffers.alloc(&sim->p.slot_bits, static_cast<size_t>(d.n_real) * d.SP * d.MW));
     int rc;
-    if ((rc = upload(sim, sim->jump256, jump)) || (rc = upload(sim, sim->jump64, jump_fine)) ||
+    if ((rc = upload(sim, sim->jump_unit, jump_unit)) ||
         (rc = upload(sim, sim->jorg_thr, thr)) ||
         (rc = upload(sim, sim->fk_thr, thr_fk)) || (rc = upload(sim, sim->cmr_thr, thr_cmr)))
         return rc;
     if (configure_cluster_kernels() != hipSuccess) return fail(sim, PA_ERR_DEVICE, "kernel LDS configuration failed");
-    sim->p.jump256 = sim->jump256;
-    sim->p.jump64 = sim->jump64;
+    sim->p.jump_unit = sim->jump_unit;
     sim->p.jorg_thr = sim->jorg_thr;
     sim->p.fk_thr = sim->fk_thr;
     sim->p.cmr_thr = sim->cmr_thr;
     uint32_t r0 = 0;
     for (auto &g : sim->groups) {
-        g.p.jump256 = sim->jump256;
-        g.p.jump64 = sim->jump64;
+        g.p.jump_unit = sim->jump_unit;
+        g.p.stream_error = sim->p.stream_error;
+        g.p.stream_bits = sim->p.stream_bits ? sim->p.stream_bits + stream_per_real * r0 : nullptr;
+        g.p.stream_raw = sim->p.stream_raw ? sim->p.stream_raw + stream_per_real * r0 : nullptr;
         g.p.jorg_thr = sim->jorg_thr;
         g.p.fk_thr = sim->fk_thr;
         g.p.cmr_thr = sim->cmr_thr;
@@ -1722,6 +1723,11 @@ int pa_sim_synchronize(pa_sim *sim) {
         uint32_t gave_up = 0;
         PA_HIP(sim, hipMemcpy(&gave_up, sim->p.slab_error, sizeof(gave_up), hipMemcpyDeviceToHost));
         if (gave_up) return fail(sim, PA_ERR_DEVICE, "a slab of the pipelined sweep gave up waiting for its predecessor");
+    }
+    if (sim->p.stream_error) {
+        uint32_t short_stream = 0;
+        PA_HIP(sim, hipMemcpy(&short_stream, sim->p.stream_error, sizeof(short_stream), hipMemcpyDeviceToHost));
+        if (short_stream) return fail(sim, PA_ERR_DEVICE, "a cluster move needed more draws than its pre-drawn stream holds");
     }
     return PA_OK;
 }

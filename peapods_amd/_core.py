@@ -4,6 +4,7 @@
 """
 
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -45,7 +46,10 @@ def _parse_overlap_modes(text):
                 raise ValueError(f"Houdayer group size must be even and >= 2, got {n}")
             if n > 32:
                 raise NotImplementedError(f"houd{n}: groups above 32 replicas are not built on the HIP path")
-            modes.append(_OC_MODES["houdayer"] | (n << 8))  # experimental upstream (config.rs:135-140)
+            if n > 2:  # the reference says so on stderr too (config.rs:135-140); measured: see DESIGN.md
+                print(f"WARNING: houd{n} (group_size > 2) is experimental and very likely "
+                      "does not satisfy detailed balance", file=sys.stderr)
+            modes.append(_OC_MODES["houdayer"] | (n << 8))
         else:
             raise ValueError(
                 f"unknown overlap_cluster_build_mode '{name}', expected 'houdayer', 'houdN', "

@@ -1154,7 +1154,14 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     uint32_t target_block = 128;
     // a jump table (32 KB) is staged once per workgroup: with few systems sharing it (small ensembles on large
     // lattices) the staging traffic dominates and longer blocks win (64^3 x 64 systems: 43 -> 32 us per sweep)
-    if (static_cast<uint64_t>(d.n_real) * d.W * 32 < 4096) target_block = 256;
+    // small ensembles altogether (the sizes of the reference's physics scripts): the block is one lane's serial
+    // loop, so shorter blocks until ~2 workgroups per CU exist (32^2 x 8 systems: 46 -> 34 us per sweep; 8^3
+    // Gaussian x 64 samples: 173 -> 102 us)
+    const uint64_t rng_groups = (static_cast<uint64_t>(d.n_real) * d.W + 7) / 8; // workgroups per block of sites
+    if (static_cast<uint64_t>(d.n_real) * d.W * 32 < 4096 && rng_groups * (d.N / 256) >= 512)
+        target_block = 256;
+    else if (rng_groups * (d.N / 128) < 512)
+        target_block = static_cast<uint32_t>(std::min<uint64_t>(128, std::max<uint64_t>(32, rng_groups * d.N / 512)));
     if (const char *env = std::getenv("PEAPODS_RNG_BLOCK")) {
         const long v = std::strtol(env, nullptr, 10);
         if (v >= 16 && v <= 65536) target_block = static_cast<uint32_t>(v);

@@ -112,6 +112,32 @@ def cpu_baseline(couplings, temps, dynamics_seed, schedule, seconds):
     }
 
 
+def valu_limiter(kernels_ms, disorder_per_gpu):
+    """The resource that actually bounds the two sweep kernels: VALU issue slots.  A wave64 VALU
+    instruction holds a SIMD for 4 cycles, so the chip retires 256 CUs x 4 SIMDs x 2.4 GHz / 4
+    wave-instructions per second.  Instruction counts per launch are SQ_INSTS_VALU of the committed
+    PMC pass (profiles/r01_pmc_per_launch.csv, 128 realisations per launch; they scale with the
+    ensemble and do not depend on the data)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_per_launch.csv")
+    if not os.path.exists(path):
+        return None
+    import csv
+
+    counts = {}
+    with open(path) as fh:
+        for row in csv.DictReader(fh):
+            name = row["kernel"]
+            if name.startswith("pa::k_rng_overlap"):
+                counts["k_rng"] = float(row["SQ_INSTS_VALU"])
+            elif name.startswith("pa::k_sweep<"):
+                counts["k_sweep"] = float(row["SQ_INSTS_VALU"])
+    peak = 256 * 4 * 2.4e9 / 4
+    scale = disorder_per_gpu / 128.0
+    frac = {k: counts[k] * scale / (kernels_ms[k] * 1e-3) / peak for k in counts if kernels_ms.get(k, 0) > 0}
+    return {"resource": "VALU issue (wave64 instructions)", "wave_insts_per_launch": {k: v * scale for k, v in counts.items()},
+            "peak_wave_insts_per_s": peak, "frac": frac}
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -214,6 +240,7 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": kernels_ms,
+                "limiter": valu_limiter(kernels_ms, args.disorder_per_gpu),
             },
             "observable_allgather_ms": gather_ms,
             "checksum_energy_mean": float(mean[3 * N_TEMPS:4 * N_TEMPS].sum()),

@@ -225,14 +225,16 @@ enum { kSwHoudayer = 0, kSwJorg = 1, kSwFk = 2, kSwCmr = 3 };
 // group: replicas per task (2 except for the experimental "houdN" moves: N replicas whose spins
 // sum to zero on the active sites, all of them flipped).  wolff: single-cluster variant of a
 // deterministic-bond move (find_seed, utils.rs:107-119, then flip the seed's component).
-// EXTRAS = false is the lean build of the plain moves (no reporting; single-cluster form only for the
+// LEVEL = 0 is the lean build of the plain moves (no reporting; single-cluster form only for the
 // deterministic Houdayer bonds): the reporting code costs ~100 VGPRs and a third of the occupancy.
 // The lean Houdayer build (no bond draws) is capped at 128 VGPRs: four workgroups per CU instead of three, 461 ->
 // 400 us per call on 6144 pairs.  The moves that draw bonds lose more to the spills than they gain (Joerg 792 -> 853 us,
 // FK 312 -> 363 us), and the reporting builds need their registers.
-template <int MODE, bool EXTRAS>
-__global__ __launch_bounds__(kSwThreads, (!EXTRAS && MODE == kSwHoudayer) ? 4 : 2) void k_cluster_sw(
+template <int MODE, int LEVEL>
+__global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4 : (LEVEL == 1 ? 3 : 2)) void k_cluster_sw(
     SimDims d, DevPtrs p, uint32_t group, int wolff, ClusterAux aux) {
+    constexpr bool EXTRAS = LEVEL > 0; // sizes / top four and the single-cluster forms
+    constexpr bool FULL = LEVEL > 1;   // + observation metrics, winding, snapshots
     constexpr bool JORG = MODE == kSwJorg, FK = MODE == kSwFk, CMR = MODE == kSwCmr;
     constexpr bool STOCHASTIC = JORG || FK || CMR; // bonds are drawn
     constexpr uint32_t N_PHASES = CMR ? 2 : 1;     // CMR: blue clusters, then grey = blue + red bonds
@@ -277,8 +279,8 @@ __global__ __launch_bounds__(kSwThreads, (!EXTRAS && MODE == kSwHoudayer) ? 4 : 
                                                        static_cast<size_t>(t) * d.n_pairs + g) * 4;
     uint32_t *Stile = p.S + static_cast<size_t>(real) * d.W * d.N; // all words (groups above two)
     // snapshots are those of the first realisation's first group at every temperature (mod.rs:302,683-705)
-    const bool snap_here = EXTRAS && !FK && (aux.flags & kAuxSnapshot) && real == 0 && g == 0;
-    const bool observe = EXTRAS && (aux.flags & kAuxObserve) != 0, metrics = EXTRAS && (aux.flags & kAuxMetrics) != 0;
+    const bool snap_here = FULL && !FK && (aux.flags & kAuxSnapshot) && real == 0 && g == 0;
+    const bool observe = FULL && (aux.flags & kAuxObserve) != 0, metrics = FULL && (aux.flags & kAuxMetrics) != 0;
     const uint32_t n_rounds = (d.N + kSwThreads - 1) / kSwThreads; // site i = r * 256 + tid
     // write the ballot of a predicate over sites r*256 + tid into a bitmap (two words per wave)
     auto put_ballot = [&](uint32_t *bitmap, uint32_t r, bool pred) {
@@ -507,11 +509,16 @@ __global__ __launch_bounds__(kSwThreads, (!EXTRAS && MODE == kSwHoudayer) ? 4 : 
         uint32_t mine[4] = {0, 0, 0, 0}; // ascending
         uint32_t n_large = 0;
         const uint32_t large_from = (d.N + 19) / 20; // ceil(0.05 N)
+        uint32_t n_small[3] = {0, 0, 0}; // clusters of one, two, three sites: counted per lane, one atomic per wave below
         for (uint32_t i = tid; i < d.N; i += kSwThreads) {
             if (L.label[i] != i) continue;
             const uint32_t c = L.aux[i];
-            atomicAdd(&row[c], 1ull);
-            if (metrics) atomicAdd(&orow[kObsWords + c], 1ull);
+            if (c <= 3) {
+                ++n_small[c - 1];
+            } else {
+                atomicAdd(&row[c], 1ull);
+                if (metrics) atomicAdd(&orow[kObsWords + c], 1ull);
+            }
             n_large += c >= large_from;
             if (c > mine[0]) {
                 mine[0] = c;
@@ -522,6 +529,16 @@ __global__ __launch_bounds__(kSwThreads, (!EXTRAS && MODE == kSwHoudayer) ? 4 : 
                         mine[a] = mine[a + 1];
                         mine[a + 1] = tmp;
                     }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            uint32_t sum = n_small[c];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+            if (lane == 0 && sum) {
+                atomicAdd(&row[c + 1], static_cast<unsigned long long>(sum));
+                if (metrics) atomicAdd(&orow[kObsWords + c + 1], static_cast<unsigned long long>(sum));
             }
         }
         uint32_t top[4];
@@ -1452,14 +1469,18 @@ hipError_t launch_exp_selftest(float *out, hipStream_t stream) {
 size_t cluster_sw_lds_bytes(const SimDims &d) { return cluster_sw_lds_words(d) * 4; }
 
 hipError_t configure_cluster_kernels() {
-    for (const void *fn : {reinterpret_cast<const void *>(k_cluster_sw<kSwHoudayer, false>),
-                           reinterpret_cast<const void *>(k_cluster_sw<kSwJorg, false>),
-                           reinterpret_cast<const void *>(k_cluster_sw<kSwFk, false>),
-                           reinterpret_cast<const void *>(k_cluster_sw<kSwCmr, false>),
-                           reinterpret_cast<const void *>(k_cluster_sw<kSwHoudayer, true>),
-                           reinterpret_cast<const void *>(k_cluster_sw<kSwJorg, true>),
-                           reinterpret_cast<const void *>(k_cluster_sw<kSwFk, true>),
-                           reinterpret_cast<const void *>(k_cluster_sw<kSwCmr, true>),
+    for (const void *fn : {reinterpret_cast<const void *>(k_cluster_sw<kSwHoudayer, 0>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwJorg, 0>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwFk, 0>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwCmr, 0>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwHoudayer, 1>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwJorg, 1>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwFk, 1>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwCmr, 1>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwHoudayer, 2>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwJorg, 2>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwFk, 2>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwCmr, 2>),
                            reinterpret_cast<const void *>(k_fk_wolff),
                            reinterpret_cast<const void *>(k_wolff_wave<kSwJorg>),
                            reinterpret_cast<const void *>(k_wolff_wave<kSwFk>),
@@ -1470,6 +1491,24 @@ hipError_t configure_cluster_kernels() {
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+// Which build of k_cluster_sw a call needs: 0 the plain move, 1 + sizes / top four and the single-cluster
+// union-find forms, 2 + observation metrics, winding and snapshots (230 VGPRs).
+static int cluster_sw_level(uint32_t flags, bool single_form) {
+    if (flags & ~static_cast<uint32_t>(kAuxSizes)) return 2;
+    return (flags != 0 || single_form) ? 1 : 0;
+}
+template <int MODE>
+static void launch_sw_build(int level, dim3 grid, hipStream_t stream, const SimDims &d, const DevPtrs &p, uint32_t group,
+                            int single, const ClusterAux &aux) {
+    const size_t lds = cluster_sw_lds_bytes(d);
+    if (level == 0)
+        hipLaunchKernelGGL((k_cluster_sw<MODE, 0>), grid, dim3(kSwThreads), lds, stream, d, p, group, single, aux);
+    else if (level == 1)
+        hipLaunchKernelGGL((k_cluster_sw<MODE, 1>), grid, dim3(kSwThreads), lds, stream, d, p, group, single, aux);
+    else
+        hipLaunchKernelGGL((k_cluster_sw<MODE, 2>), grid, dim3(kSwThreads), lds, stream, d, p, group, single, aux);
 }
 
 hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, uint32_t group, bool wolff,
@@ -1487,26 +1526,15 @@ hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, ui
         else
             hipLaunchKernelGGL(k_pair_stream<true>, sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, first, 0);
     }
-    const dim3 grid(d.n_real * d.n_temps * (d.n_replicas / group)), block(kSwThreads);
-    const size_t lds = cluster_sw_lds_bytes(d);
-    const int single = wolff ? 1 : 0;
-    const bool extras = aux.flags != 0 || (wolff && oc_mode != 1); // PA_OC_HOUDAYER = 1 has its single-cluster form in both builds
-    if (oc_mode == 2) { // PA_OC_JORG
-        if (extras)
-            hipLaunchKernelGGL((k_cluster_sw<kSwJorg, true>), grid, block, lds, stream, d, p, 2u, single, aux);
-        else
-            hipLaunchKernelGGL((k_cluster_sw<kSwJorg, false>), grid, block, lds, stream, d, p, 2u, single, aux);
-    } else if (oc_mode == 3) { // PA_OC_CMR
-        if (extras)
-            hipLaunchKernelGGL((k_cluster_sw<kSwCmr, true>), grid, block, lds, stream, d, p, 2u, single, aux);
-        else
-            hipLaunchKernelGGL((k_cluster_sw<kSwCmr, false>), grid, block, lds, stream, d, p, 2u, single, aux);
-    } else {
-        if (extras)
-            hipLaunchKernelGGL((k_cluster_sw<kSwHoudayer, true>), grid, block, lds, stream, d, p, group, single, aux);
-        else
-            hipLaunchKernelGGL((k_cluster_sw<kSwHoudayer, false>), grid, block, lds, stream, d, p, group, single, aux);
-    }
+    const dim3 grid(d.n_real * d.n_temps * (d.n_replicas / group));
+    // PA_OC_HOUDAYER = 1 has its single-cluster form in every build
+    const int level = cluster_sw_level(aux.flags, wolff && oc_mode != 1);
+    if (oc_mode == 2) // PA_OC_JORG
+        launch_sw_build<kSwJorg>(level, grid, stream, d, p, 2u, wolff ? 1 : 0, aux);
+    else if (oc_mode == 3) // PA_OC_CMR
+        launch_sw_build<kSwCmr>(level, grid, stream, d, p, 2u, wolff ? 1 : 0, aux);
+    else
+        launch_sw_build<kSwHoudayer>(level, grid, stream, d, p, group, wolff ? 1 : 0, aux);
     return hipGetLastError();
 }
 
@@ -1564,12 +1592,7 @@ hipError_t launch_fk(const SimDims &d, const DevPtrs &p, bool wolff, const Clust
         else
             hipLaunchKernelGGL(k_pair_stream<true>, sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, p.fk_thr, 1);
     }
-    if (aux.flags != 0 || wolff)
-        hipLaunchKernelGGL((k_cluster_sw<kSwFk, true>), dim3(d.n_real * d.n_sys), dim3(kSwThreads),
-                           cluster_sw_lds_bytes(d), stream, d, p, 1u, wolff ? 1 : 0, aux);
-    else
-        hipLaunchKernelGGL((k_cluster_sw<kSwFk, false>), dim3(d.n_real * d.n_sys), dim3(kSwThreads),
-                           cluster_sw_lds_bytes(d), stream, d, p, 1u, 0, aux);
+    launch_sw_build<kSwFk>(cluster_sw_level(aux.flags, wolff), dim3(d.n_real * d.n_sys), stream, d, p, 1u, wolff ? 1 : 0, aux);
     return hipGetLastError();
 }
 

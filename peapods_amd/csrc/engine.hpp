@@ -58,6 +58,9 @@ struct DevPtrs {
     uint2 *planes;           // [n_real][W][N]  .x/.y = bit 0/1 of the acceptance level
     uint32_t *planes_hi;     // [n_real][W][N]  bit 2 of the acceptance level (Gibbs sweeps; allocated on first use)
     uint32_t *cursor;        // [n_real][8][SP]  xoshiro state of the system in each slot
+    uint32_t *cursor_out;    // same shape: where a random-stream launch leaves the advanced states (its workgroups all start
+                             // from `cursor`, so the one that finishes a system's stream must not overwrite it); the host
+                             // exchanges the two after the launch
     uint32_t *system_ids;    // [n_real][n_sys]  slot -> system
     uint32_t *slot_of;       // [n_real][n_sys]  system -> slot
     const uint32_t *thr;     // [2][2][3][n_temps] thresholds: even set (dE=-2,-4,-6), odd set (-1,-3,-5);

@@ -180,7 +180,7 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
         }
         if (active && block == d.B - 1) {
             rng.store(st);
-            store_cursor(p.cursor, real, d.SP, slot, st);
+            store_cursor(p.cursor_out, real, d.SP, slot, st);
         }
         return;
     }
@@ -230,7 +230,7 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
     // The last block ends exactly N draws after the cursor: that is the next cursor.
     if (active && block == d.B - 1) {
         rng.store(st);
-        store_cursor(p.cursor, real, d.SP, slot, st);
+        store_cursor(p.cursor_out, real, d.SP, slot, st);
     }
 }
 

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void k_rng_f(SimDims d, DevPtrs p) {
     }
     if (active && block == d.B - 1) {
         rng.store(st);
-        store_cursor(p.cursor, real, d.SP, slot, st);
+        store_cursor(p.cursor_out, real, d.SP, slot, st);
     }
 }
 

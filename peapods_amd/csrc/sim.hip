@@ -339,6 +339,7 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
         q.planes += static_cast<size_t>(d.planes_stride) * d.W * r0;
     }
     q.cursor += static_cast<size_t>(8) * d.SP * r0;
+    q.cursor_out += static_cast<size_t>(8) * d.SP * r0;
     q.system_ids += static_cast<size_t>(d.n_sys) * r0;
     q.slot_of += static_cast<size_t>(d.n_sys) * r0;
     q.mpar += static_cast<size_t>(d.MW) * r0;
@@ -415,8 +416,12 @@ int make_groups(pa_sim *sim) {
     return PA_OK;
 }
 
-// k_sweep reads S and writes S_next: exchange the roles everywhere after every sweep launch.
+// k_sweep reads S and writes S_next, the random-stream launch reads cursor and writes cursor_out: exchange the
+// roles everywhere after every sweep's launches.
 void toggle_spin_buffers(pa_sim *sim) {
+    // (the random-stream launch of the sweep left the advanced generator states in cursor_out)
+    std::swap(sim->p.cursor, sim->p.cursor_out);
+    for (auto &g : sim->groups) std::swap(g.p.cursor, g.p.cursor_out);
     if (sim->p.S_next == sim->p.S) return; // paths that sweep in place
     std::swap(sim->p.S, sim->p.S_next);
     for (auto &g : sim->groups) std::swap(g.p.S, g.p.S_next);
@@ -1584,6 +1589,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         ok(bufs.alloc(&p.xw, tile_words * d.n_real * (d.nn <= 3 ? 4 : 8)));
     }
     ok(bufs.alloc(&p.cursor, static_cast<size_t>(d.n_real) * 8 * d.SP));
+    ok(bufs.alloc(&p.cursor_out, static_cast<size_t>(d.n_real) * 8 * d.SP));
     ok(bufs.alloc(&p.system_ids, static_cast<size_t>(d.n_real) * d.n_sys));
     ok(bufs.alloc(&p.slot_of, static_cast<size_t>(d.n_real) * d.n_sys));
     ok(bufs.alloc(&sim->thr, thr.size()));

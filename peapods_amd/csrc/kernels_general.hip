@@ -100,7 +100,7 @@ __device__ __forceinline__ float signed_by_spin(float j, uint32_t word, uint32_t
 // ---------------------------------------------------------------------------
 // k_rng_f: same work split as k_rng (4 waves share one site block and its jump table; lanes
 // 0-31 / 32-63 are the 32 slots of two tile words).  Every lane walks the block's sites in
-// order and stores the f32 threshold of its slot: thr_f[tile word][site][32 slots].
+// order and stores the f32 threshold of its slot: thr_f[tile word][schedule position of the site][32 slots].
 // ---------------------------------------------------------------------------
 template <bool GIBBS>
 __global__ __launch_bounds__(256) void k_rng_f(SimDims d, DevPtrs p) {
@@ -134,11 +134,13 @@ __global__ __launch_bounds__(256) void k_rng_f(SimDims d, DevPtrs p) {
     const float half_t = active ? __fdiv_rn(p.temps[slot % d.n_temps], 2.0f) : 1.0f;
     const uint32_t begin = block * d.BS;
     const uint32_t len = min(d.BS, d.N - begin);
-    float *out = p.thr_f + (static_cast<size_t>(tw_ok ? tw : 0) * d.N + begin) * 32 + bit;
+    // filed at the site's position in the sweep's schedule: k_sweep_f then knows a threshold's address
+    // without first reading the site record
+    float *out = p.thr_f + static_cast<size_t>(tw_ok ? tw : 0) * d.N * 32 + bit;
     for (uint32_t j = 0; j < len; ++j) {
         const float u = uniform_of_draw(rng.next_top() >> 8);
         const float l = dev_logf(GIBBS ? logit_arg(u) : u, log_tab);
-        if (active) out[static_cast<size_t>(j) * 32] = __fmul_rn(half_t, l);
+        if (active) out[static_cast<size_t>(p.pos_of[begin + j]) * 32] = __fmul_rn(half_t, l);
     }
     if (active && block == d.B - 1) {
         rng.store(st);
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(kSweepFThreads) void k_sweep_f(SimDims d, DevPtrs p
         if (!live_item) return it;
 #pragma unroll
         for (int k = 0; k < (NN <= 3 ? 2 : 4); ++k) it.r[k] = nbr[static_cast<size_t>(pos) * 4 + k];
-        it.t = thr[static_cast<size_t>(it.r[0].x) * 8 + g];
+        it.t = thr[static_cast<size_t>(pos) * 8 + g];
         return it;
     };
     // s * J for the lane's four slots of neighbour word `word`, added to h[0..3]
@@ -242,18 +244,53 @@ __global__ __launch_bounds__(kSweepFThreads) void k_sweep_f(SimDims d, DevPtrs p
         }
     };
 
-    for (uint32_t pass = 0; pass < d.n_passes; ++pass) {
-        const uint32_t begin = p.pass_start[pass], end = p.pass_start[pass + 1];
-        const uint32_t n_items = (end - begin) * 8;
-        Item cur = fetch(begin + (tid >> 3), tid < n_items);
-        for (uint32_t item = tid; item < n_items; item += kSweepFThreads) {
-            const uint32_t next_item = item + kSweepFThreads;
-            const Item nxt = fetch(begin + (next_item >> 3), next_item < n_items);
-            run(cur);
-            cur = nxt;
+    // A step is one round of a level: items [base, base + 512) of the level's (site, slot group) pairs.  The
+    // loads of step k + 1 (record and thresholds, neither depends on the spins) are issued before step k is
+    // computed and stay in flight across the level barrier; the two item buffers alternate explicitly, so no
+    // register copy waits for them.  (Fetching after the barrier exposed two dependent global latencies per level:
+    // 16^3, 90 levels of one round each, 2.2 us per level.)
+    struct Step {
+        uint32_t pass, begin, end, base;
+        bool valid;
+    };
+    auto items_of = [](const Step &s) -> uint32_t { return (s.end - s.begin) * 8; };
+    auto next_step = [&](Step s) -> Step {
+        if (s.base + kSweepFThreads < items_of(s)) {
+            s.base += kSweepFThreads;
+            return s;
         }
-        if (BIG) drain_global_stores(); // the flips of this level are in the L2 before the next level loads
-        __syncthreads();
+        s.pass += 1;
+        s.base = 0;
+        s.valid = s.pass < d.n_passes;
+        if (s.valid) {
+            s.begin = s.end;
+            s.end = p.pass_start[s.pass + 1];
+        }
+        return s;
+    };
+    auto live_in = [&](const Step &s) -> bool { return s.valid && s.base + tid < items_of(s); };
+    auto fetch_step = [&](const Step &s) -> Item { return fetch(s.begin + ((s.base + tid) >> 3), live_in(s)); };
+    auto level_barrier = [&](const Step &s) {
+        if (s.base + kSweepFThreads < items_of(s)) return; // more rounds of this level follow
+        if (BIG) {
+            drain_global_stores(); // the flips of this level are in the L2 before the next level loads
+            __syncthreads();
+        } else {
+            lds_barrier(); // orders the LDS flips only: the next step's loads stay in flight
+        }
+    };
+    Step sa{0, p.pass_start[0], p.pass_start[1], 0, d.n_passes > 0};
+    Item A = fetch_step(sa);
+    while (sa.valid) {
+        Step sb = next_step(sa);
+        const Item B = fetch_step(sb);
+        if (live_in(sa)) run(A);
+        level_barrier(sa);
+        if (!sb.valid) break;
+        sa = next_step(sb);
+        A = fetch_step(sa);
+        if (live_in(sb)) run(B);
+        level_barrier(sb);
     }
     if (!BIG)
         for (uint32_t i = tid; i < d.N; i += kSweepFThreads) Sg[i] = sw[i];
@@ -286,15 +323,16 @@ __global__ __launch_bounds__(256) void k_bonds_f(SimDims d, DevPtrs p) {
 // ---------------------------------------------------------------------------
 // k_energy_f: the reference's energy is a strictly sequential f32 sum over (site, direction)
 // in typewriter order (energy.rs:92-107), so each system is one dependent chain of N z'
-// additions (about 8 cycles each on a lone wave: ~40 us at 16^3 whatever else happens).
-// Workgroup = (realisation, pair of tile words), 8 waves.  Wave 0 CONSUMES: lane = one of the
-// pair's 64 slots, nothing but LDS reads and the additions.  Waves 1-7 PRODUCE the signed terms
+// additions (4.2 ns each on a lone wave, tools/probe/addchain.hip: 52 us at 16^3 whatever else happens;
+// the kernel takes 72 us: with 7 producer waves it took 90 us, the producers are the slower side).
+// Workgroup = (realisation, pair of tile words), 16 waves.  Wave 0 CONSUMES: lane = one of the
+// pair's 64 slots, nothing but LDS reads and the additions.  Waves 1-15 PRODUCE the signed terms
 // +-J of the next chunk of sites into LDS (sign = the bond word's bit of the lane's slot):
 // one pass of a producer wave serves 4 consecutive sites of both words (4 z' terms = z'
 // 16-byte LDS writes per lane).  The producers' inputs (bond words, couplings) are loaded from
 // global memory two chunks ahead and staged through LDS; one barrier per chunk.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kEnergyThreads = 512;  // 1 consumer + 7 producer waves
+constexpr uint32_t kEnergyThreads = 1024; // 1 consumer + 15 producer waves
 constexpr uint32_t kProducers = kEnergyThreads / 64 - 1;
 
 template <int NN> struct EnergyLds {
@@ -441,6 +479,10 @@ __global__ __launch_bounds__(kEnergyThreads) void k_energy_f(SimDims d, DevPtrs 
     __syncthreads();
     if (wave > 0) produce(0);
     __syncthreads();
+    // The chain of additions is the critical path (4.2 ns per addition on a lone wave, tools/probe/addchain.hip):
+    // the consumer wave outranks the producer waves on its SIMD, and the chunk barrier orders LDS traffic only
+    // (__syncthreads() would also wait for the producers' global loads of chunk + 3, issued just before it).
+    if (wave == 0) __builtin_amdgcn_s_setprio(3);
     for (uint32_t chunk = 0; chunk < n_chunks; ++chunk) {
         if (wave == 0) {
             consume(chunk);
@@ -449,8 +491,9 @@ __global__ __launch_bounds__(kEnergyThreads) void k_energy_f(SimDims d, DevPtrs 
             stash_raw(chunk + 2);   // overwrites raw(chunk), which produce(chunk) finished with
             load_raw(chunk + 3);
         }
-        __syncthreads();
+        lds_barrier();
     }
+    if (wave == 0) __builtin_amdgcn_s_setprio(0);
     if (wave > 0) atomicAdd(&L.neg_total[lane], neg);
     __syncthreads();
     const uint32_t slot = (w0 + half) * 32 + bit;

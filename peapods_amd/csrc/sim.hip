@@ -1439,6 +1439,10 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     std::vector<uint32_t> pos_of;
     std::vector<uint4> recS;
     std::vector<uint32_t> xportS;
+    if (d.general) { // k_rng_f files a site's thresholds at its schedule position
+        pos_of.assign(d.N, 0u);
+        for (uint32_t pos = 0; pos < d.N; ++pos) pos_of[order[pos]] = pos;
+    }
     if (d.pipe_lds) {
         const uint32_t K = d.pipe_K, own = d.N / K, P = d.plane;
         slab_seg.assign(static_cast<size_t>(n_levels) * K, make_uint2(0u, 0u));
@@ -1565,10 +1569,10 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         p.S_next = p.S; // these paths sweep in place
     else
         ok(bufs.alloc(&p.S_next, tile_words * d.n_real));
+    if (!pos_of.empty()) ok(bufs.alloc(&sim->pos_of, pos_of.size()));
     if (d.pipe_lds) {
         ok(bufs.alloc(&sim->halo_start, sim->halo_start_host.size()));
         ok(bufs.alloc(&sim->slab_seg, slab_seg.size()));
-        ok(bufs.alloc(&sim->pos_of, pos_of.size()));
         ok(bufs.alloc(&sim->recS, recS.size()));
         ok(bufs.alloc(&sim->xportS, xportS.size()));
         ok(bufs.alloc(&p.xchg, static_cast<size_t>(d.n_real) * d.W * d.pipe_K * 2 * d.plane + 256));
@@ -1650,10 +1654,10 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     p.pos_of = sim->pos_of;
     p.recS = sim->recS;
     p.xportS = sim->xportS;
+    if (!pos_of.empty() && (rc = upload(sim, sim->pos_of, pos_of))) return bail(rc);
     if (d.pipe_lds) {
         if ((rc = upload(sim, sim->halo_start, sim->halo_start_host))) return bail(rc);
         if ((rc = upload(sim, sim->slab_seg, slab_seg))) return bail(rc);
-        if ((rc = upload(sim, sim->pos_of, pos_of))) return bail(rc);
         if ((rc = upload(sim, sim->recS, recS))) return bail(rc);
         if ((rc = upload(sim, sim->xportS, xportS))) return bail(rc);
         if (hipMemsetAsync(p.xchg, 0, sizeof(uint4) * (static_cast<size_t>(d.n_real) * d.W * d.pipe_K * 2 * d.plane + 256),

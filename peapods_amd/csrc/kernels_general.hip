@@ -44,16 +44,12 @@ __device__ const double kLogfLogC[16] = {
 
 // tab: [16][2] doubles (1/c, ln c); the kernels stage it in LDS (a per-lane index into constant
 // memory would be a global gather in front of every draw).
+// Only draws reach it: x = u = k 2^-24 or x = u / (1 - u), i.e. zero or a positive normal number, for which
+// glibc's special cases reduce to log(1) = +0 and log(0) = -inf -- applied as selects after the arithmetic, so
+// the draw loop has no branches and unrolls.  (The self-test below compares all 2^24 values of both arguments
+// with the host's logf before the first general sweep.)
 __device__ __forceinline__ float dev_logf(float x, const double2 *tab) {
-    uint32_t ix = __float_as_uint(x);
-    if (ix == 0x3f800000u) return 0.0f;
-    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
-        if (ix * 2u == 0u) return -INFINITY;          // log(+-0)
-        if (ix == 0x7f800000u) return x;              // log(inf)
-        if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u) return NAN;
-        ix = __float_as_uint(__fmul_rn(x, 0x1p23f));  // subnormal: normalise
-        ix -= 23u << 23;
-    }
+    const uint32_t ix = __float_as_uint(x);
     const uint32_t tmp = ix - 0x3f330000u;
     const uint32_t i = (tmp >> 19) & 15u;
     const int32_t k = static_cast<int32_t>(tmp) >> 23;
@@ -67,7 +63,10 @@ __device__ __forceinline__ float dev_logf(float x, const double2 *tab) {
     double y = __dadd_rn(__dmul_rn(0x1.5575b0be00b6ap-2, r), -0x1.ffffef20a4123p-2);
     y = __dadd_rn(__dmul_rn(-0x1.00ea348b88334p-2, r2), y);
     y = __dadd_rn(__dmul_rn(y, r2), __dadd_rn(y0, r));
-    return static_cast<float>(y);
+    float result = static_cast<float>(y);
+    result = ix == 0x3f800000u ? 0.0f : result;
+    result = ix == 0u ? -INFINITY : result;
+    return result;
 }
 
 __device__ __forceinline__ void stage_logf_table(double2 *tab, uint32_t tid) {
@@ -137,7 +136,24 @@ __global__ __launch_bounds__(256) void k_rng_f(SimDims d, DevPtrs p) {
     // filed at the site's position in the sweep's schedule: k_sweep_f then knows a threshold's address
     // without first reading the site record
     float *out = p.thr_f + static_cast<size_t>(tw_ok ? tw : 0) * d.N * 32 + bit;
-    for (uint32_t j = 0; j < len; ++j) {
+    // four draws per round: the logarithms (a table look-up and a dozen dependent f64 operations each) overlap
+    uint32_t j = 0;
+    for (; j + 4 <= len; j += 4) {
+        float u[4], l[4];
+        uint32_t at[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            u[k] = uniform_of_draw(rng.next_top() >> 8);
+            at[k] = p.pos_of[begin + j + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) l[k] = dev_logf(GIBBS ? logit_arg(u[k]) : u[k], log_tab);
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out[static_cast<size_t>(at[k]) * 32] = __fmul_rn(half_t, l[k]);
+        }
+    }
+    for (; j < len; ++j) {
         const float u = uniform_of_draw(rng.next_top() >> 8);
         const float l = dev_logf(GIBBS ? logit_arg(u) : u, log_tab);
         if (active) out[static_cast<size_t>(p.pos_of[begin + j]) * 32] = __fmul_rn(half_t, l);

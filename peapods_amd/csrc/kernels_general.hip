@@ -179,7 +179,7 @@ constexpr uint32_t kSweepFThreads = 512;
 template <int NN> struct JRow { static constexpr int kWidth = NN <= 3 ? 4 : 8; };
 
 template <bool BIG, int NN>
-__global__ __launch_bounds__(kSweepFThreads) void k_sweep_f(SimDims d, DevPtrs p) {
+__global__ __launch_bounds__(kSweepFThreads) void k_sweep_f(SimDims d, DevPtrs p, int with_bonds) {
     constexpr int JW = JRow<NN>::kWidth;
     extern __shared__ uint32_t lds[];
     const uint32_t real = blockIdx.x / d.W, w = blockIdx.x % d.W;
@@ -308,8 +308,24 @@ __global__ __launch_bounds__(kSweepFThreads) void k_sweep_f(SimDims d, DevPtrs p
         if (live_in(sb)) run(B);
         level_barrier(sb);
     }
-    if (!BIG)
+    if (!BIG) {
         for (uint32_t i = tid; i < d.N; i += kSweepFThreads) Sg[i] = sw[i];
+        if (with_bonds) { // the bond words k_energy_f reads (k_bonds_f's job), while the new spins are still in LDS
+            for (uint32_t pos = tid; pos < d.N; pos += kSweepFThreads) {
+                const uint32_t *row = p.nbr_wide + static_cast<size_t>(pos) * 16;
+                const uint32_t site = row[0], s = sw[site];
+                uint32_t out[JW];
+#pragma unroll
+                for (int k = 0; k < JW; ++k) out[k] = 0;
+#pragma unroll
+                for (int dd = 0; dd < NN; ++dd) out[dd] = s ^ sw[row[1 + 2 * dd]];
+                out[JW - 1] = s;
+                uint32_t *dst = p.xw + (static_cast<size_t>(tw) * d.N + site) * JW;
+#pragma unroll
+                for (int k = 0; k < JW; ++k) dst[k] = out[k];
+            }
+        }
+    }
 }
 
 // xw[tile word][site][XW] = S_i ^ S_fwd(i, d) for every direction, then S_i itself (XW = 4 for up
@@ -568,12 +584,13 @@ static void launch_sweep_f_nn(const SimDims &d, const DevPtrs &p, bool with_ener
     if (do_sweep) {
         const dim3 grid(d.n_real * d.W), block(kSweepFThreads);
         if (d.big)
-            hipLaunchKernelGGL((k_sweep_f<true, NN>), grid, block, 0, stream, d, p);
+            hipLaunchKernelGGL((k_sweep_f<true, NN>), grid, block, 0, stream, d, p, 0);
         else
-            hipLaunchKernelGGL((k_sweep_f<false, NN>), grid, block, sweep_f_lds_bytes(d), stream, d, p);
+            hipLaunchKernelGGL((k_sweep_f<false, NN>), grid, block, sweep_f_lds_bytes(d), stream, d, p, with_energy ? 1 : 0);
     }
     if (with_energy) {
-        hipLaunchKernelGGL(k_bonds_f<NN>, dim3((d.N + 255) / 256, d.n_real * d.W), dim3(256), 0, stream, d, p);
+        if (!do_sweep || d.big) // (the on-chip sweep has written the bond words itself)
+            hipLaunchKernelGGL(k_bonds_f<NN>, dim3((d.N + 255) / 256, d.n_real * d.W), dim3(256), 0, stream, d, p);
         hipLaunchKernelGGL(k_energy_f<NN>, dim3(d.n_real * ((d.W + 1) / 2)), dim3(kEnergyThreads),
                            sizeof(EnergyLds<NN>), stream, d, p);
     }

@@ -539,6 +539,45 @@ __global__ __launch_bounds__(kEnergyThreads) void k_energy_f(SimDims d, DevPtrs 
 // ---------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// k_energy_unit_f: unit couplings on the general path (four to six forward directions: bcc, fcc).  Every term of
+// the reference's sequential f32 sum is -1, 0 or +1, so every partial sum is an integer below 2^24 in magnitude:
+// exact in f32 in any order.  The chain of k_energy_f is then unnecessary -- count in parallel, convert once.
+// Workgroup = (realisation, tile word), 8 waves over the sites; lane = slot (two half-waves: even / odd sites).
+// ---------------------------------------------------------------------------
+template <int NN>
+__global__ __launch_bounds__(512) void k_energy_unit_f(SimDims d, DevPtrs p) {
+    constexpr int XW = JRow<NN>::kWidth;
+    __shared__ int e_sum[32], neg_sum[32];
+    const uint32_t real = blockIdx.x / d.W, w = blockIdx.x % d.W;
+    const uint32_t tid = threadIdx.x, bit = tid & 31u;
+    if (tid < 32) {
+        e_sum[tid] = 0;
+        neg_sum[tid] = 0;
+    }
+    __syncthreads();
+    const uint32_t *xw = p.xw + static_cast<size_t>(real * d.W + w) * d.N * XW;
+    const float *J = p.Jf + static_cast<size_t>(real) * d.N * NN;
+    int e = 0, neg = 0;
+    for (uint32_t site = tid >> 5; site < d.N; site += 512 / 32) {
+        const uint32_t *x = xw + static_cast<size_t>(site) * XW;
+#pragma unroll
+        for (int dd = 0; dd < NN; ++dd) {
+            const int j = static_cast<int>(J[site * NN + dd]); // -1, 0, +1
+            e += ((x[dd] >> bit) & 1u) ? -j : j;                // s_i s_j = -1 where the bond word's bit is set
+        }
+        neg += (x[XW - 1] >> bit) & 1u;
+    }
+    atomicAdd(&e_sum[bit], e);
+    atomicAdd(&neg_sum[bit], neg);
+    __syncthreads();
+    const uint32_t slot = w * 32 + bit;
+    if (tid < 32 && slot < d.n_sys) {
+        p.Esum[static_cast<size_t>(real) * d.n_sys + slot] = __float_as_int(static_cast<float>(e_sum[bit])); // raw f32 bits
+        p.Msum[static_cast<size_t>(real) * d.n_sys + slot] = static_cast<int32_t>(d.N) - 2 * neg_sum[bit];
+    }
+}
+
 size_t sweep_f_lds_bytes(const SimDims &d) {
     const size_t jw = d.nn <= 3 ? 4 : 8;
     return ((static_cast<size_t>(d.N) + 3) / 4 * 4 + static_cast<size_t>(d.N) * jw) * 4;
@@ -591,8 +630,11 @@ static void launch_sweep_f_nn(const SimDims &d, const DevPtrs &p, bool with_ener
     if (with_energy) {
         if (!do_sweep || d.big) // (the on-chip sweep has written the bond words itself)
             hipLaunchKernelGGL(k_bonds_f<NN>, dim3((d.N + 255) / 256, d.n_real * d.W), dim3(256), 0, stream, d, p);
-        hipLaunchKernelGGL(k_energy_f<NN>, dim3(d.n_real * ((d.W + 1) / 2)), dim3(kEnergyThreads),
-                           sizeof(EnergyLds<NN>), stream, d, p);
+        if (d.unit && static_cast<uint64_t>(d.N) * NN < (1u << 24)) // every partial sum is an exact f32 integer
+            hipLaunchKernelGGL(k_energy_unit_f<NN>, dim3(d.n_real * d.W), dim3(512), 0, stream, d, p);
+        else
+            hipLaunchKernelGGL(k_energy_f<NN>, dim3(d.n_real * ((d.W + 1) / 2)), dim3(kEnergyThreads),
+                               sizeof(EnergyLds<NN>), stream, d, p);
     }
 }
 

@@ -513,7 +513,7 @@ __global__ __launch_bounds__(kEnergyThreads) void k_energy_f(SimDims d, DevPtrs 
     __syncthreads();
     // The chain of additions is the critical path (4.2 ns per addition on a lone wave, tools/probe/addchain.hip):
     // the consumer wave outranks the producer waves on its SIMD, and the chunk barrier orders LDS traffic only
-    // (__syncthreads() would also wait for the producers' global loads of chunk + 3, issued just before it).
+    // (everything the waves exchange goes through LDS; the producers' global loads of chunk + 3 stay in flight).
     if (wave == 0) __builtin_amdgcn_s_setprio(3);
     for (uint32_t chunk = 0; chunk < n_chunks; ++chunk) {
         if (wave == 0) {

@@ -200,7 +200,6 @@ struct SwLds {
     uint32_t *bond;    // [6][MW] eligible, later accepted, forward bonds per direction
     uint32_t *blue;    // [6][MW] CMR: accepted blue bonds, kept for the grey clusters
     uint32_t *acc;     // [6][MW] accepted bonds of the current phase
-    uint32_t *blk;     // [n_bit_words] generator states at the 256-draw block boundaries in use
     uint32_t *thr;     // [N nn] non-unit couplings: threshold of every eligible bond by its draw rank
     uint32_t *wbase;   // [MW + 1] exclusive prefix (eligible bonds / drawing roots) per 32-site word
     uint32_t *roots;   // [MW] roots that draw
@@ -216,7 +215,7 @@ __host__ __device__ inline size_t cluster_sw_bit_words(const SimDims &d) {
     return (static_cast<size_t>(d.N) * d.nn + 255) / 256 * 8 + 16;
 }
 __host__ __device__ inline size_t cluster_sw_lds_words(const SimDims &d) {
-    return 2 * static_cast<size_t>(d.N) + 26 * static_cast<size_t>(d.MW) + 1 + 3 * cluster_sw_bit_words(d) + 24 +
+    return 2 * static_cast<size_t>(d.N) + 26 * static_cast<size_t>(d.MW) + 1 + 2 * cluster_sw_bit_words(d) + 24 +
            (d.unit ? 0 : static_cast<size_t>(d.N) * d.nn);
 }
 
@@ -250,7 +249,6 @@ __global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4
         L.bond = q; q += 6 * d.MW;
         L.blue = q; q += 6 * d.MW;
         L.acc = q; q += 6 * d.MW;
-        L.blk = q; q += cluster_sw_bit_words(d);
         L.wbase = q; q += d.MW + 1;
         L.roots = q; q += d.MW;
         L.flip_a = q; q += d.MW;

@@ -1155,8 +1155,8 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
                                           : jorg_threshold(j_abs, temp));
                     }
                     if (draw < limit) {
-                        if (lane == 0) {
-                            member[target >> 5] |= 1u << (target & 31u);
+                        if (lane == 0) { // (an LDS atomic without return: nothing to wait for; LDS operations of a wave stay in order)
+                            atomicOr(&member[target >> 5], 1u << (target & 31u));
                             stack[top] = static_cast<uint16_t>(target);
                         }
                         ++top;

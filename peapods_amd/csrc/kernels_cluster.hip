@@ -1026,6 +1026,7 @@ __host__ __device__ inline size_t wolff_wave_lds_words(const SimDims &d, uint32_
 }
 __host__ inline uint32_t wolff_wave_tasks(const SimDims &d) {
     uint32_t tasks = 16;
+    if (const char *env = std::getenv("PEAPODS_WAVE_TASKS")) tasks = static_cast<uint32_t>(std::max(1l, std::min(16l, std::strtol(env, nullptr, 10))));
     while (tasks > 1 && wolff_wave_lds_words(d, tasks) * 4 > 160 * 1024) tasks /= 2;
     return tasks;
 }
@@ -1127,19 +1128,20 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
                 const uint32_t site = next_known ? next : __builtin_amdgcn_readfirstlane(stack[top]);
                 next_known = false;
                 const uint32_t jm = jbits[site];
-                // lanes 0..11: is the bond of slot `lane` eligible?
-                uint32_t nb = site;
-                bool eligible = false;
-                if (lane < 2 * d.nn) {
-                    nb = nbr[site * 12 + lane];
-                    const bool a_sat = (bit(spa, site) ^ bit(spa, nb) ^ ((jm >> lane) & 1u)) == 0;
-                    bool wanted = a_sat && bit(act, nb);
-                    if (CMR) {
-                        const bool b_sat = (bit(spb, site) ^ bit(spb, nb) ^ ((jm >> lane) & 1u)) == 0;
-                        wanted = phase == 0 ? (a_sat && b_sat) : (a_sat != b_sat);
-                    }
-                    eligible = ((jm >> (12 + lane)) & 1u) && !bit(member, nb) && wanted;
+                // lanes 0..11: is the bond of slot `lane` eligible?  Every bitmap word is requested before any is
+                // looked at (no short-circuit: each would be another LDS round trip on the search's critical path)
+                const bool slot_ok = lane < 2 * d.nn;
+                const uint32_t nb = slot_ok ? nbr[site * 12 + lane] : site;
+                const uint32_t w_site = spa[site >> 5], w_nb = spa[nb >> 5], w_act = act[nb >> 5], w_mem = member[nb >> 5];
+                const uint32_t w_site_b = CMR ? spb[site >> 5] : 0u, w_nb_b = CMR ? spb[nb >> 5] : 0u;
+                const uint32_t neg = (jm >> lane) & 1u, nzb = (jm >> (12 + lane)) & 1u;
+                const uint32_t a_unsat = ((w_site >> (site & 31u)) ^ (w_nb >> (nb & 31u)) ^ neg) & 1u;
+                uint32_t wanted = (a_unsat ^ 1u) & (w_act >> (nb & 31u));
+                if (CMR) {
+                    const uint32_t b_unsat = ((w_site_b >> (site & 31u)) ^ (w_nb_b >> (nb & 31u)) ^ neg) & 1u;
+                    wanted = phase == 0 ? ((a_unsat | b_unsat) ^ 1u) : (a_unsat ^ b_unsat);
                 }
+                const bool eligible = slot_ok && ((nzb & ~(w_mem >> (nb & 31u)) & wanted & 1u) != 0);
                 uint32_t todo = static_cast<uint32_t>(__ballot(eligible));
                 while (todo) {
                     const uint32_t q = __ffs(todo) - 1;

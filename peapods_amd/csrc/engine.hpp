@@ -113,6 +113,7 @@ struct DevPtrs {
     const uint32_t *nbr_wide; // [N][16] in schedule order: site, f0, b0, ..., f5, b5, 0, 0, 0 (general path)
     const float *jorg_p;      // [n_temps] 1 - exp(-4 / T) by the host libm (Joerg bond probability)
     uint16_t *dfs_stack;      // [n_real][n_temps * n_pairs][N] scratch of k_jorg
+    uint32_t *hd_scratch;     // [n_real][2][W][N] k_houdayer -> k_houdayer_grow: active masks, seeded clusters
     uint64_t *pair_rng;      // [n_real][n_temps * n_pairs][4] xoshiro state of the overlap-move generators
     // "sw" inner variant of the overlap-cluster moves (kernels_cluster.hip; built on first use)
     uint32_t *pair_slots;    // [n_real][n_temps][n_replicas] slots in the shuffled order of each temperature

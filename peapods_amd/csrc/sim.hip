@@ -373,6 +373,7 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
         q.eq_ckpt += static_cast<size_t>(64) * 2 * d.n_temps * r0;
     }
     q.dfs_stack += static_cast<size_t>(std::max(d.n_temps * d.n_pairs, d.n_sys)) * d.N * r0;
+    if (q.hd_scratch) q.hd_scratch += 2 * tile_words * r0;
     if (q.slot_bits) q.slot_bits += static_cast<size_t>(d.SP) * d.MW * r0;
     const size_t stream_per_real = static_cast<size_t>(d.n_sys) * cluster_stream_units(d) * 64;
     if (q.stream_bits) q.stream_bits += stream_per_real * r0;
@@ -1630,6 +1631,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     ok(bufs.alloc(&sim->nbr_wide, nbr_wide.size()));
     ok(bufs.alloc(&sim->jorg_p, jorg_p.size()));
     ok(bufs.alloc(&p.dfs_stack, d.big ? 1 : static_cast<size_t>(d.n_real) * std::max(d.n_temps * d.n_pairs, d.n_sys) * d.N));
+    if (!d.big && d.n_pairs) ok(bufs.alloc(&p.hd_scratch, 2 * tile_words * d.n_real));
     ok(bufs.alloc(&p.big_counts, static_cast<size_t>(d.n_real) * d.n_sys * 4));
     if (e != hipSuccess) {
         sim->error = std::string("hipMalloc: ") + hipGetErrorString(e);

@@ -1,23 +1,27 @@
 #!/usr/bin/env python3
-"""Headline benchmark: spin-flip attempts / second on the 3D 16^3 +-J glass,
-24 temperatures x 4 replicas x 128 disorder realisations per GPU (BASELINE.json configs[2],
-SURVEY.md section 8d).
+"""Benchmark of the hot path: spin-flip attempts / second.
 
-    python bench.py --gpus 1 --steps 2000 --warmup 100
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py                                  # 1 GPU, BASELINE configs[2] (the headline metric)
+    python bench.py --gpus 8 --steps 20 --warmup 5   # starts 8 worker processes itself, one per GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # also fine
+    python bench.py --config c1 | c4                 # BASELINE configs[1] (64^3 ferromagnet) / configs[4]
+                                                     # (12^3 glass with the Houdayer move): same JSON shape
 
-One step = one full sweep of the protocol over the rank's ensemble: Metropolis sweep of every
-system, energies + magnetisations, replica-overlap measurement, running statistics, and one
-parallel-tempering event per replica ladder.  State is resident in HBM before the timed region.
-Disorder realisations shard over ranks with no data-path collective (weak scaling, 128 per GPU);
-the only exchange is the final all-gather of the per-realisation observable blocks.
-
-torch is used for the process group / RCCL all-gather only; the hot path is libpeapods_amd.so.
+One step = one full sweep of the protocol over the rank's ensemble: Metropolis sweep of every system,
+energies + magnetisations, replica-overlap measurement, running statistics and one parallel-tempering
+event per replica ladder (c4: plus the overlap-cluster move).  State is resident in HBM before the timed
+region.  Disorder realisations shard over ranks with no data-path collective (weak scaling, 128 per
+GPU); the only exchange is the final all-gather of the per-realisation observable blocks, over RCCL
+through the library's own C ABI (pa_comm_*).  No torch anywhere: when launched by torch.distributed.run
+only its RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* environment is read.
 """
 
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,13 +31,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-SHAPE = (16, 16, 16)
-N_TEMPS, N_REPLICAS, N_DISORDER_PER_GPU = 24, 4, 128
-T_MIN, T_MAX = 0.8, 1.4          # reference tests/spin_glass_crossings.py:16
 ROOT_SEED = 42                   # reference tests/spin_glass_crossings.py:11
-BYTES_PER_ATTEMPT = 0.625        # N/8 read + N/8 write spins + 3N/8 coupling signs
-BYTES_PER_ATTEMPT_OVERLAP = 0.125  # 2N/8 read per pair and recorded sweep, 2 pairs per 4 replicas
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BYTES_OVERLAP = 0.125            # 2N/8 read per pair and recorded sweep = 1/8 B per attempt
+
+# shapes, temperature grids and protocols of the BASELINE.json configs.
+# bytes = algorithmic bytes per attempt of the sweep (1 bit/spin read + written, 1 sign bit per +-J bond;
+# the uniform ferromagnet has no couplings to load).
+WORKLOADS = {
+    "c2": dict(title="BASELINE configs[2]: 16^3 +-J, linspace(0.8,1.4,24) x 4 replicas x {n} disorder per GPU; "
+                     "Metropolis + energies + overlap + statistics + parallel tempering every sweep",
+               metric="spin-flips/sec on 3D 16^3 +-J glass, 24T x 4rep x 128 disorder per GPU",
+               shape=(16, 16, 16), n_temps=24, n_replicas=4, n_disorder=128, t_range=(0.8, 1.4),
+               couplings="bimodal", bytes=0.625, sample={}),
+    "c1": dict(title="BASELINE configs[1]: 64^3 ferromagnet, linspace(4.111,4.911,32) x 2 replicas; Metropolis + "
+                     "energies + overlap + statistics + parallel tempering every sweep",
+               metric="spin-flips/sec on 3D 64^3 ferromagnet, 32T x 2rep",
+               shape=(64, 64, 64), n_temps=32, n_replicas=2, n_disorder=1, t_range=(4.111, 4.911),
+               couplings="ferro", bytes=0.25, sample={}),
+    "c4": dict(title="BASELINE configs[4]: 12^3 +-J, linspace(0.8,1.4,24) x 4 replicas x {n} disorder per GPU; the "
+                     "configs[2] protocol + the {mode} overlap-cluster move every sweep",
+               metric="spin-flips/sec on 3D 12^3 +-J glass with the overlap-cluster move, 24T x 4rep x 128 disorder per GPU",
+               shape=(12, 12, 12), n_temps=24, n_replicas=4, n_disorder=128, t_range=(0.8, 1.4),
+               couplings="bimodal", bytes=0.625, sample=dict(overlap_cluster_update_interval=1)),
+}
 
 
 def parse_args():
@@ -41,26 +62,96 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--disorder-per-gpu", type=int, default=N_DISORDER_PER_GPU)
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default="c2")
+    ap.add_argument("--disorder-per-gpu", type=int, default=None)
     ap.add_argument("--pt-schedule", default="single_random_edge")
+    ap.add_argument("--oc-mode", default="houdayer", help="c4: overlap_cluster_build_mode (houdayer, jorg, cmr)")
+    ap.add_argument("--oc-variant", default="wolff", help="c4: overlap_cluster_mode (wolff, sw)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--profile-sweeps", type=int, default=64)
     return ap.parse_args()
 
 
-def build_ensemble(rank, n_per_gpu, world):
+# ------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` starts N workers before anything touches the GPU
+# ------------------------------------------------------------------------------------------------
+def count_gpus_without_touching_them():
+    """GPU agents in the KFD topology (sysfs): nodes with SIMDs.  The launcher must not initialise HIP --
+    its children are started by fork + exec."""
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    count = 0
+    for path in nodes:
+        try:
+            with open(path) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                count += 1
+        except (OSError, ValueError):
+            pass
+    if nodes:
+        # a container may expose fewer devices than the host has
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            if os.environ.get(var):
+                count = min(count, len([x for x in os.environ[var].split(",") if x.strip() != ""]))
+        return count
+    # no sysfs view: ask a child process (the parent stays clean)
+    probe = subprocess.run([sys.executable, "-c",
+                            "import sys; sys.path.insert(0, %r); from peapods_amd import _native as n; "
+                            "print(n.lib().pa_device_count())" % ROOT], capture_output=True, text=True)
+    try:
+        return int(probe.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return 0
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_workers(args):
+    have = count_gpus_without_touching_them()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 3
+    port = free_port()
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in pending:  # one rank failed: the others would wait for it forever
+                    other.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# worker
+# ------------------------------------------------------------------------------------------------
+def build_ensemble(work, rank, n_per_gpu, world, device):
     from peapods_amd import IsingSimulation
     from peapods_amd.spin_models import generate_couplings, seed_material
 
     coupling_seq, dynamics_seed = seed_material(ROOT_SEED)
     mine = range(rank * n_per_gpu, (rank + 1) * n_per_gpu)
-    couplings = np.stack(generate_couplings("bimodal", SHAPE, 3, n_per_gpu * world, coupling_seq,
+    couplings = np.stack(generate_couplings(work["couplings"], work["shape"], 3, n_per_gpu * world, coupling_seq,
                                             realizations=mine))
-    temps = np.linspace(T_MIN, T_MAX, N_TEMPS).astype(np.float32)
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    sim = IsingSimulation(list(SHAPE), couplings, temps, N_REPLICAS, None, dynamics_seed,
-                          device=local_rank, first_realization=mine.start)
+    temps = np.linspace(*work["t_range"], work["n_temps"]).astype(np.float32)
+    sim = IsingSimulation(list(work["shape"]), couplings, temps, work["n_replicas"], None, dynamics_seed,
+                          device=device, first_realization=mine.start)
     return sim, couplings, temps, dynamics_seed
 
 
@@ -78,7 +169,7 @@ def host_cores():
     return int(env) if env else cores
 
 
-def cpu_baseline(couplings, temps, dynamics_seed, schedule, seconds):
+def cpu_baseline(work, couplings, temps, dynamics_seed, sample_kw, seconds):
     """Times the oracle (the reference's algorithm restated in C: i8 spins, f32 couplings,
     typewriter order, xoshiro256**, integer table) on this box's host cores: one thread per
     disorder realisation, replicas sequential inside, i.e. the reference's outer rayon level."""
@@ -90,10 +181,10 @@ def cpu_baseline(couplings, temps, dynamics_seed, schedule, seconds):
         lib = ob.load()
     cores = host_cores()
     n_real = min(cores, couplings.shape[0])
-    sim = ob.OracleSimulation(list(SHAPE), couplings[:n_real], temps, N_REPLICAS, None,
+    sim = ob.OracleSimulation(list(work["shape"]), couplings[:n_real], temps, work["n_replicas"], None,
                               dynamics_seed, lib=lib)
-    per_sweep = int(np.prod(SHAPE)) * N_TEMPS * N_REPLICAS * n_real
-    kw = dict(pt_interval=1, pt_schedule=schedule, warmup_ratio=0.0, n_threads=cores)
+    per_sweep = int(np.prod(work["shape"])) * work["n_temps"] * work["n_replicas"] * n_real
+    kw = dict(sample_kw, warmup_ratio=0.0, n_threads=cores)
     t0 = time.perf_counter()
     sim.run(sim.make_config(2, "metropolis", **kw))
     probe = (time.perf_counter() - t0) / 2
@@ -101,158 +192,192 @@ def cpu_baseline(couplings, temps, dynamics_seed, schedule, seconds):
     t0 = time.perf_counter()
     sim.run(sim.make_config(sweeps, "metropolis", **kw))
     dt = time.perf_counter() - t0
+    side = "x".join(str(s) for s in work["shape"])
     return {
         "value": per_sweep * sweeps / dt,
         "unit": "spin-flip attempts/s",
-        "cores": cores,
+        "cores": min(cores, n_real),
         "kind": "port",
-        "sample": f"{n_real} of {couplings.shape[0]} disorder realisations x {N_TEMPS}T x "
-                  f"{N_REPLICAS} replicas of 16^3, {sweeps} sweeps (Metropolis + PT + overlap "
-                  f"every sweep), {dt:.1f} s on {cores} threads, gcc -O3 -march=native",
+        "sample": f"{n_real} of {couplings.shape[0]} disorder realisations x {work['n_temps']}T x "
+                  f"{work['n_replicas']} replicas of {side}, {sweeps} sweeps of the same protocol, "
+                  f"{dt:.1f} s on {min(cores, n_real)} threads, gcc -O3 -march=native",
     }
 
 
-def valu_limiter(kernels_ms, disorder_per_gpu):
-    """The resource that actually bounds the two sweep kernels: VALU issue slots.  A wave64 VALU
-    instruction holds a SIMD for 4 cycles, so the chip retires 256 CUs x 4 SIMDs x 2.4 GHz / 4
-    wave-instructions per second.  Instruction counts per launch are SQ_INSTS_VALU of the committed
-    PMC pass (profiles/r01_pmc_per_launch.csv, 128 realisations per launch; they scale with the
-    ensemble and do not depend on the data)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_per_launch.csv")
+def load_json(name):
+    path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
         return None
-    import csv
-
-    counts = {}
     with open(path) as fh:
-        for row in csv.DictReader(fh):
-            name = row["kernel"]
-            if name.startswith("pa::k_rng_overlap"):
-                counts["k_rng"] = float(row["SQ_INSTS_VALU"])
-            elif name.startswith("pa::k_sweep<"):
-                counts["k_sweep"] = float(row["SQ_INSTS_VALU"])
-    peak = 256 * 4 * 2.4e9 / 4
-    scale = disorder_per_gpu / 128.0
-    frac = {k: counts[k] * scale / (kernels_ms[k] * 1e-3) / peak for k in counts if kernels_ms.get(k, 0) > 0}
-    return {"resource": "VALU issue (wave64 instructions)", "wave_insts_per_launch": {k: v * scale for k, v in counts.items()},
-            "peak_wave_insts_per_s": peak, "frac": frac}
+        return json.load(fh)
 
 
-def main():
-    args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    dist = None
-    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with 1 rank)
-        import torch
-        import torch.distributed as dist
+def valu_limiter(kernels_ms, scale):
+    """What actually bounds the two sweep kernels: VALU issue.  Peaks are MEASURED on this chip by
+    tools/probe/valu_issue.hip (profiles/r02_valu_issue.json): gfx950 issues simple integer ops
+    (xor / and / add / sub / bitop3 / mov) at ~2.3 cycles per wave-instruction per SIMD once two waves
+    share it, but shifts-left, rotates (v_alignbit), 64-bit shift-adds, compares into SGPRs,
+    v_writelane / v_readlane and DPP moves hold the SIMD ~4.2 cycles -- and a stream that mixes both
+    classes runs close to the slow rate.  `peak_wave_insts_per_s` is the probe's own run of the
+    generator step of k_rng (xoshiro256** + 3 compares + ballot parking, 23 VALU instructions) at 8 waves
+    per SIMD; wave-instruction counts per launch are SQ_INSTS_VALU of the committed PMC pass (they scale
+    with the ensemble and do not depend on the data)."""
+    counters = load_json("counters.json")
+    probe = load_json("r02_valu_issue.json")
+    if not counters or not probe:
+        return None
+    rate = {}
+    for row in probe["rows"]:
+        if row["waves_per_simd"] == 8:
+            rate[row["op"]] = row["wall_inst_per_s"]
+    counts = {k: v * scale for k, v in counters.get("wave_insts_per_launch", {}).items()}
+    peak = rate.get("rng_step_full")
+    frac = {k: counts[k] / (kernels_ms[k] * 1e-3) / peak for k in counts if kernels_ms.get(k, 0) > 0 and peak}
+    return {"resource": "VALU issue (wave64 instructions)", "wave_insts_per_launch": counts,
+            "counters_collected_at": counters.get("commit"),
+            "peak_wave_insts_per_s": peak,
+            "peak_source": "profiles/r02_valu_issue.json: rng_step_full at 8 waves/SIMD (tools/probe/valu_issue.hip)",
+            "class_peaks_wave_insts_per_s": {"simple_int (v_xor/v_add/v_bitop3)": rate.get("v_xor_b32"),
+                                             "shift/rotate/lane/64-bit (v_alignbit/v_writelane/v_lshl_add_u64)":
+                                                 rate.get("v_alignbit_b32")},
+            "frac": frac}
 
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}", file=sys.stderr)
 
-    sim, couplings, temps, dynamics_seed = build_ensemble(rank, args.disorder_per_gpu, world)
-    n_spins = int(np.prod(SHAPE))
-    attempts_per_step = n_spins * N_TEMPS * N_REPLICAS * args.disorder_per_gpu
+def worker(args, rank, world, local_rank):
+    from peapods_amd import _native as nat
+    from peapods_amd.distributed import Comm, aggregate_mean
+
+    work = WORKLOADS[args.config]
+    n_per_gpu = args.disorder_per_gpu or work["n_disorder"]
+    comm = Comm(rank, world, local_rank) if world > 1 else None
+
+    sim, couplings, temps, dynamics_seed = build_ensemble(work, rank, n_per_gpu, world, local_rank)
+    n_spins = int(np.prod(work["shape"]))
+    attempts_per_step = n_spins * work["n_temps"] * work["n_replicas"] * n_per_gpu
+    sample_kw = dict(work["sample"], pt_interval=1, pt_schedule=args.pt_schedule)
+    if "overlap_cluster_update_interval" in sample_kw:
+        sample_kw.update(overlap_cluster_build_mode=args.oc_mode, overlap_cluster_mode=args.oc_variant)
 
     def config(n):
-        return sim.make_config(n, "metropolis", pt_interval=1, pt_schedule=args.pt_schedule,
-                               warmup_ratio=0.0)
+        return sim.make_config(n, "metropolis", warmup_ratio=0.0, **sample_kw)
 
     def sync_all():
         sim.synchronize()
-        if dist is not None:
-            import torch
+        if comm is not None:
+            comm.barrier()
 
-            torch.cuda.synchronize()
-            dist.barrier()
+    # attainable HBM bandwidth of this device, measured in this run (SURVEY 8d) -- before the timed region, so
+    # that the short default run of the driver (20 steps = 1.5 ms) does not start on an idle chip's clocks
+    copy_gbs = None
+    if True:  # every rank: the ranks stay in step
+        import ctypes as C
 
+        out_bw, err = C.c_double(), C.create_string_buffer(256)
+        if nat.lib().pa_device_copy_bandwidth(local_rank, 1 << 30, 8, C.byref(out_bw), err, len(err)) == nat.PA_OK:
+            copy_gbs = out_bw.value
     if args.warmup > 0:
         sim.run(config(args.warmup))
     sync_all()
     t0 = time.perf_counter()
     sim.run(config(args.steps), wait=False)
-    sync_all()
+    enqueue_ms = (time.perf_counter() - t0) * 1e3
+    sim.synchronize()
+    own = time.perf_counter() - t0
+    if comm is not None:
+        comm.barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    per_rank = [attempts_per_step * args.steps / own]
+    if comm is not None:
+        elapsed = comm.max_f64(elapsed)
+        per_rank = (attempts_per_step * args.steps / comm.all_gather(np.array([own]))).reshape(-1).tolist()
 
     # final observable exchange: per-realisation blocks, all-gathered over RCCL, aggregated in
     # realisation order (results.rs:165-282) so the result is independent of the GPU count
     t_gather = time.perf_counter()
-    from peapods_amd.distributed import aggregate_mean, all_gather_blocks
-
-    blocks = all_gather_blocks(sim.result_blocks(), dist, device="cuda" if dist is not None else None)
-    mean = aggregate_mean(blocks)
+    blocks = comm.gather_result_blocks(sim, n_per_gpu * world) if comm is not None else sim.result_blocks()
     gather_ms = (time.perf_counter() - t_gather) * 1e3
+    mean = aggregate_mean(blocks)
 
-    kernels_ms = sim.profile_kernels(config(args.profile_sweeps), args.profile_sweeps)
-
+    profiled = "overlap_cluster_update_interval" not in sample_kw
+    kernels_ms = sim.profile_kernels(sim.make_config(args.profile_sweeps, "metropolis", warmup_ratio=0.0, pt_interval=1,
+                                                     pt_schedule=args.pt_schedule), args.profile_sweeps)
     if rank == 0:
-        total_attempts = attempts_per_step * world * args.steps
-        value = total_attempts / elapsed
+        value = attempts_per_step * world * args.steps / elapsed
         sweep_ms = kernels_ms["k_rng"] + kernels_ms["k_sweep"]
         # the random-stream launch also carries the overlap measurement of the previous sweep
         # (k_rng_overlap), so its algorithmic bytes (SURVEY 8d: +0.125 B/attempt) count with it
-        alg_bytes = (BYTES_PER_ATTEMPT + BYTES_PER_ATTEMPT_OVERLAP) * attempts_per_step
+        alg_bytes = (work["bytes"] + BYTES_OVERLAP) * attempts_per_step
         achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
-        traffic = None
-        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(traffic_file):
-            with open(traffic_file) as fh:
-                traffic = json.load(fh).get("hbm_bytes_per_sweep")
+        counters = load_json("counters.json") if args.config == "c2" else None
+        scale = n_per_gpu / 128.0
         out = {
-            "metric": "spin-flips/sec on 3D 16^3 +-J glass, 24T x 4rep x 128 disorder per GPU",
+            "metric": work["metric"],
             "value": value,
             "unit": "spin-flip attempts/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "host_enqueue_ms": enqueue_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32 bit-sliced spins (1 bit/spin); u64 xoshiro256**; i32 reductions; f64 sums",
-            "data": "synthetic: i.i.d. +-1 couplings (numpy SeedSequence(42) children, as the "
-                    "reference generates them), random initial spins",
+            "data": f"synthetic: {'i.i.d. +-1' if work['couplings'] == 'bimodal' else 'uniform +1'} couplings "
+                    "(numpy SeedSequence(42) children, as the reference generates them), random initial spins",
             "config": {
-                "workload": "BASELINE configs[2]: 16^3 +-J, linspace(0.8,1.4,24) x 4 replicas x "
-                            f"{args.disorder_per_gpu} disorder per GPU; Metropolis + energies + "
-                            "overlap + statistics + parallel tempering every sweep",
+                "workload": work["title"].format(n=n_per_gpu, mode=f"{args.oc_mode}/{args.oc_variant}"),
                 "pt_schedule": args.pt_schedule,
                 "update_order": "reference typewriter order and xoshiro256** stream (bit-exact)",
                 "attempts_per_step_per_gpu": attempts_per_step,
                 "parallelism": f"disorder sharded over {world} GPU(s), no data-path collective",
             },
+            "ranks": {"launched": world, "rccl_ranks": comm.world if comm is not None else 1,
+                      "attempts_per_s_per_rank": per_rank},
             "roofline": {
                 "bound": "hbm",
                 "kernel": "k_rng_overlap + k_sweep (the two launches of one Metropolis sweep; the first "
-                          "also measures the previous sweep's replica overlap)",
+                          "also measures the previous sweep's replica overlap)" if args.config != "c1" else
+                          "k_rng + k_sweep_slab (random stream + LDS-resident slab sweep of one Metropolis sweep)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
+                "attainable_copy_gbs": copy_gbs,
+                "frac_of_attainable": achieved / copy_gbs if copy_gbs else None,
+                "traffic": counters.get("hbm_bytes_per_sweep") * scale if counters else None,
+                "traffic_collected_at": counters.get("commit") if counters else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": kernels_ms,
-                "limiter": valu_limiter(kernels_ms, args.disorder_per_gpu),
+                "kernel_ms_protocol": "sweep pipeline of the timed protocol" if profiled else
+                                      "sweep pipeline only (the cluster move is in ms_per_step, not here)",
+                "limiter": valu_limiter(kernels_ms, scale) if args.config == "c2" else None,
             },
             "observable_allgather_ms": gather_ms,
-            "checksum_energy_mean": float(mean[3 * N_TEMPS:4 * N_TEMPS].sum()),
+            "checksum_energy_mean": float(mean[3 * work["n_temps"]:4 * work["n_temps"]].sum()),
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(couplings, temps, dynamics_seed, args.pt_schedule,
-                                               args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(work, couplings, temps, dynamics_seed,
+                                               {k: v for k, v in sample_kw.items()}, args.cpu_seconds)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
+
+
+def main():
+    args = parse_args()
+    if "RANK" in os.environ:  # a worker: started by launch_workers below or by torch.distributed.run
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world != args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+            sys.exit(2)
+        worker(args, int(os.environ["RANK"]), world, int(os.environ.get("LOCAL_RANK", os.environ["RANK"])))
+    elif args.gpus > 1:
+        sys.exit(launch_workers(args))
+    else:
+        worker(args, 0, 1, 0)
 
 
 if __name__ == "__main__":

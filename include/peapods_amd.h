@@ -135,10 +135,15 @@ int pa_validate_sample_config(const pa_sample_config *cfg, uint64_t n_replicas, 
 
 /* ---- the driver loop (ss/simulation/mod.rs:405-797 for every realisation) -- */
 int pa_sim_sample(pa_sim *sim, const pa_sample_config *cfg);
-/* Asynchronous variant for timing: enqueue only; pa_sim_synchronize waits. */
+/* Asynchronous variant for timing: returns once the last sweeps are enqueued (the host runs at most two
+ * batches of 256 sweeps ahead of the device); pa_sim_synchronize waits for them. */
 int pa_sim_sample_async(pa_sim *sim, const pa_sample_config *cfg);
 int pa_sim_synchronize(pa_sim *sim);
-/* Cooperative cancel, polled between kernel batches (src/lib.rs:304-308). */
+/* Cooperative cancel (the reference's AtomicBool polled once per sweep, src/lib.rs:304-308,
+ * ss/simulation/mod.rs:406-408).  May be called from another thread while sample() runs: the run stops
+ * within two batches of 256 queued sweeps, sample() returns PA_ERR_INTERRUPTED ("interrupted"), and the
+ * ensemble is left in the state after the last sweep that ran -- statistics hold whole sweeps only and a
+ * following sample() continues from there.  A request made while no sample() is running is dropped. */
 void pa_sim_request_interrupt(pa_sim *sim);
 
 /* Per-kernel device time of the sweep pipeline, measured with HIP events on the handle's stream
@@ -219,6 +224,47 @@ uint64_t pa_sim_n_equil_checkpoints(const pa_sim *sim);
 int pa_sim_get_equilibration(pa_sim *sim, uint64_t realization, uint64_t *sweeps, double *energy_avg,
                              double *link_overlap_avg);
 int pa_sim_get_result_blocks(pa_sim *sim, double *out /* [n_realizations][block_len] */);
+
+/* ---- multi-GPU: disorder shards + ONE collective (RCCL over xGMI) ---------------------------------
+ * The reference has a single process whose outer rayon loop runs the realisations
+ * (ss/simulation/mod.rs:887-903) and aggregates them serially (ss/statistics/results.rs:165-282).  Here
+ * rank g of G owns a contiguous block of realisations (pa_sim_desc.first_realization), runs with no
+ * data-path collective, and the fixed-size per-realisation result blocks are all-gathered once at the
+ * end; every rank then applies pa_aggregate_* in realisation order, which reproduces a single-GPU run
+ * bit for bit.  One communicator rank per process / GPU.  The 128-byte id is created by one rank and
+ * handed to the others by the caller over any channel.  RCCL is bound at run time: without librccl
+ * these calls return PA_ERR_DEVICE and a message, the rest of the library is unaffected. */
+#define PA_COMM_ID_BYTES 128
+typedef struct pa_comm pa_comm;
+int pa_comm_unique_id(uint8_t id_out[PA_COMM_ID_BYTES], char *err, size_t err_len); /* ncclGetUniqueId */
+int pa_comm_init_rank(const uint8_t id[PA_COMM_ID_BYTES], int32_t n_ranks, int32_t rank, int32_t device,
+                      pa_comm **out, char *err, size_t err_len);                   /* ncclCommInitRank */
+void pa_comm_destroy(pa_comm *comm);
+const char *pa_comm_last_error(const pa_comm *comm);
+int32_t pa_comm_n_ranks(const pa_comm *comm);
+int32_t pa_comm_rank(const pa_comm *comm);
+/* Host buffers, staged through device memory: recv_host receives n_ranks * bytes_per_rank in rank order. */
+int pa_comm_allgather(pa_comm *comm, const void *send_host, void *recv_host, uint64_t bytes_per_rank);
+int pa_comm_allreduce_max_f64(pa_comm *comm, double *inout, uint64_t count); /* e.g. max-over-ranks timing */
+int pa_comm_allreduce_sum_u64(pa_comm *comm, uint64_t *inout, uint64_t count); /* exact; e.g. summed P(q) counts */
+int pa_comm_barrier(pa_comm *comm);
+/* All ranks' pa_sim_get_result_blocks in rank (= global realisation) order; ranks may own different numbers
+ * of realisations.  out: [out_capacity][pa_sim_result_block_len] f64; *n_total_out = blocks gathered. */
+int pa_comm_gather_result_blocks(pa_comm *comm, pa_sim *sim, double *out, uint64_t out_capacity,
+                                 uint64_t *n_total_out);
+uint64_t pa_sim_n_realizations(const pa_sim *sim);
+
+/* ---- measurement helpers -------------------------------------------------------------------------
+ * Attainable HBM bandwidth of `device` beside the 8 TB/s specification: a float4 copy of
+ * `bytes` (read + write both counted), best of `iterations` launches, HIP-event timed. */
+int pa_device_copy_bandwidth(int32_t device, uint64_t bytes, int32_t iterations, double *gbytes_per_s_out,
+                             char *err, size_t err_len);
+/* sizeof and field offsets of the two argument structs as this library was compiled:
+ * out = { sizeof(pa_sim_desc), n_fields, offsets..., sizeof(pa_sample_config), n_fields, offsets... } in
+ * declaration order; returns the number of entries (written up to `capacity`).  Bindings assert their
+ * own layout against it (tests/test_host_logic.py does so for the ctypes binding, INTEGRATION.md's Rust
+ * structs are generated from it). */
+uint64_t pa_abi_layout(uint64_t *out, uint64_t capacity);
 
 /* ---- host-only helpers (no device needed) --------------------------------- */
 uint64_t pa_splitmix64(uint64_t value);

@@ -5,6 +5,7 @@
 
 import ctypes as C
 import sys
+import threading
 
 import numpy as np
 
@@ -216,8 +217,31 @@ class IsingSimulation:
 
     # ---- hot path ---------------------------------------------------------
     def run(self, cfg, wait=True):
+        """pa_sim_sample.  The reference releases the GIL for the whole run and polls Python's signal state
+        from its progress callback (src/lib.rs:304-333); a ctypes call cannot be interrupted, so on the main
+        thread the call runs on a helper thread while this one stays interruptible: Ctrl-C asks the library to
+        stop (pa_sim_request_interrupt: honoured within two batches of 256 queued sweeps), waits for it and
+        re-raises.  The ensemble is then in the state after the last sweep that ran; sample() continues from it."""
         fn = self._lib.pa_sim_sample if wait else self._lib.pa_sim_sample_async
-        self._check(fn(self._handle, C.byref(cfg)))
+        if not wait or threading.current_thread() is not threading.main_thread():  # (timing runs enqueue directly)
+            self._check(fn(self._handle, C.byref(cfg)))
+            return
+        outcome = {}
+
+        def call():
+            outcome["code"] = fn(self._handle, C.byref(cfg))
+
+        helper = threading.Thread(target=call, daemon=True)
+        helper.start()
+        try:
+            while helper.is_alive():
+                helper.join(0.2)
+        except KeyboardInterrupt:
+            self._lib.pa_sim_request_interrupt(self._handle)
+            helper.join()
+            self._lib.pa_sim_synchronize(self._handle)
+            raise
+        self._check(outcome["code"])
 
     def profile_kernels(self, cfg, n_sweeps):
         """Average device milliseconds per launch of (k_rng, k_sweep, k_measure)."""

@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpeapods_amd.so")
 
 PA_OK, PA_ERR_INVALID, PA_ERR_UNSUPPORTED, PA_ERR_DEVICE, PA_ERR_INTERRUPTED = range(5)
+PA_COMM_ID_BYTES = 128
 
 
 class PaSimDesc(C.Structure):
@@ -106,6 +107,20 @@ SIGNATURES = {
     "pa_aggregate_mean": (None, [_vp, _u64, _u64, _vp]),
     "pa_aggregate_sum_u64": (None, [_vp, _u64, _u64, _vp]),
     "pa_aggregate_sum_f64": (None, [_vp, _u64, _u64, _vp]),
+    "pa_comm_unique_id": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
+    "pa_comm_init_rank": (C.c_int, [_vp, _i32, _i32, _i32, C.POINTER(_vp), C.c_char_p, C.c_size_t]),
+    "pa_comm_destroy": (None, [_vp]),
+    "pa_comm_last_error": (C.c_char_p, [_vp]),
+    "pa_comm_n_ranks": (_i32, [_vp]),
+    "pa_comm_rank": (_i32, [_vp]),
+    "pa_comm_allgather": (C.c_int, [_vp, _vp, _vp, _u64]),
+    "pa_comm_allreduce_max_f64": (C.c_int, [_vp, _vp, _u64]),
+    "pa_comm_allreduce_sum_u64": (C.c_int, [_vp, _vp, _u64]),
+    "pa_comm_barrier": (C.c_int, [_vp]),
+    "pa_comm_gather_result_blocks": (C.c_int, [_vp, _vp, _vp, _u64, _vp]),
+    "pa_sim_n_realizations": (_u64, [_vp]),
+    "pa_device_copy_bandwidth": (C.c_int, [_i32, _u64, _i32, _vp, C.c_char_p, C.c_size_t]),
+    "pa_abi_layout": (_u64, [_vp, _u64]),
     "pa_device_count": (C.c_int, []),
     "pa_version": (C.c_char_p, []),
 }

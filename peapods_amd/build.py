@@ -2,31 +2,35 @@
 
     python -m peapods_amd.build            # hipcc cross-compiles without a GPU
 
-The library is the only compiled artefact of the product; the parity oracle is
-built separately by oracle/Makefile and never linked here.
+Every translation unit is compiled to its own object (in parallel, only when it or a header
+changed), then linked.  The library is the only compiled artefact of the product; the parity
+oracle is built separately by oracle/Makefile and never linked here.
 """
 
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libpeapods_amd.so")
-SOURCES = ["host_util.cpp", "kernels.hip", "kernels_general.hip", "kernels_cluster.hip", "sim.hip"]
+SOURCES = ["host_util.cpp", "kernels.hip", "kernels_general.hip", "kernels_cluster.hip", "sim.hip", "comm.hip", "bandwidth.hip"]
 HEADERS = ["engine.hpp", "host_util.hpp", "device_util.hpp", os.path.join("..", "..", "include", "peapods_amd.h")]
 FLAGS = [
     "--offload-arch=gfx950",
     "-O3",
     "-std=c++17",
     "-fPIC",
-    "-shared",
     "-ffp-contract=off",  # no fused multiply-add anywhere: the reference never fuses
     "-fno-fast-math",
     "-Wall",
     "-Wno-unused-result",
 ]
+# RCCL is bound at run time (dlopen in comm.hip), so a single-GPU box without it still loads the library
+LINK_FLAGS = ["-shared", "-ldl", "-lpthread"]
 
 
 def hipcc():
@@ -36,21 +40,44 @@ def hipcc():
     raise RuntimeError("hipcc not found: the peapods_amd extension cannot be built")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def _newer(target, deps):
+    if not os.path.exists(target):
         return True
-    built = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    built = os.path.getmtime(target)
     return any(os.path.getmtime(d) > built for d in deps)
 
 
+def _header_paths():
+    return [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+
+
+def needs_build():
+    return _newer(LIB, [os.path.join(CSRC, s) for s in SOURCES] + _header_paths())
+
+
 def build(force=False, verbose=False, extra_flags=()):
-    if not force and not needs_build():
+    if not force and not needs_build() and not extra_flags:
         return LIB
-    cmd = [hipcc(), *FLAGS, *extra_flags, "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    tag = "".join(c if c.isalnum() else "_" for c in "".join(extra_flags))
+    jobs = []
+    objects = []
+    for src in SOURCES:
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(OBJ, os.path.splitext(src)[0] + tag + ".o")
+        objects.append(obj)
+        if force or _newer(obj, [path] + _header_paths()):
+            jobs.append([cc, *FLAGS, *extra_flags, "-c", path, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as pool:
+        list(pool.map(run, jobs))
+    run([cc, "--offload-arch=gfx950", "-fPIC", *LINK_FLAGS, "-o", LIB, *objects])
     return LIB
 
 

@@ -97,6 +97,10 @@ struct DevPtrs {
     uint64_t *hist;          // [n_real][n_temps][N + 1]
     double *qlq;             // [n_real][n_temps][N + 1]
     double *ql2q;            // [n_real][n_temps][N + 1]
+    uint32_t *hist_touched;  // [n_real][n_temps][ceil((N + 1) / 32)] bins of hist / qlq / ql2q written since the
+                             //   accumulators were last cleared: the three big arrays are never memset (302 MB at
+                             //   the bench shape); a bin's first value of a run is stored, later ones are added,
+                             //   and the getter reads untouched bins as zero
     uint64_t *edge_att;      // [n_real][n_edges]
     uint64_t *edge_acc;      // [n_real][n_edges]
     uint64_t *round_trips;   // [n_real][n_sys] by system

@@ -1048,11 +1048,19 @@ __device__ __forceinline__ void measure_block(const SimDims &d, const DevPtrs &p
                 o[3] = __dadd_rn(o[3], static_cast<double>(ql));
                 o[4] = __dadd_rn(o[4], static_cast<double>(ql2));
                 o[5] = __dadd_rn(o[5], static_cast<double>(ql4));
-                const size_t bin =
-                    hbase + static_cast<size_t>((dot_spin + static_cast<int32_t>(d.N)) / 2);
-                p.hist[bin] += 1;
-                p.qlq[bin] = __dadd_rn(p.qlq[bin], static_cast<double>(ql));
-                p.ql2q[bin] = __dadd_rn(p.ql2q[bin], static_cast<double>(ql2));
+                const uint32_t qbin = static_cast<uint32_t>((dot_spin + static_cast<int32_t>(d.N)) / 2);
+                const size_t bin = hbase + qbin;
+                // row t of the bitmap belongs to this thread alone; all four loads are in flight together
+                uint32_t *seen = p.hist_touched +
+                                 (static_cast<size_t>(real) * d.n_temps + t) * ((d.N + 32) / 32) + (qbin >> 5);
+                const uint32_t seen_word = *seen;
+                const uint64_t h_old = p.hist[bin];
+                const double a_old = p.qlq[bin], b_old = p.ql2q[bin];
+                const bool fresh = ((seen_word >> (qbin & 31u)) & 1u) == 0; // first value of this run: the old
+                p.hist[bin] = (fresh ? 0ull : h_old) + 1;                   // contents are from an earlier run
+                p.qlq[bin] = __dadd_rn(fresh ? 0.0 : a_old, static_cast<double>(ql));
+                p.ql2q[bin] = __dadd_rn(fresh ? 0.0 : b_old, static_cast<double>(ql2));
+                if (fresh) *seen = seen_word | (1u << (qbin & 31u));
             }
             for (int k = 0; k < 6; ++k) ovm[k * d.n_temps + t] = o[k];
             if (pt.ac_index) // mod.rs:588-594
@@ -1651,8 +1659,9 @@ __global__ __launch_bounds__(256) void k_sweep_pipe(SimDims d, DevPtrs p, int gi
                                                               __HIP_MEMORY_SCOPE_AGENT) -
                                             (base + level)) < 0) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 26)) { // never reached unless a predecessor died: leave
-                        gave_up = 1;
+                    if (++spins > (1u << 26)) { // never reached unless a predecessor died: leave, and say so
+                        gave_up = 1;            // (pa_sim_synchronize reports PA_ERR_DEVICE)
+                        atomicExch(p.slab_error, 1u);
                         break;
                     }
                 }

@@ -12,7 +12,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -119,6 +121,7 @@ struct pa_sim {
     };
     std::vector<Group> groups;
     hipEvent_t fork = nullptr;
+    hipEvent_t batch_events[2] = {nullptr, nullptr}; // run-ahead bound of run_sweeps (cooperative cancel)
 };
 
 namespace {
@@ -315,9 +318,11 @@ int zero_accumulators(pa_sim *sim) {
     if (d.n_pairs) {
         const size_t bins = static_cast<size_t>(d.n_real) * d.n_temps * (d.N + 1);
         PA_HIP(sim, hipMemsetAsync(sim->p.ovm, 0, sizeof(double) * d.n_real * 6 * d.n_temps, sim->stream));
-        PA_HIP(sim, hipMemsetAsync(sim->p.hist, 0, sizeof(uint64_t) * bins, sim->stream));
-        PA_HIP(sim, hipMemsetAsync(sim->p.qlq, 0, sizeof(double) * bins, sim->stream));
-        PA_HIP(sim, hipMemsetAsync(sim->p.ql2q, 0, sizeof(double) * bins, sim->stream));
+        // the three histogram arrays (3 x 8 B x bins: 302 MB at 16^3 x 24 T x 128 samples) are not cleared:
+        // k_measure stores a bin's first value of the run and marks it here (1 bit per bin)
+        (void)bins;
+        PA_HIP(sim, hipMemsetAsync(sim->p.hist_touched, 0,
+                                   sizeof(uint32_t) * d.n_real * d.n_temps * ((d.N + 32) / 32), sim->stream));
     }
     return PA_OK;
 }
@@ -360,6 +365,7 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
         q.hist += bins * r0;
         q.qlq += bins * r0;
         q.ql2q += bins * r0;
+        q.hist_touched += static_cast<size_t>(d.n_temps) * ((d.N + 32) / 32) * r0;
     }
     q.edge_att += static_cast<size_t>(d.n_edges) * r0;
     q.edge_acc += static_cast<size_t>(d.n_edges) * r0;
@@ -404,6 +410,7 @@ int make_groups(pa_sim *sim) {
     }
     n_groups = std::min<uint32_t>(n_groups, sim->d.n_real);
     PA_HIP(sim, hipEventCreateWithFlags(&sim->fork, hipEventDisableTiming));
+    for (auto &e : sim->batch_events) PA_HIP(sim, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (uint32_t g = 0; g < n_groups; ++g) {
         const uint32_t r0 = sim->d.n_real * g / n_groups, r1 = sim->d.n_real * (g + 1) / n_groups;
         pa_sim::Group grp;
@@ -608,19 +615,26 @@ int ensure_cluster_stats(pa_sim *sim, uint32_t modes, bool snapshots) {
     const size_t bins = static_cast<size_t>(d.n_real) * d.n_temps * (d.N + 1);
     const size_t pairs = std::max(d.n_pairs, 1u);
     if (!sim->cs_ready || modes > sim->cs_modes) {
-        if (sim->cs_ready) {
-            (void)hipFree(sim->p.cs_ov_csd);
-            (void)hipFree(sim->p.cs_top4_acc);
-        } else {
+        if (!sim->cs_ready) {
             PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&sim->p.cs_fk_csd), sizeof(uint64_t) * bins));
             PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&sim->p.cs_top4_raw),
                                   sizeof(uint32_t) * 4 * d.n_real * d.n_temps * pairs));
             PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&sim->p.obs_acc),
                                   sizeof(uint64_t) * 4 * d.n_real * d.n_temps * (kObsWords + d.N + 1)));
         }
-        PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&sim->p.cs_ov_csd), sizeof(uint64_t) * bins * modes));
-        PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&sim->p.cs_top4_acc),
-                              sizeof(double) * 4 * d.n_real * d.n_temps * modes));
+        // the new buffers first, then swap: a failed allocation leaves the old ones in place and valid
+        uint64_t *csd = nullptr;
+        double *top4 = nullptr;
+        PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&csd), sizeof(uint64_t) * bins * modes));
+        if (hipMalloc(reinterpret_cast<void **>(&top4), sizeof(double) * 4 * d.n_real * d.n_temps * modes) != hipSuccess) {
+            (void)hipFree(csd);
+            return fail(sim, PA_ERR_DEVICE, "hipMalloc: cluster statistics");
+        }
+        PA_HIP(sim, hipStreamSynchronize(sim->stream));
+        if (sim->p.cs_ov_csd) (void)hipFree(sim->p.cs_ov_csd);
+        if (sim->p.cs_top4_acc) (void)hipFree(sim->p.cs_top4_acc);
+        sim->p.cs_ov_csd = csd;
+        sim->p.cs_top4_acc = top4;
         sim->cs_modes = modes;
         sim->cs_ready = true;
     }
@@ -782,11 +796,10 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     const bool want_overlap = d.n_pairs > 0 && cfg->measure_overlap;
     sim->n_recorded = 0;
     sim->overlap_collected = want_overlap;
-    // fork: every group stream starts after what is already queued on the main stream
-    PA_HIP(sim, hipEventRecord(sim->fork, sim->stream));
-    for (auto &g : sim->groups) PA_HIP(sim, hipStreamWaitEvent(g.stream, sim->fork, 0));
-    int status = PA_OK;
-    uint64_t overlap_call_count = 0; // mod.rs:300
+    // every capability check comes before the first launch: a configuration this build declines is
+    // rejected with the state untouched and no group stream forked
+    if (has_oc && static_cast<size_t>(d.N) * d.W * 12 + 4096 > 160 * 1024)
+        return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the overlap-cluster kernel");
     // equilibration diagnostic: energies and the link overlap of EVERY sweep (mod.rs:492,527)
     const bool equil = cfg->equilibration_diagnostic != 0;
     sim->equil_sweeps.clear();
@@ -796,15 +809,46 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             sim->equil_sweeps.push_back(cfg->n_sweeps);
         if (sim->equil_sweeps.size() > 64) return fail(sim, PA_ERR_UNSUPPORTED, "more than 64 equilibration checkpoints");
     }
+    // fork: every group stream starts after what is already queued on the main stream
+    PA_HIP(sim, hipEventRecord(sim->fork, sim->stream));
+    for (auto &g : sim->groups) PA_HIP(sim, hipStreamWaitEvent(g.stream, sim->fork, 0));
+    uint64_t overlap_call_count = 0; // mod.rs:300
     size_t equil_next = 0;
     const bool fused = want_overlap && !gibbs && !fk && !equil && !autocorr && cfg->overlap_cluster_interval == 0 && !d.big &&
                        !d.general && !std::getenv("PEAPODS_NO_FUSE");
     bool overlap_owed = false; // the last recorded sweep's overlap has not been measured yet
-    for (uint64_t sweep_id = 0; sweep_id < cfg->n_sweeps && status == PA_OK; ++sweep_id) {
+    // Cooperative cancel (src/lib.rs:304-308, mod.rs:406-408): the host runs at most two batches of
+    // kBatch sweeps ahead of the device, so a request is honoured within that much queued work; the
+    // state then is the one after the last enqueued sweep (a continuation from it is well defined).
+    constexpr uint64_t kBatch = 256;
+    hipEvent_t batch_done[2] = {sim->batch_events[0], sim->batch_events[1]};
+    bool batch_pending[2] = {false, false};
+    // The sweeps are enqueued inside a lambda so that every failure (a HIP error, an interrupt) leaves
+    // through the join below: the main stream always waits for the group streams before anything else
+    // -- a getter, a reset, the next call -- touches the buffers.
+    auto enqueue_all = [&]() -> int {
+    for (uint64_t sweep_id = 0; sweep_id < cfg->n_sweeps; ++sweep_id) {
+        if (sweep_id % kBatch == 0) {
+            const unsigned slot = static_cast<unsigned>((sweep_id / kBatch) & 1u);
+            if (batch_pending[slot]) { // the batch before the previous one: wait for it, polling the flag
+                for (;;) {
+                    const hipError_t q = hipEventQuery(batch_done[slot]);
+                    if (q == hipSuccess) break;
+                    if (q != hipErrorNotReady) return fail(sim, PA_ERR_DEVICE, std::string("hipEventQuery: ") + hipGetErrorString(q));
+                    if (sim->interrupt.load(std::memory_order_relaxed)) break;
+                    std::this_thread::sleep_for(std::chrono::microseconds(50));
+                }
+                batch_pending[slot] = false;
+            }
+            if (sweep_id > 0) { // marks the end of the batch just enqueued (last group stream finishes last)
+                const unsigned prev = slot ^ 1u;
+                PA_HIP(sim, hipEventRecord(batch_done[prev], sim->groups.back().stream));
+                batch_pending[prev] = true;
+            }
+        }
         if ((sweep_id & 31u) == 0 && sim->interrupt.load(std::memory_order_relaxed)) {
             sim->interrupt.store(false);
-            status = fail(sim, PA_ERR_INTERRUPTED, "interrupted");
-            break;
+            return fail(sim, PA_ERR_INTERRUPTED, "interrupted");
         }
         const bool record = sweep_id >= cfg->warmup_sweeps; // mod.rs:410
         const bool pt_this = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0; // :486-488
@@ -868,13 +912,13 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                 if (record || equil)
                     PA_HIP(sim, launch_measure(g.d, g.p, pt, false, record, record && want_overlap, false, g.stream));
                 pt.equil = 0; // the tempering launch below must not accumulate the diagnostic again
-                if (g.d.N * g.d.W * 12 + 4096 > 160 * 1024)
-                    return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the overlap-cluster kernel");
                 const uint64_t mode_idx = overlap_call_count % static_cast<uint64_t>(cfg->n_overlap_cluster_modes);
                 const int oc_mode = cfg->overlap_cluster_modes[mode_idx];
                 const int oc_kind = oc_mode & 0xFF;
                 const uint32_t oc_group = (oc_mode >> 8) > 2 ? static_cast<uint32_t>(oc_mode >> 8) : 2u;
-                const bool first_group = &g == &sim->groups.front();
+                // ... of GLOBAL realisation 0 (realization_idx == 0, mod.rs:302): a handle holding a later shard
+                // of the ensemble takes none, and its first realisation stays on the search path like the rest
+                const bool first_group = &g == &sim->groups.front() && sim->first_realization == 0;
                 // mod.rs:604-658: sizes / metrics on recorded calls, snapshots of the first realisation
                 const bool take_snapshot = snapshot_interval > 0 && sweep_id % snapshot_interval == 0 && record;
                 ClusterAux aux{};
@@ -966,21 +1010,41 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         }
         if (pt_this && cfg->pt_schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
     }
-    sim->ac_samples = autocorr ? sim->n_recorded : 0;
-    if (overlap_owed && status == PA_OK) {
+    if (overlap_owed) {
         PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
         for (auto &g : sim->groups) {
             PA_HIP(sim, launch_overlap(g.d, g.p, g.stream));
             PA_HIP(sim, launch_measure(g.d, g.p, pt, false, false, true, false, g.stream));
         }
+        overlap_owed = false;
     }
-    // join: the main stream continues after every group
+    return PA_OK;
+    };
+    int status = enqueue_all();
+    if (status != PA_OK && overlap_owed) {
+        // stopped between a recorded sweep and its deferred overlap measurement: take it now, so that the
+        // accumulators hold whole sweeps only
+        PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
+        for (auto &g : sim->groups) {
+            (void)launch_overlap(g.d, g.p, g.stream);
+            (void)launch_measure(g.d, g.p, pt, false, false, true, false, g.stream);
+        }
+    }
+    sim->ac_samples = autocorr ? sim->n_recorded : 0;
+    // join: the main stream continues after every group -- on every path out of this function
     for (auto &g : sim->groups) {
-        PA_HIP(sim, hipEventRecord(g.done, g.stream));
-        PA_HIP(sim, hipStreamWaitEvent(sim->stream, g.done, 0));
+        const hipError_t e1 = hipEventRecord(g.done, g.stream);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(sim->stream, g.done, 0) : e1;
+        if (e2 != hipSuccess) {
+            (void)hipStreamSynchronize(g.stream); // no event: wait for the group on the host instead
+            if (status == PA_OK) status = fail(sim, PA_ERR_DEVICE, std::string("join of a stream group: ") + hipGetErrorString(e2));
+        }
     }
     if (status != PA_OK) {
+        const std::string keep = sim->error;
+        (void)flush_swaps(sim);
         (void)hipStreamSynchronize(sim->stream);
+        sim->error = keep;
         return status;
     }
     return flush_swaps(sim); // the last tempering event's bit-column swaps become visible in S
@@ -1612,6 +1676,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     ok(bufs.alloc(&p.hist, bins));
     ok(bufs.alloc(&p.qlq, bins));
     ok(bufs.alloc(&p.ql2q, bins));
+    ok(bufs.alloc(&p.hist_touched, d.n_pairs ? static_cast<size_t>(d.n_real) * d.n_temps * ((d.N + 32) / 32) : 0));
     ok(bufs.alloc(&p.edge_att, static_cast<size_t>(d.n_real) * d.n_edges));
     ok(bufs.alloc(&p.edge_acc, static_cast<size_t>(d.n_real) * d.n_edges));
     ok(bufs.alloc(&p.round_trips, static_cast<size_t>(d.n_real) * d.n_sys));
@@ -1720,6 +1785,15 @@ void pa_sim_destroy(pa_sim *sim) {
             if (g.done) (void)hipEventDestroy(g.done);
         }
         if (sim->fork) (void)hipEventDestroy(sim->fork);
+        for (auto &e : sim->batch_events)
+            if (e) (void)hipEventDestroy(e);
+        // cluster-statistics buffers are allocated outside DeviceBuffers (they are regrown)
+        for (void *extra : {static_cast<void *>(sim->p.cs_fk_csd), static_cast<void *>(sim->p.cs_top4_raw),
+                            static_cast<void *>(sim->p.obs_acc), static_cast<void *>(sim->p.cs_ov_csd),
+                            static_cast<void *>(sim->p.cs_top4_acc), static_cast<void *>(sim->p.snap_bonds),
+                            static_cast<void *>(sim->p.snap_ids), static_cast<void *>(sim->p.snap_blue),
+                            static_cast<void *>(sim->p.snap_spins), static_cast<void *>(sim->p.snap_sids)})
+            if (extra) (void)hipFree(extra);
         sim->buffers.release();
         (void)hipStreamDestroy(sim->stream);
     }
@@ -1738,7 +1812,7 @@ void pa_sim_request_interrupt(pa_sim *sim) { sim->interrupt.store(true); }
 int pa_sim_synchronize(pa_sim *sim) {
     PA_HIP(sim, hipSetDevice(sim->device));
     PA_HIP(sim, hipStreamSynchronize(sim->stream));
-    if (sim->d.pipe_lds) { // a slab workgroup that gave up waiting leaves the state unusable: say so
+    if (sim->d.pipe_K) { // a slab workgroup that gave up waiting leaves the state unusable: say so
         uint32_t gave_up = 0;
         PA_HIP(sim, hipMemcpy(&gave_up, sim->p.slab_error, sizeof(gave_up), hipMemcpyDeviceToHost));
         if (gave_up) return fail(sim, PA_ERR_DEVICE, "a slab of the pipelined sweep gave up waiting for its predecessor");
@@ -1756,6 +1830,7 @@ int pa_sim_sample_async(pa_sim *sim, const pa_sample_config *cfg) {
     const std::string text = validate_text(cfg, sim->n_replicas, &code);
     if (code != PA_OK) return fail(sim, code, text);
     PA_HIP(sim, hipSetDevice(sim->device));
+    sim->interrupt.store(false); // a request belongs to the call it was made during
     return run_sweeps(sim, cfg);
 }
 
@@ -1934,6 +2009,50 @@ int pa_sim_overlap_dots(pa_sim *sim, int64_t *dot_spin, int64_t *dot_link) {
 uint64_t pa_sim_n_spins(const pa_sim *sim) { return sim->d.N; }
 uint64_t pa_sim_n_neighbors(const pa_sim *sim) { return sim->d.nn; }
 uint64_t pa_sim_n_systems(const pa_sim *sim) { return sim->d.n_sys; }
+uint64_t pa_sim_n_realizations(const pa_sim *sim) { return sim->d.n_real; }
+
+uint64_t pa_abi_layout(uint64_t *out, uint64_t capacity) {
+    std::vector<uint64_t> v;
+#define PA_FIELD(type, field) v.push_back(offsetof(type, field))
+    v.push_back(sizeof(pa_sim_desc));
+    v.push_back(12);
+    PA_FIELD(pa_sim_desc, n_dims);
+    PA_FIELD(pa_sim_desc, shape);
+    PA_FIELD(pa_sim_desc, n_neighbors);
+    PA_FIELD(pa_sim_desc, neighbor_offsets);
+    PA_FIELD(pa_sim_desc, couplings);
+    PA_FIELD(pa_sim_desc, n_realizations);
+    PA_FIELD(pa_sim_desc, temperatures);
+    PA_FIELD(pa_sim_desc, n_temps);
+    PA_FIELD(pa_sim_desc, n_replicas);
+    PA_FIELD(pa_sim_desc, seed);
+    PA_FIELD(pa_sim_desc, device);
+    PA_FIELD(pa_sim_desc, first_realization);
+    v.push_back(sizeof(pa_sample_config));
+    v.push_back(19);
+    PA_FIELD(pa_sample_config, n_sweeps);
+    PA_FIELD(pa_sample_config, warmup_sweeps);
+    PA_FIELD(pa_sample_config, sweep_mode);
+    PA_FIELD(pa_sample_config, pt_interval);
+    PA_FIELD(pa_sample_config, pt_schedule);
+    PA_FIELD(pa_sample_config, overlap_cluster_interval);
+    PA_FIELD(pa_sample_config, overlap_cluster_modes);
+    PA_FIELD(pa_sample_config, n_overlap_cluster_modes);
+    PA_FIELD(pa_sample_config, overlap_cluster_mode);
+    PA_FIELD(pa_sample_config, measure_overlap);
+    PA_FIELD(pa_sample_config, cluster_interval);
+    PA_FIELD(pa_sample_config, cluster_mode);
+    PA_FIELD(pa_sample_config, equilibration_diagnostic);
+    PA_FIELD(pa_sample_config, autocorrelation_max_lag);
+    PA_FIELD(pa_sample_config, collect_cluster_stats);
+    PA_FIELD(pa_sample_config, cluster_action);
+    PA_FIELD(pa_sample_config, overlap_cluster_action);
+    PA_FIELD(pa_sample_config, autocorrelation_backend);
+    PA_FIELD(pa_sample_config, snapshot_interval);
+#undef PA_FIELD
+    for (uint64_t k = 0; k < v.size() && k < capacity; ++k) out[k] = v[k];
+    return v.size();
+}
 
 #define PA_CHECK_REAL(sim, r)                                                                      \
     if ((r) >= (sim)->d.n_real) return fail(sim, PA_ERR_INVALID, "realization index out of range")
@@ -2083,7 +2202,19 @@ int pa_sim_get_result_histograms(pa_sim *sim, uint64_t realization, uint64_t *hi
                                hipMemcpyDeviceToHost, sim->stream));
     PA_HIP(sim, hipMemcpyAsync(ql2_at_q_sum, sim->p.ql2q + bins * realization, bins * sizeof(double),
                                hipMemcpyDeviceToHost, sim->stream));
-    PA_HIP(sim, hipStreamSynchronize(sim->stream));
+    // bins no sweep of the last run reached hold whatever an earlier run left: they read as zero
+    const size_t row_words = (d.N + 32) / 32;
+    std::vector<uint32_t> touched;
+    if (int rc = download(sim, touched, sim->p.hist_touched + row_words * d.n_temps * realization, row_words * d.n_temps))
+        return rc;
+    for (uint32_t t = 0; t < d.n_temps; ++t)
+        for (uint32_t b = 0; b <= d.N; ++b)
+            if (!((touched[t * row_words + (b >> 5)] >> (b & 31u)) & 1u)) {
+                const size_t at = static_cast<size_t>(t) * (d.N + 1) + b;
+                histogram[at] = 0;
+                ql_at_q_sum[at] = 0.0;
+                ql2_at_q_sum[at] = 0.0;
+            }
     return PA_OK;
 }
 

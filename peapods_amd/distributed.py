@@ -3,10 +3,20 @@
 Disorder realisations are independent (reference simulation/mod.rs:887-903), so rank g of G owns
 a contiguous block of them and runs with no data-path collective.  Realisation seeds depend only
 on the global realisation index (src/lib.rs:30-32), hence per-realisation results do not depend
-on G.  The only exchange is one all-gather of the fixed-size per-realisation observable blocks
-(RCCL when the process group backend is "nccl"; gloo in the CPU tests), after which the
-reference's disorder aggregation runs in realisation order.
+on G.  The only exchange is one all-gather of the fixed-size per-realisation observable blocks,
+after which the reference's disorder aggregation (statistics/results.rs:165-282) runs in
+realisation order.
+
+On GPUs the exchange is `Comm`: RCCL through the library's own C ABI (pa_comm_*, csrc/comm.hip) --
+no torch.  The 128-byte RCCL id travels from rank 0 to the others over a plain TCP socket on
+MASTER_ADDR:MASTER_PORT (`exchange_id`).  The CPU rehearsal in tests/ passes a gloo
+`torch.distributed` module to `all_gather_blocks` instead; that branch is test plumbing only.
 """
+
+import ctypes as C
+import os
+import socket
+import time
 
 import numpy as np
 
@@ -20,25 +30,150 @@ def shard_range(n_total, rank, world):
     return start, stop
 
 
-def all_gather_blocks(blocks, dist=None, device=None):
-    """All-gathers [n_local][block_len] f64 blocks into [n_total][block_len] in rank order.
-    Ranks may own different numbers of realisations."""
+def exchange_id(rank, world, make_id, addr=None, port=None, timeout=120.0):
+    """Rank 0 creates the communicator id (`make_id()` -> bytes) and serves it to the other
+    world - 1 ranks over TCP; they connect (retrying until rank 0 listens) and read it."""
+    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(port or os.environ.get("MASTER_PORT", "29500"))
+    if world == 1:
+        return make_id()
+    if rank == 0:
+        payload = make_id()
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            for _ in range(world - 1):
+                conn, _peer = srv.accept()
+                with conn:
+                    conn.sendall(payload)
+        return payload
+    deadline = time.monotonic() + timeout
+    while True:
+        try:
+            with socket.create_connection((addr, port), timeout=5.0) as conn:
+                chunks = b""
+                while True:
+                    part = conn.recv(4096)
+                    if not part:
+                        break
+                    chunks += part
+            if chunks:
+                return chunks
+        except OSError:
+            pass
+        if time.monotonic() > deadline:
+            raise TimeoutError(f"rank {rank}: no communicator id from {addr}:{port}")
+        time.sleep(0.05)
+
+
+class Comm:
+    """One RCCL communicator rank (pa_comm, include/peapods_amd.h): all-gather of host arrays staged
+    through device memory, max / sum all-reduce, barrier."""
+
+    def __init__(self, rank, world, device, addr=None, port=None):
+        from . import _native as nat
+
+        self._nat = nat
+        self._lib = nat.lib()
+        self._handle = None
+        self.rank, self.world = int(rank), int(world)
+
+        def make_id():
+            buf = C.create_string_buffer(nat.PA_COMM_ID_BYTES)
+            err = C.create_string_buffer(512)
+            if self._lib.pa_comm_unique_id(buf, err, len(err)) != nat.PA_OK:
+                raise RuntimeError(err.value.decode())
+            return buf.raw
+
+        uid = exchange_id(self.rank, self.world, make_id, addr, port)
+        if len(uid) != nat.PA_COMM_ID_BYTES:
+            raise RuntimeError("communicator id of the wrong size")
+        handle = C.c_void_p()
+        err = C.create_string_buffer(512)
+        code = self._lib.pa_comm_init_rank(C.create_string_buffer(uid, len(uid)), self.world, self.rank,
+                                           int(device), C.byref(handle), err, len(err))
+        if code != nat.PA_OK:
+            raise RuntimeError(err.value.decode())
+        self._handle = handle
+
+    def close(self):
+        if self._handle:
+            self._lib.pa_comm_destroy(self._handle)
+            self._handle = None
+
+    __del__ = close
+
+    def _check(self, code):
+        if code != self._nat.PA_OK:
+            raise RuntimeError(self._lib.pa_comm_last_error(self._handle).decode())
+
+    def barrier(self):
+        self._check(self._lib.pa_comm_barrier(self._handle))
+
+    def max_f64(self, value):
+        buf = np.array([value], dtype=np.float64)
+        self._check(self._lib.pa_comm_allreduce_max_f64(self._handle, self._nat.ptr(buf), 1))
+        return float(buf[0])
+
+    def sum_u64(self, values):
+        buf = np.ascontiguousarray(values, dtype=np.uint64).copy()
+        self._check(self._lib.pa_comm_allreduce_sum_u64(self._handle, self._nat.ptr(buf), buf.size))
+        return buf
+
+    def all_gather(self, array):
+        """[world, *array.shape]: every rank's array (same shape and dtype everywhere)."""
+        array = np.ascontiguousarray(array)
+        out = np.empty((self.world,) + array.shape, dtype=array.dtype)
+        self._check(self._lib.pa_comm_allgather(self._handle, self._nat.ptr(array), self._nat.ptr(out), array.nbytes))
+        return out
+
+    def gather_result_blocks(self, sim, n_total):
+        """Every rank's per-realisation result blocks in global realisation order: [n_total][block]."""
+        length = int(self._lib.pa_sim_result_block_len(sim._handle))
+        out = np.empty((int(n_total), length), dtype=np.float64)
+        got = C.c_uint64()
+        self._check(self._lib.pa_comm_gather_result_blocks(self._handle, sim._handle, self._nat.ptr(out), int(n_total),
+                                                           C.byref(got)))
+        if got.value != n_total:
+            raise RuntimeError(f"gathered {got.value} result blocks, expected {n_total}")
+        return out
+
+
+def all_gather_blocks(blocks, comm=None):
+    """All-gathers [n_local][block_len] f64 blocks into [n_total][block_len] in rank order.  Ranks
+    may own different numbers of realisations.  `comm` is a `Comm` (RCCL), None (one process), or --
+    in the CPU tests only -- an initialised `torch.distributed` module (gloo)."""
     blocks = np.ascontiguousarray(blocks, dtype=np.float64)
-    if dist is None or not dist.is_initialized():
+    if comm is None:
+        return blocks
+    if isinstance(comm, Comm):
+        counts = comm.all_gather(np.array([blocks.shape[0]], dtype=np.uint64)).reshape(-1)
+        n_max = int(counts.max())
+        padded = np.zeros((n_max, blocks.shape[1]), dtype=np.float64)
+        padded[: blocks.shape[0]] = blocks
+        gathered = comm.all_gather(padded)
+        return np.concatenate([gathered[r, : int(counts[r])] for r in range(comm.world)], axis=0)
+    return _all_gather_blocks_gloo(blocks, comm)
+
+
+def _all_gather_blocks_gloo(blocks, dist):
+    """CPU rehearsal of the same exchange with torch.distributed (gloo) -- tests only."""
+    if not dist.is_initialized():
         return blocks
     import torch
 
     world = dist.get_world_size()
-    dev = device if device is not None else "cpu"
-    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    counts = torch.zeros(world, dtype=torch.int64)
     counts[dist.get_rank()] = blocks.shape[0]
     dist.all_reduce(counts)
     n_max = int(counts.max().item())
-    padded = torch.zeros((n_max, blocks.shape[1]), dtype=torch.float64, device=dev)
-    padded[: blocks.shape[0]] = torch.from_numpy(blocks).to(dev)
+    padded = torch.zeros((n_max, blocks.shape[1]), dtype=torch.float64)
+    padded[: blocks.shape[0]] = torch.from_numpy(blocks)
     gathered = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(gathered, padded)
-    rows = [gathered[r][: int(counts[r].item())].cpu().numpy() for r in range(world)]
+    rows = [gathered[r][: int(counts[r].item())].numpy() for r in range(world)]
     return np.concatenate(rows, axis=0)
 
 

@@ -67,3 +67,47 @@ def test_two_rank_gather_equals_single_process(tmp_path):
     single = _blocks(0, n_dis)
     np.testing.assert_array_equal(got[1:], single)  # shards 3 + 2 realisations, seeds by global index
     np.testing.assert_array_equal(got[0], aggregate_mean(single))
+
+
+def _id_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    from peapods_amd.distributed import exchange_id
+
+    got = exchange_id(rank, world, lambda: bytes(range(128)), "127.0.0.1", port, timeout=30.0)
+    with open(os.path.join(out_dir, f"id{rank}.bin"), "wb") as fh:
+        fh.write(got)
+
+
+def test_communicator_id_travels_from_rank_0_over_tcp(tmp_path):
+    """The torch-free rendezvous of the RCCL path: rank 0 serves the 128-byte id, the others read it
+    (they may connect before rank 0 listens)."""
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_id_worker, args=(r, 3, port, str(tmp_path))) for r in (2, 1, 0)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in range(3):
+        assert open(tmp_path / f"id{r}.bin", "rb").read() == bytes(range(128))
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """`python bench.py --gpus N` starts N workers itself and exits non-zero when fewer devices exist
+    (it must never report n_gpus smaller than asked)."""
+    import subprocess
+
+    env = dict(os.environ)
+    for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(key, None)
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=env, timeout=120)
+    assert run.returncode != 0
+    assert "GPU(s) are visible" in run.stderr
+    # a worker environment whose world size contradicts --gpus is refused too
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=dict(env, RANK="0", WORLD_SIZE="1"), timeout=120)
+    assert run.returncode == 2 and "WORLD_SIZE=1" in run.stderr

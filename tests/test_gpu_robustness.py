@@ -1,0 +1,161 @@
+"""GPU robustness checks around the hot path: sharded handles with snapshots, cooperative cancel, histogram
+accumulators across calls (they are never memset), and a seed soak of the kernels whose correctness rests on
+inter-workgroup protocols (the slab pipeline, the small-block random stream, the fused overlap launch).
+Everything is compared with the oracle bit for bit."""
+
+import signal
+import threading
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bimodal(shape, n_dis, seed):
+    rng = np.random.default_rng(seed)
+    return (2 * rng.integers(0, 2, size=(n_dis,) + tuple(shape) + (len(shape),)) - 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("build", ["jorg", "cmr", "houdayer"])
+def test_sharded_handles_with_snapshots_match_one_handle(oracle, build):
+    """Snapshots (and the union-find form of the single-cluster moves they force) belong to GLOBAL realisation
+    0 only (mod.rs:302, overlap.rs:376-380): a handle that holds a later shard takes none and keeps its first
+    realisation on the search path, so the per-realisation trajectories do not depend on the sharding."""
+    from peapods_amd import IsingSimulation
+
+    shape, n_dis, n_rep = (6, 6, 6), 4, 4
+    temps = np.linspace(0.8, 1.6, 5).astype(np.float32)
+    J = bimodal(shape, n_dis, 11)
+    kw = dict(pt_interval=1, warmup_ratio=0.25, overlap_cluster_update_interval=2, overlap_cluster_build_mode=build,
+              overlap_cluster_mode="wolff", snapshot_interval=4)
+    whole = IsingSimulation(list(shape), J, temps, n_rep, None, 5)
+    cpu = oracle.OracleSimulation(list(shape), J, temps, n_rep, None, 5)
+    out_whole = whole.sample(16, "metropolis", **kw)
+    cpu.sample(16, "metropolis", **kw)
+    lo = IsingSimulation(list(shape), J[:2], temps, n_rep, None, 5, first_realization=0)
+    hi = IsingSimulation(list(shape), J[2:], temps, n_rep, None, 5, first_realization=2)
+    out_lo = lo.sample(16, "metropolis", **kw)
+    out_hi = hi.sample(16, "metropolis", **kw)
+    assert "cluster_snapshots" in out_whole and "cluster_snapshots" in out_lo
+    assert "cluster_snapshots" not in out_hi
+    for r in range(n_dis):
+        part, local = (lo, r) if r < 2 else (hi, r - 2)
+        np.testing.assert_array_equal(part.get_spins(local), cpu.get_spins(r))
+        np.testing.assert_array_equal(part.get_spins(local), whole.get_spins(r))
+        np.testing.assert_array_equal(part.get_system_ids(local), whole.get_system_ids(r))
+        for s in range(whole.n_systems):
+            np.testing.assert_array_equal(part.get_rng_state(local, s), whole.get_rng_state(r, s))
+
+
+def _advance_oracle_until_equal(cpu, gpu, kw, limit_chunks):
+    """The interrupted GPU run stopped after a multiple of 32 sweeps: find it by stepping the oracle."""
+    for chunk in range(limit_chunks):
+        if all(np.array_equal(gpu.get_spins(r), cpu.get_spins(r)) for r in range(gpu.n_realizations)):
+            return 32 * chunk
+        cpu.run(cpu.make_config(32, "metropolis", **kw))
+    return None
+
+
+@pytest.mark.parametrize("how", ["request", "sigint"])
+def test_interrupted_sample_stops_early_and_leaves_a_replayable_state(oracle, how):
+    """src/lib.rs:304-333: a cancel request ends the run with KeyboardInterrupt("interrupted"); the state is the
+    one after the last sweep that ran, and sampling continues from it exactly as the reference would."""
+    from peapods_amd import IsingSimulation
+
+    shape, n_rep = (6, 6, 6), 2
+    temps = np.linspace(1.0, 2.0, 4).astype(np.float32)
+    J = bimodal(shape, 2, 3)
+    gpu = IsingSimulation(list(shape), J, temps, n_rep, None, 9)
+    cpu = oracle.OracleSimulation(list(shape), J, temps, n_rep, None, 9)
+    kw = dict(pt_interval=1, warmup_ratio=0.0)
+    n_asked = 4_000_000  # minutes of work if it were not interrupted
+    if how == "request":
+        timer = threading.Timer(0.3, lambda: gpu._lib.pa_sim_request_interrupt(gpu._handle))
+    else:
+        timer = threading.Timer(0.3, lambda: signal.raise_signal(signal.SIGINT))
+    t0 = time.perf_counter()
+    timer.start()
+    with pytest.raises(KeyboardInterrupt):
+        gpu.run(gpu.make_config(n_asked, "metropolis", **kw))
+    took = time.perf_counter() - t0
+    timer.cancel()
+    assert took < 30.0, "the request was not honoured while work was queued"
+    n_ran = _advance_oracle_until_equal(cpu, gpu, kw, limit_chunks=4000)
+    assert n_ran is not None and 0 < n_ran < n_asked, "the stopped state is not a state of the reference's trajectory"
+    for r in range(2):
+        np.testing.assert_array_equal(gpu.get_system_ids(r), cpu.get_system_ids(r))
+        for s in range(gpu.n_systems):
+            np.testing.assert_array_equal(gpu.get_rng_state(r, s), cpu.get_rng_state(r, s))
+    # ... and it continues like the reference
+    a = gpu.sample(24, "metropolis", pt_interval=1, warmup_ratio=0.25)
+    b = cpu.sample(24, "metropolis", pt_interval=1, warmup_ratio=0.25)
+    for key in ("energies", "mags2", "overlap2", "link_overlap"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    for r in range(2):
+        np.testing.assert_array_equal(gpu.get_spins(r), cpu.get_spins(r))
+
+
+def test_histograms_restart_with_every_sample_call(oracle):
+    """P(q) and the conditional link-overlap sums restart with every sample() (OverlapAccum::new per run,
+    overlap.rs:206-249) although the device arrays are never cleared: bins the second run does not reach must
+    read zero, bins it reaches must not carry the first run's counts."""
+    from peapods_amd import IsingSimulation
+
+    shape, n_rep = (4, 4, 4), 4
+    temps = np.array([0.5, 1.0, 3.0, 8.0], dtype=np.float32)  # cold: few bins; hot: many
+    J = bimodal(shape, 3, 21)
+    gpu = IsingSimulation(list(shape), J, temps, n_rep, None, 2)
+    cpu = oracle.OracleSimulation(list(shape), J, temps, n_rep, None, 2)
+    for n_sweeps, warm in ((40, 0.0), (6, 0.5), (25, 0.2)):
+        a = gpu.sample(n_sweeps, "metropolis", pt_interval=1, warmup_ratio=warm)
+        b = cpu.sample(n_sweeps, "metropolis", pt_interval=1, warmup_ratio=warm)
+        np.testing.assert_array_equal(a["per_sample_overlap_histogram"], b["per_sample_overlap_histogram"])
+        np.testing.assert_array_equal(a["per_sample_ql_at_q_sum"], b["per_sample_ql_at_q_sum"])
+        np.testing.assert_array_equal(a["per_sample_ql2_at_q_sum"], b["per_sample_ql2_at_q_sum"])
+        np.testing.assert_array_equal(a["ql_at_q_sum"], b["ql_at_q_sum"])
+        assert int(np.sum(a["per_sample_overlap_histogram"])) == 3 * 4 * 2 * (n_sweeps - int(np.floor(n_sweeps * warm + 0.5)))
+
+
+# ---- soak: many seeds through the kernels that hand data between workgroups ---------------------------------
+def _soak(oracle, shape, n_temps, n_rep, n_dis, seeds, sweeps, kind="ferro", **kw):
+    from peapods_amd import IsingSimulation
+
+    temps = np.linspace(2.0, 5.0, n_temps).astype(np.float32)
+    for seed in seeds:
+        if kind == "ferro":
+            J = np.ones((n_dis,) + tuple(shape) + (len(shape),), dtype=np.float32)
+        else:
+            J = bimodal(shape, n_dis, 1000 + seed)
+        gpu = IsingSimulation(list(shape), J, temps, n_rep, None, seed)
+        cpu = oracle.OracleSimulation(list(shape), J, temps, n_rep, None, seed)
+        a = gpu.sample(sweeps, "metropolis", **kw)
+        b = cpu.sample(sweeps, "metropolis", **kw)
+        gpu.synchronize()  # reports slab_error / stream_error as PA_ERR_DEVICE
+        for r in range(n_dis):
+            np.testing.assert_array_equal(gpu.get_spins(r), cpu.get_spins(r), err_msg=f"seed {seed}")
+            np.testing.assert_array_equal(gpu.get_system_ids(r), cpu.get_system_ids(r), err_msg=f"seed {seed}")
+        for key in ("energies", "mags2"):
+            np.testing.assert_array_equal(a[key], b[key], err_msg=f"{key}, seed {seed}")
+        if n_rep >= 2:
+            np.testing.assert_array_equal(a["overlap2"], b["overlap2"], err_msg=f"seed {seed}")
+
+
+def test_soak_slab_pipeline_24_cubed(oracle):
+    """k_sweep_slab (LDS-resident slabs, tagged exchange records, speculative re-reads): 50 seeds."""
+    _soak(oracle, (24, 24, 24), 4, 2, 1, range(50), 2, pt_interval=1, warmup_ratio=0.0)
+
+
+def test_soak_slab_pipeline_64_cubed(oracle):
+    _soak(oracle, (64, 64, 64), 2, 1, 1, range(6), 2, pt_interval=1, warmup_ratio=0.0)
+
+
+def test_soak_small_block_random_stream(oracle):
+    """Small ensembles take short random-stream blocks (31-site rule): cursor in / cursor_out race class."""
+    _soak(oracle, (8, 8), 3, 2, 1, range(50), 6, kind="glass", pt_interval=1, warmup_ratio=0.0)
+
+
+def test_soak_fused_overlap_launch(oracle):
+    """k_rng_overlap: the overlap of sweep s-1 measured inside the launch that draws sweep s."""
+    _soak(oracle, (8, 8, 8), 6, 4, 3, range(50), 5, kind="glass", pt_interval=1, warmup_ratio=0.2)

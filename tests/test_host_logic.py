@@ -31,6 +31,38 @@ def test_library_exports_every_declared_symbol():
     assert nat.lib().pa_version().startswith(b"peapods_amd")
 
 
+def test_abi_layout_and_generated_bindings():
+    """The three descriptions of the argument structs -- the header (parsed by tools/gen_bindings.py, which
+    writes the Rust binding of INTEGRATION.md), the ctypes binding every GPU test goes through, and the
+    compiled library (pa_abi_layout) -- agree field by field, offset by offset (src/lib.rs:176-284 is
+    what the structs carry)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("gen_bindings", os.path.join(ROOT, "tools", "gen_bindings.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    committed = open(os.path.join(ROOT, "bindings", "peapods_amd.rs")).read()
+    assert committed == gen.generate(), "bindings/peapods_amd.rs is stale: python tools/gen_bindings.py"
+    structs = gen.parse_structs(gen.strip_comments(open(gen.HEADER).read()))
+    layout = np.zeros(64, dtype=np.uint64)
+    n = int(nat.lib().pa_abi_layout(ptr(layout), layout.size))
+    assert n <= layout.size
+    at = 0
+    for cname, binding in (("pa_sim_desc", nat.PaSimDesc), ("pa_sample_config", nat.PaSampleConfig)):
+        names = [f[0] for f in binding._fields_]
+        assert [f[0] for f in structs[cname]] == names, f"{cname}: header and ctypes fields differ"
+        assert int(layout[at]) == C.sizeof(binding), f"sizeof({cname})"
+        assert int(layout[at + 1]) == len(names)
+        offsets = [int(x) for x in layout[at + 2:at + 2 + len(names)]]
+        assert offsets == [getattr(binding, name).offset for name in names], f"{cname}: field offsets"
+        for name in names:  # and the generated Rust struct names every field
+            assert f"pub {name}:" in committed
+        at += 2 + len(names)
+    assert at == n
+    exported = set(re.findall(r"pub fn (pa_\w+)\(", committed))
+    assert exported == set(nat.SIGNATURES)
+
+
 def test_create_fails_loudly_without_a_device():
     if nat.lib().pa_device_count() > 0:
         pytest.skip("a HIP device is present")

@@ -145,6 +145,8 @@ int pa_sim_synchronize(pa_sim *sim);
  * ensemble is left in the state after the last sweep that ran -- statistics hold whole sweeps only and a
  * following sample() continues from there.  A request made while no sample() is running is dropped. */
 void pa_sim_request_interrupt(pa_sim *sim);
+/* Sweeps the last sample() ran: n_sweeps, or fewer when it was interrupted (always whole sweeps). */
+uint64_t pa_sim_sweeps_completed(const pa_sim *sim);
 
 /* Per-kernel device time of the sweep pipeline, measured with HIP events on the handle's stream
  * while running `n_sweeps` sweeps of `cfg`'s protocol (state advances like sample()).

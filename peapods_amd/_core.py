@@ -227,18 +227,24 @@ class IsingSimulation:
             self._check(fn(self._handle, C.byref(cfg)))
             return
         outcome = {}
+        done = threading.Event()
 
         def call():
-            outcome["code"] = fn(self._handle, C.byref(cfg))
+            try:
+                outcome["code"] = fn(self._handle, C.byref(cfg))
+            finally:
+                done.set()
 
-        helper = threading.Thread(target=call, daemon=True)
-        helper.start()
+        # (an Event, not Thread.join: on CPython 3.10 a KeyboardInterrupt inside join(timeout) marks the thread
+        # as stopped while it is still running, so a following join() would return at once)
+        threading.Thread(target=call, daemon=True).start()
         try:
-            while helper.is_alive():
-                helper.join(0.2)
+            while not done.wait(0.2):
+                pass
         except KeyboardInterrupt:
             self._lib.pa_sim_request_interrupt(self._handle)
-            helper.join()
+            while not done.wait(0.2):  # the call returns PA_ERR_INTERRUPTED within two batches of queued sweeps
+                pass
             self._lib.pa_sim_synchronize(self._handle)
             raise
         self._check(outcome["code"])

@@ -50,7 +50,17 @@ struct SimDims {
     uint32_t slab_lead;  // k_sweep_slab: levels a slab starts behind the slab it reads from (tuning knob PEAPODS_SLAB_LEAD)
     uint32_t planes_stride; // entries of planes / planes_hi per (realisation, word): N, or the padded
                          //    schedule length when the slab kernel reads them in schedule order
+    // Implicit neighbours (k_sweep_hc): every one of the 2 nn neighbour slots f0,b0,f1,b1,f2,b2 of a site lies
+    // at site + one of two offsets -- the regular one or the one through the periodic wrap -- so a site needs
+    // one flag bit per slot instead of a 16-byte neighbour record (lattice.rs:44-99 builds tables; on a
+    // hypercubic lattice of any extents they collapse to this).  Byte offsets into a u32[N] array.
+    uint32_t hc;         // 1: hc_tab is built and the on-chip Metropolis sweep uses it
+    int32_t hc_d0[6];    // regular offset of each slot (x 4)
+    int32_t hc_dd[6];    // (wrapped - regular) offset of each slot (x 4)
 };
+
+// hc_tab entry of a site (schedule order): site | wrap flags << 14 | coupling sign bits << 20
+constexpr uint32_t kHcSiteBits = 14, kHcFlagShift = 14, kHcNegShift = 20;
 
 struct DevPtrs {
     uint32_t *S;             // [n_real][W][N] current spins
@@ -73,6 +83,7 @@ struct DevPtrs {
                              //   site,f0 | b0,f1 | b1,f2 | b2,jmeta
                              //   jmeta = neg[0..5] | nz[6..11] | h[12..13] for bonds f0,b0,f1,b1,f2,b2
     const uint32_t *pass_start; // [n_passes + 1]
+    const uint32_t *hc_tab;  // [n_real][N] schedule order: site | wrap flags << 14 | neg bits << 20 (SimDims::hc)
     const uint32_t *seg;     // [n_levels][pipe_K + 1] schedule positions where each slab's part of a level starts
     uint32_t *progress;      // [n_real * W][pipe_K] levels completed by each slab workgroup (epoch-based, monotone)
     const uint32_t *halo_start; // [pipe_K][n_levels + 2] k_sweep_slab: the exchange records a slab first reads at level l are
@@ -191,6 +202,9 @@ struct PtParams {
     // autocorrelation series (autocorrelation.rs): ac_index = 1 + index of this recorded sweep in the
     // per-realisation history of ac_stride entries, 0 = not collected
     uint32_t ac_index, ac_stride;
+    // bit 0: the moment sums start from zero with this launch; bit 1: the overlap sums and the P(q) bitmap do
+    // (the accumulators are never memset: the first accumulating launch of a run stores instead of adding)
+    uint32_t fresh;
 };
 
 // All launchers enqueue on `stream` and return the hipGetLastError() of the launch.
@@ -212,6 +226,7 @@ hipError_t launch_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt
 hipError_t launch_measure_stamped(const SimDims &d, const DevPtrs &p, const PtParams &pt,
                                   unsigned long long *stamps, hipStream_t stream);
 size_t sweep_lds_bytes(const SimDims &d, bool gibbs);
+size_t sweep_hc_lds_bytes(const SimDims &d);
 size_t sweep_slab_lds_bytes(const SimDims &d);
 size_t sweep_slab_lds_bytes_for(uint32_t own_sites, uint32_t plane_sites, uint32_t n_levels);
 // kernels_cluster.hip

@@ -734,6 +734,255 @@ __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_en
 }
 
 // ---------------------------------------------------------------------------
+// k_sweep_hc: the same sweep for lattices whose neighbours follow from index arithmetic (SimDims::hc: every
+// hypercubic lattice; sweep.rs:8-19 reads neighbour tables, lattice.rs:44-99 builds them) and whose bonds are
+// all non-zero (+-J, ferromagnets).  Differences from k_sweep:
+//   * no 16-byte site records from global memory: the word's schedule table (4 bytes per site: site index,
+//     six wrap flags, six coupling signs) is staged in the LDS with the spins and the acceptance planes, and
+//     the seven LDS addresses of a site come from three instructions per neighbour;
+//   * the pass loop is software-pipelined by hand: the table entry of pass p + 2 and the addresses of pass
+//     p + 1 are produced while the nine LDS reads of pass p are in flight, so the dependent chain of a pass is
+//     barrier -> reads -> accept logic -> write -> barrier and nothing else;
+//   * the energy epilogue walks the same table in the LDS (no second pass over global records).
+// LDS: (3 (N + 1) + N) words + pass boundaries = 66 KB at 16^3: two workgroups per CU.
+// ---------------------------------------------------------------------------
+// LDS accesses by 32-bit LDS address: the base of the dynamic LDS is a link-time constant, so going through
+// generic pointers costs one v_add per access; here it is folded into the site address once.
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+struct LdsPair { uint32_t x, y; };
+typedef __attribute__((address_space(3))) LdsPair lds_u32x2_t;
+__device__ __forceinline__ uint32_t lds_addr_of(const uint32_t *ptr) {
+    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const lds_u32_t *)ptr));
+}
+__device__ __forceinline__ uint32_t lds_load(uint32_t addr) { return *reinterpret_cast<const lds_u32_t *>(static_cast<uintptr_t>(addr)); }
+__device__ __forceinline__ uint2 lds_load2(uint32_t addr) { // 8-byte aligned address: one ds_read_b64
+    const lds_u32x2_t *q = reinterpret_cast<const lds_u32x2_t *>(static_cast<uintptr_t>(addr));
+    return make_uint2(q->x, q->y);
+}
+__device__ __forceinline__ void lds_store(uint32_t addr, uint32_t v) { *reinterpret_cast<lds_u32_t *>(static_cast<uintptr_t>(addr)) = v; }
+
+struct HcSite {
+    uint32_t site;    // LDS address of the site's word
+    uint32_t nb[6];   // LDS addresses of f0, b0, f1, b1, f2, b2
+    uint32_t site4;   // byte offset of the site inside the word array
+    uint32_t neg;     // coupling sign bits of those bonds
+};
+
+// sw_addr: LDS address of the word array
+template <int NN>
+__device__ __forceinline__ HcSite hc_decode(const SimDims &d, uint32_t e, uint32_t sw_addr) {
+    HcSite h;
+    h.site4 = (e & ((1u << kHcSiteBits) - 1u)) << 2;
+    h.site = sw_addr + h.site4;
+    h.neg = e >> kHcNegShift;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (k < 2 * NN) {
+            // site + regular offset + flag * (wrapped - regular): v_bfe_u32, v_add_u32, v_mad_i32_i24 (written
+            // out: the compiler turns the product into and / compare / select / add3)
+            const uint32_t flag = __builtin_amdgcn_ubfe(e, kHcFlagShift + k, 1);
+            const uint32_t base = h.site + static_cast<uint32_t>(d.hc_d0[k]);
+            uint32_t addr;
+            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr) : "v"(flag), "s"(d.hc_dd[k]), "v"(base));
+            h.nb[k] = addr;
+        } else {
+            h.nb[k] = h.site;
+        }
+    }
+    return h;
+}
+
+__host__ __device__ inline size_t sweep_hc_lds_words(const SimDims &d) {
+    const size_t n1 = static_cast<size_t>(d.N) + 1, n_pad = (n1 + 3) & ~size_t(3);
+    const size_t tab = (static_cast<size_t>(d.N) + 3) & ~size_t(3);
+    return n_pad + ((2 * n1 + 3) & ~size_t(3)) + tab + ((static_cast<size_t>(d.n_passes) + 5 + 3) & ~size_t(3)) + 5 * 48;
+}
+
+// STAMPS: diagnostic build, every workgroup files s_memrealtime (100 MHz) stamps of its phases in stamps[block][8]
+#define PA_HC_STAMP(k)                                                                             \
+    if (STAMPS && threadIdx.x == 0) stamps[blockIdx.x * 8 + (k)] = wall_clock64();
+template <int NN, bool STAMPS = false>
+__global__ __launch_bounds__(256, 2) void k_sweep_hc(SimDims d, DevPtrs p, int with_energy, int do_sweep,
+                                                     unsigned long long *stamps) {
+    extern __shared__ uint32_t lds[];
+    PA_HC_STAMP(0)
+    const uint32_t n1 = d.N + 1;
+    const uint32_t n_pad = (n1 + 3u) & ~3u;
+    uint32_t *sw = lds;                                   // [N + 1] spins of this word (+ spare slot N)
+    uint32_t *pl = sw + n_pad;                            // [N + 1][2] acceptance-level planes
+    uint32_t *tab = pl + ((2 * n1 + 3u) & ~3u);           // [N] schedule table of this realisation
+    uint32_t *ps = tab + ((d.N + 3u) & ~3u);              // [n_passes + 5] pass boundaries (padded with N)
+    uint32_t *scratch = ps + ((d.n_passes + 5u + 3u) & ~3u); // [5][48]
+    const uint32_t real = blockIdx.x / d.W, w = blockIdx.x % d.W;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t *Sin = p.S + (static_cast<size_t>(real) * d.W + w) * d.N;
+    uint32_t *Sout = p.S_next + (static_cast<size_t>(real) * d.W + w) * d.N;
+    const uint32_t *tab_g = p.hc_tab + static_cast<size_t>(real) * d.N;
+    const uint32_t epoch = p.swap_epoch[real];
+    const uint32_t applied = p.applied_epoch[static_cast<size_t>(real) * d.W + w];
+    uint32_t mp[2], mc[2], mn[2];
+    {
+        const uint32_t *masks = p.swap_masks + static_cast<size_t>(real) * 2 * d.W;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            mp[r] = w > 0 ? masks[r * d.W + w - 1] : 0u;
+            mc[r] = masks[r * d.W + w];
+            mn[r] = w + 1 < d.W ? masks[r * d.W + w + 1] : 0u;
+        }
+    }
+    // spins, acceptance planes and the schedule table are requested together (one memory round trip)
+    const uint32_t *planes_in =
+        reinterpret_cast<const uint32_t *>(p.planes + (static_cast<size_t>(real) * d.W + w) * d.N);
+    {
+        const uint32_t qa = d.N >> 2, qb = do_sweep ? (2 * d.N) >> 2 : 0u, qc = d.N >> 2;
+        const bool wide = (d.N & 3u) == 0 && qa <= 4 * 256 && qb <= 8 * 256 &&
+                          ((reinterpret_cast<uintptr_t>(Sin) | reinterpret_cast<uintptr_t>(planes_in) |
+                            reinterpret_cast<uintptr_t>(tab_g)) & 15u) == 0;
+        if (wide) {
+            const uint4 *a4 = reinterpret_cast<const uint4 *>(Sin), *b4 = reinterpret_cast<const uint4 *>(planes_in),
+                        *c4 = reinterpret_cast<const uint4 *>(tab_g);
+            uint4 va[4], vb[8], vc[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) va[k] = k * 256 + tid < qa ? a4[k * 256 + tid] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) vb[k] = k * 256 + tid < qb ? b4[k * 256 + tid] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) vc[k] = k * 256 + tid < qc ? c4[k * 256 + tid] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k * 256 + tid < qa) reinterpret_cast<uint4 *>(sw)[k * 256 + tid] = va[k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k * 256 + tid < qb) reinterpret_cast<uint4 *>(pl)[k * 256 + tid] = vb[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k * 256 + tid < qc) reinterpret_cast<uint4 *>(tab)[k * 256 + tid] = vc[k];
+        } else {
+            copy_to_lds(sw, Sin, d.N, tid, 256);
+            if (do_sweep) copy_to_lds(pl, planes_in, 2 * d.N, tid, 256);
+            copy_to_lds(tab, tab_g, d.N, tid, 256);
+        }
+    }
+    for (uint32_t k = tid; k < d.n_passes + 5; k += 256) ps[k] = k <= d.n_passes ? p.pass_start[k] : d.N;
+    if (do_sweep && epoch != applied) {
+        // tempering swaps accepted after the previous sweep: exchange the bit columns now
+        const bool window = (((mp[0] | mp[1] | mc[0] | mc[1]) >> 31) != 0); // a pair straddles words
+        __syncthreads();
+        for (uint32_t i = tid; i < d.N; i += 256) {
+            const uint32_t v = sw[i];
+            uint32_t prev = 0, next = 0;
+            if (window) { // old neighbouring words (the input buffer is not written in this launch)
+                if (w > 0) prev = Sin[static_cast<ptrdiff_t>(i) - static_cast<ptrdiff_t>(d.N)];
+                if (w + 1 < d.W) next = Sin[static_cast<size_t>(i) + d.N];
+            }
+            sw[i] = apply_swaps_window(prev, v, next, mp, mc, mn);
+        }
+        if (tid == 0) p.applied_epoch[static_cast<size_t>(real) * d.W + w] = epoch;
+    }
+    if (tid == 0) {
+        sw[d.N] = 0;
+        pl[2 * d.N] = 0;
+        pl[2 * d.N + 1] = 0;
+    }
+    const uint32_t live = d.n_sys - w * 32;
+    const uint32_t valid_bits = live >= 32 ? 0xFFFFFFFFu : ((1u << live) - 1u);
+    __syncthreads();
+
+    PA_HC_STAMP(1)
+    const uint32_t sw_addr = lds_addr_of(sw), pl_addr = lds_addr_of(pl), tab_addr = lds_addr_of(tab);
+    if (do_sweep) {
+        const uint32_t spare = sw_addr + d.N * 4;
+        // Software pipeline, three stages deep.  In iteration `pass`:
+        //   registers hold the decoded addresses of `pass` (cur), the table entry of pass + 1 (e_next) and the
+        //   boundaries of pass + 2 (b0, b1);
+        //   issued: the nine reads of `pass`, then the table read of pass + 2 and the boundary read of pass + 3
+        //   (both consumed in the NEXT iteration, after this one's barrier has drained the LDS queue);
+        //   computed while the nine reads fly: the addresses of pass + 1.
+        // So nothing but "reads -> accept logic -> write -> barrier" sits between two barriers.
+        auto pick = [&](uint32_t b0, uint32_t b1, bool &active) -> uint32_t { // LDS address of the table entry
+            const uint32_t pos = b0 + tid;
+            active = pos < b1;
+            return tab_addr + (active ? pos : 0u) * 4;
+        };
+        bool act_cur, act_next;
+        const uint32_t e_cur = lds_load(pick(ps[0], ps[1], act_cur));
+        uint32_t e_next = lds_load(pick(ps[1], ps[2], act_next)); // (ps is padded: passes past the last are empty)
+        uint32_t b0 = ps[2], b1 = ps[3];
+        HcSite cur = hc_decode<NN>(d, e_cur, sw_addr);
+        uint32_t wr_cur = act_cur ? cur.site : spare;
+        const uint32_t ps_addr = lds_addr_of(ps);
+        for (uint32_t pass = 0; pass < d.n_passes; ++pass) {
+            // (1) the nine reads of this pass
+            uint32_t nb[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) nb[k] = k < 2 * NN ? lds_load(cur.nb[k]) : 0u;
+            const uint32_t s = lds_load(cur.site);
+            const uint2 lv = lds_load2(pl_addr + 2 * cur.site4);
+            // (2) prefetches for later passes (their data is first used after the barrier below)
+            bool act_after;
+            const uint32_t e_after = lds_load(pick(b0, b1, act_after));
+            const uint32_t nb0 = lds_load(ps_addr + (pass + 3) * 4), nb1 = lds_load(ps_addr + (pass + 4) * 4);
+            // (3) while the reads are in flight: addresses of the next pass
+            const HcSite nxt = hc_decode<NN>(d, e_next, sw_addr);
+            const uint32_t wr_next = act_next ? nxt.site : spare;
+            // (4) accept, write, hand over to the next level
+            const uint32_t acc = accept_mask_dense<NN>(s, nb, cur.neg, lv.x, lv.y);
+            lds_store(wr_cur, s ^ (acc & valid_bits));
+            lds_barrier();
+            cur = nxt;
+            wr_cur = wr_next;
+            e_next = e_after;
+            act_next = act_after;
+            b0 = nb0;
+            b1 = nb1;
+        }
+        PA_HC_STAMP(2)
+        for (uint32_t i = tid; i < d.N; i += 256) Sout[i] = sw[i];
+    }
+    PA_HC_STAMP(3)
+
+    if (with_energy & 1) {
+        uint32_t c[3][8];
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c[s][j] = 0;
+#pragma unroll 1
+        for (uint32_t base = 0; base < d.N; base += 16 * 256) {
+            uint32_t qa[16], qb[16], qc[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t pos = base + k * 256 + tid;
+                const bool live_site = pos < d.N;
+                const HcSite h = hc_decode<NN>(d, tab[live_site ? pos : 0u], sw_addr);
+                const uint32_t s = lds_load(h.site);
+                uint32_t u[3] = {0u, 0u, 0u};
+#pragma unroll
+                for (int q = 0; q < NN; ++q) // unsatisfied forward bonds (energy.rs:92-107)
+                    u[q] = s ^ lds_load(h.nb[2 * q]) ^ static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(h.neg), 2 * q, 1));
+                qa[k] = live_site ? (u[0] ^ u[1] ^ u[2]) : 0u;   // weight 1
+                qb[k] = live_site ? maj3(u[0], u[1], u[2]) : 0u; // weight 2
+                qc[k] = live_site ? s : 0u;                      // spins equal to -1
+            }
+            count16(qa, c[0]);
+            count16(qb, c[1]);
+            count16(qc, c[2]);
+        }
+        PA_HC_STAMP(4)
+        uint32_t tot[3];
+        block_bit_totals<3>(c, scratch, tot);
+        if (tid < 32 && w * 32 + tid < d.n_sys) {
+            const uint32_t slot = w * 32 + tid;
+            const int32_t unsat = static_cast<int32_t>(tot[0] + 2 * tot[1]);
+            p.Esum[static_cast<size_t>(real) * d.n_sys + slot] = p.nz_bonds[real] - 2 * unsat;
+            p.Msum[static_cast<size_t>(real) * d.n_sys + slot] =
+                static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(tot[2]);
+        }
+    }
+    PA_HC_STAMP(5)
+}
+
+// ---------------------------------------------------------------------------
 // k_overlap: workgroup = (tile, word), 256 threads.  Replica 2p and 2p+1 at
 // temperature t sit n_temps bit positions apart, so Y = V ^ (V >> n_temps) lines
 // every pair up in the bits of the even replica.  V = S gives q_i; V = S ^ S(fwd_d)
@@ -999,8 +1248,11 @@ __device__ __forceinline__ void measure_block(const SimDims &d, const DevPtrs &p
         const float n_f = static_cast<float>(d.N);
         if (do_accum) {
         double *mom = p.mom + static_cast<size_t>(real) * 5 * d.n_temps;
-        double m0 = mom[0 * d.n_temps + t], m1 = mom[1 * d.n_temps + t], m2s = mom[2 * d.n_temps + t];
-        double e0 = mom[3 * d.n_temps + t], e1 = mom[4 * d.n_temps + t];
+        double m0 = 0.0, m1 = 0.0, m2s = 0.0, e0 = 0.0, e1 = 0.0;
+        if (!(pt.fresh & 1u)) {
+            m0 = mom[0 * d.n_temps + t], m1 = mom[1 * d.n_temps + t], m2s = mom[2 * d.n_temps + t];
+            e0 = mom[3 * d.n_temps + t], e1 = mom[4 * d.n_temps + t];
+        }
         double m2_ac = 0.0;
         for (uint32_t rep = 0; rep < d.n_replicas; ++rep) {
             const uint32_t slot = rep * d.n_temps + t;
@@ -1028,7 +1280,14 @@ __device__ __forceinline__ void measure_block(const SimDims &d, const DevPtrs &p
         if (accum_overlap && d.n_pairs) {
             double *ovm = p.ovm + static_cast<size_t>(real) * 6 * d.n_temps;
             double o[6];
-            for (int k = 0; k < 6; ++k) o[k] = ovm[k * d.n_temps + t];
+            const uint32_t row_words = (d.N + 32) / 32;
+            uint32_t *seen_row = p.hist_touched + (static_cast<size_t>(real) * d.n_temps + t) * row_words;
+            if (pt.fresh & 2u) { // first overlap accumulation of the run: sums from zero, no bin seen yet
+                for (int k = 0; k < 6; ++k) o[k] = 0.0;
+                for (uint32_t wq = 0; wq < row_words; ++wq) seen_row[wq] = 0u;
+            } else {
+                for (int k = 0; k < 6; ++k) o[k] = ovm[k * d.n_temps + t];
+            }
             const float n_bonds_f = static_cast<float>(d.N * d.nn);
             const size_t hbase = (static_cast<size_t>(real) * d.n_temps + t) * (d.N + 1);
             double q2_ac = 0.0;
@@ -1051,8 +1310,7 @@ __device__ __forceinline__ void measure_block(const SimDims &d, const DevPtrs &p
                 const uint32_t qbin = static_cast<uint32_t>((dot_spin + static_cast<int32_t>(d.N)) / 2);
                 const size_t bin = hbase + qbin;
                 // row t of the bitmap belongs to this thread alone; all four loads are in flight together
-                uint32_t *seen = p.hist_touched +
-                                 (static_cast<size_t>(real) * d.n_temps + t) * ((d.N + 32) / 32) + (qbin >> 5);
+                uint32_t *seen = seen_row + (qbin >> 5);
                 const uint32_t seen_word = *seen;
                 const uint64_t h_old = p.hist[bin];
                 const double a_old = p.qlq[bin], b_old = p.ql2q[bin];
@@ -2131,6 +2389,7 @@ size_t sweep_lds_bytes(const SimDims &d, bool gibbs) {
     return ((n1 + 1) / 2 * 2 + (gibbs ? 3 : 2) * n1 + 5 * 48) * 4;
 }
 size_t measure_lds_bytes(const SimDims &d) { return measure_lds_words(d) * 4; }
+size_t sweep_hc_lds_bytes(const SimDims &d) { return sweep_hc_lds_words(d) * 4; }
 static size_t overlap_lds_bytes(const SimDims &d) {
     return ((static_cast<size_t>(d.N) + 1) + 5 * 48) * 4;
 }
@@ -2146,6 +2405,10 @@ hipError_t configure_kernels(const SimDims &) {
                            reinterpret_cast<const void *>(k_sweep<false, 3>),
                            reinterpret_cast<const void *>(k_sweep<true, 0>),
                            reinterpret_cast<const void *>(k_sweep<true, 3>),
+                           reinterpret_cast<const void *>(k_sweep_hc<1>),
+                           reinterpret_cast<const void *>(k_sweep_hc<2>),
+                           reinterpret_cast<const void *>(k_sweep_hc<3>),
+                           reinterpret_cast<const void *>(k_sweep_hc<3, true>),
                            reinterpret_cast<const void *>(k_overlap),
                            reinterpret_cast<const void *>(k_overlap_wide),
                            reinterpret_cast<const void *>(k_rng_overlap<false>),
@@ -2220,6 +2483,16 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
         hipLaunchKernelGGL((k_sweep<false, 0, true>), grid, block, lds, stream, d, p, e, s, no_stamps);
         return hipGetLastError();
     }
+    static const bool no_hc = std::getenv("PEAPODS_NO_HC") != nullptr;
+    if (d.hc && !no_hc) { // implicit neighbours, table in the LDS
+        const size_t lds_hc = sweep_hc_lds_bytes(d);
+        switch (d.dense_nn) {
+        case 1: hipLaunchKernelGGL((k_sweep_hc<1>), grid, block, lds_hc, stream, d, p, e, s, no_stamps); break;
+        case 2: hipLaunchKernelGGL((k_sweep_hc<2>), grid, block, lds_hc, stream, d, p, e, s, no_stamps); break;
+        default: hipLaunchKernelGGL((k_sweep_hc<3>), grid, block, lds_hc, stream, d, p, e, s, no_stamps); break;
+        }
+        return hipGetLastError();
+    }
     switch (d.dense_nn) {
     case 1: hipLaunchKernelGGL((k_sweep<false, 1>), grid, block, lds, stream, d, p, e, s, no_stamps); break;
     case 2: hipLaunchKernelGGL((k_sweep<false, 2>), grid, block, lds, stream, d, p, e, s, no_stamps); break;
@@ -2259,6 +2532,10 @@ hipError_t launch_sweep_pipe(const SimDims &d, const DevPtrs &p, bool gibbs, uin
 hipError_t launch_sweep_stamped(const SimDims &d, const DevPtrs &p, unsigned long long *stamps,
                                 hipStream_t stream) {
     const dim3 grid(d.n_real * d.W), block(256);
+    if (d.hc && d.dense_nn == 3) { // every workgroup stamps: stamps[grid][8]
+        hipLaunchKernelGGL((k_sweep_hc<3, true>), grid, block, sweep_hc_lds_bytes(d), stream, d, p, 1, 1, stamps);
+        return hipGetLastError();
+    }
     if (d.dense_nn == 3)
         hipLaunchKernelGGL((k_sweep<true, 3>), grid, block, sweep_lds_bytes(d, false), stream, d, p,
                            1 | (std::getenv("PEAPODS_DBG") ? std::atoi(std::getenv("PEAPODS_DBG")) << 8 : 0), 1, stamps);

@@ -65,6 +65,7 @@ struct pa_sim {
     // non-const aliases of the static tables (filled once in create)
     uint32_t *thr = nullptr, *mpar = nullptr, *pass_start = nullptr, *jump = nullptr;
     uint4 *rec = nullptr;
+    uint32_t *hc_tab = nullptr;
     uint16_t *nbr_site = nullptr;
     uint32_t *jsite = nullptr, *nbr_wide = nullptr;
     uint4 *fwd_big = nullptr;
@@ -106,6 +107,7 @@ struct pa_sim {
     std::vector<uint32_t> snap_ids_host, snap_blue_host; // ids persist from call to call (overlap.rs:246-248)
     // bookkeeping of the last sample()
     uint64_t n_recorded = 0;
+    uint64_t n_sweeps_run = 0; // sweeps the last sample() enqueued (= n_sweeps unless it was interrupted)
     bool overlap_collected = false;
     bool swaps_pending = false; // a tempering event ran after the last sweep (deferred bit-column swaps)
     std::atomic<bool> interrupt{false};
@@ -118,8 +120,13 @@ struct pa_sim {
         DevPtrs p;
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;
+        uint32_t fresh = 3; // see pa_sim::fresh
     };
     std::vector<Group> groups;
+    // Running sums are never memset between sample() calls: bit 0 (moments) / bit 1 (overlap moments, P(q)
+    // bitmap) says that the next accumulating k_measure launch starts them from zero (PtParams::fresh).  One
+    // copy per stream group (run_sweeps) and one for whole-ensemble launches (pa_sim_profile_kernels).
+    uint32_t fresh = 3;
     hipEvent_t fork = nullptr;
     hipEvent_t batch_events[2] = {nullptr, nullptr}; // run-ahead bound of run_sweeps (cooperative cancel)
 };
@@ -313,18 +320,29 @@ int seed_state(pa_sim *sim, uint64_t seed) {
 }
 
 int zero_accumulators(pa_sim *sim) {
-    const SimDims &d = sim->d;
-    PA_HIP(sim, hipMemsetAsync(sim->p.mom, 0, sizeof(double) * d.n_real * 5 * d.n_temps, sim->stream));
-    if (d.n_pairs) {
-        const size_t bins = static_cast<size_t>(d.n_real) * d.n_temps * (d.N + 1);
-        PA_HIP(sim, hipMemsetAsync(sim->p.ovm, 0, sizeof(double) * d.n_real * 6 * d.n_temps, sim->stream));
-        // the three histogram arrays (3 x 8 B x bins: 302 MB at 16^3 x 24 T x 128 samples) are not cleared:
-        // k_measure stores a bin's first value of the run and marks it here (1 bit per bin)
-        (void)bins;
-        PA_HIP(sim, hipMemsetAsync(sim->p.hist_touched, 0,
-                                   sizeof(uint32_t) * d.n_real * d.n_temps * ((d.N + 32) / 32), sim->stream));
-    }
+    // No device work: the first accumulating k_measure of the run stores instead of adding (moment sums) and
+    // clears its rows of the P(q) bitmap; the three histogram arrays (302 MB at the bench shape) are
+    // validated by that bitmap and never cleared.  A run that records nothing leaves the flags set and the
+    // getters report zeros.
+    sim->fresh = 3;
+    for (auto &g : sim->groups) g.fresh = 3;
     return PA_OK;
+}
+
+// launch_measure with the "start from zero" bits of `fresh` this launch consumes
+hipError_t measure_launch(uint32_t &fresh, const SimDims &d, const DevPtrs &p, PtParams pt, bool do_accum,
+                          bool accum_overlap, bool do_pt, hipStream_t stream) {
+    pt.fresh = (do_accum ? fresh & 1u : 0u) | ((accum_overlap && d.n_pairs) ? fresh & 2u : 0u);
+    fresh &= ~pt.fresh;
+    return launch_measure(d, p, pt, false, do_accum, accum_overlap, do_pt, stream);
+}
+
+// true while no launch since the last zero_accumulators has accumulated into (bit 0: moments, bit 1: overlap)
+bool nothing_accumulated(const pa_sim *sim, uint32_t bit) {
+    if (!(sim->fresh & bit)) return false;
+    for (const auto &g : sim->groups)
+        if (!(g.fresh & bit)) return false;
+    return true;
 }
 
 // DevPtrs of the sub-ensemble starting at realisation r0 (every per-realisation array advanced).
@@ -349,6 +367,7 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     q.slot_of += static_cast<size_t>(d.n_sys) * r0;
     q.mpar += static_cast<size_t>(d.MW) * r0;
     q.rec += (static_cast<size_t>(d.N) + 1) * (d.big ? 2 : 1) * r0;
+    if (d.hc) q.hc_tab += static_cast<size_t>(d.N) * r0;
     if (d.pipe_lds) q.recS += static_cast<size_t>(d.planes_stride) * r0;
     if (d.pipe_K) q.progress += static_cast<size_t>(d.W) * d.pipe_K * r0;
     if (d.pipe_lds) q.xchg += static_cast<size_t>(d.W) * d.pipe_K * 2 * d.plane * r0;
@@ -795,6 +814,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     }
     const bool want_overlap = d.n_pairs > 0 && cfg->measure_overlap;
     sim->n_recorded = 0;
+    sim->n_sweeps_run = 0;
     sim->overlap_collected = want_overlap;
     // every capability check comes before the first launch: a configuration this build declines is
     // rejected with the state untouched and no group stream forked
@@ -850,6 +870,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             sim->interrupt.store(false);
             return fail(sim, PA_ERR_INTERRUPTED, "interrupted");
         }
+        sim->n_sweeps_run = sweep_id + 1;
         const bool record = sweep_id >= cfg->warmup_sweeps; // mod.rs:410
         const bool pt_this = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0; // :486-488
         const bool fk_this = fk && sweep_id % cfg->cluster_interval == 0;               // :434-437
@@ -870,7 +891,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             toggle_spin_buffers(sim);
             if (record || pt_this || overlap_owed)
                 for (auto &g : sim->groups)
-                    PA_HIP(sim, launch_measure(g.d, g.p, pt, false, record, overlap_owed, pt_this, g.stream));
+                    PA_HIP(sim, measure_launch(g.fresh, g.d, g.p, pt, record, overlap_owed, pt_this, g.stream));
             overlap_owed = record;
             if (pt_this) sim->swaps_pending = true;
             if (record) sim->n_recorded += 1;
@@ -906,11 +927,11 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                         static_cast<uint32_t>(sim->ac_capacity)};
             if (!oc_this) {
                 if (record || pt_this || equil) // statistics :543-578, tempering :748-796
-                    PA_HIP(sim, launch_measure(g.d, g.p, pt, false, record, record && want_overlap, pt_this,
+                    PA_HIP(sim, measure_launch(g.fresh, g.d, g.p, pt, record, record && want_overlap, pt_this,
                                                g.stream));
             } else {
                 if (record || equil)
-                    PA_HIP(sim, launch_measure(g.d, g.p, pt, false, record, record && want_overlap, false, g.stream));
+                    PA_HIP(sim, measure_launch(g.fresh, g.d, g.p, pt, record, record && want_overlap, false, g.stream));
                 pt.equil = 0; // the tempering launch below must not accumulate the diagnostic again
                 const uint64_t mode_idx = overlap_call_count % static_cast<uint64_t>(cfg->n_overlap_cluster_modes);
                 const int oc_mode = cfg->overlap_cluster_modes[mode_idx];
@@ -997,7 +1018,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                 }
                 if (pt_this) { // energies are recomputed after a mutating move (:749-756)
                     if (!observe_overlap) PA_HIP(sim, launch_sweep(g.d, g.p, true, false, false, g.stream));
-                    PA_HIP(sim, launch_measure(g.d, g.p, pt, false, false, false, true, g.stream));
+                    PA_HIP(sim, measure_launch(g.fresh, g.d, g.p, pt, false, false, true, g.stream));
                 }
             }
         }
@@ -1014,7 +1035,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
         for (auto &g : sim->groups) {
             PA_HIP(sim, launch_overlap(g.d, g.p, g.stream));
-            PA_HIP(sim, launch_measure(g.d, g.p, pt, false, false, true, false, g.stream));
+            PA_HIP(sim, measure_launch(g.fresh, g.d, g.p, pt, false, true, false, g.stream));
         }
         overlap_owed = false;
     }
@@ -1027,7 +1048,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
         for (auto &g : sim->groups) {
             (void)launch_overlap(g.d, g.p, g.stream);
-            (void)launch_measure(g.d, g.p, pt, false, false, true, false, g.stream);
+            (void)measure_launch(g.fresh, g.d, g.p, pt, false, true, false, g.stream);
         }
     }
     sim->ac_samples = autocorr ? sim->n_recorded : 0;
@@ -1047,7 +1068,9 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         sim->error = keep;
         return status;
     }
-    return flush_swaps(sim); // the last tempering event's bit-column swaps become visible in S
+    // The last tempering event's bit-column swaps stay deferred (swaps_pending): the next sweep applies them
+    // while it loads, every other reader (getters, standalone phases) materialises them first (flush_swaps).
+    return PA_OK;
 }
 
 } // namespace
@@ -1497,6 +1520,59 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     }
     d.dense_nn = all_nonzero ? d.nn : 0;
 
+    // ---- implicit neighbours (k_sweep_hc): usable when every neighbour slot of every site lies at one of two
+    // offsets from the site (regular / through the periodic wrap) -- true for hypercubic lattices of any
+    // extents -- all bonds are non-zero and the on-chip kernels apply.  The table replaces the 16-byte site
+    // records on the sweep path: 4 bytes per site, staged in the LDS.
+    d.hc = 0;
+    std::vector<uint32_t> hc_tab;
+    if (!d.big && !d.general && d.dense_nn == d.nn && d.nn >= 1 && d.nn <= 3 && d.N < (1u << kHcSiteBits) &&
+        !std::getenv("PEAPODS_NO_HC")) {
+        bool ok = true;
+        int64_t d0[6] = {0, 0, 0, 0, 0, 0}, d1[6] = {0, 0, 0, 0, 0, 0};
+        for (uint32_t k = 0; k < 2 * d.nn && ok; ++k) {
+            std::map<int64_t, uint32_t> seen; // offset -> sites using it
+            for (uint32_t i = 0; i < d.N; ++i) {
+                const uint32_t j = (k & 1u) ? lat.bwd[i * d.nn + k / 2] : lat.fwd[i * d.nn + k / 2];
+                seen[static_cast<int64_t>(j) - static_cast<int64_t>(i)] += 1;
+            }
+            if (seen.size() > 2) {
+                ok = false;
+                break;
+            }
+            auto it = seen.begin();
+            d0[k] = d1[k] = it->first;
+            if (seen.size() == 2) {
+                auto other = std::next(it);
+                if (other->second > it->second) std::swap(it, other); // the common offset is the regular one
+                d0[k] = it->first;
+                d1[k] = other->first;
+            }
+        }
+        // 66 KB at 16^3 leaves room for two workgroups per CU; beyond one workgroup's LDS the records stay
+        SimDims probe = d;
+        probe.hc = 1;
+        if (ok && sweep_hc_lds_bytes(probe) <= 160 * 1024) {
+            d.hc = 1;
+            for (uint32_t k = 0; k < 6; ++k) {
+                d.hc_d0[k] = static_cast<int32_t>(d0[k] * 4);
+                d.hc_dd[k] = static_cast<int32_t>((d1[k] - d0[k]) * 4);
+            }
+            hc_tab.resize(static_cast<size_t>(d.n_real) * d.N);
+            for (uint32_t real = 0; real < d.n_real; ++real)
+                for (uint32_t pos = 0; pos < d.N; ++pos) {
+                    const uint32_t site = order[pos];
+                    uint32_t flags = 0;
+                    for (uint32_t k = 0; k < 2 * d.nn; ++k) {
+                        const uint32_t j = (k & 1u) ? lat.bwd[site * d.nn + k / 2] : lat.fwd[site * d.nn + k / 2];
+                        if (static_cast<int64_t>(j) - static_cast<int64_t>(site) != d0[k]) flags |= 1u << k;
+                    }
+                    const uint32_t neg = jsite[static_cast<size_t>(real) * d.N + site] & 63u; // f0,b0,f1,b1,f2,b2
+                    hc_tab[static_cast<size_t>(real) * d.N + pos] = site | (flags << kHcFlagShift) | (neg << kHcNegShift);
+                }
+        }
+    }
+
     // ---- k_sweep_slab streams its inputs in schedule order: per (level, slab) segment, padded to
     // start at a multiple of four entries (16-byte aligned pieces for the LDS-DMA loads)
     d.planes_stride = d.N;
@@ -1665,6 +1741,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     ok(bufs.alloc(&sim->mpar, mpar.size()));
     ok(bufs.alloc(&sim->rec, rec.size()));
     ok(bufs.alloc(&sim->pass_start, pass_start.size()));
+    if (d.hc) ok(bufs.alloc(&sim->hc_tab, hc_tab.size()));
     ok(bufs.alloc(&sim->jump, jump.size()));
     ok(bufs.alloc(&p.Esum, static_cast<size_t>(d.n_real) * d.n_sys));
     ok(bufs.alloc(&p.Msum, static_cast<size_t>(d.n_real) * d.n_sys));
@@ -1706,6 +1783,8 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     p.mpar = sim->mpar;
     p.rec = sim->rec;
     p.pass_start = sim->pass_start;
+    p.hc_tab = sim->hc_tab;
+    if (d.hc && (rc = upload(sim, sim->hc_tab, hc_tab))) return bail(rc);
     p.jump = sim->jump;
     p.nz_bonds = sim->nz_bonds;
     p.dbeta = sim->dbeta;
@@ -1881,10 +1960,10 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
         PA_HIP(sim, hipEventRecord(ev[2], sim->stream));
         if (measured) {
             if (fused) {
-                PA_HIP(sim, launch_measure(d, sim->p, pt, false, record, overlap_owed, pt_this, sim->stream));
+                PA_HIP(sim, measure_launch(sim->fresh, d, sim->p, pt, record, overlap_owed, pt_this, sim->stream));
             } else {
                 if (record && want_overlap) PA_HIP(sim, launch_overlap(d, sim->p, sim->stream));
-                PA_HIP(sim, launch_measure(d, sim->p, pt, false, record, record && want_overlap, pt_this,
+                PA_HIP(sim, measure_launch(sim->fresh, d, sim->p, pt, record, record && want_overlap, pt_this,
                                            sim->stream));
             }
             if (pt_this && cfg->pt_schedule == PA_PT_FULL_LADDER)
@@ -1906,7 +1985,7 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
     if (overlap_owed) {
         PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
         PA_HIP(sim, launch_overlap(d, sim->p, sim->stream));
-        PA_HIP(sim, launch_measure(d, sim->p, pt, false, false, true, false, sim->stream));
+        PA_HIP(sim, measure_launch(sim->fresh, d, sim->p, pt, false, true, false, sim->stream));
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
     for (int k = 0; k < 3; ++k) ms_out[k] = count[k] ? total[k] / static_cast<double>(count[k]) : 0.0;
@@ -1928,6 +2007,26 @@ int pa_debug_sweep_stamps(pa_sim *sim, unsigned long long out[6]) {
     PA_HIP(sim, hipMemcpy(out, dev, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     (void)hipFree(dev);
     return PA_OK;
+}
+
+// Diagnostic only: s_memrealtime stamps (100 MHz) of every workgroup of one k_sweep_hc launch, out[n_blocks][8];
+// returns the number of workgroups (0 when the handle does not use that kernel).
+int pa_debug_sweep_hc_stamps(pa_sim *sim, unsigned long long *out, uint64_t capacity_blocks) {
+    if (!sim->d.hc || sim->d.dense_nn != 3) return 0;
+    PA_HIP(sim, hipSetDevice(sim->device));
+    const size_t n_blocks = static_cast<size_t>(sim->d.n_real) * sim->d.W;
+    if (n_blocks > capacity_blocks) return fail(sim, PA_ERR_INVALID, "stamp buffer too small");
+    unsigned long long *dev = nullptr;
+    PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&dev), n_blocks * 8 * sizeof(unsigned long long)));
+    PA_HIP(sim, hipMemset(dev, 0, n_blocks * 8 * sizeof(unsigned long long)));
+    PA_HIP(sim, launch_rng(sim->d, sim->p, false, sim->stream));
+    PA_HIP(sim, launch_sweep_stamped(sim->d, sim->p, dev, sim->stream));
+    sim->swaps_pending = false;
+    toggle_spin_buffers(sim);
+    PA_HIP(sim, hipStreamSynchronize(sim->stream));
+    PA_HIP(sim, hipMemcpy(out, dev, n_blocks * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    (void)hipFree(dev);
+    return static_cast<int>(n_blocks);
 }
 
 int pa_debug_measure_stamps(pa_sim *sim, unsigned long long out[7]) {
@@ -1981,7 +2080,7 @@ int pa_sim_parallel_tempering(pa_sim *sim, int32_t schedule) {
     if (int rc = flush_swaps(sim)) return rc;
     PA_HIP(sim, launch_sweep(sim->d, sim->p, true, false, false, sim->stream));
     PtParams pt{schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
-    PA_HIP(sim, launch_measure(sim->d, sim->p, pt, false, false, false, true, sim->stream));
+    PA_HIP(sim, measure_launch(sim->fresh, sim->d, sim->p, pt, false, false, true, sim->stream));
     if (schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
     sim->swaps_pending = true;
     if (int rc = flush_swaps(sim)) return rc;
@@ -2010,6 +2109,7 @@ uint64_t pa_sim_n_spins(const pa_sim *sim) { return sim->d.N; }
 uint64_t pa_sim_n_neighbors(const pa_sim *sim) { return sim->d.nn; }
 uint64_t pa_sim_n_systems(const pa_sim *sim) { return sim->d.n_sys; }
 uint64_t pa_sim_n_realizations(const pa_sim *sim) { return sim->d.n_real; }
+uint64_t pa_sim_sweeps_completed(const pa_sim *sim) { return sim->n_sweeps_run; }
 
 uint64_t pa_abi_layout(uint64_t *out, uint64_t capacity) {
     std::vector<uint64_t> v;
@@ -2171,6 +2271,7 @@ int pa_sim_get_result_moments(pa_sim *sim, uint64_t realization, double *out) {
     int rc = download(sim, sums, sim->p.mom + static_cast<size_t>(realization) * 5 * d.n_temps,
                       static_cast<size_t>(5) * d.n_temps);
     if (rc) return rc;
+    if (nothing_accumulated(sim, 1u)) std::fill(sums.begin(), sums.end(), 0.0); // the sums were never started
     average_into(out, sums.data(), sums.size(), sim->n_recorded * d.n_replicas);
     return PA_OK;
 }
@@ -2184,6 +2285,7 @@ int pa_sim_get_result_overlap(pa_sim *sim, uint64_t realization, double *out) {
     int rc = download(sim, sums, sim->p.ovm + static_cast<size_t>(realization) * 6 * d.n_temps,
                       static_cast<size_t>(6) * d.n_temps);
     if (rc) return rc;
+    if (nothing_accumulated(sim, 2u)) std::fill(sums.begin(), sums.end(), 0.0);
     average_into(out, sums.data(), sums.size(),
                  sim->overlap_collected ? sim->n_recorded * d.n_pairs : 0);
     return PA_OK;
@@ -2196,6 +2298,12 @@ int pa_sim_get_result_histograms(pa_sim *sim, uint64_t realization, uint64_t *hi
     if (d.n_pairs == 0) return fail(sim, PA_ERR_INVALID, "overlap needs n_replicas >= 2");
     PA_HIP(sim, hipSetDevice(sim->device));
     const size_t bins = static_cast<size_t>(d.n_temps) * (d.N + 1);
+    if (nothing_accumulated(sim, 2u)) { // no recorded overlap since the accumulators were reset
+        std::fill(histogram, histogram + bins, uint64_t(0));
+        std::fill(ql_at_q_sum, ql_at_q_sum + bins, 0.0);
+        std::fill(ql2_at_q_sum, ql2_at_q_sum + bins, 0.0);
+        return PA_OK;
+    }
     PA_HIP(sim, hipMemcpyAsync(histogram, sim->p.hist + bins * realization, bins * sizeof(uint64_t),
                                hipMemcpyDeviceToHost, sim->stream));
     PA_HIP(sim, hipMemcpyAsync(ql_at_q_sum, sim->p.qlq + bins * realization, bins * sizeof(double),

@@ -49,15 +49,6 @@ def test_sharded_handles_with_snapshots_match_one_handle(oracle, build):
             np.testing.assert_array_equal(part.get_rng_state(local, s), whole.get_rng_state(r, s))
 
 
-def _advance_oracle_until_equal(cpu, gpu, kw, limit_chunks):
-    """The interrupted GPU run stopped after a multiple of 32 sweeps: find it by stepping the oracle."""
-    for chunk in range(limit_chunks):
-        if all(np.array_equal(gpu.get_spins(r), cpu.get_spins(r)) for r in range(gpu.n_realizations)):
-            return 32 * chunk
-        cpu.run(cpu.make_config(32, "metropolis", **kw))
-    return None
-
-
 @pytest.mark.parametrize("how", ["request", "sigint"])
 def test_interrupted_sample_stops_early_and_leaves_a_replayable_state(oracle, how):
     """src/lib.rs:304-333: a cancel request ends the run with KeyboardInterrupt("interrupted"); the state is the
@@ -82,8 +73,11 @@ def test_interrupted_sample_stops_early_and_leaves_a_replayable_state(oracle, ho
     took = time.perf_counter() - t0
     timer.cancel()
     assert took < 30.0, "the request was not honoured while work was queued"
-    n_ran = _advance_oracle_until_equal(cpu, gpu, kw, limit_chunks=4000)
-    assert n_ran is not None and 0 < n_ran < n_asked, "the stopped state is not a state of the reference's trajectory"
+    n_ran = int(gpu._lib.pa_sim_sweeps_completed(gpu._handle))
+    assert 0 < n_ran < n_asked and n_ran % 32 == 0
+    cpu.run(cpu.make_config(n_ran, "metropolis", **kw))  # the reference's state after that many sweeps
+    for r in range(2):
+        np.testing.assert_array_equal(gpu.get_spins(r), cpu.get_spins(r))
     for r in range(2):
         np.testing.assert_array_equal(gpu.get_system_ids(r), cpu.get_system_ids(r))
         for s in range(gpu.n_systems):

@@ -1026,30 +1026,62 @@ __device__ __forceinline__ void overlap_block(const SimDims &d, const DevPtrs &p
     for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) c[s][j] = 0;
-    for (uint32_t base = 0; base < d.N; base += 16 * 256) {
-        uint4 rr[16];
+    if (d.hc) { // implicit neighbours: 4 bytes per site from the schedule table instead of a 16-byte record
+        const uint32_t *tab_g = p.hc_tab + static_cast<size_t>(real) * d.N;
+        const uint32_t y_addr = lds_addr_of(Y);
+#pragma unroll 1
+        for (uint32_t base = 0; base < d.N; base += 16 * 256) {
+            uint32_t ee[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const uint32_t pos = base + k * 256 + tid;
-            rr[k] = rec[pos < d.N ? pos : d.N];
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t pos = base + k * 256 + tid;
+                ee[k] = tab_g[pos < d.N ? pos : 0u];
+            }
+            uint32_t qa[16], qb[16], qc[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const bool live_site = base + k * 256 + tid < d.N;
+                const HcSite h = hc_decode<3>(d, ee[k], y_addr); // (slots of absent directions: flag 0, offset 0)
+                const uint32_t y = lds_load(h.site);
+                uint32_t z[3] = {0u, 0u, 0u};
+#pragma unroll
+                for (int dir = 0; dir < 3; ++dir) // 1 where q_i * q_k = -1
+                    if (dir < static_cast<int>(d.nn)) z[dir] = y ^ lds_load(h.nb[2 * dir]);
+                qa[k] = live_site ? y : 0u;
+                qb[k] = live_site ? (z[0] ^ z[1] ^ z[2]) : 0u;
+                qc[k] = live_site ? maj3(z[0], z[1], z[2]) : 0u;
+            }
+            count16(qa, c[0]);
+            count16(qb, c[1]);
+            count16(qc, c[2]);
         }
-        uint32_t qa[16], qb[16], qc[16];
+    } else {
+#pragma unroll 1
+        for (uint32_t base = 0; base < d.N; base += 16 * 256) {
+            uint4 rr[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const bool live_site = base + k * 256 + tid < d.N;
-            const SiteRec sr(rr[k]);
-            const uint32_t y = lds_word(Y, sr.site);
-            uint32_t z[3];
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t pos = base + k * 256 + tid;
+                rr[k] = rec[pos < d.N ? pos : d.N];
+            }
+            uint32_t qa[16], qb[16], qc[16];
 #pragma unroll
-            for (int dir = 0; dir < 3; ++dir) // 1 where q_i * q_k = -1
-                z[dir] = dir < static_cast<int>(d.nn) ? (y ^ lds_word(Y, sr.nb[2 * dir])) : 0u;
-            qa[k] = live_site ? y : 0u;
-            qb[k] = live_site ? (z[0] ^ z[1] ^ z[2]) : 0u;
-            qc[k] = live_site ? maj3(z[0], z[1], z[2]) : 0u;
+            for (int k = 0; k < 16; ++k) {
+                const bool live_site = base + k * 256 + tid < d.N;
+                const SiteRec sr(rr[k]);
+                const uint32_t y = lds_word(Y, sr.site);
+                uint32_t z[3];
+#pragma unroll
+                for (int dir = 0; dir < 3; ++dir) // 1 where q_i * q_k = -1
+                    z[dir] = dir < static_cast<int>(d.nn) ? (y ^ lds_word(Y, sr.nb[2 * dir])) : 0u;
+                qa[k] = live_site ? y : 0u;
+                qb[k] = live_site ? (z[0] ^ z[1] ^ z[2]) : 0u;
+                qc[k] = live_site ? maj3(z[0], z[1], z[2]) : 0u;
+            }
+            count16(qa, c[0]);
+            count16(qb, c[1]);
+            count16(qc, c[2]);
         }
-        count16(qa, c[0]);
-        count16(qb, c[1]);
-        count16(qc, c[2]);
     }
     uint32_t tot[3];
     block_bit_totals<3>(c, scratch, tot);
@@ -2208,6 +2240,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
         return in;
     };
     slab_barrier(); // the loader's pieces of the first level and the first flag are in place
+    const bool dense3 = !GIBBS && d.dense_nn == 3;
     Inputs cur = pick_up(first);
     for (uint32_t level = first; level <= last; ++level) {
         slab_barrier(); // X(level): last level's spins are visible; the pieces of level + 1 have landed
@@ -2247,8 +2280,10 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
                               lds[r.z & 0xFFFFu], lds[r.z >> 16],     lds[r.w & 0xFFFFu]};
             const uint32_t jm = r.w >> 16;
             const uint32_t sv = lds[at];
+            // (every bond non-zero in three directions -- ferromagnets, +-J: no non-zero masks, no case split)
             const uint32_t acc = (GIBBS ? accept_mask_gibbs(sv, nb, jm, d.nn, cur.lv.x, cur.lv.y, cur.hi)
-                                        : accept_mask(sv, nb, jm, cur.lv.x, cur.lv.y)) & valid_bits;
+                                  : dense3 ? accept_mask_dense<3>(sv, nb, jm, cur.lv.x, cur.lv.y)
+                                           : accept_mask(sv, nb, jm, cur.lv.x, cur.lv.y)) & valid_bits;
             const uint32_t value = sv ^ acc;
             lds[at] = value;
             coherent_store(Snew + a + at, value);

@@ -1,26 +1,38 @@
 #!/bin/bash
-# Runs on the GPU box (from the repo root): rocprofv3 summaries behind profiles/rNN_*.
-#   bash tools/collect_profiles.sh r01
-# 1. kernel trace + stats of the default bench command (shorter run, same workload)
+# Runs on the GPU box (from the repo root): rocprofv3 summaries behind profiles/<tag>_*.
+#   bash tools/collect_profiles.sh r02          (normally through tools/run_collect.sh, which labels the commit)
+# 1. kernel trace + stats of the bench command (shorter run, same workload), 2 stream groups and 1
 # 2. PMC passes, each in its own run with --kernel-trace only (no other trace domain)
-tag=${1:-r01}
+# 3. kernel stats of the other BASELINE configs (c1: 64^3 ferromagnet, c4: 12^3 with the overlap moves)
+tag=${1:-r02}
 out=$PWD/gpurun_out/prof_$tag
 repo=$PWD
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- \
     python3 "$repo/bench.py" --steps 500 --warmup 50 --no-cpu-baseline > "$out/stats.log" 2>&1
+echo "stats done" >> "$out/progress.log"
 # the default run interleaves two stream groups of 64 realisations, so its per-launch averages are
 # for half the ensemble; the remaining passes use one group (every launch = the full ensemble, as
 # in bench.py's roofline.kernel_ms)
 export PEAPODS_STREAMS=1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_1stream" -o bench -- \
     python3 "$repo/bench.py" --steps 500 --warmup 50 --no-cpu-baseline > "$out/stats_1stream.log" 2>&1
+echo "stats 1 stream done" >> "$out/progress.log"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU"; do
     name=$(echo "$pass" | tr ' ' '_' | cut -c1-24)
     rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$out/pmc_$name" -o pmc -- \
         python3 "$repo/bench.py" --steps 25 --warmup 5 --no-cpu-baseline --profile-sweeps 4 > "$out/pmc_$name.log" 2>&1
     echo "pass $name done" >> "$out/progress.log"
+done
+unset PEAPODS_STREAMS
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_c1" -o bench -- \
+    python3 "$repo/bench.py" --config c1 --steps 300 --warmup 30 --no-cpu-baseline > "$out/stats_c1.log" 2>&1
+echo "c1 done" >> "$out/progress.log"
+for mode in houdayer jorg cmr; do
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_c4_$mode" -o bench -- \
+        python3 "$repo/bench.py" --config c4 --oc-mode $mode --steps 200 --warmup 20 --no-cpu-baseline > "$out/stats_c4_$mode.log" 2>&1
+    echo "c4 $mode done" >> "$out/progress.log"
 done
 cd "$repo" && python3 tools/summarize_profiles.py "$out" "$tag" > "$out/summary.log" 2>&1
 cat "$out/summary.log"

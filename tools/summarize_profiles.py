@@ -1,7 +1,9 @@
 """Condenses rocprofv3 CSV output (tools/collect_profiles.sh) into the files kept under profiles/:
-   <tag>_kernel_stats.csv       rocprofv3 --stats kernel summary (copied)
+   <tag>_kernel_stats*.csv      rocprofv3 --stats kernel summaries (copied; c2 with two stream groups and one, c1, c4)
    <tag>_pmc_per_launch.csv     average counter value per launch and kernel
-   traffic.json                 HBM bytes per sweep of the two sweep launches (FETCH_SIZE / WRITE_SIZE)
+   counters.json                what bench.py prints as roofline.traffic / limiter counts: HBM bytes per sweep of the
+                                two sweep launches (FETCH_SIZE / WRITE_SIZE), wave-instruction counts, and the commit
+                                they were collected at (profiles/collect_head.txt, written by tools/run_collect.sh)
 Usage: summarize_profiles.py gpurun_out/prof_<tag> <tag>"""
 import csv
 import glob
@@ -19,9 +21,10 @@ stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursi
 if stats:
     shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
     print("kernel stats:", stats[0])
-stats1 = glob.glob(os.path.join(src, "stats_1stream", "**", "*kernel_stats.csv"), recursive=True)
-if stats1:
-    shutil.copy(stats1[0], os.path.join(dst, f"{tag}_kernel_stats_1stream.csv"))
+for sub in ("1stream", "c1", "c4_houdayer", "c4_jorg", "c4_cmr"):
+    found = glob.glob(os.path.join(src, f"stats_{sub}", "**", "*kernel_stats.csv"), recursive=True)
+    if found:
+        shutil.copy(found[0], os.path.join(dst, f"{tag}_kernel_stats_{sub}.csv"))
 
 sums = defaultdict(lambda: defaultdict(float))
 counts = defaultdict(lambda: defaultdict(int))
@@ -54,15 +57,33 @@ def avg(kernel_prefix, counter):
     return tot / n if n else None
 
 
-fetch = [avg("pa::k_rng_overlap", "FETCH_SIZE"), avg("pa::k_sweep<", "FETCH_SIZE")]
-write = [avg("pa::k_rng_overlap", "WRITE_SIZE"), avg("pa::k_sweep<", "WRITE_SIZE")]
+SWEEP = ("pa::k_sweep_hc<", "pa::k_sweep<")  # the on-chip sweep of this build, whichever variant ran
+
+
+def avg_any(prefixes, counter):
+    for prefix in prefixes:
+        v = avg(prefix, counter)
+        if v is not None:
+            return v
+    return None
+
+
+fetch = [avg("pa::k_rng_overlap", "FETCH_SIZE"), avg_any(SWEEP, "FETCH_SIZE")]
+write = [avg("pa::k_rng_overlap", "WRITE_SIZE"), avg_any(SWEEP, "WRITE_SIZE")]
+insts = {"k_rng": avg("pa::k_rng_overlap", "SQ_INSTS_VALU"), "k_sweep": avg_any(SWEEP, "SQ_INSTS_VALU")}
+head_file = os.path.join(dst, "collect_head.txt")
+commit = open(head_file).read().strip() if os.path.exists(head_file) else "unlabelled"
 if all(v is not None for v in fetch + write):
     fetch_kb, write_kb = sum(fetch), sum(write)
-    traffic = {
+    counters_out = {
+        "commit": commit,
+        "workload": "bench.py --config c2, 128 realisations per launch, one stream group (PEAPODS_STREAMS=1)",
+        "wave_insts_per_launch": {k: v for k, v in insts.items() if v is not None},
         "hbm_bytes_per_sweep": (2 * fetch_kb + write_kb) * 1024,
-        "kernels": "k_rng_overlap + k_sweep (one Metropolis sweep of 50 331 648 attempts and the overlap "
+        "kernels": "k_rng_overlap + the on-chip sweep (one Metropolis sweep of 50 331 648 attempts and the overlap "
                    "measurement of the previous one)",
         "fetch_size_kb_raw": fetch_kb,
+        "fetch_size_kb_by_kernel": {"k_rng_overlap": fetch[0], "k_sweep": fetch[1]},
         "write_size_kb": write_kb,
         "correction": "MI355X_MICROARCH.md: FETCH_SIZE reports half of a wide coalesced 16 B/lane stream on "
                       "gfx950 -> read side doubled; WRITE_SIZE exact. Separate --pmc passes for FETCH_SIZE "
@@ -71,6 +92,6 @@ if all(v is not None for v in fetch + write):
                 "and counted 1:1).",
         "source": f"profiles/{tag}_pmc_per_launch.csv (tools/collect_profiles.sh)",
     }
-    with open(os.path.join(dst, "traffic.json"), "w") as fh:
-        json.dump(traffic, fh, indent=1)
-    print("traffic:", traffic["hbm_bytes_per_sweep"] / 1e6, "MB per sweep (corrected)")
+    with open(os.path.join(dst, "counters.json"), "w") as fh:
+        json.dump(counters_out, fh, indent=1)
+    print("traffic:", counters_out["hbm_bytes_per_sweep"] / 1e6, "MB per sweep (corrected); collected at", commit)

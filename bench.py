@@ -249,7 +249,8 @@ def worker(args, rank, world, local_rank):
 
     work = WORKLOADS[args.config]
     n_per_gpu = args.disorder_per_gpu or work["n_disorder"]
-    comm = Comm(rank, world, local_rank) if world > 1 else None
+    # (PEAPODS_BENCH_FORCE_COMM: take the RCCL path with one rank too -- how a 1-GPU box rehearses the 8-GPU run)
+    comm = Comm(rank, world, local_rank) if world > 1 or os.environ.get("PEAPODS_BENCH_FORCE_COMM") else None
 
     sim, couplings, temps, dynamics_seed = build_ensemble(work, rank, n_per_gpu, world, local_rank)
     n_spins = int(np.prod(work["shape"]))

@@ -16,6 +16,7 @@ MASTER_ADDR:MASTER_PORT (`exchange_id`).  The CPU rehearsal in tests/ passes a g
 import ctypes as C
 import os
 import socket
+import sys
 import time
 
 import numpy as np
@@ -87,13 +88,22 @@ class Comm:
                 raise RuntimeError(err.value.decode())
             return buf.raw
 
-        uid = exchange_id(self.rank, self.world, make_id, addr, port)
-        if len(uid) != nat.PA_COMM_ID_BYTES:
-            raise RuntimeError("communicator id of the wrong size")
-        handle = C.c_void_p()
-        err = C.create_string_buffer(512)
-        code = self._lib.pa_comm_init_rank(C.create_string_buffer(uid, len(uid)), self.world, self.rank,
-                                           int(device), C.byref(handle), err, len(err))
+        # RCCL prints a version banner on stdout when it initialises; programs that print machine-readable
+        # results there (bench.py) must not carry it, so file descriptor 1 points at stderr meanwhile
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            uid = exchange_id(self.rank, self.world, make_id, addr, port)
+            if len(uid) != nat.PA_COMM_ID_BYTES:
+                raise RuntimeError("communicator id of the wrong size")
+            handle = C.c_void_p()
+            err = C.create_string_buffer(512)
+            code = self._lib.pa_comm_init_rank(C.create_string_buffer(uid, len(uid)), self.world, self.rank,
+                                               int(device), C.byref(handle), err, len(err))
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
         if code != nat.PA_OK:
             raise RuntimeError(err.value.decode())
         self._handle = handle

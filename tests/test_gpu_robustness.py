@@ -153,3 +153,31 @@ def test_soak_small_block_random_stream(oracle):
 def test_soak_fused_overlap_launch(oracle):
     """k_rng_overlap: the overlap of sweep s-1 measured inside the launch that draws sweep s."""
     _soak(oracle, (8, 8, 8), 6, 4, 3, range(50), 5, kind="glass", pt_interval=1, warmup_ratio=0.2)
+
+
+def test_rccl_communicator_single_rank(oracle):
+    """pa_comm_* (RCCL bound by dlopen, no torch): a one-rank communicator on this box's GPU runs the same code
+    path the 8-GPU bench takes -- id, init, barrier, all-reduce, all-gather, gathered result blocks."""
+    from peapods_amd import IsingSimulation
+    from peapods_amd.distributed import Comm, aggregate_mean, all_gather_blocks
+
+    comm = Comm(0, 1, 0)
+    try:
+        comm.barrier()
+        assert comm.max_f64(2.5) == 2.5
+        np.testing.assert_array_equal(comm.sum_u64([3, 4]), np.array([3, 4], dtype=np.uint64))
+        x = np.arange(12, dtype=np.float64).reshape(3, 4)
+        np.testing.assert_array_equal(comm.all_gather(x), x[None])
+        shape, n_rep = (4, 4, 4), 2
+        temps = np.linspace(1.0, 2.0, 3).astype(np.float32)
+        J = bimodal(shape, 3, 8)
+        sim = IsingSimulation(list(shape), J, temps, n_rep, None, 4)
+        sim.sample(10, "metropolis", pt_interval=1)
+        blocks = sim.result_blocks()
+        np.testing.assert_array_equal(comm.gather_result_blocks(sim, 3), blocks)
+        np.testing.assert_array_equal(all_gather_blocks(blocks, comm), blocks)
+        cpu = oracle.OracleSimulation(list(shape), J, temps, n_rep, None, 4)
+        want = cpu.sample(10, "metropolis", pt_interval=1)
+        np.testing.assert_array_equal(aggregate_mean(blocks)[:3], want["mags"])
+    finally:
+        comm.close()

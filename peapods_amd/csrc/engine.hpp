@@ -73,6 +73,10 @@ struct DevPtrs {
                              // exchanges the two after the launch
     uint32_t *system_ids;    // [n_real][n_sys]  slot -> system
     uint32_t *slot_of;       // [n_real][n_sys]  system -> slot
+    uint32_t *system_ids_out; // same shapes: where a RELAYED tempering event (PtParams::relay: the measurement block
+    uint32_t *slot_of_out;    //   rides in the next sweep's random-stream launch) leaves the new permutation -- the
+                             //   random-stream workgroups of that launch still read the old one; the host exchanges
+                             //   the pairs after the launch
     const uint32_t *thr;     // [2][2][3][n_temps] thresholds: even set (dE=-2,-4,-6), odd set (-1,-3,-5);
                              //   second copy shifted left by 8 (valid when thr_preshifted)
     const uint32_t *thr_gibbs; // [2][7][n_temps] Gibbs thresholds, falling: even set dE = 2z', 2z'-2, ..;
@@ -103,6 +107,9 @@ struct DevPtrs {
     const int32_t *nz_bonds; // [n_real] number of non-zero forward bonds
     int32_t *dot_spin;       // [n_real][n_pairs][n_temps]
     int32_t *dot_link;       // [n_real][n_pairs][n_temps]
+    int32_t *dot_spin_prev;  // the pair the latest overlap launch wrote: the host exchanges dot_* and dot_*_prev after
+    int32_t *dot_link_prev;  //   every overlap launch, measurement blocks read *_prev (an overlap block of their own
+                             //   launch may already be writing dot_* for the next sweep)
     double *mom;             // [n_real][5][n_temps] running f64 sums
     double *ovm;             // [n_real][6][n_temps]
     uint64_t *hist;          // [n_real][n_temps][N + 1]
@@ -205,6 +212,10 @@ struct PtParams {
     // bit 0: the moment sums start from zero with this launch; bit 1: the overlap sums and the P(q) bitmap do
     // (the accumulators are never memset: the first accumulating launch of a run stores instead of adding)
     uint32_t fresh;
+    // 1: this event runs inside the random-stream launch of the NEXT sweep (k_rng_overlap): its workgroups replay
+    // the swap decisions themselves and fetch their generators from the slots the systems come from, so the event
+    // neither permutes cursors nor rewrites energies, and it files the permutation in system_ids_out / slot_of_out
+    uint32_t relay;
 };
 
 // All launchers enqueue on `stream` and return the hipGetLastError() of the launch.
@@ -213,6 +224,11 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
                         bool gibbs, hipStream_t stream);
 hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 hipError_t launch_rng_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream);
+// The random stream of a sweep with the previous sweep's overlap measurement (with_overlap) and / or its deferred
+// measurement block (statistics + tempering event, pt.relay = 1) riding in the same launch.
+hipError_t launch_rng_relay(const SimDims &d, const DevPtrs &p, bool with_overlap, const PtParams &pt, bool do_accum,
+                            bool accum_overlap, bool do_pt, hipStream_t stream);
+bool rng_relay_supported(const SimDims &d);
 hipError_t launch_sweep_pipe(const SimDims &d, const DevPtrs &p, bool gibbs, uint32_t epoch, hipStream_t stream);
 hipError_t launch_apply_swaps(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 hipError_t launch_houdayer(const SimDims &d, const DevPtrs &p, hipStream_t stream);

@@ -32,6 +32,21 @@ template <int LANE> __device__ __forceinline__ uint32_t park_in_lane(uint32_t ve
     return vec;
 }
 
+// Esum entry -> f32 energy sum: an exact integer on the unit-coupling path, raw f32 bits of the
+// reference's sequential sum on the general path.
+__device__ __forceinline__ float energy_sum(int32_t raw, uint32_t general) {
+    return general ? __int_as_float(raw) : static_cast<float>(raw);
+}
+
+// The tempering criterion N (e2 - e1) (1/T1 - 1/T2) >= ln u (tempering.rs:88-91) in the reference's f32 order.
+__device__ __forceinline__ bool pt_accept(float n_f, int32_t e_left_raw, int32_t e_right_raw, uint32_t general,
+                                          float dbeta, float ln_u) {
+    const float e1 = __fdiv_rn(energy_sum(e_left_raw, general), n_f);
+    const float e2 = __fdiv_rn(energy_sum(e_right_raw, general), n_f);
+    const float delta = __fmul_rn(__fmul_rn(n_f, __fsub_rn(e2, e1)), dbeta);
+    return delta >= ln_u;
+}
+
 // PRESHIFTED: the thresholds were shifted left by 8 on the host (all of them < 2^24), so the
 // high word is compared directly: (top >> 8) < c  <=>  top < (c << 8).
 template <int JJ, bool PRESHIFTED>
@@ -105,7 +120,13 @@ __device__ __forceinline__ void rng_chunk32_gibbs(Rng32 &rng, const uint32_t c[7
 // ---------------------------------------------------------------------------
 // GIBBS: seven thresholds per parity class and a third level plane (planes_hi); thresholds are
 // compared unshifted (a Gibbs threshold can be 2^24 = "every draw").
-template <bool PRESHIFTED, bool GIBBS>
+// REPLAY: the tempering event of the previous sweep has not been applied to the cursors (it runs as a measurement
+// block of this very launch, PtParams::relay).  Every workgroup therefore replays the swap decisions of the
+// replica ladders its tile words belong to (one lane per ladder: the generator of system r * n_temps as the
+// previous sweep left it, gen_range for the edge, the f32 criterion -- the same code the event runs) and each lane
+// then fetches the state of the system that sits in its slot AFTER the event: its own slot's, or the neighbouring
+// slot's when its edge was accepted; the lane that receives the ladder's generator skips the draws the event used.
+template <bool PRESHIFTED, bool GIBBS, bool REPLAY = false>
 __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, uint32_t bid, uint32_t *tab) {
     // tab: [64 * 16 * 8] dwords of LDS for the block's jump table
     const uint32_t block = bid % d.B;
@@ -125,7 +146,64 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
         for (uint32_t i = tid; i < 64 * 16 * 2; i += 256) dst[i] = src[i];
     }
     uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (active) load_cursor(p.cursor, real, d.SP, slot, st);
+    uint32_t src_slot = slot, skip_draws = 0;
+    if (REPLAY) {
+        uint32_t *dec = tab + 64 * 16 * 8; // [<= 256] edge | accepted << 16 | draws << 17 per (realisation, ladder)
+        const uint32_t tw0 = group * 8, real0 = tw0 / d.W;
+        const uint32_t real1 = min(tw0 + 7u, n_tw - 1u) / d.W;
+        const uint32_t n_tasks = (real1 - real0 + 1u) * d.n_replicas; // (<= 256: rng_relay_supported)
+        if (tid < n_tasks) {
+            const uint32_t r = real0 + tid / d.n_replicas, offset = (tid % d.n_replicas) * d.n_temps;
+            uint32_t gs[8];
+            load_cursor(p.cursor, r, d.SP, p.slot_of[static_cast<size_t>(r) * d.n_sys + offset], gs);
+            DevRng g;
+            g.s0 = (static_cast<uint64_t>(gs[1]) << 32) | gs[0];
+            g.s1 = (static_cast<uint64_t>(gs[3]) << 32) | gs[2];
+            g.s2 = (static_cast<uint64_t>(gs[5]) << 32) | gs[4];
+            g.s3 = (static_cast<uint64_t>(gs[7]) << 32) | gs[6];
+            // rand 0.8.5 gen_range(0..n_temps-1) on usize (tempering.rs:33), then the uniform draw (:89)
+            const uint64_t range = d.n_temps - 1;
+            const uint64_t zone = (range << __clzll(range)) - 1;
+            uint32_t n_draws = 0, edge;
+            for (;;) {
+                const uint64_t v = g.next();
+                ++n_draws;
+                if (v * range <= zone) {
+                    edge = static_cast<uint32_t>(__umul64hi(v, range));
+                    break;
+                }
+            }
+            const uint32_t draw = static_cast<uint32_t>(g.next() >> 40);
+            ++n_draws;
+            const int32_t *E = p.Esum + static_cast<size_t>(r) * d.n_sys + offset + edge;
+            const bool accepted = pt_accept(static_cast<float>(d.N), E[0], E[1], d.general, p.dbeta[edge], p.ln_table[draw]);
+            dec[tid] = edge | (accepted ? 1u << 16 : 0u) | (n_draws << 17);
+        }
+        __syncthreads();
+        if (active) {
+            const uint32_t rep = slot / d.n_temps, t = slot % d.n_temps;
+            const uint32_t v = dec[(real - real0) * d.n_replicas + rep];
+            const uint32_t edge = v & 0xFFFFu;
+            if ((v >> 16) & 1u) {
+                if (t == edge) src_slot = slot + 1;
+                else if (t == edge + 1) src_slot = slot - 1;
+            }
+            if (p.system_ids[static_cast<size_t>(real) * d.n_sys + src_slot] == rep * d.n_temps) skip_draws = v >> 17;
+        }
+    }
+    if (active) load_cursor(p.cursor, real, d.SP, src_slot, st);
+    if (REPLAY && skip_draws) { // the ladder's generator: the event's draws come before this sweep's
+        DevRng g;
+        g.s0 = (static_cast<uint64_t>(st[1]) << 32) | st[0];
+        g.s1 = (static_cast<uint64_t>(st[3]) << 32) | st[2];
+        g.s2 = (static_cast<uint64_t>(st[5]) << 32) | st[4];
+        g.s3 = (static_cast<uint64_t>(st[7]) << 32) | st[6];
+        for (uint32_t k = 0; k < skip_draws; ++k) (void)g.next();
+        st[0] = static_cast<uint32_t>(g.s0); st[1] = static_cast<uint32_t>(g.s0 >> 32);
+        st[2] = static_cast<uint32_t>(g.s1); st[3] = static_cast<uint32_t>(g.s1 >> 32);
+        st[4] = static_cast<uint32_t>(g.s2); st[5] = static_cast<uint32_t>(g.s2 >> 32);
+        st[6] = static_cast<uint32_t>(g.s3); st[7] = static_cast<uint32_t>(g.s3 >> 32);
+    }
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane((group * 4 + wave) * 2) >= n_tw) return; // idle wave
     if (block > 0) jump_state_lds(st, tab);
@@ -1195,12 +1273,6 @@ __global__ __launch_bounds__(256) void k_rng_overlap(SimDims d, DevPtrs p, uint3
 //      the generator of system r*n_temps; accepted swaps exchange adjacent bit
 //      columns of the tile, and the slot cursors are permuted accordingly.
 // ---------------------------------------------------------------------------
-// Esum entry -> f32 energy sum: an exact integer on the unit-coupling path, raw f32 bits of the
-// reference's sequential sum on the general path.
-__device__ __forceinline__ float energy_sum(int32_t raw, uint32_t general) {
-    return general ? __int_as_float(raw) : static_cast<float>(raw);
-}
-
 struct MeasureLds {
     uint32_t *scratch; // [17][48]
     int32_t *dot_spin; // [n_sys]
@@ -1269,8 +1341,10 @@ __device__ __forceinline__ void measure_block(const SimDims &d, const DevPtrs &p
     // ---- (1) overlap dots come from k_overlap (previous launch on this stream) --------
     if ((accum_overlap || pt.equil) && d.n_pairs)
         for (uint32_t k = tid; k < d.n_pairs * d.n_temps; k += nthreads) {
-            m.dot_spin[k] = p.dot_spin[static_cast<size_t>(real) * d.n_pairs * d.n_temps + k];
-            m.dot_link[k] = p.dot_link[static_cast<size_t>(real) * d.n_pairs * d.n_temps + k];
+            // (the most recent overlap launch: the host exchanged dot_* and dot_*_prev after it -- an overlap
+            // block of THIS launch may be writing dot_* for the next sweep already)
+            m.dot_spin[k] = p.dot_spin_prev[static_cast<size_t>(real) * d.n_pairs * d.n_temps + k];
+            m.dot_link[k] = p.dot_link_prev[static_cast<size_t>(real) * d.n_pairs * d.n_temps + k];
         }
     __syncthreads();
     PA_STAMP(2)
@@ -1430,11 +1504,8 @@ __device__ __forceinline__ void measure_block(const SimDims &d, const DevPtrs &p
             }
             const uint32_t sl = offset + edge, sr = sl + 1;
             const uint32_t left = m.sid[sl], right = m.sid[sr];
-            const float e1 = __fdiv_rn(energy_sum(m.E[sl], d.general), n_f);
-            const float e2 = __fdiv_rn(energy_sum(m.E[sr], d.general), n_f);
-            const float delta = __fmul_rn(__fmul_rn(n_f, __fsub_rn(e2, e1)), p.dbeta[edge]);
             const uint32_t draw = static_cast<uint32_t>(rng.next() >> 40);
-            const bool accepted = delta >= p.ln_table[draw];
+            const bool accepted = pt_accept(n_f, m.E[sl], m.E[sr], d.general, p.dbeta[edge], p.ln_table[draw]);
             atomicAdd(&m.att[edge], 1u);
             if (accepted) {
                 atomicAdd(&m.acc[edge], 1u);
@@ -1470,6 +1541,19 @@ __device__ __forceinline__ void measure_block(const SimDims &d, const DevPtrs &p
         if (m.acc[k]) p.edge_acc[static_cast<size_t>(real) * d.n_edges + k] += m.acc[k];
     }
     const bool any_swap = m.flags[0] != 0;
+    if (pt.relay) {
+        // The random-stream workgroups of this launch replay the event and take every slot's generator from the
+        // slot its system comes from (rng_block), so nothing is permuted here; the new permutation goes to the
+        // second pair of tables (those workgroups still read the old one), the energies are recomputed by the
+        // sweep that follows before anything reads them.
+        for (uint32_t k = tid; k < d.n_sys; k += nthreads) {
+            p.system_ids_out[static_cast<size_t>(real) * d.n_sys + k] = m.sid[k];
+            p.slot_of_out[static_cast<size_t>(real) * d.n_sys + m.sid[k]] = k;
+        }
+        if (tid < 2 * d.W) p.swap_masks[static_cast<size_t>(real) * 2 * d.W + tid] = m.masks[tid];
+        if (tid == 0 && any_swap) p.swap_epoch[real] += 1;
+        return;
+    }
     // cursors follow their systems: new cursor[slot] = old cursor[old slot of the system now there].
     // All loads complete (registers) before any store, so the permutation needs no ordering.
     // (a thread owns up to two slots: n_sys <= 2 * blockDim.x, checked on the host)
@@ -1538,6 +1622,23 @@ __global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams
     extern __shared__ uint32_t lds_dyn[];
     (void)do_overlap;
     measure_block<STAMPS>(d, p, pt, do_accum, accum_overlap, do_pt, stamps, blockIdx.x, lds_dyn);
+}
+
+// One launch, three kinds of workgroups: [0, n_overlap) measure the overlap of the state the previous sweep left,
+// [n_overlap, n_overlap + n_measure) are that sweep's measurement blocks (statistics + tempering event, one per
+// realisation, PtParams::relay), the rest draw the random stream of the next sweep -- with REPLAY they apply the
+// event's cursor permutation themselves.  A sweep of the plain protocol is then two launches (this one and the
+// sweep kernel) instead of three, and the latency-bound measurement hides under the VALU-bound random stream.
+template <bool PRESHIFTED, bool REPLAY>
+__global__ __launch_bounds__(256) void k_rng_relay(SimDims d, DevPtrs p, uint32_t n_overlap, uint32_t n_measure, PtParams pt,
+                                                   int do_accum, int accum_overlap, int do_pt) {
+    extern __shared__ uint32_t lds_dyn[];
+    if (blockIdx.x < n_overlap)
+        overlap_block(d, p, blockIdx.x, lds_dyn);
+    else if (blockIdx.x < n_overlap + n_measure)
+        measure_block<false>(d, p, pt, do_accum, accum_overlap, do_pt, nullptr, blockIdx.x - n_overlap, lds_dyn);
+    else
+        rng_block<PRESHIFTED, false, REPLAY>(d, p, blockIdx.x - n_overlap - n_measure, lds_dyn);
 }
 
 // ---------------------------------------------------------------------------
@@ -2271,6 +2372,9 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
                 return;
             }
         }
+        // the next level's inputs have landed (the loader's counted wait before X(level)): request them now, so that
+        // their LDS round trip runs beside this level's instead of after it
+        const Inputs upcoming = pick_up(level + 1);
         // ---- this level's sites
         if (tid < cur.count) {
             const uint4 r = cur.r;
@@ -2293,7 +2397,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
                 asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(xchg + (cur.target - 1)), "v"(record) : "memory");
             }
         }
-        cur = pick_up(level + 1);
+        cur = upcoming;
     }
 }
 
@@ -2446,6 +2550,10 @@ hipError_t configure_kernels(const SimDims &) {
                            reinterpret_cast<const void *>(k_sweep_hc<3, true>),
                            reinterpret_cast<const void *>(k_overlap),
                            reinterpret_cast<const void *>(k_overlap_wide),
+                           reinterpret_cast<const void *>(k_rng_relay<false, false>),
+                           reinterpret_cast<const void *>(k_rng_relay<false, true>),
+                           reinterpret_cast<const void *>(k_rng_relay<true, false>),
+                           reinterpret_cast<const void *>(k_rng_relay<true, true>),
                            reinterpret_cast<const void *>(k_rng_overlap<false>),
                            reinterpret_cast<const void *>(k_rng_overlap<true>),
                            reinterpret_cast<const void *>(k_houdayer),
@@ -2487,6 +2595,35 @@ hipError_t launch_rng_overlap(const SimDims &d, const DevPtrs &p, hipStream_t st
         hipLaunchKernelGGL(k_rng_overlap<true>, dim3(n_overlap + groups * d.B), dim3(256), lds, stream, d, p, n_overlap);
     else
         hipLaunchKernelGGL(k_rng_overlap<false>, dim3(n_overlap + groups * d.B), dim3(256), lds, stream, d, p, n_overlap);
+    return hipGetLastError();
+}
+
+// A relayed measurement block needs: a workgroup of 256 threads (measure_block: n_sys <= 2 x 256, n_temps,
+// n_replicas, 2 W <= 256), one replay lane per (realisation, ladder) of a random-stream workgroup's eight tile words,
+// the on-chip table kernels.
+bool rng_relay_supported(const SimDims &d) {
+    const uint32_t reals_per_block = 7u / d.W + 2u;
+    return !d.general && !d.big && d.n_sys <= 512 && d.n_temps <= 256 && d.n_replicas <= 256 && 2 * d.W <= 256 &&
+           reals_per_block * d.n_replicas <= 256 && measure_lds_bytes(d) <= kRngLds;
+}
+
+hipError_t launch_rng_relay(const SimDims &d, const DevPtrs &p, bool with_overlap, const PtParams &pt, bool do_accum,
+                            bool accum_overlap, bool do_pt, hipStream_t stream) {
+    const uint32_t n_pairs_tw = (d.n_real * d.W + 1) / 2;
+    const uint32_t groups = (n_pairs_tw + 3) / 4;
+    const uint32_t n_overlap = with_overlap ? d.n_real * d.W : 0u;
+    const uint32_t n_measure = (do_accum || accum_overlap || do_pt) ? d.n_real : 0u;
+    const bool replay = n_measure && do_pt && d.n_temps >= 2;
+    const size_t lds = std::max(kRngLds + 1024, overlap_lds_bytes(d)); // + the replayed decisions
+    const dim3 grid(n_overlap + n_measure + groups * d.B), block(256);
+    const int a = do_accum ? 1 : 0, o = accum_overlap ? 1 : 0, t = do_pt ? 1 : 0;
+    if (d.thr_preshifted) {
+        if (replay) hipLaunchKernelGGL((k_rng_relay<true, true>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
+        else hipLaunchKernelGGL((k_rng_relay<true, false>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
+    } else {
+        if (replay) hipLaunchKernelGGL((k_rng_relay<false, true>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
+        else hipLaunchKernelGGL((k_rng_relay<false, false>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
+    }
     return hipGetLastError();
 }
 

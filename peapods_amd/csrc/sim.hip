@@ -329,14 +329,39 @@ int zero_accumulators(pa_sim *sim) {
     return PA_OK;
 }
 
+// the "start from zero" bits of `fresh` a measurement with these flags consumes
+uint32_t consume_fresh(uint32_t &fresh, const SimDims &d, bool do_accum, bool accum_overlap) {
+    const uint32_t bits = (do_accum ? fresh & 1u : 0u) | ((accum_overlap && d.n_pairs) ? fresh & 2u : 0u);
+    fresh &= ~bits;
+    return bits;
+}
+
 // launch_measure with the "start from zero" bits of `fresh` this launch consumes
 hipError_t measure_launch(uint32_t &fresh, const SimDims &d, const DevPtrs &p, PtParams pt, bool do_accum,
                           bool accum_overlap, bool do_pt, hipStream_t stream) {
-    pt.fresh = (do_accum ? fresh & 1u : 0u) | ((accum_overlap && d.n_pairs) ? fresh & 2u : 0u);
-    fresh &= ~pt.fresh;
+    pt.fresh = consume_fresh(fresh, d, do_accum, accum_overlap);
     return launch_measure(d, p, pt, false, do_accum, accum_overlap, do_pt, stream);
 }
 
+// The dot products of an overlap launch go to dot_*; measurement blocks read dot_*_prev: exchange after the launch.
+void toggle_dots(DevPtrs &p) {
+    std::swap(p.dot_spin, p.dot_spin_prev);
+    std::swap(p.dot_link, p.dot_link_prev);
+}
+hipError_t overlap_launch(const SimDims &d, DevPtrs &p, hipStream_t stream) {
+    const hipError_t e = launch_overlap(d, p, stream);
+    toggle_dots(p);
+    return e;
+}
+// A relayed tempering event filed the new slot <-> system permutation in the second pair of tables.
+void toggle_system_tables(pa_sim *sim) {
+    std::swap(sim->p.system_ids, sim->p.system_ids_out);
+    std::swap(sim->p.slot_of, sim->p.slot_of_out);
+    for (auto &g : sim->groups) {
+        std::swap(g.p.system_ids, g.p.system_ids_out);
+        std::swap(g.p.slot_of, g.p.slot_of_out);
+    }
+}
 // true while no launch since the last zero_accumulators has accumulated into (bit 0: moments, bit 1: overlap)
 bool nothing_accumulated(const pa_sim *sim, uint32_t bit) {
     if (!(sim->fresh & bit)) return false;
@@ -365,6 +390,8 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     q.cursor_out += static_cast<size_t>(8) * d.SP * r0;
     q.system_ids += static_cast<size_t>(d.n_sys) * r0;
     q.slot_of += static_cast<size_t>(d.n_sys) * r0;
+    q.system_ids_out += static_cast<size_t>(d.n_sys) * r0;
+    q.slot_of_out += static_cast<size_t>(d.n_sys) * r0;
     q.mpar += static_cast<size_t>(d.MW) * r0;
     q.rec += (static_cast<size_t>(d.N) + 1) * (d.big ? 2 : 1) * r0;
     if (d.hc) q.hc_tab += static_cast<size_t>(d.N) * r0;
@@ -378,6 +405,8 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     q.nz_bonds += r0;
     q.dot_spin += static_cast<size_t>(d.n_pairs) * d.n_temps * r0;
     q.dot_link += static_cast<size_t>(d.n_pairs) * d.n_temps * r0;
+    q.dot_spin_prev += static_cast<size_t>(d.n_pairs) * d.n_temps * r0;
+    q.dot_link_prev += static_cast<size_t>(d.n_pairs) * d.n_temps * r0;
     q.mom += static_cast<size_t>(5) * d.n_temps * r0;
     q.ovm += static_cast<size_t>(6) * d.n_temps * r0;
     if (d.n_pairs) {
@@ -837,6 +866,13 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     const bool fused = want_overlap && !gibbs && !fk && !equil && !autocorr && cfg->overlap_cluster_interval == 0 && !d.big &&
                        !d.general && !std::getenv("PEAPODS_NO_FUSE");
     bool overlap_owed = false; // the last recorded sweep's overlap has not been measured yet
+    // the measurement block of the previous sweep when it is relayed into the next sweep's random-stream launch
+    struct {
+        bool any = false, do_accum = false, accum_overlap = false, do_pt = false;
+        PtParams pt{};
+    } pending;
+    const bool relay = fused && cfg->pt_schedule == PA_PT_SINGLE_RANDOM_EDGE && rng_relay_supported(d) &&
+                       !std::getenv("PEAPODS_NO_RELAY");
     // Cooperative cancel (src/lib.rs:304-308, mod.rs:406-408): the host runs at most two batches of
     // kBatch sweeps ahead of the device, so a request is honoured within that much queued work; the
     // state then is the one after the last enqueued sweep (a continuation from it is well defined).
@@ -877,23 +913,46 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         if (fused) {
             // Plain protocol on the LDS kernels: the overlap of the state sweep s-1 left is measured
             // inside the launch that draws the random stream of sweep s, and its statistics are
-            // accumulated by the measurement kernel of sweep s.  Every accumulator still receives
+            // accumulated by the measurement block of sweep s.  Every accumulator still receives
             // its values in sweep order, so the f64 sums are unchanged.
-            PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
+            // With `relay` the measurement block of sweep s-1 (statistics + tempering event) rides in that
+            // launch too: the random-stream workgroups replay the swap decisions and fetch their generators
+            // from the slots the systems come from, so a sweep is two launches, not three.
+            const bool relayed = relay && pending.any;
             for (auto &g : sim->groups) {
-                if (overlap_owed)
+                if (relayed) {
+                    PtParams q = pending.pt;
+                    q.relay = 1;
+                    q.fresh = consume_fresh(g.fresh, g.d, pending.do_accum, pending.accum_overlap);
+                    PA_HIP(sim, launch_rng_relay(g.d, g.p, overlap_owed, q, pending.do_accum, pending.accum_overlap,
+                                                 pending.do_pt, g.stream));
+                } else if (overlap_owed) {
                     PA_HIP(sim, launch_rng_overlap(g.d, g.p, g.stream));
-                else
+                } else {
                     PA_HIP(sim, launch_rng(g.d, g.p, false, g.stream));
+                }
+                if (overlap_owed) toggle_dots(g.p);
                 PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, record || pt_this, false, g.stream));
             }
+            if (relayed && pending.do_pt && d.n_temps >= 2) toggle_system_tables(sim);
+            pending.any = false;
             sim->swaps_pending = false;
             toggle_spin_buffers(sim);
-            if (record || pt_this || overlap_owed)
-                for (auto &g : sim->groups)
-                    PA_HIP(sim, measure_launch(g.fresh, g.d, g.p, pt, record, overlap_owed, pt_this, g.stream));
+            PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
+            if (record || pt_this || overlap_owed) {
+                if (relay) { // deferred into the next sweep's launch (or the tail of the run)
+                    pending.any = true;
+                    pending.pt = pt;
+                    pending.do_accum = record;
+                    pending.accum_overlap = overlap_owed;
+                    pending.do_pt = pt_this;
+                } else {
+                    for (auto &g : sim->groups)
+                        PA_HIP(sim, measure_launch(g.fresh, g.d, g.p, pt, record, overlap_owed, pt_this, g.stream));
+                    if (pt_this) sim->swaps_pending = true;
+                }
+            }
             overlap_owed = record;
-            if (pt_this) sim->swaps_pending = true;
             if (record) sim->n_recorded += 1;
             if (pt_this && cfg->pt_schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
             continue;
@@ -918,7 +977,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                 PA_HIP(sim, launch_fk(g.d, g.p, cfg->cluster_mode == PA_CLUSTER_WOLFF, aux, g.stream));
                 if (record || pt_this || equil) PA_HIP(sim, launch_sweep(g.d, g.p, true, false, false, g.stream));
             }
-            if (((record && want_overlap) || equil) && d.n_pairs) PA_HIP(sim, launch_overlap(g.d, g.p, g.stream)); // :527-529
+            if (((record && want_overlap) || equil) && d.n_pairs) PA_HIP(sim, overlap_launch(g.d, g.p, g.stream)); // :527-529
             const bool oc_this = cfg->overlap_cluster_interval > 0 &&
                                  sweep_id % cfg->overlap_cluster_interval == 0; // :598-599
             PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot,
@@ -1031,25 +1090,29 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         }
         if (pt_this && cfg->pt_schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
     }
-    if (overlap_owed) {
-        PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
-        for (auto &g : sim->groups) {
-            PA_HIP(sim, launch_overlap(g.d, g.p, g.stream));
-            PA_HIP(sim, measure_launch(g.fresh, g.d, g.p, pt, false, true, false, g.stream));
-        }
-        overlap_owed = false;
-    }
     return PA_OK;
     };
     int status = enqueue_all();
-    if (status != PA_OK && overlap_owed) {
-        // stopped between a recorded sweep and its deferred overlap measurement: take it now, so that the
-        // accumulators hold whole sweeps only
+    // The tail of the fused protocol -- also after an interrupt or a failed launch, so that the accumulators hold
+    // whole sweeps only and the last sweep's tempering event has run: the deferred measurement block of the last
+    // sweep (as its own launch now), then that sweep's overlap.
+    if (pending.any) {
+        for (auto &g : sim->groups) {
+            const hipError_t e = measure_launch(g.fresh, g.d, g.p, pending.pt, pending.do_accum, pending.accum_overlap,
+                                                pending.do_pt, g.stream);
+            if (e != hipSuccess && status == PA_OK) status = fail(sim, PA_ERR_DEVICE, std::string("launch_measure: ") + hipGetErrorString(e));
+        }
+        if (pending.do_pt) sim->swaps_pending = true;
+        pending.any = false;
+    }
+    if (overlap_owed) {
         PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
         for (auto &g : sim->groups) {
-            (void)launch_overlap(g.d, g.p, g.stream);
-            (void)measure_launch(g.fresh, g.d, g.p, pt, false, true, false, g.stream);
+            hipError_t e = overlap_launch(g.d, g.p, g.stream);
+            if (e == hipSuccess) e = measure_launch(g.fresh, g.d, g.p, pt, false, true, false, g.stream);
+            if (e != hipSuccess && status == PA_OK) status = fail(sim, PA_ERR_DEVICE, std::string("overlap tail: ") + hipGetErrorString(e));
         }
+        overlap_owed = false;
     }
     sim->ac_samples = autocorr ? sim->n_recorded : 0;
     // join: the main stream continues after every group -- on every path out of this function
@@ -1748,6 +1811,10 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     ok(bufs.alloc(&sim->nz_bonds, nz_bonds.size()));
     ok(bufs.alloc(&p.dot_spin, n_pair_slots));
     ok(bufs.alloc(&p.dot_link, n_pair_slots));
+    ok(bufs.alloc(&p.dot_spin_prev, n_pair_slots));
+    ok(bufs.alloc(&p.dot_link_prev, n_pair_slots));
+    ok(bufs.alloc(&p.system_ids_out, static_cast<size_t>(d.n_real) * d.n_sys));
+    ok(bufs.alloc(&p.slot_of_out, static_cast<size_t>(d.n_real) * d.n_sys));
     ok(bufs.alloc(&p.mom, static_cast<size_t>(d.n_real) * 5 * d.n_temps));
     ok(bufs.alloc(&p.ovm, static_cast<size_t>(d.n_real) * 6 * d.n_temps));
     ok(bufs.alloc(&p.hist, bins));
@@ -1939,37 +2006,61 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
     for (auto &e : ev) PA_HIP(sim, hipEventCreate(&e));
     double total[3] = {0, 0, 0};
     uint64_t count[3] = {0, 0, 0};
-    // same launch sequence as run_sweeps on one stream; with the fused path the overlap of the
-    // previous sweep rides in the random-stream launch (reported under k_rng)
+    // same launch sequence as run_sweeps on one stream; with the fused path the overlap of the previous sweep --
+    // and, relayed, its measurement block -- ride in the random-stream launch (reported under k_rng)
     const bool fused = want_overlap && !gibbs && !d.big && !d.general && !std::getenv("PEAPODS_NO_FUSE");
+    const bool relay = fused && cfg->pt_schedule == PA_PT_SINGLE_RANDOM_EDGE && rng_relay_supported(d) &&
+                       !std::getenv("PEAPODS_NO_RELAY");
+    struct {
+        bool any = false, do_accum = false, accum_overlap = false, do_pt = false;
+        PtParams pt{};
+    } pending;
     bool overlap_owed = false;
     for (uint64_t sweep_id = 0; sweep_id < n_sweeps; ++sweep_id) {
         const bool record = sweep_id >= cfg->warmup_sweeps;
         const bool pt_this = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0;
         PA_HIP(sim, hipEventRecord(ev[0], sim->stream));
-        if (fused && overlap_owed)
+        const bool relayed = relay && pending.any;
+        if (relayed) {
+            PtParams q = pending.pt;
+            q.relay = 1;
+            q.fresh = consume_fresh(sim->fresh, d, pending.do_accum, pending.accum_overlap);
+            PA_HIP(sim, launch_rng_relay(d, sim->p, overlap_owed, q, pending.do_accum, pending.accum_overlap, pending.do_pt,
+                                         sim->stream));
+            if (pending.do_pt && d.n_temps >= 2) toggle_system_tables(sim);
+        } else if (fused && overlap_owed) {
             PA_HIP(sim, launch_rng_overlap(d, sim->p, sim->stream));
-        else
+        } else {
             PA_HIP(sim, launch_rng(d, sim->p, gibbs, sim->stream));
+        }
+        if (fused && overlap_owed) toggle_dots(sim->p);
+        pending.any = false;
         PA_HIP(sim, hipEventRecord(ev[1], sim->stream));
-        const bool measured = record || pt_this || (fused && overlap_owed);
         PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
         PA_HIP(sim, enqueue_sweep(sim, d, sim->p, record || pt_this, gibbs, sim->stream));
         sim->swaps_pending = false;
         toggle_spin_buffers(sim);
         PA_HIP(sim, hipEventRecord(ev[2], sim->stream));
-        if (measured) {
+        const bool wants_measure = record || pt_this || (fused && overlap_owed);
+        bool measured = false;
+        if (wants_measure && relay) {
+            pending.any = true;
+            pending.pt = pt;
+            pending.do_accum = record;
+            pending.accum_overlap = overlap_owed;
+            pending.do_pt = pt_this;
+        } else if (wants_measure) {
+            measured = true;
             if (fused) {
                 PA_HIP(sim, measure_launch(sim->fresh, d, sim->p, pt, record, overlap_owed, pt_this, sim->stream));
             } else {
-                if (record && want_overlap) PA_HIP(sim, launch_overlap(d, sim->p, sim->stream));
+                if (record && want_overlap) PA_HIP(sim, overlap_launch(d, sim->p, sim->stream));
                 PA_HIP(sim, measure_launch(sim->fresh, d, sim->p, pt, record, record && want_overlap, pt_this,
                                            sim->stream));
             }
-            if (pt_this && cfg->pt_schedule == PA_PT_FULL_LADDER)
-                sim->next_parity = 1 - sim->next_parity;
             if (pt_this) sim->swaps_pending = true;
         }
+        if (pt_this && cfg->pt_schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
         if (fused) overlap_owed = record;
         if (record) sim->n_recorded += 1;
         PA_HIP(sim, hipEventRecord(ev[3], sim->stream));
@@ -1982,9 +2073,14 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
             count[k] += 1;
         }
     }
+    if (pending.any) {
+        PA_HIP(sim, measure_launch(sim->fresh, d, sim->p, pending.pt, pending.do_accum, pending.accum_overlap, pending.do_pt,
+                                   sim->stream));
+        if (pending.do_pt) sim->swaps_pending = true;
+    }
     if (overlap_owed) {
         PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
-        PA_HIP(sim, launch_overlap(d, sim->p, sim->stream));
+        PA_HIP(sim, overlap_launch(d, sim->p, sim->stream));
         PA_HIP(sim, measure_launch(sim->fresh, d, sim->p, pt, false, true, false, sim->stream));
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
@@ -2037,7 +2133,7 @@ int pa_debug_measure_stamps(pa_sim *sim, unsigned long long out[7]) {
     PA_HIP(sim, launch_rng(sim->d, sim->p, false, sim->stream));
     PA_HIP(sim, launch_sweep(sim->d, sim->p, true, true, false, sim->stream));
     toggle_spin_buffers(sim);
-    PA_HIP(sim, launch_overlap(sim->d, sim->p, sim->stream));
+    PA_HIP(sim, overlap_launch(sim->d, sim->p, sim->stream));
     PtParams pt{0, sim->next_parity, sim->hot_slot, sim->cold_slot};
     PA_HIP(sim, launch_measure_stamped(sim->d, sim->p, pt, dev, sim->stream));
     sim->swaps_pending = true;
@@ -2092,11 +2188,11 @@ int pa_sim_overlap_dots(pa_sim *sim, int64_t *dot_spin, int64_t *dot_link) {
     if (d.n_pairs == 0) return fail(sim, PA_ERR_INVALID, "overlap needs n_replicas >= 2");
     PA_HIP(sim, hipSetDevice(sim->device));
     if (int rc = flush_swaps(sim)) return rc;
-    PA_HIP(sim, launch_overlap(d, sim->p, sim->stream));
+    PA_HIP(sim, overlap_launch(d, sim->p, sim->stream));
     const size_t count = static_cast<size_t>(d.n_real) * d.n_pairs * d.n_temps;
     std::vector<int32_t> a, b;
     int rc;
-    if ((rc = download(sim, a, sim->p.dot_spin, count)) || (rc = download(sim, b, sim->p.dot_link, count)))
+    if ((rc = download(sim, a, sim->p.dot_spin_prev, count)) || (rc = download(sim, b, sim->p.dot_link_prev, count)))
         return rc;
     for (size_t i = 0; i < count; ++i) {
         dot_spin[i] = a[i];

@@ -72,6 +72,59 @@ __device__ __forceinline__ void rng_chunk32(Rng32 &rng, uint32_t ca0, uint32_t c
     (rng_step<JJ, PRESHIFTED>(rng, ca0, ca1, ca2, keep0, keep1), ...);
 }
 
+// ---------------------------------------------------------------------------
+// The same 32 draws without ballots.  On gfx950 a compare into an SGPR pair and a v_writelane each hold the SIMD
+// about 4.2 cycles, v_sub / v_xor / v_bitop3 / v_lshrrev about 2.3 (tools/probe/valu_issue.hip,
+// profiles/r02_valu_issue.json), so per draw: draw24 - c has its sign set exactly when draw24 < c (both below 2^25),
+// the three signs fold into the two level bits, and one v_alignbit each shifts them into per-lane accumulators
+// ((acc << 1) | sign).  After 32 draws lane = slot holds 32 sites; a 32 x 32 bit transpose inside each half wave
+// (five butterfly stages: ds_swizzle xor-exchange, rotate, bit-field select) turns that into lane = site, bit = slot
+// -- the tile words.  7 slow instructions per draw become 2 slow + 5 fast, + 2 x 5 x 3 per 32 draws.
+// ---------------------------------------------------------------------------
+struct TransposeLanes {
+    uint32_t amt[5], keep[5]; // per stage s = 16, 8, 4, 2, 1: rotate-right amount of the partner's word, bits this lane keeps
+    __device__ __forceinline__ explicit TransposeLanes(uint32_t lane_in_half) {
+        const uint32_t low[5] = {0x0000FFFFu, 0x00FF00FFu, 0x0F0F0F0Fu, 0x33333333u, 0x55555555u};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const uint32_t s = 16u >> k;
+            const bool upper = (lane_in_half & s) != 0;
+            amt[k] = upper ? s : 32u - s;
+            keep[k] = upper ? ~low[k] : low[k];
+        }
+    }
+};
+
+// rows = lanes of a half wave, columns = bits: returns the transposed matrix's row of this lane
+__device__ __forceinline__ uint32_t transpose32(uint32_t x, const TransposeLanes &tl) {
+#define PA_SWZ(v, mask) static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(v), ((mask) << 10) | 0x1F))
+    uint32_t q;
+    q = PA_SWZ(x, 16); q = __builtin_amdgcn_alignbit(q, q, tl.amt[0]); x = (x & tl.keep[0]) | (q & ~tl.keep[0]);
+    q = PA_SWZ(x, 8);  q = __builtin_amdgcn_alignbit(q, q, tl.amt[1]); x = (x & tl.keep[1]) | (q & ~tl.keep[1]);
+    q = PA_SWZ(x, 4);  q = __builtin_amdgcn_alignbit(q, q, tl.amt[2]); x = (x & tl.keep[2]) | (q & ~tl.keep[2]);
+    q = PA_SWZ(x, 2);  q = __builtin_amdgcn_alignbit(q, q, tl.amt[3]); x = (x & tl.keep[3]) | (q & ~tl.keep[3]);
+    q = PA_SWZ(x, 1);  q = __builtin_amdgcn_alignbit(q, q, tl.amt[4]); x = (x & tl.keep[4]) | (q & ~tl.keep[4]);
+#undef PA_SWZ
+    return x;
+}
+
+// c0 >= c1 >= c2: the slot's three UNSHIFTED thresholds (<= 2^24).  On return lane r of a half wave holds the two
+// level planes of the site drawn at step 31 - r.
+__device__ __forceinline__ void rng_chunk32_signs(Rng32 &rng, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t &keep0,
+                                                  uint32_t &keep1, const TransposeLanes &tl) {
+    uint32_t acc0 = 0, acc1 = 0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const uint32_t draw = rng.next_top() >> 8;
+        const uint32_t d0 = draw - c0, d1 = draw - c1, d2 = draw - c2;
+        const uint32_t x = __builtin_amdgcn_bitop3_b32(d0, d1, d2, 0x96); // sign = bit 0 of the level
+        acc0 = __builtin_amdgcn_alignbit(acc0, x, 31);                    // (acc << 1) | (x >> 31)
+        acc1 = __builtin_amdgcn_alignbit(acc1, d1, 31);                   // bit 1 of the level: draw < c1
+    }
+    keep0 = transpose32(acc0, tl);
+    keep1 = transpose32(acc1, tl);
+}
+
 // Gibbs: seven thresholds c[0] >= ... >= c[6] (dE = e_max, e_max - 2, ...; checked on the host),
 // so the comparisons are nested and the level L = #{j : draw < c[j]} in 0..7 has the bits
 //   bit2 = b3,  bit1 = b1 ^ b3 ^ b5,  bit0 = b0 ^ ... ^ b6      (b_j = draw < c[j]).
@@ -275,9 +328,29 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
         cb2 = thr[5 * d.n_temps + t];
     }
 
+    // Measured on MI355X (bench workload): the sign form below is bit-equal but SLOWER, k_rng 51 -> 61 us per
+    // launch, although it trades five 4.2-cycle instructions for 2.3-cycle ones by the isolated-stream numbers of
+    // tools/probe/valu_issue.hip -- in this mix every instruction of the sign form costs ~4.2 cycles, while the
+    // compares-into-SGPR and v_writelane of the ballot form overlap with other waves' work.  Kept as the
+    // alternative (flip the constant), not used.
+    constexpr bool kBallots = true;
+    const TransposeLanes tl(bit);
+    uint32_t ua0 = 0, ua1 = 0, ua2 = 0; // the even set again, unshifted, for the sign form
+    if (active) {
+        const uint32_t t = slot % d.n_temps;
+        ua0 = p.thr[0 * d.n_temps + t];
+        ua1 = p.thr[1 * d.n_temps + t];
+        ua2 = p.thr[2 * d.n_temps + t];
+    }
     for (uint32_t j0 = 0; j0 < len; j0 += 32) {
         uint32_t keep0 = 0, keep1 = 0;
         const uint32_t chunk = min(32u, len - j0);
+        if (chunk == 32 && !d.has_odd && !kBallots) {
+            rng_chunk32_signs(rng, ua0, ua1, ua2, keep0, keep1, tl);
+            // lane r holds the site of step 31 - r: the store below is the same 256 coalesced bytes, mirrored
+            if (tw_ok) planes[filed(begin + j0 + (31u - bit))] = make_uint2(keep0, keep1);
+            continue;
+        }
         if (chunk == 32 && !d.has_odd) {
             rng_chunk32<PRESHIFTED>(rng, ca0, ca1, ca2, keep0, keep1,
                                     std::make_integer_sequence<int, 32>{});

@@ -185,9 +185,10 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
     const uint32_t block = bid % d.B;
     const uint32_t group = bid / d.B;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t nthreads = blockDim.x, nw = nthreads >> 6; // 4 waves (k_rng, k_rng_relay) or 8 (k_rs)
     const uint32_t bit = lane & 31u, half = lane >> 5;
     const uint32_t n_tw = d.n_real * d.W;
-    const uint32_t tw = (group * 4 + wave) * 2 + half;
+    const uint32_t tw = (group * nw + wave) * 2 + half;
     const bool tw_ok = tw < n_tw;
     const uint32_t real = tw_ok ? tw / d.W : 0, w = tw_ok ? tw % d.W : 0;
     const uint32_t slot = w * 32 + bit;
@@ -196,14 +197,14 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
     if (block > 0) {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.jump + static_cast<size_t>(block) * (64 * 16 * 8));
         uint4 *dst = reinterpret_cast<uint4 *>(tab);
-        for (uint32_t i = tid; i < 64 * 16 * 2; i += 256) dst[i] = src[i];
+        for (uint32_t i = tid; i < 64 * 16 * 2; i += nthreads) dst[i] = src[i];
     }
     uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t src_slot = slot, skip_draws = 0;
     if (REPLAY) {
         uint32_t *dec = tab + 64 * 16 * 8; // [<= 256] edge | accepted << 16 | draws << 17 per (realisation, ladder)
-        const uint32_t tw0 = group * 8, real0 = tw0 / d.W;
-        const uint32_t real1 = min(tw0 + 7u, n_tw - 1u) / d.W;
+        const uint32_t tw0 = group * 2 * nw, real0 = tw0 / d.W;
+        const uint32_t real1 = min(tw0 + 2 * nw - 1u, n_tw - 1u) / d.W;
         const uint32_t n_tasks = (real1 - real0 + 1u) * d.n_replicas; // (<= 256: rng_relay_supported)
         if (tid < n_tasks) {
             const uint32_t r = real0 + tid / d.n_replicas, offset = (tid % d.n_replicas) * d.n_temps;
@@ -258,7 +259,7 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
         st[6] = static_cast<uint32_t>(g.s3); st[7] = static_cast<uint32_t>(g.s3 >> 32);
     }
     __syncthreads();
-    if (__builtin_amdgcn_readfirstlane((group * 4 + wave) * 2) >= n_tw) return; // idle wave
+    if (__builtin_amdgcn_readfirstlane((group * nw + wave) * 2) >= n_tw) return; // idle wave
     if (block > 0) jump_state_lds(st, tab);
     Rng32 rng;
     rng.load(st);
@@ -523,7 +524,7 @@ template <int NSET>
 __device__ __forceinline__ void block_bit_totals(const uint32_t (*c)[8], uint32_t *scratch,
                                                  uint32_t out[NSET]) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t n_waves = blockDim.x >> 6;
+    constexpr uint32_t n_waves = 4; // every caller is a 256-thread role (possibly the first four waves of a wider block)
 #pragma unroll
     for (int s = 0; s < NSET; ++s) {
 #pragma unroll
@@ -951,11 +952,19 @@ __host__ __device__ inline size_t sweep_hc_lds_words(const SimDims &d) {
 
 // STAMPS: diagnostic build, every workgroup files s_memrealtime (100 MHz) stamps of its phases in stamps[block][8]
 #define PA_HC_STAMP(k)                                                                             \
-    if (STAMPS && threadIdx.x == 0) stamps[blockIdx.x * 8 + (k)] = wall_clock64();
-template <int NN, bool STAMPS = false>
-__global__ __launch_bounds__(256, 2) void k_sweep_hc(SimDims d, DevPtrs p, int with_energy, int do_sweep,
-                                                     unsigned long long *stamps) {
-    extern __shared__ uint32_t lds[];
+    if (STAMPS && threadIdx.x == 0) stamps[bid * 8 + (k)] = wall_clock64();
+// RsWait: the block runs inside k_rs, behind the random-stream blocks of the same launch: before it touches the
+// acceptance planes (and the tempering swap masks) it waits until their producers have published them.
+struct RsWait {
+    const uint32_t *ready;   // [rng groups] launches completed by the random-stream workgroup group that covers a tile word
+    const uint32_t *measured; // [n_real] launches in which the realisation's measurement block has run
+    uint32_t ready_target, measured_target, tw_per_group;
+    uint32_t *error;         // set when a wait gives up (pa_sim_synchronize reports it)
+};
+
+template <int NN, bool STAMPS, bool FUSED>
+__device__ __forceinline__ void sweep_hc_block(const SimDims &d, const DevPtrs &p, uint32_t bid, int with_energy, int do_sweep,
+                                               unsigned long long *stamps, const RsWait &wait, uint32_t *lds) {
     PA_HC_STAMP(0)
     const uint32_t n1 = d.N + 1;
     const uint32_t n_pad = (n1 + 3u) & ~3u;
@@ -964,15 +973,16 @@ __global__ __launch_bounds__(256, 2) void k_sweep_hc(SimDims d, DevPtrs p, int w
     uint32_t *tab = pl + ((2 * n1 + 3u) & ~3u);           // [N] schedule table of this realisation
     uint32_t *ps = tab + ((d.N + 3u) & ~3u);              // [n_passes + 5] pass boundaries (padded with N)
     uint32_t *scratch = ps + ((d.n_passes + 5u + 3u) & ~3u); // [5][48]
-    const uint32_t real = blockIdx.x / d.W, w = blockIdx.x % d.W;
+    const uint32_t real = bid / d.W, w = bid % d.W;
     const uint32_t tid = threadIdx.x;
     const uint32_t *Sin = p.S + (static_cast<size_t>(real) * d.W + w) * d.N;
     uint32_t *Sout = p.S_next + (static_cast<size_t>(real) * d.W + w) * d.N;
     const uint32_t *tab_g = p.hc_tab + static_cast<size_t>(real) * d.N;
-    const uint32_t epoch = p.swap_epoch[real];
-    const uint32_t applied = p.applied_epoch[static_cast<size_t>(real) * d.W + w];
-    uint32_t mp[2], mc[2], mn[2];
-    {
+    uint32_t epoch = 0, applied = 0;
+    uint32_t mp[2] = {0, 0}, mc[2] = {0, 0}, mn[2] = {0, 0};
+    auto read_swap_state = [&]() {
+        epoch = p.swap_epoch[real];
+        applied = p.applied_epoch[static_cast<size_t>(real) * d.W + w];
         const uint32_t *masks = p.swap_masks + static_cast<size_t>(real) * 2 * d.W;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -980,13 +990,16 @@ __global__ __launch_bounds__(256, 2) void k_sweep_hc(SimDims d, DevPtrs p, int w
             mc[r] = masks[r * d.W + w];
             mn[r] = w + 1 < d.W ? masks[r * d.W + w + 1] : 0u;
         }
-    }
-    // spins, acceptance planes and the schedule table are requested together (one memory round trip)
+    };
+    if (!FUSED) read_swap_state(); // (requested first: their latency hides behind the bulk copy)
+    // spins, acceptance planes and the schedule table are requested together (one memory round trip); inside k_rs
+    // the planes (and the swap state) come later, once their producers in this launch have published them
     const uint32_t *planes_in =
         reinterpret_cast<const uint32_t *>(p.planes + (static_cast<size_t>(real) * d.W + w) * d.N);
+    const bool planes_now = do_sweep && !FUSED;
     {
-        const uint32_t qa = d.N >> 2, qb = do_sweep ? (2 * d.N) >> 2 : 0u, qc = d.N >> 2;
-        const bool wide = (d.N & 3u) == 0 && qa <= 4 * 256 && qb <= 8 * 256 &&
+        const uint32_t qa = d.N >> 2, qb = planes_now ? (2 * d.N) >> 2 : 0u, qc = d.N >> 2;
+        const bool wide = (d.N & 3u) == 0 && qa <= 4 * 256 && (2 * d.N) >> 2 <= 8 * 256 &&
                           ((reinterpret_cast<uintptr_t>(Sin) | reinterpret_cast<uintptr_t>(planes_in) |
                             reinterpret_cast<uintptr_t>(tab_g)) & 15u) == 0;
         if (wide) {
@@ -995,24 +1008,50 @@ __global__ __launch_bounds__(256, 2) void k_sweep_hc(SimDims d, DevPtrs p, int w
             uint4 va[4], vb[8], vc[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) va[k] = k * 256 + tid < qa ? a4[k * 256 + tid] : make_uint4(0, 0, 0, 0);
+            if (!FUSED) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) vb[k] = k * 256 + tid < qb ? b4[k * 256 + tid] : make_uint4(0, 0, 0, 0);
+                for (int k = 0; k < 8; ++k) vb[k] = k * 256 + tid < qb ? b4[k * 256 + tid] : make_uint4(0, 0, 0, 0);
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) vc[k] = k * 256 + tid < qc ? c4[k * 256 + tid] : make_uint4(0, 0, 0, 0);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (k * 256 + tid < qa) reinterpret_cast<uint4 *>(sw)[k * 256 + tid] = va[k];
+            if (!FUSED) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (k * 256 + tid < qb) reinterpret_cast<uint4 *>(pl)[k * 256 + tid] = vb[k];
+                for (int k = 0; k < 8; ++k)
+                    if (k * 256 + tid < qb) reinterpret_cast<uint4 *>(pl)[k * 256 + tid] = vb[k];
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (k * 256 + tid < qc) reinterpret_cast<uint4 *>(tab)[k * 256 + tid] = vc[k];
         } else {
             copy_to_lds(sw, Sin, d.N, tid, 256);
-            if (do_sweep) copy_to_lds(pl, planes_in, 2 * d.N, tid, 256);
+            if (planes_now) copy_to_lds(pl, planes_in, 2 * d.N, tid, 256);
             copy_to_lds(tab, tab_g, d.N, tid, 256);
         }
+    }
+    if (FUSED) {
+        // ---- wait for this launch's producers: the measurement block of the realisation (swap masks) and the
+        // random-stream workgroups that draw this tile word's planes.  One lane polls (relaxed, agent scope), then
+        // acquires once; the workgroup's loads come after the barrier (producers: store drain, barrier, release).
+        if (tid == 0) {
+            const uint32_t *flag_a = wait.measured ? wait.measured + real : nullptr;
+            const uint32_t *flag_b = wait.ready + bid / wait.tw_per_group;
+            uint32_t spins = 0;
+            while ((flag_a && __hip_atomic_load(flag_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != wait.measured_target) ||
+                   __hip_atomic_load(flag_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != wait.ready_target) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 22)) { // never reached unless a producer died: leave, and say so
+                    atomicExch(wait.error, 1u);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        read_swap_state();
+        if (do_sweep) copy_to_lds(pl, planes_in, 2 * d.N, tid, 256);
     }
     for (uint32_t k = tid; k < d.n_passes + 5; k += 256) ps[k] = k <= d.n_passes ? p.pass_start[k] : d.N;
     if (do_sweep && epoch != applied) {
@@ -1125,12 +1164,19 @@ __global__ __launch_bounds__(256, 2) void k_sweep_hc(SimDims d, DevPtrs p, int w
         if (tid < 32 && w * 32 + tid < d.n_sys) {
             const uint32_t slot = w * 32 + tid;
             const int32_t unsat = static_cast<int32_t>(tot[0] + 2 * tot[1]);
-            p.Esum[static_cast<size_t>(real) * d.n_sys + slot] = p.nz_bonds[real] - 2 * unsat;
-            p.Msum[static_cast<size_t>(real) * d.n_sys + slot] =
+            (FUSED ? p.Esum_out : p.Esum)[static_cast<size_t>(real) * d.n_sys + slot] = p.nz_bonds[real] - 2 * unsat;
+            (FUSED ? p.Msum_out : p.Msum)[static_cast<size_t>(real) * d.n_sys + slot] =
                 static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(tot[2]);
         }
     }
     PA_HC_STAMP(5)
+}
+
+template <int NN, bool STAMPS = false>
+__global__ __launch_bounds__(256, 2) void k_sweep_hc(SimDims d, DevPtrs p, int with_energy, int do_sweep,
+                                                     unsigned long long *stamps) {
+    extern __shared__ uint32_t lds[];
+    sweep_hc_block<NN, STAMPS, false>(d, p, blockIdx.x, with_energy, do_sweep, stamps, RsWait{}, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -1712,6 +1758,53 @@ __global__ __launch_bounds__(256) void k_rng_relay(SimDims d, DevPtrs p, uint32_
         measure_block<false>(d, p, pt, do_accum, accum_overlap, do_pt, nullptr, blockIdx.x - n_overlap, lds_dyn);
     else
         rng_block<PRESHIFTED, false, REPLAY>(d, p, blockIdx.x - n_overlap - n_measure, lds_dyn);
+}
+
+// ---------------------------------------------------------------------------
+// k_rs: one launch per sweep.  Workgroups of 512 threads in blockIdx order:
+//   overlap blocks | measurement blocks | random-stream blocks (8 waves share a jump table) | sweep blocks
+// The first three are k_rng_relay's; the sweep blocks (k_sweep_hc's body, first four waves) load their spins and table,
+// then wait inside the launch until the random-stream workgroups covering their tile word have published the
+// acceptance planes (and the realisation's measurement block its swap masks): producers drain their stores, meet at
+// the workgroup barrier and release-increment a counter at agent scope; the consumer polls relaxed, acquires once,
+// meets at its barrier and only then loads (the per-CU L1 and the per-XCD L2s are not coherent with each other).
+// Blocks are dispatched in blockIdx order, so a waiting block only waits for blocks that are already on the machine;
+// random-stream groups finish in tile-word order, so the first sweep blocks start while the stream is still running.
+// Saves the ~5 us a dependent launch spends before its first wave, and the sweep's prologue hides under the stream.
+// ---------------------------------------------------------------------------
+template <bool PRESHIFTED, bool REPLAY, int NN>
+__global__ __launch_bounds__(512, 4) void k_rs(SimDims d, DevPtrs p, uint32_t n_overlap, uint32_t n_measure, uint32_t n_rng,
+                                               PtParams pt, int do_accum, int accum_overlap, int do_pt, int with_energy,
+                                               uint32_t ready_target, uint32_t measured_target) {
+    extern __shared__ uint32_t lds_dyn[];
+    const uint32_t bid = blockIdx.x, tid = threadIdx.x;
+    if (bid < n_overlap) {
+        if (tid >= 256) return; // (a barrier waits for the surviving waves only)
+        overlap_block(d, p, bid, lds_dyn);
+    } else if (bid < n_overlap + n_measure) {
+        const uint32_t real = bid - n_overlap;
+        measure_block<false>(d, p, pt, do_accum, accum_overlap, do_pt, nullptr, real, lds_dyn);
+        drain_global_stores();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(p.rs_measured + real, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (bid < n_overlap + n_measure + n_rng) {
+        const uint32_t rb = bid - n_overlap - n_measure;
+        rng_block<PRESHIFTED, false, REPLAY>(d, p, rb, lds_dyn);
+        drain_global_stores();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(p.rs_ready + rb / d.B, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        if (tid >= 256) return;
+        __builtin_amdgcn_s_setprio(3); // the sweep is a latency chain: its instructions go first on a shared SIMD
+        RsWait wait;
+        wait.ready = p.rs_ready;
+        wait.measured = n_measure ? p.rs_measured : nullptr;
+        wait.ready_target = ready_target;
+        wait.measured_target = measured_target;
+        wait.tw_per_group = 16;
+        wait.error = p.rs_error;
+        sweep_hc_block<NN, false, true>(d, p, bid - n_overlap - n_measure - n_rng, with_energy, 1, nullptr, wait, lds_dyn);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2623,6 +2716,12 @@ hipError_t configure_kernels(const SimDims &) {
                            reinterpret_cast<const void *>(k_sweep_hc<3, true>),
                            reinterpret_cast<const void *>(k_overlap),
                            reinterpret_cast<const void *>(k_overlap_wide),
+                           reinterpret_cast<const void *>(k_rs<true, false, 1>),
+                           reinterpret_cast<const void *>(k_rs<true, false, 2>),
+                           reinterpret_cast<const void *>(k_rs<true, false, 3>),
+                           reinterpret_cast<const void *>(k_rs<true, true, 1>),
+                           reinterpret_cast<const void *>(k_rs<true, true, 2>),
+                           reinterpret_cast<const void *>(k_rs<true, true, 3>),
                            reinterpret_cast<const void *>(k_rng_relay<false, false>),
                            reinterpret_cast<const void *>(k_rng_relay<false, true>),
                            reinterpret_cast<const void *>(k_rng_relay<true, false>),
@@ -2697,6 +2796,43 @@ hipError_t launch_rng_relay(const SimDims &d, const DevPtrs &p, bool with_overla
         if (replay) hipLaunchKernelGGL((k_rng_relay<false, true>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
         else hipLaunchKernelGGL((k_rng_relay<false, false>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
     }
+    return hipGetLastError();
+}
+
+bool rs_supported(const SimDims &d) {
+    const uint32_t reals_per_block = 15u / d.W + 2u; // the replay lanes of an 8-wave random-stream workgroup: 16 tile words
+    return rng_relay_supported(d) && d.hc && d.dense_nn == d.nn && d.thr_preshifted && reals_per_block * d.n_replicas <= 256 &&
+           sweep_hc_lds_bytes(d) + 2048 <= 80 * 1024; // two workgroups per CU
+}
+
+hipError_t launch_rs(const SimDims &d, const DevPtrs &p, bool with_overlap, const PtParams &pt, bool do_accum,
+                     bool accum_overlap, bool do_pt, bool with_energy, uint32_t ready_epoch, uint32_t measured_epoch,
+                     hipStream_t stream) {
+    const uint32_t n_tw = d.n_real * d.W;
+    const uint32_t groups = (n_tw + 15) / 16; // 8 waves x 2 tile words
+    const uint32_t n_overlap = with_overlap ? n_tw : 0u;
+    const uint32_t n_measure = (do_accum || accum_overlap || do_pt) ? d.n_real : 0u;
+    const uint32_t n_rng = groups * d.B;
+    const bool replay = n_measure && do_pt && d.n_temps >= 2;
+    const size_t lds = std::max(std::max(sweep_hc_lds_bytes(d), kRngLds + 1024), std::max(overlap_lds_bytes(d), measure_lds_bytes(d)));
+    const dim3 grid(n_overlap + n_measure + n_rng + n_tw), block(512);
+    const int a = do_accum ? 1 : 0, o = accum_overlap ? 1 : 0, t = do_pt ? 1 : 0, e = with_energy ? 1 : 0;
+    const uint32_t ready_target = ready_epoch * d.B, measured_target = measured_epoch;
+#define PA_RS(R, NN) hipLaunchKernelGGL((k_rs<true, R, NN>), grid, block, lds, stream, d, p, n_overlap, n_measure, n_rng, pt, a, o, t, e, ready_target, measured_target)
+    if (replay) {
+        switch (d.dense_nn) {
+        case 1: PA_RS(true, 1); break;
+        case 2: PA_RS(true, 2); break;
+        default: PA_RS(true, 3); break;
+        }
+    } else {
+        switch (d.dense_nn) {
+        case 1: PA_RS(false, 1); break;
+        case 2: PA_RS(false, 2); break;
+        default: PA_RS(false, 3); break;
+        }
+    }
+#undef PA_RS
     return hipGetLastError();
 }
 

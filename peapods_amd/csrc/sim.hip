@@ -890,6 +890,8 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     const bool relay = fused && cfg->pt_schedule == PA_PT_SINGLE_RANDOM_EDGE && rng_relay_supported(d) &&
                        !std::getenv("PEAPODS_NO_RELAY");
     // (opt-in: measured slower than two launches)
+    const bool relay_nf = !fused && !gibbs && !d.big && !d.general && cfg->pt_schedule == PA_PT_SINGLE_RANDOM_EDGE &&
+                          rng_relay_supported(d) && !std::getenv("PEAPODS_NO_RELAY");
     bool rs = relay && std::getenv("PEAPODS_RS") != nullptr;
     for (auto &g : sim->groups) rs = rs && rs_supported(g.d);
     // Cooperative cancel (src/lib.rs:304-308, mod.rs:406-408): the host runs at most two batches of
@@ -990,11 +992,25 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             if (pt_this && cfg->pt_schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
             continue;
         }
+        // (general protocol) the previous sweep's measurement launch that carries its tempering event rides in this
+        // sweep's random-stream launch when it can (relay_nf): one launch less per sweep
+        const bool relayed_nf = relay_nf && pending.any;
         for (auto &g : sim->groups) {
-            PA_HIP(sim, launch_rng(g.d, g.p, gibbs, g.stream));                         // :412-432
+            if (relayed_nf) {
+                PtParams q = pending.pt;
+                q.relay = 1;
+                q.fresh = consume_fresh(g.fresh, g.d, pending.do_accum, pending.accum_overlap);
+                PA_HIP(sim, launch_rng_relay(g.d, g.p, false, q, pending.do_accum, pending.accum_overlap, pending.do_pt,
+                                             g.stream));
+            } else {
+                PA_HIP(sim, launch_rng(g.d, g.p, gibbs, g.stream));                     // :412-432
+            }
             // energies are computed after every mutating move of the sweep (:492-509)
             PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, (record || pt_this || equil) && !fk_this, gibbs, g.stream));
         }
+        if (relayed_nf && pending.do_pt && d.n_temps >= 2) toggle_system_tables(sim);
+        pending.any = false;
+        bool pt_deferred = false;
         sim->swaps_pending = false;
         toggle_spin_buffers(sim);
         uint32_t equil_ckpt = 0; // 1 + index of the checkpoint this sweep completes
@@ -1018,9 +1034,19 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                         (autocorr && record) ? static_cast<uint32_t>(sim->n_recorded + 1) : 0u,
                         static_cast<uint32_t>(sim->ac_capacity)};
             if (!oc_this) {
-                if (record || pt_this || equil) // statistics :543-578, tempering :748-796
-                    PA_HIP(sim, measure_launch(g.fresh, g.d, g.p, pt, record, record && want_overlap, pt_this,
-                                               g.stream));
+                if (record || pt_this || equil) { // statistics :543-578, tempering :748-796
+                    if (relay_nf && pt_this) { // rides in the next sweep's random-stream launch
+                        pending.any = true;
+                        pending.pt = pt;
+                        pending.do_accum = record;
+                        pending.accum_overlap = record && want_overlap;
+                        pending.do_pt = true;
+                        pt_deferred = true;
+                    } else {
+                        PA_HIP(sim, measure_launch(g.fresh, g.d, g.p, pt, record, record && want_overlap, pt_this,
+                                                   g.stream));
+                    }
+                }
             } else {
                 if (record || equil)
                     PA_HIP(sim, measure_launch(g.fresh, g.d, g.p, pt, record, record && want_overlap, false, g.stream));
@@ -1110,11 +1136,19 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                 }
                 if (pt_this) { // energies are recomputed after a mutating move (:749-756)
                     if (!observe_overlap) PA_HIP(sim, launch_sweep(g.d, g.p, true, false, false, g.stream));
-                    PA_HIP(sim, measure_launch(g.fresh, g.d, g.p, pt, false, false, true, g.stream));
+                    if (relay_nf) { // the tempering event rides in the next sweep's random-stream launch
+                        pending.any = true;
+                        pending.pt = pt;
+                        pending.do_accum = pending.accum_overlap = false;
+                        pending.do_pt = true;
+                        pt_deferred = true;
+                    } else {
+                        PA_HIP(sim, measure_launch(g.fresh, g.d, g.p, pt, false, false, true, g.stream));
+                    }
                 }
             }
         }
-        if (pt_this) sim->swaps_pending = true;
+        if (pt_this && !pt_deferred) sim->swaps_pending = true;
         if (record) sim->n_recorded += 1;
         if (cfg->overlap_cluster_interval > 0 && sweep_id % cfg->overlap_cluster_interval == 0) {
             if (collect_overlap && record) // :734

@@ -8,8 +8,8 @@ after which the reference's disorder aggregation (statistics/results.rs:165-282)
 realisation order.
 
 On GPUs the exchange is `Comm`: RCCL through the library's own C ABI (pa_comm_*, csrc/comm.hip) --
-no torch.  The 128-byte RCCL id travels from rank 0 to the others over a plain TCP socket on
-MASTER_ADDR:MASTER_PORT (`exchange_id`).  The CPU rehearsal in tests/ passes a gloo
+no torch.  The 128-byte RCCL id travels from rank 0 to the others through a file named after the launch (one
+node) or a plain TCP socket on MASTER_ADDR:MASTER_PORT (`exchange_id`).  The CPU rehearsal in tests/ passes a gloo
 `torch.distributed` module to `all_gather_blocks` instead; that branch is test plumbing only.
 """
 
@@ -31,13 +31,23 @@ def shard_range(n_total, rank, world):
     return start, stop
 
 
-def exchange_id(rank, world, make_id, addr=None, port=None, timeout=120.0):
-    """Rank 0 creates the communicator id (`make_id()` -> bytes) and serves it to the other
-    world - 1 ranks over TCP; they connect (retrying until rank 0 listens) and read it."""
+def exchange_id(rank, world, make_id, addr=None, port=None, timeout=120.0, channel=None):
+    """Rank 0 creates the communicator id (`make_id()` -> bytes) and hands it to the other world - 1 ranks.
+
+    channel "file" (default when MASTER_ADDR is this host): rank 0 writes the id to a file named after
+    MASTER_PORT and the launcher's pid -- every rank of one launch has the same parent, torch.distributed.run's
+    agent or bench.py's own launcher -- and the others poll for it.  Nothing is bound: under torch.distributed.run
+    MASTER_PORT is already held by the agent's rendezvous store.
+    channel "tcp" (default otherwise): rank 0 serves the id on MASTER_ADDR:MASTER_PORT, the others connect
+    (retrying until rank 0 listens)."""
     addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = int(port or os.environ.get("MASTER_PORT", "29500"))
     if world == 1:
         return make_id()
+    if channel is None:
+        channel = "file" if addr in ("127.0.0.1", "localhost", "::1") else "tcp"
+    if channel == "file":
+        return _exchange_id_file(rank, make_id, port, timeout)
     if rank == 0:
         payload = make_id()
         with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
@@ -67,6 +77,45 @@ def exchange_id(rank, world, make_id, addr=None, port=None, timeout=120.0):
         if time.monotonic() > deadline:
             raise TimeoutError(f"rank {rank}: no communicator id from {addr}:{port}")
         time.sleep(0.05)
+
+
+_ID_FILES = []
+
+
+def forget_id_files():
+    """Rank 0: remove the id files it wrote (call after the communicator exists: every rank has read them)."""
+    while _ID_FILES:
+        try:
+            os.remove(_ID_FILES.pop())
+        except OSError:
+            pass
+
+
+def _exchange_id_file(rank, make_id, port, timeout):
+    import tempfile
+
+    restart = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+    path = os.path.join(tempfile.gettempdir(), f"peapods_comm_{os.getppid()}_{port}_{restart}.id")
+    if rank == 0:
+        payload = make_id()
+        scratch = f"{path}.{os.getpid()}"
+        with open(scratch, "wb") as fh:
+            fh.write(payload)
+        os.replace(scratch, path)  # readers see the whole id or nothing
+        _ID_FILES.append(path)     # removed by forget_id_files() once every rank holds the id
+        return payload
+    deadline = time.monotonic() + timeout
+    while True:
+        try:
+            with open(path, "rb") as fh:
+                payload = fh.read()
+            if payload:
+                return payload
+        except OSError:
+            pass
+        if time.monotonic() > deadline:
+            raise TimeoutError(f"rank {rank}: no communicator id in {path}")
+        time.sleep(0.02)
 
 
 class Comm:
@@ -107,6 +156,7 @@ class Comm:
         if code != nat.PA_OK:
             raise RuntimeError(err.value.decode())
         self._handle = handle
+        forget_id_files()  # ncclCommInitRank returned: every rank has the id
 
     def close(self):
         if self._handle:

@@ -6,8 +6,10 @@ under test is the product's sharding, gather and aggregation code."""
 import os
 import socket
 import sys
+import time
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -69,23 +71,36 @@ def test_two_rank_gather_equals_single_process(tmp_path):
     np.testing.assert_array_equal(got[0], aggregate_mean(single))
 
 
-def _id_worker(rank, world, port, out_dir):
+def _id_worker(rank, world, port, out_dir, channel):
     sys.path.insert(0, ROOT)
     from peapods_amd.distributed import exchange_id
 
-    got = exchange_id(rank, world, lambda: bytes(range(128)), "127.0.0.1", port, timeout=30.0)
+    got = exchange_id(rank, world, lambda: bytes(range(128)), "127.0.0.1", port, timeout=30.0, channel=channel)
     with open(os.path.join(out_dir, f"id{rank}.bin"), "wb") as fh:
         fh.write(got)
+    if rank == 0 and channel == "file":  # (Comm removes the file once the communicator exists; here: once all have it)
+        from peapods_amd.distributed import forget_id_files
+
+        deadline = time.monotonic() + 30
+        while time.monotonic() < deadline and not all(os.path.exists(os.path.join(out_dir, f"id{r}.bin")) for r in range(world)):
+            time.sleep(0.05)
+        forget_id_files()
 
 
-def test_communicator_id_travels_from_rank_0_over_tcp(tmp_path):
-    """The torch-free rendezvous of the RCCL path: rank 0 serves the 128-byte id, the others read it
-    (they may connect before rank 0 listens)."""
+@pytest.mark.parametrize("channel", ["file", "tcp"])
+def test_communicator_id_travels_from_rank_0(tmp_path, channel):
+    """The torch-free rendezvous of the RCCL path: rank 0 hands the 128-byte id to the others (who may ask before
+    rank 0 is ready) -- through a file named after the launch (the default on one node: under torch.distributed.run
+    MASTER_PORT belongs to the agent's store and cannot be bound) or over TCP."""
     import multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_id_worker, args=(r, 3, port, str(tmp_path))) for r in (2, 1, 0)]
+    if channel == "file":  # hold the port, as torch.distributed.run's agent does
+        holder = socket.socket()
+        holder.bind(("127.0.0.1", port))
+        holder.listen(1)
+    procs = [ctx.Process(target=_id_worker, args=(r, 3, port, str(tmp_path), channel)) for r in (2, 1, 0)]
     for p in procs:
         p.start()
     for p in procs:

@@ -1582,75 +1582,85 @@ __device__ __forceinline__ void measure_block(const SimDims &d, const DevPtrs &p
     if (!do_pt || d.n_temps < 2) return;
     __syncthreads();
 
-    // ---- (3) parallel tempering: one lane per replica ladder -------------------
+    // ---- (3) parallel tempering -------------------------------------------------
+    // single_random_edge: one lane per replica ladder draws the edge and decides it.  full_ladder: the ladder's lane
+    // draws its n_temps - 1 uniforms in order (they are consumed one per edge in the sequence "edges of parity p
+    // ascending, then parity 1 - p", tempering.rs:59-70), then the edges of one parity are decided side by side --
+    // they touch disjoint slots and systems -- and the other parity follows after a barrier on the exchanged energies.
     DevRng rng;
     rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
+    uint64_t *trips = p.round_trips + static_cast<size_t>(real) * d.n_sys;
+    uint8_t *trip = p.trip_state + static_cast<size_t>(real) * d.n_sys;
+    const float n_f_pt = static_cast<float>(d.N);
+    const uint32_t n_edges = d.n_temps - 1;
+    auto attempt = [&](uint32_t offset, uint32_t edge, uint32_t round, uint32_t draw) {
+        const uint32_t sl = offset + edge, sr = sl + 1;
+        const uint32_t left = m.sid[sl], right = m.sid[sr];
+        const bool accepted = pt_accept(n_f_pt, m.E[sl], m.E[sr], d.general, p.dbeta[edge], p.ln_table[draw]);
+        atomicAdd(&m.att[edge], 1u);
+        if (accepted) {
+            atomicAdd(&m.acc[edge], 1u);
+            // record_arrival(left, edge + 1), record_arrival(right, edge)
+            const uint32_t arr_sys[2] = {left, right};
+            const uint32_t arr_slot[2] = {edge + 1, edge};
+            for (int k = 0; k < 2; ++k) {
+                const uint32_t sys = arr_sys[k], slt = arr_slot[k];
+                if (slt == pt.hot_slot) {
+                    if (trip[sys] == 2) trips[sys] += 1;
+                    trip[sys] = 1;
+                } else if (slt == pt.cold_slot && trip[sys] == 1) {
+                    trip[sys] = 2;
+                }
+            }
+            m.sid[sl] = right;
+            m.sid[sr] = left;
+            const int32_t te = m.E[sl];
+            m.E[sl] = m.E[sr];
+            m.E[sr] = te;
+            const int32_t tm = m.M[sl];
+            m.M[sl] = m.M[sr];
+            m.M[sr] = tm;
+            atomicOr(&m.masks[round * d.W + (sl >> 5)], 1u << (sl & 31u));
+            m.flags[0] = 1;
+        }
+    };
     if (tid < d.n_replicas) {
-        const uint32_t rep = tid, offset = rep * d.n_temps;
-        uint64_t *trips = p.round_trips + static_cast<size_t>(real) * d.n_sys;
-        uint8_t *trip = p.trip_state + static_cast<size_t>(real) * d.n_sys;
         uint32_t st[8];
-        load_cursor(p.cursor, real, d.SP, m.sof0[offset], st);
+        load_cursor(p.cursor, real, d.SP, m.sof0[tid * d.n_temps], st);
         rng.s0 = (static_cast<uint64_t>(st[1]) << 32) | st[0];
         rng.s1 = (static_cast<uint64_t>(st[3]) << 32) | st[2];
         rng.s2 = (static_cast<uint64_t>(st[5]) << 32) | st[4];
         rng.s3 = (static_cast<uint64_t>(st[7]) << 32) | st[6];
-        const float n_f = static_cast<float>(d.N);
-        const uint32_t n_edges = d.n_temps - 1;
-        const uint32_t n_attempts = pt.schedule == 0 ? 1u : n_edges;
-        for (uint32_t a = 0; a < n_attempts; ++a) {
-            uint32_t edge, round = 0;
-            if (pt.schedule == 0) {
-                // rand 0.8.5 gen_range(0..n_temps-1) on usize: widening multiply + zone
-                const uint64_t range = n_edges;
-                const uint64_t zone = (range << __clzll(range)) - 1;
-                for (;;) {
-                    const uint64_t v = rng.next();
-                    if (v * range <= zone) {
-                        edge = static_cast<uint32_t>(__umul64hi(v, range));
-                        break;
-                    }
-                }
-            } else {
-                // edges of parity p first, then 1-p (tempering.rs:59-70)
-                const uint32_t n_first = (n_edges + 1 - pt.first_parity) / 2;
-                if (a < n_first) {
-                    edge = pt.first_parity + 2 * a;
-                } else {
-                    edge = (1 - pt.first_parity) + 2 * (a - n_first);
-                    round = 1;
+    }
+    if (pt.schedule == 0) {
+        if (tid < d.n_replicas) {
+            // rand 0.8.5 gen_range(0..n_temps-1) on usize: widening multiply + zone
+            const uint64_t range = n_edges;
+            const uint64_t zone = (range << __clzll(range)) - 1;
+            uint32_t edge;
+            for (;;) {
+                const uint64_t v = rng.next();
+                if (v * range <= zone) {
+                    edge = static_cast<uint32_t>(__umul64hi(v, range));
+                    break;
                 }
             }
-            const uint32_t sl = offset + edge, sr = sl + 1;
-            const uint32_t left = m.sid[sl], right = m.sid[sr];
-            const uint32_t draw = static_cast<uint32_t>(rng.next() >> 40);
-            const bool accepted = pt_accept(n_f, m.E[sl], m.E[sr], d.general, p.dbeta[edge], p.ln_table[draw]);
-            atomicAdd(&m.att[edge], 1u);
-            if (accepted) {
-                atomicAdd(&m.acc[edge], 1u);
-                // record_arrival(left, edge + 1), record_arrival(right, edge)
-                const uint32_t arr_sys[2] = {left, right};
-                const uint32_t arr_slot[2] = {edge + 1, edge};
-                for (int k = 0; k < 2; ++k) {
-                    const uint32_t sys = arr_sys[k], slt = arr_slot[k];
-                    if (slt == pt.hot_slot) {
-                        if (trip[sys] == 2) trips[sys] += 1;
-                        trip[sys] = 1;
-                    } else if (slt == pt.cold_slot && trip[sys] == 1) {
-                        trip[sys] = 2;
-                    }
-                }
-                m.sid[sl] = right;
-                m.sid[sr] = left;
-                const int32_t te = m.E[sl];
-                m.E[sl] = m.E[sr];
-                m.E[sr] = te;
-                const int32_t tm = m.M[sl];
-                m.M[sl] = m.M[sr];
-                m.M[sr] = tm;
-                atomicOr(&m.masks[round * d.W + (sl >> 5)], 1u << (sl & 31u));
-                m.flags[0] = 1;
+            attempt(tid * d.n_temps, edge, 0u, static_cast<uint32_t>(rng.next() >> 40));
+        }
+    } else {
+        uint32_t *pt_draw = reinterpret_cast<uint32_t *>(m.dot_spin); // [n_replicas][n_edges] (the dots are spent)
+        if (tid < d.n_replicas)
+            for (uint32_t a = 0; a < n_edges; ++a) pt_draw[tid * n_edges + a] = static_cast<uint32_t>(rng.next() >> 40);
+        __syncthreads();
+        const uint32_t n_first = (n_edges + 1 - pt.first_parity) / 2; // edges of parity p come first
+        for (uint32_t round = 0; round < 2; ++round) {
+            for (uint32_t idx = tid; idx < d.n_replicas * n_edges; idx += nthreads) {
+                const uint32_t rep = idx / n_edges, a = idx % n_edges;
+                if ((a >= n_first) != (round == 1)) continue;
+                const uint32_t edge = round == 0 ? pt.first_parity + 2 * a : (1 - pt.first_parity) + 2 * (a - n_first);
+                attempt(rep * d.n_temps, edge, round, pt_draw[idx]);
             }
+            __syncthreads();
         }
     }
     __syncthreads();

@@ -181,3 +181,33 @@ def test_rccl_communicator_single_rank(oracle):
         np.testing.assert_array_equal(aggregate_mean(blocks)[:3], want["mags"])
     finally:
         comm.close()
+
+
+@pytest.mark.parametrize("schedule", ["single_random_edge", "full_ladder"])
+def test_profile_kernels_advances_the_state_like_sample(oracle, schedule):
+    """pa_sim_profile_kernels times the launches of the same protocol (relayed measurement block included) and
+    must leave the ensemble exactly where sample() would: bench.py calls it on the live handle."""
+    from peapods_amd import IsingSimulation
+
+    shape, n_rep = (8, 8, 8), 4
+    temps = np.linspace(0.8, 1.4, 6).astype(np.float32)
+    J = bimodal(shape, 3, 17)
+    gpu = IsingSimulation(list(shape), J, temps, n_rep, None, 12)
+    cpu = oracle.OracleSimulation(list(shape), J, temps, n_rep, None, 12)
+    kw = dict(pt_interval=1, pt_schedule=schedule, warmup_ratio=0.0)
+    gpu.sample(7, "metropolis", **kw)
+    cpu.sample(7, "metropolis", **kw)
+    times = gpu.profile_kernels(gpu.make_config(9, "metropolis", **kw), 9)
+    assert times["k_rng"] > 0 and times["k_sweep"] > 0
+    want = cpu.sample(9, "metropolis", **kw)
+    for r in range(3):
+        np.testing.assert_array_equal(gpu.get_spins(r), cpu.get_spins(r))
+        np.testing.assert_array_equal(gpu.get_system_ids(r), cpu.get_system_ids(r))
+        np.testing.assert_array_equal(gpu.get_energies(r), cpu.get_energies(r))
+    blocks = gpu.result_blocks()  # and the statistics of those 9 sweeps are the reference's
+    from peapods_amd.distributed import aggregate_mean
+
+    np.testing.assert_array_equal(aggregate_mean(blocks)[: len(temps)], want["mags"])
+    a = gpu.sample(5, "metropolis", **kw)
+    b = cpu.sample(5, "metropolis", **kw)
+    np.testing.assert_array_equal(a["overlap2"], b["overlap2"])

@@ -1857,7 +1857,54 @@ __device__ __forceinline__ uint64_t dev_gen_range_u64(DevRng &rng, uint64_t rang
 // many CUs with a third of the sites per round (94 -> 68 us per call at 12^3 x 128 samples).
 __host__ __device__ inline size_t houdayer_lds_words(const SimDims &d) {
     return 3 * static_cast<size_t>(d.N) * d.W + 2 * static_cast<size_t>(d.n_temps) * d.n_pairs +
-           d.n_sys + 4;
+           d.n_sys + 4 + static_cast<size_t>(d.n_replicas) * d.W;
+}
+
+// Active masks of one site for a tile of NW words (registers): partners sit a multiple of n_temps bit positions
+// apart (same temperature, another replica), so for every distance class c the whole tile value is shifted by
+// c * n_temps bits once, XORed with itself and masked with the slots whose partner lies that far up (cmask[c]);
+// the result is the pair's disagreement at the lower slot, and shifted back, at the upper one.
+template <int NW>
+__device__ __forceinline__ void houdayer_active_site(const uint32_t *tile, uint32_t *A, const uint32_t *cmask, uint32_t N,
+                                                     uint32_t n_temps, uint32_t n_replicas, uint32_t i) {
+    uint32_t V[NW], out[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        V[w] = tile[w * N + i];
+        out[w] = 0;
+    }
+    for (uint32_t c = 1; c < n_replicas; ++c) {
+        uint32_t any = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) any |= cmask[c * NW + w];
+        if (!any) continue; // (uniform over the workgroup)
+        const uint32_t delta = c * n_temps, wo = delta >> 5, bo = delta & 31u;
+        uint32_t X[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { // bits of V, delta positions up, brought down to w
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int u = 0; u < NW; ++u) {
+                if (static_cast<uint32_t>(u) == w + wo) lo = V[u];
+                if (static_cast<uint32_t>(u) == w + wo + 1) hi = V[u];
+            }
+            const uint32_t down = bo ? (lo >> bo) | (hi << (32u - bo)) : lo;
+            X[w] = (V[w] ^ down) & cmask[c * NW + w];
+            out[w] |= X[w];
+        }
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { // and the same bits at the partners' positions
+            uint32_t lo = 0, lower = 0;
+#pragma unroll
+            for (int u = 0; u < NW; ++u) {
+                if (static_cast<uint32_t>(u) + wo == static_cast<uint32_t>(w)) lo = X[u];
+                if (static_cast<uint32_t>(u) + wo + 1 == static_cast<uint32_t>(w)) lower = X[u];
+            }
+            out[w] |= bo ? (lo << bo) | (lower >> (32u - bo)) : lo;
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < NW; ++w) A[w * N + i] = out[w];
 }
 
 __global__ __launch_bounds__(1024) void k_houdayer(SimDims d, DevPtrs p) {
@@ -1913,6 +1960,24 @@ __global__ __launch_bounds__(1024) void k_houdayer(SimDims d, DevPtrs p) {
     __syncthreads();
 
     // ---- active mask: bit k of A = spin(k) != spin(partner(k))
+    uint32_t *cmask = partner + d.n_sys + 4; // [n_replicas][W] slots whose partner sits c * n_temps positions up
+    if (d.W <= 4) { // the tile value of a site fits a few registers: whole-word form
+        for (uint32_t k = tid; k < d.n_replicas * d.W; k += nthreads) cmask[k] = 0;
+        __syncthreads();
+        for (uint32_t k = tid; k < d.n_sys; k += nthreads) {
+            const uint32_t q = partner[k];
+            if (q > k) atomicOr(&cmask[((q - k) / d.n_temps) * d.W + (k >> 5)], 1u << (k & 31u));
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < d.N; i += nthreads) {
+            switch (d.W) {
+            case 1: houdayer_active_site<1>(tile, A, cmask, d.N, d.n_temps, d.n_replicas, i); break;
+            case 2: houdayer_active_site<2>(tile, A, cmask, d.N, d.n_temps, d.n_replicas, i); break;
+            case 3: houdayer_active_site<3>(tile, A, cmask, d.N, d.n_temps, d.n_replicas, i); break;
+            default: houdayer_active_site<4>(tile, A, cmask, d.N, d.n_temps, d.n_replicas, i); break;
+            }
+        }
+    } else
     for (uint32_t i = tid; i < d.N; i += nthreads) {
         for (uint32_t w = 0; w < d.W; ++w) {
             uint32_t a = 0;

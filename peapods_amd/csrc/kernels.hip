@@ -953,6 +953,49 @@ __host__ __device__ inline size_t sweep_hc_lds_words(const SimDims &d) {
 // STAMPS: diagnostic build, every workgroup files s_memrealtime (100 MHz) stamps of its phases in stamps[block][8]
 #define PA_HC_STAMP(k)                                                                             \
     if (STAMPS && threadIdx.x == 0) stamps[bid * 8 + (k)] = wall_clock64();
+// Energy sum_{i,d} J s_i s_fwd and magnetisation sum_i s_i of the 32 slots of one tile word (energy.rs:92-109) from the
+// word in the LDS (sw_addr) and the schedule table (`tab`: LDS or global), by byte-sliced vertical counters.  For the
+// first 256 threads of a workgroup (the others must have left); scratch: [5][48] words of LDS.
+template <int NN>
+__device__ __forceinline__ void hc_energy(const SimDims &d, const DevPtrs &p, uint32_t real, uint32_t w, const uint32_t *tab,
+                                          uint32_t sw_addr, uint32_t *scratch, int32_t *Esum, int32_t *Msum) {
+    const uint32_t tid = threadIdx.x;
+    uint32_t c[3][8];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[s][j] = 0;
+#pragma unroll 1
+    for (uint32_t base = 0; base < d.N; base += 16 * 256) {
+        uint32_t qa[16], qb[16], qc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t pos = base + k * 256 + tid;
+            const bool live_site = pos < d.N;
+            const HcSite h = hc_decode<NN>(d, tab[live_site ? pos : 0u], sw_addr);
+            const uint32_t s = lds_load(h.site);
+            uint32_t u[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (int q = 0; q < NN; ++q) // unsatisfied forward bonds
+                u[q] = s ^ lds_load(h.nb[2 * q]) ^ static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(h.neg), 2 * q, 1));
+            qa[k] = live_site ? (u[0] ^ u[1] ^ u[2]) : 0u;   // weight 1
+            qb[k] = live_site ? maj3(u[0], u[1], u[2]) : 0u; // weight 2
+            qc[k] = live_site ? s : 0u;                      // spins equal to -1
+        }
+        count16(qa, c[0]);
+        count16(qb, c[1]);
+        count16(qc, c[2]);
+    }
+    uint32_t tot[3];
+    block_bit_totals<3>(c, scratch, tot);
+    if (tid < 32 && w * 32 + tid < d.n_sys) {
+        const uint32_t slot = w * 32 + tid;
+        const int32_t unsat = static_cast<int32_t>(tot[0] + 2 * tot[1]);
+        Esum[static_cast<size_t>(real) * d.n_sys + slot] = p.nz_bonds[real] - 2 * unsat;
+        Msum[static_cast<size_t>(real) * d.n_sys + slot] = static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(tot[2]);
+    }
+}
+
 // RsWait: the block runs inside k_rs, behind the random-stream blocks of the same launch: before it touches the
 // acceptance planes (and the tempering swap masks) it waits until their producers have published them.
 struct RsWait {
@@ -1132,42 +1175,8 @@ __device__ __forceinline__ void sweep_hc_block(const SimDims &d, const DevPtrs &
     PA_HC_STAMP(3)
 
     if (with_energy & 1) {
-        uint32_t c[3][8];
-#pragma unroll
-        for (int s = 0; s < 3; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) c[s][j] = 0;
-#pragma unroll 1
-        for (uint32_t base = 0; base < d.N; base += 16 * 256) {
-            uint32_t qa[16], qb[16], qc[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const uint32_t pos = base + k * 256 + tid;
-                const bool live_site = pos < d.N;
-                const HcSite h = hc_decode<NN>(d, tab[live_site ? pos : 0u], sw_addr);
-                const uint32_t s = lds_load(h.site);
-                uint32_t u[3] = {0u, 0u, 0u};
-#pragma unroll
-                for (int q = 0; q < NN; ++q) // unsatisfied forward bonds (energy.rs:92-107)
-                    u[q] = s ^ lds_load(h.nb[2 * q]) ^ static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(h.neg), 2 * q, 1));
-                qa[k] = live_site ? (u[0] ^ u[1] ^ u[2]) : 0u;   // weight 1
-                qb[k] = live_site ? maj3(u[0], u[1], u[2]) : 0u; // weight 2
-                qc[k] = live_site ? s : 0u;                      // spins equal to -1
-            }
-            count16(qa, c[0]);
-            count16(qb, c[1]);
-            count16(qc, c[2]);
-        }
         PA_HC_STAMP(4)
-        uint32_t tot[3];
-        block_bit_totals<3>(c, scratch, tot);
-        if (tid < 32 && w * 32 + tid < d.n_sys) {
-            const uint32_t slot = w * 32 + tid;
-            const int32_t unsat = static_cast<int32_t>(tot[0] + 2 * tot[1]);
-            (FUSED ? p.Esum_out : p.Esum)[static_cast<size_t>(real) * d.n_sys + slot] = p.nz_bonds[real] - 2 * unsat;
-            (FUSED ? p.Msum_out : p.Msum)[static_cast<size_t>(real) * d.n_sys + slot] =
-                static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(tot[2]);
-        }
+        hc_energy<NN>(d, p, real, w, tab, sw_addr, scratch, FUSED ? p.Esum_out : p.Esum, FUSED ? p.Msum_out : p.Msum);
     }
     PA_HC_STAMP(5)
 }
@@ -2018,11 +2027,17 @@ __global__ __launch_bounds__(1024) void k_houdayer(SimDims d, DevPtrs p) {
 }
 
 // grow every cluster of one tile word to its connected component inside the active graph, then flip
-__global__ __launch_bounds__(1024) void k_houdayer_grow(SimDims d, DevPtrs p) {
+// with_energy (lattices with the schedule table, SimDims::hc): the workgroup also leaves the energies and
+// magnetisations of its word's 32 slots after the move (mod.rs:749-756 recomputes them before the tempering event) --
+// the flipped word is in the LDS anyway, so this replaces an energy-only launch of the sweep kernel.  A word without a
+// seed changes nothing and keeps the sums the sweep left.
+__global__ __launch_bounds__(1024) void k_houdayer_grow(SimDims d, DevPtrs p, int with_energy) {
     extern __shared__ uint32_t lds[];
     uint32_t *A = lds;             // [N] active mask of the word
     uint32_t *F = lds + d.N;       // [N] cluster membership
     uint32_t *changed = F + d.N;   // [1]
+    uint32_t *sw = changed + 4;    // [N + 1] the word after the move (with_energy)
+    uint32_t *scratch = sw + d.N + 4; // [5][48]
     const uint32_t real = blockIdx.x / d.W, w = blockIdx.x % d.W;
     const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
     const size_t tile_words = static_cast<size_t>(d.N) * d.W;
@@ -2048,21 +2063,37 @@ __global__ __launch_bounds__(1024) void k_houdayer_grow(SimDims d, DevPtrs p) {
     // Growth is monotone (a bit is only ever set, and only where a path of active sites leads to the seed), so the
     // passes need no barrier between them: a pass may read its neighbours before or after their update, the fixed
     // point is the same.  Convergence is checked every four passes.
+    // a thread visits the same (up to four) sites in every pass: their records are fetched once, not once per pass
+    constexpr int kCached = 4;
+    const bool cached = d.N <= kCached * nthreads;
+    uint4 mine[kCached];
+#pragma unroll
+    for (int k = 0; k < kCached; ++k) {
+        const uint32_t pos = tid + k * nthreads;
+        mine[k] = (cached && pos < d.N) ? rec[pos] : make_uint4(0, 0, 0, 0);
+    }
+    auto grow_site = [&](const uint4 raw, bool &grew) {
+        const SiteRec r(raw);
+        const uint32_t f = lds_word(F, r.site);
+        uint32_t g = f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g |= lds_word(F, r.nb[k]);
+        g &= lds_word(A, r.site);
+        g |= f;
+        if (g != f) {
+            F[r.site >> 2] = g;
+            grew = true;
+        }
+    };
     for (uint32_t iter = 0; iter <= d.N; ++iter) {
         bool grew = false;
         for (int pass = 0; pass < 4; ++pass) {
-            for (uint32_t pos = tid; pos < d.N; pos += nthreads) {
-                const SiteRec r(rec[pos]);
-                const uint32_t f = lds_word(F, r.site);
-                uint32_t g = f;
+            if (cached) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) g |= lds_word(F, r.nb[k]);
-                g &= lds_word(A, r.site);
-                g |= f;
-                if (g != f) {
-                    F[r.site >> 2] = g;
-                    grew = true;
-                }
+                for (int k = 0; k < kCached; ++k)
+                    if (tid + k * nthreads < d.N) grow_site(mine[k], grew);
+            } else {
+                for (uint32_t pos = tid; pos < d.N; pos += nthreads) grow_site(rec[pos], grew);
             }
         }
         if (grew) changed[0] = 1;
@@ -2074,9 +2105,25 @@ __global__ __launch_bounds__(1024) void k_houdayer_grow(SimDims d, DevPtrs p) {
         __syncthreads();
     }
     // ---- flip both replicas of every pair on its cluster
+    if (!with_energy) {
+        for (uint32_t i = tid; i < d.N; i += nthreads) {
+            const uint32_t f = F[i];
+            if (f) Sg[i] ^= f;
+        }
+        return;
+    }
     for (uint32_t i = tid; i < d.N; i += nthreads) {
-        const uint32_t f = F[i];
-        if (f) Sg[i] ^= f;
+        const uint32_t f = F[i], v = Sg[i] ^ f;
+        sw[i] = v;
+        if (f) Sg[i] = v;
+    }
+    __syncthreads();
+    if (tid >= 256) return; // (the sums are a 256-thread role; a barrier waits for the surviving waves only)
+    const uint32_t *tab = p.hc_tab + static_cast<size_t>(real) * d.N;
+    switch (d.nn) {
+    case 1: hc_energy<1>(d, p, real, w, tab, lds_addr_of(sw), scratch, p.Esum, p.Msum); break;
+    case 2: hc_energy<2>(d, p, real, w, tab, lds_addr_of(sw), scratch, p.Esum, p.Msum); break;
+    default: hc_energy<3>(d, p, real, w, tab, lds_addr_of(sw), scratch, p.Esum, p.Msum); break;
     }
 }
 
@@ -2804,6 +2851,7 @@ hipError_t configure_kernels(const SimDims &) {
                            reinterpret_cast<const void *>(k_rng_overlap<false>),
                            reinterpret_cast<const void *>(k_rng_overlap<true>),
                            reinterpret_cast<const void *>(k_houdayer),
+                           reinterpret_cast<const void *>(k_houdayer_grow),
                            reinterpret_cast<const void *>(k_jorg),
                            reinterpret_cast<const void *>(k_measure<false>),
                            reinterpret_cast<const void *>(k_measure<true>)}) {
@@ -3024,11 +3072,14 @@ hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream
     return hipGetLastError();
 }
 
-hipError_t launch_houdayer(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
+hipError_t launch_houdayer(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool with_energy) {
     hipLaunchKernelGGL(k_houdayer, dim3(d.n_real), dim3(1024), houdayer_lds_words(d) * 4, stream, d, p);
-    hipLaunchKernelGGL(k_houdayer_grow, dim3(d.n_real * d.W), dim3(1024), (2 * static_cast<size_t>(d.N) + 4) * 4, stream, d, p);
+    const bool e = with_energy && d.hc && d.dense_nn == d.nn;
+    const size_t lds = (2 * static_cast<size_t>(d.N) + 4 + (e ? d.N + 4 + 5 * 48 : 0)) * 4;
+    hipLaunchKernelGGL(k_houdayer_grow, dim3(d.n_real * d.W), dim3(1024), lds, stream, d, p, e ? 1 : 0);
     return hipGetLastError();
 }
+bool houdayer_computes_energy(const SimDims &d) { return d.hc && d.dense_nn == d.nn; }
 size_t houdayer_lds_bytes(const SimDims &d) { return houdayer_lds_words(d) * 4; }
 
 hipError_t launch_jorg(const SimDims &d, const DevPtrs &p, hipStream_t stream) {

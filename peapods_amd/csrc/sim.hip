@@ -1058,6 +1058,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                 // ... of GLOBAL realisation 0 (realization_idx == 0, mod.rs:302): a handle holding a later shard
                 // of the ensemble takes none, and its first realisation stays on the search path like the rest
                 const bool first_group = &g == &sim->groups.front() && sim->first_realization == 0;
+                bool energy_done = false; // the move's kernel left the new energies itself (Houdayer growth kernel)
                 // mod.rs:604-658: sizes / metrics on recorded calls, snapshots of the first realisation
                 const bool take_snapshot = snapshot_interval > 0 && sweep_id % snapshot_interval == 0 && record;
                 ClusterAux aux{};
@@ -1107,8 +1108,10 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                     PA_HIP(sim, launch_jorg_wave(g.d, g.p, g.stream)); // one wave per pair, tables in the LDS
                 else if (oc_kind == PA_OC_JORG)
                     PA_HIP(sim, launch_jorg(g.d, g.p, g.stream)); // :601-602,660-680
-                else
-                    PA_HIP(sim, launch_houdayer(g.d, g.p, g.stream));
+                else {
+                    energy_done = pt_this && !observe_overlap && houdayer_computes_energy(g.d);
+                    PA_HIP(sim, launch_houdayer(g.d, g.p, g.stream, energy_done));
+                }
                 if (aux.flags & kAuxSizes) PA_HIP(sim, launch_top4_accumulate(g.d, g.p, aux, g.stream)); // :725-735
                 if (take_snapshot && first_group) { // :682-714
                     PA_HIP(sim, launch_uf_replay(g.d, g.p, oc_kind == PA_OC_CMR, g.stream));
@@ -1135,7 +1138,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                     sim->snapshots.push_back(std::move(snap));
                 }
                 if (pt_this) { // energies are recomputed after a mutating move (:749-756)
-                    if (!observe_overlap) PA_HIP(sim, launch_sweep(g.d, g.p, true, false, false, g.stream));
+                    if (!observe_overlap && !energy_done) PA_HIP(sim, launch_sweep(g.d, g.p, true, false, false, g.stream));
                     if (relay_nf) { // the tempering event rides in the next sweep's random-stream launch
                         pending.any = true;
                         pending.pt = pt;

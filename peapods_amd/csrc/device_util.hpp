@@ -96,12 +96,20 @@ struct Rng32 {
 __device__ __forceinline__ void jump_state_lds(uint32_t st[8], const uint32_t *tab) {
     uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int p = 0; p < 64; ++p) {
-        const uint32_t nib = (st[p >> 3] >> ((p & 7) * 4)) & 15u;
-        const uint4 *e = reinterpret_cast<const uint4 *>(tab + (p * 16 + nib) * 8);
-        const uint4 a = e[0], b = e[1];
-        acc[0] ^= a.x; acc[1] ^= a.y; acc[2] ^= a.z; acc[3] ^= a.w;
-        acc[4] ^= b.x; acc[5] ^= b.y; acc[6] ^= b.z; acc[7] ^= b.w;
+    for (int p = 0; p < 64; p += 2) { // two table rows per round: one three-input XOR (v_bitop3) folds both in
+        const uint32_t nib0 = (st[p >> 3] >> ((p & 7) * 4)) & 15u;
+        const uint32_t nib1 = (st[(p + 1) >> 3] >> (((p + 1) & 7) * 4)) & 15u;
+        const uint4 *e0 = reinterpret_cast<const uint4 *>(tab + (p * 16 + nib0) * 8);
+        const uint4 *e1 = reinterpret_cast<const uint4 *>(tab + ((p + 1) * 16 + nib1) * 8);
+        const uint4 a = e0[0], b = e0[1], c = e1[0], e = e1[1];
+        acc[0] = __builtin_amdgcn_bitop3_b32(acc[0], a.x, c.x, 0x96);
+        acc[1] = __builtin_amdgcn_bitop3_b32(acc[1], a.y, c.y, 0x96);
+        acc[2] = __builtin_amdgcn_bitop3_b32(acc[2], a.z, c.z, 0x96);
+        acc[3] = __builtin_amdgcn_bitop3_b32(acc[3], a.w, c.w, 0x96);
+        acc[4] = __builtin_amdgcn_bitop3_b32(acc[4], b.x, e.x, 0x96);
+        acc[5] = __builtin_amdgcn_bitop3_b32(acc[5], b.y, e.y, 0x96);
+        acc[6] = __builtin_amdgcn_bitop3_b32(acc[6], b.z, e.z, 0x96);
+        acc[7] = __builtin_amdgcn_bitop3_b32(acc[7], b.w, e.w, 0x96);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) st[j] = acc[j];

@@ -1019,16 +1019,42 @@ __global__ __launch_bounds__(64) void k_uf_replay(SimDims d, DevPtrs p, int cmr)
 // (k_jorg / k_fk_wolff, one lane per task with stacks in global memory, remain for lattices
 // whose tables do not fit: Joerg 2.1 ms -> 0.2 ms per call on 6144 pairs of 12^3).
 // ---------------------------------------------------------------------------
-// tasks (waves) per workgroup share the lattice tables: as many as the LDS holds, up to 16 -- a wave alone issues an
-// instruction every five cycles or so, so the throughput is the number of waves a CU can keep resident
-__host__ __device__ inline size_t wolff_wave_lds_words(const SimDims &d, uint32_t tasks) {
-    return static_cast<size_t>(d.N) * 6 + d.N + tasks * (5 * static_cast<size_t>(d.MW) + (d.N + 1) / 2) + 16;
+// tasks (waves) per workgroup share the lattice tables.  A lone wave issues an instruction every five cycles or so and
+// waits out two LDS round trips per site, so the throughput is the number of searches in flight: the workgroup size is
+// the one that lets every task of the launch be resident at once if the LDS allows it (12^3, 6144 pairs: 12 waves and
+// 78 KB per workgroup, two workgroups per CU, instead of 16 waves and 93 KB in two rounds)
+__host__ __device__ inline uint32_t wolff_wave_bitmaps(int mode) { return mode == kSwFk ? 2u : (mode == kSwCmr ? 4u : 3u); }
+__host__ __device__ inline size_t wolff_wave_lds_words(const SimDims &d, uint32_t tasks, int mode) {
+    return static_cast<size_t>(d.N) * d.nn + d.N + tasks * (static_cast<size_t>(wolff_wave_bitmaps(mode)) * d.MW + (d.N + 1) / 2) + 16;
 }
-__host__ inline uint32_t wolff_wave_tasks(const SimDims &d) {
-    uint32_t tasks = 16;
-    if (const char *env = std::getenv("PEAPODS_WAVE_TASKS")) tasks = static_cast<uint32_t>(std::max(1l, std::min(16l, std::strtol(env, nullptr, 10))));
-    while (tasks > 1 && wolff_wave_lds_words(d, tasks) * 4 > 160 * 1024) tasks /= 2;
-    return tasks;
+__host__ inline uint32_t wolff_wave_tasks(const SimDims &d, int mode) {
+    const uint32_t n_tasks = mode == kSwFk ? d.n_sys : d.n_temps * d.n_pairs;
+    if (const char *env = std::getenv("PEAPODS_WAVE_TASKS")) {
+        uint32_t tasks = static_cast<uint32_t>(std::max(1l, std::min(16l, std::strtol(env, nullptr, 10))));
+        while (tasks > 1 && wolff_wave_lds_words(d, tasks, mode) * 4 > 160 * 1024) tasks /= 2;
+        return tasks;
+    }
+    uint32_t best = 1;
+    uint64_t best_rounds = ~0ull;
+    for (uint32_t tasks : {16u, 12u, 8u, 6u, 4u, 2u, 1u}) {
+        const size_t bytes = wolff_wave_lds_words(d, tasks, mode) * 4;
+        if (bytes > 160 * 1024) continue;
+        const uint64_t resident = std::min<uint64_t>(160 * 1024 / ((bytes + 511) & ~size_t(511)), 32 / tasks);
+        const uint64_t groups = static_cast<uint64_t>(d.n_real) * ((n_tasks + tasks - 1) / tasks);
+        const uint64_t rounds = (groups + 256 * resident - 1) / (256 * resident);
+        if (rounds < best_rounds) {
+            best_rounds = rounds;
+            best = tasks;
+        }
+    }
+    return best;
+}
+
+// a value every lane holds alike, told to the compiler (the generator of a search then lives in scalar registers)
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32)); // (the builtin returns int)
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+    return (static_cast<uint64_t>(hi) << 32) | lo;
 }
 
 template <int MODE>
@@ -1036,21 +1062,24 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
     const uint32_t kWaveTasks = blockDim.x / 64;
     constexpr bool FK = MODE == kSwFk, CMR = MODE == kSwCmr;
     extern __shared__ uint32_t lds[];
-    uint16_t *nbr = reinterpret_cast<uint16_t *>(lds); // [N][12] neighbours by site: f0, b0, f1, b1, ...
-    uint32_t *jbits = lds + static_cast<size_t>(d.N) * 6; // [N] neg[0..11] | nz[12..23] of the twelve bond slots
+    uint16_t *nbr = reinterpret_cast<uint16_t *>(lds); // [N][2 nn] neighbours by site: f0, b0, f1, b1, ...
+    uint32_t *jbits = lds + static_cast<size_t>(d.N) * d.nn; // [N] neg[0..11] | nz[12..23] of the twelve bond slots
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t per_task = 5 * d.MW + (d.N + 1) / 2;
+    const uint32_t per_task = wolff_wave_bitmaps(MODE) * d.MW + (d.N + 1) / 2;
     uint32_t *mine = jbits + d.N + wave * per_task;
-    uint32_t *act = mine, *spa = mine + d.MW, *member = mine + 2 * d.MW;
-    uint32_t *spb = mine + 3 * d.MW, *blue = mine + 4 * d.MW; // CMR: spins of the second system, the blue cluster
-    uint16_t *stack = reinterpret_cast<uint16_t *>(mine + 5 * d.MW);
+    // the task's bitmaps: spins of the first system, the cluster; Joerg: the active sites; CMR: spins of the second
+    // system, the blue cluster (FK and CMR grow over every site: no activity map)
+    uint32_t *spa = mine, *member = mine + d.MW;
+    uint32_t *act = (FK || CMR) ? nullptr : mine + 2 * d.MW;
+    uint32_t *spb = CMR ? mine + 2 * d.MW : nullptr, *blue = CMR ? mine + 3 * d.MW : nullptr;
+    uint16_t *stack = reinterpret_cast<uint16_t *>(mine + wolff_wave_bitmaps(MODE) * d.MW);
     const uint32_t n_tasks = FK ? d.n_sys : d.n_temps * d.n_pairs;
     const uint32_t blocks_per_real = (n_tasks + kWaveTasks - 1) / kWaveTasks;
     const uint32_t real = blockIdx.x / blocks_per_real;
     const uint32_t task = __builtin_amdgcn_readfirstlane((blockIdx.x % blocks_per_real) * kWaveTasks + wave);
     {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(p.nbr_site);
-        for (uint32_t i = tid; i < d.N * 6; i += blockDim.x) lds[i] = src[i];
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(p.nbr_site); // [N][12] u16: the first 2 nn slots are used
+        for (uint32_t i = tid; i < d.N * d.nn; i += blockDim.x) lds[i] = src[(i / d.nn) * 6 + i % d.nn];
         const uint32_t *js = p.jsite + static_cast<size_t>(real) * d.N;
         for (uint32_t i = tid; i < d.N; i += blockDim.x) jbits[i] = js[i];
     }
@@ -1071,15 +1100,15 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
         const unsigned long long mb = __ballot(vb != 0);
         const uint32_t word = i0 >> 5;
         if (lane == 0) {
-            act[word] = static_cast<uint32_t>(ma);
+            if (!(FK || CMR)) act[word] = static_cast<uint32_t>(ma);
             spa[word] = static_cast<uint32_t>(ms);
-            spb[word] = static_cast<uint32_t>(mb);
+            if (CMR) spb[word] = static_cast<uint32_t>(mb);
             member[word] = 0;
         }
         if (lane == 32 && word + 1 < d.MW) {
-            act[word + 1] = static_cast<uint32_t>(ma >> 32);
+            if (!(FK || CMR)) act[word + 1] = static_cast<uint32_t>(ma >> 32);
             spa[word + 1] = static_cast<uint32_t>(ms >> 32);
-            spb[word + 1] = static_cast<uint32_t>(mb >> 32);
+            if (CMR) spb[word + 1] = static_cast<uint32_t>(mb >> 32);
             member[word + 1] = 0;
         }
     }
@@ -1115,6 +1144,7 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
     }
     if (seed != 0xFFFFFFFFu) {
         const float temp = d.unit ? 0.0f : p.temps[t];
+        rng.s0 = uniform64(rng.s0); rng.s1 = uniform64(rng.s1); rng.s2 = uniform64(rng.s2); rng.s3 = uniform64(rng.s3);
         uint32_t top = 0;
         uint32_t next = 0; // the entry on top of the stack, kept in a register: most pops never read the LDS
         bool next_known = false;
@@ -1122,7 +1152,7 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
         // bonds, or CMR's blue bonds (both systems satisfied, 1 - r^2); phase 1: CMR's red bonds (exactly one
         // system satisfied, 1 - r), which a flip of both systems on the blue cluster leaves as they are
         auto search = [&](uint32_t phase) {
-            const uint32_t threshold = FK ? p.fk_thr[t] : (CMR ? (phase == 0 ? p.cmr_thr[t] : p.fk_thr[t]) : p.jorg_thr[t]);
+            const uint32_t threshold = __builtin_amdgcn_readfirstlane(FK ? p.fk_thr[t] : (CMR ? (phase == 0 ? p.cmr_thr[t] : p.fk_thr[t]) : p.jorg_thr[t]));
             while (top > 0) {
                 --top;
                 const uint32_t site = next_known ? next : __builtin_amdgcn_readfirstlane(stack[top]);
@@ -1131,8 +1161,9 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
                 // lanes 0..11: is the bond of slot `lane` eligible?  Every bitmap word is requested before any is
                 // looked at (no short-circuit: each would be another LDS round trip on the search's critical path)
                 const bool slot_ok = lane < 2 * d.nn;
-                const uint32_t nb = slot_ok ? nbr[site * 12 + lane] : site;
-                const uint32_t w_site = spa[site >> 5], w_nb = spa[nb >> 5], w_act = act[nb >> 5], w_mem = member[nb >> 5];
+                const uint32_t nb = slot_ok ? nbr[site * 2 * d.nn + lane] : site;
+                const uint32_t w_site = spa[site >> 5], w_nb = spa[nb >> 5], w_mem = member[nb >> 5];
+                const uint32_t w_act = (FK || CMR) ? 0xFFFFFFFFu : act[nb >> 5];
                 const uint32_t w_site_b = CMR ? spb[site >> 5] : 0u, w_nb_b = CMR ? spb[nb >> 5] : 0u;
                 const uint32_t neg = (jm >> lane) & 1u, nzb = (jm >> (12 + lane)) & 1u;
                 const uint32_t a_unsat = ((w_site >> (site & 31u)) ^ (w_nb >> (nb & 31u)) ^ neg) & 1u;
@@ -1147,7 +1178,7 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
                     const uint32_t q = __ffs(todo) - 1;
                     todo &= todo - 1;
                     const uint32_t target = __builtin_amdgcn_readlane(nb, q);
-                    const uint32_t draw = static_cast<uint32_t>(rng.next() >> 40);
+                    const uint32_t draw = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(rng.next() >> 40));
                     uint32_t limit = threshold; // draw < ceil(p 2^24)  <=>  gen::<f32>() < p
                     if (!d.unit) { // this bond's own probability; the coupling belongs to the bond's forward end
                         const uint32_t owner = (q & 1u) ? target : site;
@@ -1155,6 +1186,8 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
                         limit = FK ? fk_threshold(j_abs, temp)
                                    : (CMR ? (phase == 0 ? cmr_blue_threshold(j_abs, temp) : fk_threshold(j_abs, temp))
                                           : jorg_threshold(j_abs, temp));
+                        // the same in every lane: said so, the search's control flow and the generator stay on the scalar unit
+                        limit = __builtin_amdgcn_readfirstlane(limit);
                     }
                     if (draw < limit) {
                         if (lane == 0) { // (an LDS atomic without return: nothing to wait for; LDS operations of a wave stay in order)
@@ -1538,22 +1571,23 @@ hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, ui
     return hipGetLastError();
 }
 
-size_t wolff_wave_lds_bytes(const SimDims &d) { return wolff_wave_lds_words(d, wolff_wave_tasks(d)) * 4; }
+size_t wolff_wave_lds_bytes(const SimDims &d, int mode) { return wolff_wave_lds_words(d, wolff_wave_tasks(d, mode), mode) * 4; }
+size_t wolff_wave_lds_bytes(const SimDims &d) { return wolff_wave_lds_bytes(d, kSwCmr); } // the largest of the three forms
 
 // Joerg single-cluster move, one wave per pair (after the pairing shuffle)
 hipError_t launch_jorg_wave(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
     hipLaunchKernelGGL(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
-    const uint32_t n_tasks = d.n_temps * d.n_pairs, per_block = wolff_wave_tasks(d);
+    const uint32_t n_tasks = d.n_temps * d.n_pairs, per_block = wolff_wave_tasks(d, kSwJorg);
     hipLaunchKernelGGL(k_wolff_wave<kSwJorg>, dim3(d.n_real * ((n_tasks + per_block - 1) / per_block)), dim3(64 * per_block),
-                       wolff_wave_lds_bytes(d), stream, d, p);
+                       wolff_wave_lds_bytes(d, kSwJorg), stream, d, p);
     return hipGetLastError();
 }
 
 hipError_t launch_cmr_wave(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
     hipLaunchKernelGGL(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
-    const uint32_t n_tasks = d.n_temps * d.n_pairs, per_block = wolff_wave_tasks(d);
+    const uint32_t n_tasks = d.n_temps * d.n_pairs, per_block = wolff_wave_tasks(d, kSwCmr);
     hipLaunchKernelGGL(k_wolff_wave<kSwCmr>, dim3(d.n_real * ((n_tasks + per_block - 1) / per_block)), dim3(64 * per_block),
-                       wolff_wave_lds_bytes(d), stream, d, p);
+                       wolff_wave_lds_bytes(d, kSwCmr), stream, d, p);
     return hipGetLastError();
 }
 
@@ -1575,9 +1609,10 @@ size_t fk_wolff_lds_bytes(const SimDims &d) { return fk_wolff_lds_words(d) * 4; 
 hipError_t launch_fk(const SimDims &d, const DevPtrs &p, bool wolff, const ClusterAux &aux_in, hipStream_t stream) {
     ClusterAux aux = aux_in;
     if (wolff && aux.flags == 0) { // depth-first single-cluster form: one wave per system if the tables fit the LDS
-        if (wolff_wave_lds_bytes(d) <= 160 * 1024 && d.N <= 65535)
-            hipLaunchKernelGGL(k_wolff_wave<kSwFk>, dim3(d.n_real * ((d.n_sys + wolff_wave_tasks(d) - 1) / wolff_wave_tasks(d))),
-                               dim3(64 * wolff_wave_tasks(d)), wolff_wave_lds_bytes(d), stream, d, p);
+        const uint32_t per_block = wolff_wave_tasks(d, kSwFk);
+        if (wolff_wave_lds_bytes(d, kSwFk) <= 160 * 1024 && d.N <= 65535)
+            hipLaunchKernelGGL(k_wolff_wave<kSwFk>, dim3(d.n_real * ((d.n_sys + per_block - 1) / per_block)),
+                               dim3(64 * per_block), wolff_wave_lds_bytes(d, kSwFk), stream, d, p);
         else
             hipLaunchKernelGGL(k_fk_wolff, dim3(d.n_real), dim3(1024), fk_wolff_lds_bytes(d), stream, d, p);
         return hipGetLastError();

@@ -88,10 +88,6 @@ struct DevPtrs {
                              //   jmeta = neg[0..5] | nz[6..11] | h[12..13] for bonds f0,b0,f1,b1,f2,b2
     const uint32_t *pass_start; // [n_passes + 1]
     const uint32_t *hc_tab;  // [n_real][N] schedule order: site | wrap flags << 14 | neg bits << 20 (SimDims::hc)
-    // k_rs (random stream + sweep in one launch): progress flags, monotone over the launches of a stream group
-    uint32_t *rs_ready;      // [n_real * W] by random-stream workgroup group: site blocks published so far (+ B per launch)
-    uint32_t *rs_measured;   // [n_real] measurement blocks run so far
-    uint32_t *rs_error;      // [1] a sweep block gave up waiting
     const uint32_t *seg;     // [n_levels][pipe_K + 1] schedule positions where each slab's part of a level starts
     uint32_t *progress;      // [n_real * W][pipe_K] levels completed by each slab workgroup (epoch-based, monotone)
     const uint32_t *halo_start; // [pipe_K][n_levels + 2] k_sweep_slab: the exchange records a slab first reads at level l are
@@ -108,8 +104,6 @@ struct DevPtrs {
     const uint32_t *jump;    // [B][64][16][8] nibble tables of T^(b*BS)
     int32_t *Esum;           // [n_real][n_sys] by slot: sum_{i,d} J s s (exact integer)
     int32_t *Msum;           // [n_real][n_sys] by slot: sum_i s_i
-    int32_t *Esum_out;       // where the sweep blocks of a k_rs launch leave the new sums: the measurement block and the
-    int32_t *Msum_out;       //   replay lanes of that launch still read the previous sweep's; exchanged by the host after it
     const int32_t *nz_bonds; // [n_real] number of non-zero forward bonds
     int32_t *dot_spin;       // [n_real][n_pairs][n_temps]
     int32_t *dot_link;       // [n_real][n_pairs][n_temps]
@@ -235,13 +229,6 @@ hipError_t launch_rng_overlap(const SimDims &d, const DevPtrs &p, hipStream_t st
 hipError_t launch_rng_relay(const SimDims &d, const DevPtrs &p, bool with_overlap, const PtParams &pt, bool do_accum,
                             bool accum_overlap, bool do_pt, hipStream_t stream);
 bool rng_relay_supported(const SimDims &d);
-// The whole sweep in ONE launch (k_rs): overlap blocks, measurement blocks, random-stream blocks (8 waves each), then the
-// sweep blocks, which wait inside the launch for the planes of their tile word.  ready_epoch / measured_epoch: number of
-// k_rs launches (with measurement blocks) of this stream group including this one.
-hipError_t launch_rs(const SimDims &d, const DevPtrs &p, bool with_overlap, const PtParams &pt, bool do_accum,
-                     bool accum_overlap, bool do_pt, bool with_energy, uint32_t ready_epoch, uint32_t measured_epoch,
-                     hipStream_t stream);
-bool rs_supported(const SimDims &d);
 hipError_t launch_sweep_pipe(const SimDims &d, const DevPtrs &p, bool gibbs, uint32_t epoch, hipStream_t stream);
 hipError_t launch_apply_swaps(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 hipError_t launch_houdayer(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool with_energy = false);

@@ -185,7 +185,7 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
     const uint32_t block = bid % d.B;
     const uint32_t group = bid / d.B;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t nthreads = blockDim.x, nw = nthreads >> 6; // 4 waves (k_rng, k_rng_relay) or 8 (k_rs)
+    const uint32_t nthreads = blockDim.x, nw = nthreads >> 6; // 4 waves (k_rng, k_rng_relay)
     const uint32_t bit = lane & 31u, half = lane >> 5;
     const uint32_t n_tw = d.n_real * d.W;
     const uint32_t tw = (group * nw + wave) * 2 + half;
@@ -947,7 +947,7 @@ __device__ __forceinline__ HcSite hc_decode(const SimDims &d, uint32_t e, uint32
 __host__ __device__ inline size_t sweep_hc_lds_words(const SimDims &d) {
     const size_t n1 = static_cast<size_t>(d.N) + 1, n_pad = (n1 + 3) & ~size_t(3);
     const size_t tab = (static_cast<size_t>(d.N) + 3) & ~size_t(3);
-    return n_pad + ((2 * n1 + 3) & ~size_t(3)) + tab + ((static_cast<size_t>(d.n_passes) + 5 + 3) & ~size_t(3)) + 5 * 48;
+    return n_pad + ((2 * n1 + 3) & ~size_t(3)) + tab + ((static_cast<size_t>(d.n_passes) + 6 + 3) & ~size_t(3)) + 5 * 48;
 }
 
 // STAMPS: diagnostic build, every workgroup files s_memrealtime (100 MHz) stamps of its phases in stamps[block][8]
@@ -996,36 +996,106 @@ __device__ __forceinline__ void hc_energy(const SimDims &d, const DevPtrs &p, ui
     }
 }
 
-// RsWait: the block runs inside k_rs, behind the random-stream blocks of the same launch: before it touches the
-// acceptance planes (and the tempering swap masks) it waits until their producers have published them.
-struct RsWait {
-    const uint32_t *ready;   // [rng groups] launches completed by the random-stream workgroup group that covers a tile word
-    const uint32_t *measured; // [n_real] launches in which the realisation's measurement block has run
-    uint32_t ready_target, measured_target, tw_per_group;
-    uint32_t *error;         // set when a wait gives up (pa_sim_synchronize reports it)
-};
+// The same sums by all 512 threads of the sweep workgroup, for 512 <= N <= 4096 (at most eight sites per thread, so
+// a 16-lane row sums its byte counters without widening: 8 x 16 = 128).  Four DPP steps leave the row sums in every
+// lane; the 32 rows file theirs in `part` ([32][24] words of LDS, the dead acceptance planes) and 96 threads add them up.
+__device__ __forceinline__ void count8(const uint32_t w[8], uint32_t c[8]) {
+    uint32_t s0, s1, c0, c1, t0, d0;
+    full_add(w[0], w[1], w[2], s0, c0);
+    full_add(w[3], w[4], w[5], s1, c1);
+    full_add(s0, s1, w[6], t0, d0);
+    const uint32_t p0 = t0 ^ w[7], d1 = t0 & w[7]; // weight 1
+    uint32_t u0, e0;
+    full_add(c0, c1, d0, u0, e0);
+    const uint32_t p1 = u0 ^ d1, e1 = u0 & d1;     // weight 2
+    const uint32_t p2 = e0 ^ e1, p3 = e0 & e1;     // weights 4, 8
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        c[j] = ((p0 >> j) & 0x01010101u) + (((p1 >> j) & 0x01010101u) << 1) + (((p2 >> j) & 0x01010101u) << 2) +
+               (((p3 >> j) & 0x01010101u) << 3);
+}
 
-template <int NN, bool STAMPS, bool FUSED>
+template <int NN>
+__device__ __forceinline__ void hc_energy_wide(const SimDims &d, const DevPtrs &p, uint32_t real, uint32_t w, const uint32_t *tab,
+                                               uint32_t sw_addr, uint32_t *part, uint32_t *scratch) {
+    const uint32_t tid = threadIdx.x;
+    const int32_t nz = p.nz_bonds[real]; // (asked for now: a global round trip at the end would be fully exposed)
+    uint32_t qa[8], qb[8], qc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t pos = k * 512 + tid;
+        const bool live_site = pos < d.N;
+        const HcSite h = hc_decode<NN>(d, tab[live_site ? pos : 0u], sw_addr);
+        const uint32_t s = lds_load(h.site);
+        uint32_t u[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int q = 0; q < NN; ++q) // unsatisfied forward bonds
+            u[q] = s ^ lds_load(h.nb[2 * q]) ^ static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(h.neg), 2 * q, 1));
+        qa[k] = live_site ? (u[0] ^ u[1] ^ u[2]) : 0u;   // weight 1
+        qb[k] = live_site ? maj3(u[0], u[1], u[2]) : 0u; // weight 2
+        qc[k] = live_site ? s : 0u;                      // spins equal to -1
+    }
+    uint32_t c[3][8];
+    count8(qa, c[0]);
+    count8(qb, c[1]);
+    count8(qc, c[2]);
+    __syncthreads(); // (every read of the planes is behind us: `part` may be written)
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint32_t v = c[s][j];
+            v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x128, 0xF, 0xF, false));
+            v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x124, 0xF, 0xF, false));
+            v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x122, 0xF, 0xF, false));
+            v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x121, 0xF, 0xF, false));
+            if ((tid & 15u) == 0) part[(tid >> 4) * 24 + s * 8 + j] = v;
+        }
+    __syncthreads();
+    if (tid < 96) { // thread = (set, slot); slot = j + 8 * byte of the sliced counters
+        const uint32_t set = tid >> 5, slot = tid & 31u, j = slot & 7u, shift = (slot >> 3) * 8;
+        uint32_t sum = 0;
+#pragma unroll 8
+        for (uint32_t q = 0; q < 32; ++q) sum += (part[q * 24 + set * 8 + j] >> shift) & 0xFFu;
+        scratch[tid] = sum;
+    }
+    __syncthreads();
+    if (tid < 32 && w * 32 + tid < d.n_sys) {
+        const uint32_t slot = w * 32 + tid;
+        const int32_t unsat = static_cast<int32_t>(scratch[tid] + 2 * scratch[32 + tid]);
+        p.Esum[static_cast<size_t>(real) * d.n_sys + slot] = nz - 2 * unsat;
+        p.Msum[static_cast<size_t>(real) * d.n_sys + slot] = static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(scratch[64 + tid]);
+    }
+}
+
+// Workgroup = (realisation, word), 512 threads in two sets of four waves.  A pass is a chain -- nine LDS reads, the
+// accept logic, one write, the barrier -- and a lone wave issues one instruction every ~4.7 cycles however independent
+// they are (profiles/r02_valu_issue.json), so everything that is not on the chain is done by OTHER waves: the sets take
+// the passes in turn, and while one computes pass p the other fetches the table entry of pass p + 1 and decodes its
+// seven LDS addresses, then meets it at the barrier.  Between two barriers one set does "reads -> accept -> write" and
+// nothing else.
+template <int NN, bool STAMPS>
 __device__ __forceinline__ void sweep_hc_block(const SimDims &d, const DevPtrs &p, uint32_t bid, int with_energy, int do_sweep,
-                                               unsigned long long *stamps, const RsWait &wait, uint32_t *lds) {
+                                               unsigned long long *stamps, uint32_t *lds) {
     PA_HC_STAMP(0)
+    constexpr uint32_t kThreads = 512;
     const uint32_t n1 = d.N + 1;
     const uint32_t n_pad = (n1 + 3u) & ~3u;
     uint32_t *sw = lds;                                   // [N + 1] spins of this word (+ spare slot N)
     uint32_t *pl = sw + n_pad;                            // [N + 1][2] acceptance-level planes
     uint32_t *tab = pl + ((2 * n1 + 3u) & ~3u);           // [N] schedule table of this realisation
-    uint32_t *ps = tab + ((d.N + 3u) & ~3u);              // [n_passes + 5] pass boundaries (padded with N)
-    uint32_t *scratch = ps + ((d.n_passes + 5u + 3u) & ~3u); // [5][48]
+    uint32_t *ps = tab + ((d.N + 3u) & ~3u);              // [n_passes + 6] pass boundaries (padded with N)
+    uint32_t *scratch = ps + ((d.n_passes + 6u + 3u) & ~3u); // [5][48]
     const uint32_t real = bid / d.W, w = bid % d.W;
     const uint32_t tid = threadIdx.x;
     const uint32_t *Sin = p.S + (static_cast<size_t>(real) * d.W + w) * d.N;
     uint32_t *Sout = p.S_next + (static_cast<size_t>(real) * d.W + w) * d.N;
     const uint32_t *tab_g = p.hc_tab + static_cast<size_t>(real) * d.N;
-    uint32_t epoch = 0, applied = 0;
     uint32_t mp[2] = {0, 0}, mc[2] = {0, 0}, mn[2] = {0, 0};
-    auto read_swap_state = [&]() {
-        epoch = p.swap_epoch[real];
-        applied = p.applied_epoch[static_cast<size_t>(real) * d.W + w];
+    // (requested first: their latency hides behind the bulk copy)
+    const uint32_t epoch = p.swap_epoch[real];
+    const uint32_t applied = p.applied_epoch[static_cast<size_t>(real) * d.W + w];
+    {
         const uint32_t *masks = p.swap_masks + static_cast<size_t>(real) * 2 * d.W;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -1033,75 +1103,46 @@ __device__ __forceinline__ void sweep_hc_block(const SimDims &d, const DevPtrs &
             mc[r] = masks[r * d.W + w];
             mn[r] = w + 1 < d.W ? masks[r * d.W + w + 1] : 0u;
         }
-    };
-    if (!FUSED) read_swap_state(); // (requested first: their latency hides behind the bulk copy)
-    // spins, acceptance planes and the schedule table are requested together (one memory round trip); inside k_rs
-    // the planes (and the swap state) come later, once their producers in this launch have published them
+    }
+    // spins, acceptance planes and the schedule table are requested together (one memory round trip)
     const uint32_t *planes_in =
         reinterpret_cast<const uint32_t *>(p.planes + (static_cast<size_t>(real) * d.W + w) * d.N);
-    const bool planes_now = do_sweep && !FUSED;
     {
-        const uint32_t qa = d.N >> 2, qb = planes_now ? (2 * d.N) >> 2 : 0u, qc = d.N >> 2;
-        const bool wide = (d.N & 3u) == 0 && qa <= 4 * 256 && (2 * d.N) >> 2 <= 8 * 256 &&
+        const uint32_t qa = d.N >> 2, qb = do_sweep ? (2 * d.N) >> 2 : 0u, qc = d.N >> 2;
+        const bool wide = (d.N & 3u) == 0 && qa <= 2 * kThreads && (2 * d.N) >> 2 <= 4 * kThreads &&
                           ((reinterpret_cast<uintptr_t>(Sin) | reinterpret_cast<uintptr_t>(planes_in) |
                             reinterpret_cast<uintptr_t>(tab_g)) & 15u) == 0;
         if (wide) {
             const uint4 *a4 = reinterpret_cast<const uint4 *>(Sin), *b4 = reinterpret_cast<const uint4 *>(planes_in),
                         *c4 = reinterpret_cast<const uint4 *>(tab_g);
-            uint4 va[4], vb[8], vc[4];
+            uint4 va[2], vb[4], vc[2];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) va[k] = k * 256 + tid < qa ? a4[k * 256 + tid] : make_uint4(0, 0, 0, 0);
-            if (!FUSED) {
+            for (int k = 0; k < 2; ++k) va[k] = k * kThreads + tid < qa ? a4[k * kThreads + tid] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) vb[k] = k * 256 + tid < qb ? b4[k * 256 + tid] : make_uint4(0, 0, 0, 0);
-            }
+            for (int k = 0; k < 4; ++k) vb[k] = k * kThreads + tid < qb ? b4[k * kThreads + tid] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) vc[k] = k * 256 + tid < qc ? c4[k * 256 + tid] : make_uint4(0, 0, 0, 0);
+            for (int k = 0; k < 2; ++k) vc[k] = k * kThreads + tid < qc ? c4[k * kThreads + tid] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k * 256 + tid < qa) reinterpret_cast<uint4 *>(sw)[k * 256 + tid] = va[k];
-            if (!FUSED) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (k * 256 + tid < qb) reinterpret_cast<uint4 *>(pl)[k * 256 + tid] = vb[k];
-            }
+            for (int k = 0; k < 2; ++k)
+                if (k * kThreads + tid < qa) reinterpret_cast<uint4 *>(sw)[k * kThreads + tid] = va[k];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (k * 256 + tid < qc) reinterpret_cast<uint4 *>(tab)[k * 256 + tid] = vc[k];
+                if (k * kThreads + tid < qb) reinterpret_cast<uint4 *>(pl)[k * kThreads + tid] = vb[k];
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (k * kThreads + tid < qc) reinterpret_cast<uint4 *>(tab)[k * kThreads + tid] = vc[k];
         } else {
-            copy_to_lds(sw, Sin, d.N, tid, 256);
-            if (planes_now) copy_to_lds(pl, planes_in, 2 * d.N, tid, 256);
-            copy_to_lds(tab, tab_g, d.N, tid, 256);
+            copy_to_lds(sw, Sin, d.N, tid, kThreads);
+            if (do_sweep) copy_to_lds(pl, planes_in, 2 * d.N, tid, kThreads);
+            copy_to_lds(tab, tab_g, d.N, tid, kThreads);
         }
     }
-    if (FUSED) {
-        // ---- wait for this launch's producers: the measurement block of the realisation (swap masks) and the
-        // random-stream workgroups that draw this tile word's planes.  One lane polls (relaxed, agent scope), then
-        // acquires once; the workgroup's loads come after the barrier (producers: store drain, barrier, release).
-        if (tid == 0) {
-            const uint32_t *flag_a = wait.measured ? wait.measured + real : nullptr;
-            const uint32_t *flag_b = wait.ready + bid / wait.tw_per_group;
-            uint32_t spins = 0;
-            while ((flag_a && __hip_atomic_load(flag_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != wait.measured_target) ||
-                   __hip_atomic_load(flag_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != wait.ready_target) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1u << 22)) { // never reached unless a producer died: leave, and say so
-                    atomicExch(wait.error, 1u);
-                    break;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-        read_swap_state();
-        if (do_sweep) copy_to_lds(pl, planes_in, 2 * d.N, tid, 256);
-    }
-    for (uint32_t k = tid; k < d.n_passes + 5; k += 256) ps[k] = k <= d.n_passes ? p.pass_start[k] : d.N;
+    for (uint32_t k = tid; k < d.n_passes + 6; k += kThreads) ps[k] = k <= d.n_passes ? p.pass_start[k] : d.N;
     if (do_sweep && epoch != applied) {
         // tempering swaps accepted after the previous sweep: exchange the bit columns now
         const bool window = (((mp[0] | mp[1] | mc[0] | mc[1]) >> 31) != 0); // a pair straddles words
         __syncthreads();
-        for (uint32_t i = tid; i < d.N; i += 256) {
+        for (uint32_t i = tid; i < d.N; i += kThreads) {
             const uint32_t v = sw[i];
             uint32_t prev = 0, next = 0;
             if (window) { // old neighbouring words (the input buffer is not written in this launch)
@@ -1125,67 +1166,84 @@ __device__ __forceinline__ void sweep_hc_block(const SimDims &d, const DevPtrs &
     const uint32_t sw_addr = lds_addr_of(sw), pl_addr = lds_addr_of(pl), tab_addr = lds_addr_of(tab);
     if (do_sweep) {
         const uint32_t spare = sw_addr + d.N * 4;
-        // Software pipeline, three stages deep.  In iteration `pass`:
-        //   registers hold the decoded addresses of `pass` (cur), the table entry of pass + 1 (e_next) and the
-        //   boundaries of pass + 2 (b0, b1);
-        //   issued: the nine reads of `pass`, then the table read of pass + 2 and the boundary read of pass + 3
-        //   (both consumed in the NEXT iteration, after this one's barrier has drained the LDS queue);
-        //   computed while the nine reads fly: the addresses of pass + 1.
-        // So nothing but "reads -> accept logic -> write -> barrier" sits between two barriers.
-        auto pick = [&](uint32_t b0, uint32_t b1, bool &active) -> uint32_t { // LDS address of the table entry
-            const uint32_t pos = b0 + tid;
-            active = pos < b1;
-            return tab_addr + (active ? pos : 0u) * 4;
-        };
-        bool act_cur, act_next;
-        const uint32_t e_cur = lds_load(pick(ps[0], ps[1], act_cur));
-        uint32_t e_next = lds_load(pick(ps[1], ps[2], act_next)); // (ps is padded: passes past the last are empty)
-        uint32_t b0 = ps[2], b1 = ps[3];
-        HcSite cur = hc_decode<NN>(d, e_cur, sw_addr);
-        uint32_t wr_cur = act_cur ? cur.site : spare;
         const uint32_t ps_addr = lds_addr_of(ps);
-        for (uint32_t pass = 0; pass < d.n_passes; ++pass) {
-            // (1) the nine reads of this pass
+        const uint32_t set = __builtin_amdgcn_readfirstlane(tid >> 8), lane = tid & 255u;
+        // what a pass needs, all of it prepared by `fetch`: nine LDS addresses and the coupling signs as masks
+        HcSite cur;
+        uint32_t wr_cur = spare, pl_cur = pl_addr, negm[6] = {0, 0, 0, 0, 0, 0};
+        auto fetch = [&](uint32_t b0, uint32_t b1) { // the pass whose positions are [b0, b1)
+            const uint32_t pos = b0 + lane;
+            const bool active = pos < b1;
+            cur = hc_decode<NN>(d, lds_load(tab_addr + (active ? pos : 0u) * 4), sw_addr);
+            wr_cur = active ? cur.site : spare;
+            pl_cur = pl_addr + 2 * cur.site4;
+#pragma unroll
+            for (int k = 0; k < 2 * NN; ++k) negm[k] = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(cur.neg), k, 1));
+            // all of it is computed HERE, before the barrier the set is about to wait at (left alone, the compiler sinks
+            // the address arithmetic to its first use, behind the barrier and onto the chain)
+            asm volatile("" : "+v"(cur.site), "+v"(wr_cur), "+v"(pl_cur));
+#pragma unroll
+            for (int k = 0; k < 2 * NN; ++k) asm volatile("" : "+v"(cur.nb[k]), "+v"(negm[k]));
+        };
+        auto compute = [&]() { // reads -> accept -> write: the chain between two barriers
+            const uint2 lv = lds_load2(pl_cur);
+            const uint32_t s = lds_load(cur.site);
             uint32_t nb[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) nb[k] = k < 2 * NN ? lds_load(cur.nb[k]) : 0u;
-            const uint32_t s = lds_load(cur.site);
-            const uint2 lv = lds_load2(pl_addr + 2 * cur.site4);
-            // (2) prefetches for later passes (their data is first used after the barrier below)
-            bool act_after;
-            const uint32_t e_after = lds_load(pick(b0, b1, act_after));
-            const uint32_t nb0 = lds_load(ps_addr + (pass + 3) * 4), nb1 = lds_load(ps_addr + (pass + 4) * 4);
-            // (3) while the reads are in flight: addresses of the next pass
-            const HcSite nxt = hc_decode<NN>(d, e_next, sw_addr);
-            const uint32_t wr_next = act_next ? nxt.site : spare;
-            // (4) accept, write, hand over to the next level
-            const uint32_t acc = accept_mask_dense<NN>(s, nb, cur.neg, lv.x, lv.y);
+            for (int k = 0; k < 6; ++k) nb[k] = k < 2 * NN ? (lds_load(cur.nb[k]) ^ negm[k]) : 0u;
+            const uint32_t acc = accept_mask_dense<NN>(s, nb, 0u, lv.x, lv.y);
             lds_store(wr_cur, s ^ (acc & valid_bits));
-            lds_barrier();
-            cur = nxt;
-            wr_cur = wr_next;
-            e_next = e_after;
-            act_next = act_after;
-            b0 = nb0;
-            b1 = nb1;
+        };
+        // set 0 takes the even passes, set 1 the odd ones (two loops, one barrier sequence: every wave meets the same
+        // number of barriers); ps is padded, passes past the last are empty
+        if (set == 0) {
+            fetch(ps[0], ps[1]);
+            uint32_t nb0 = ps[2], nb1 = ps[3];
+#pragma unroll 1
+            for (uint32_t pass = 0; pass < d.n_passes; pass += 2) {
+                compute(); // pass
+                lds_barrier();
+                const uint32_t f0 = lds_load(ps_addr + (pass + 4) * 4), f1 = lds_load(ps_addr + (pass + 5) * 4);
+                fetch(nb0, nb1); // pass + 2
+                nb0 = f0;
+                nb1 = f1;
+                lds_barrier();
+            }
+        } else {
+            uint32_t nb0 = ps[1], nb1 = ps[2];
+#pragma unroll 1
+            for (uint32_t pass = 0; pass < d.n_passes; pass += 2) {
+                const uint32_t f0 = lds_load(ps_addr + (pass + 3) * 4), f1 = lds_load(ps_addr + (pass + 4) * 4);
+                fetch(nb0, nb1); // pass + 1
+                nb0 = f0;
+                nb1 = f1;
+                lds_barrier();
+                compute(); // pass + 1
+                lds_barrier();
+            }
         }
         PA_HC_STAMP(2)
-        for (uint32_t i = tid; i < d.N; i += 256) Sout[i] = sw[i];
+        for (uint32_t i = tid; i < d.N; i += kThreads) Sout[i] = sw[i];
     }
     PA_HC_STAMP(3)
 
     if (with_energy & 1) {
         PA_HC_STAMP(4)
-        hc_energy<NN>(d, p, real, w, tab, sw_addr, scratch, FUSED ? p.Esum_out : p.Esum, FUSED ? p.Msum_out : p.Msum);
+        if (d.N >= 512 && d.N <= 8 * kThreads) {
+            hc_energy_wide<NN>(d, p, real, w, tab, sw_addr, pl, scratch);
+        } else {
+            if (tid >= 256) return; // (a barrier waits for the surviving waves only)
+            hc_energy<NN>(d, p, real, w, tab, sw_addr, scratch, p.Esum, p.Msum);
+        }
     }
     PA_HC_STAMP(5)
 }
 
 template <int NN, bool STAMPS = false>
-__global__ __launch_bounds__(256, 2) void k_sweep_hc(SimDims d, DevPtrs p, int with_energy, int do_sweep,
+__global__ __launch_bounds__(512, 2) void k_sweep_hc(SimDims d, DevPtrs p, int with_energy, int do_sweep,
                                                      unsigned long long *stamps) {
     extern __shared__ uint32_t lds[];
-    sweep_hc_block<NN, STAMPS, false>(d, p, blockIdx.x, with_energy, do_sweep, stamps, RsWait{}, lds);
+    sweep_hc_block<NN, STAMPS>(d, p, blockIdx.x, with_energy, do_sweep, stamps, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -1777,53 +1835,6 @@ __global__ __launch_bounds__(256) void k_rng_relay(SimDims d, DevPtrs p, uint32_
         measure_block<false>(d, p, pt, do_accum, accum_overlap, do_pt, nullptr, blockIdx.x - n_overlap, lds_dyn);
     else
         rng_block<PRESHIFTED, false, REPLAY>(d, p, blockIdx.x - n_overlap - n_measure, lds_dyn);
-}
-
-// ---------------------------------------------------------------------------
-// k_rs: one launch per sweep.  Workgroups of 512 threads in blockIdx order:
-//   overlap blocks | measurement blocks | random-stream blocks (8 waves share a jump table) | sweep blocks
-// The first three are k_rng_relay's; the sweep blocks (k_sweep_hc's body, first four waves) load their spins and table,
-// then wait inside the launch until the random-stream workgroups covering their tile word have published the
-// acceptance planes (and the realisation's measurement block its swap masks): producers drain their stores, meet at
-// the workgroup barrier and release-increment a counter at agent scope; the consumer polls relaxed, acquires once,
-// meets at its barrier and only then loads (the per-CU L1 and the per-XCD L2s are not coherent with each other).
-// Blocks are dispatched in blockIdx order, so a waiting block only waits for blocks that are already on the machine;
-// random-stream groups finish in tile-word order, so the first sweep blocks start while the stream is still running.
-// Saves the ~5 us a dependent launch spends before its first wave, and the sweep's prologue hides under the stream.
-// ---------------------------------------------------------------------------
-template <bool PRESHIFTED, bool REPLAY, int NN>
-__global__ __launch_bounds__(512, 4) void k_rs(SimDims d, DevPtrs p, uint32_t n_overlap, uint32_t n_measure, uint32_t n_rng,
-                                               PtParams pt, int do_accum, int accum_overlap, int do_pt, int with_energy,
-                                               uint32_t ready_target, uint32_t measured_target) {
-    extern __shared__ uint32_t lds_dyn[];
-    const uint32_t bid = blockIdx.x, tid = threadIdx.x;
-    if (bid < n_overlap) {
-        if (tid >= 256) return; // (a barrier waits for the surviving waves only)
-        overlap_block(d, p, bid, lds_dyn);
-    } else if (bid < n_overlap + n_measure) {
-        const uint32_t real = bid - n_overlap;
-        measure_block<false>(d, p, pt, do_accum, accum_overlap, do_pt, nullptr, real, lds_dyn);
-        drain_global_stores();
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(p.rs_measured + real, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (bid < n_overlap + n_measure + n_rng) {
-        const uint32_t rb = bid - n_overlap - n_measure;
-        rng_block<PRESHIFTED, false, REPLAY>(d, p, rb, lds_dyn);
-        drain_global_stores();
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(p.rs_ready + rb / d.B, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        if (tid >= 256) return;
-        __builtin_amdgcn_s_setprio(3); // the sweep is a latency chain: its instructions go first on a shared SIMD
-        RsWait wait;
-        wait.ready = p.rs_ready;
-        wait.measured = n_measure ? p.rs_measured : nullptr;
-        wait.ready_target = ready_target;
-        wait.measured_target = measured_target;
-        wait.tw_per_group = 16;
-        wait.error = p.rs_error;
-        sweep_hc_block<NN, false, true>(d, p, bid - n_overlap - n_measure - n_rng, with_energy, 1, nullptr, wait, lds_dyn);
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2838,12 +2849,6 @@ hipError_t configure_kernels(const SimDims &) {
                            reinterpret_cast<const void *>(k_sweep_hc<3, true>),
                            reinterpret_cast<const void *>(k_overlap),
                            reinterpret_cast<const void *>(k_overlap_wide),
-                           reinterpret_cast<const void *>(k_rs<true, false, 1>),
-                           reinterpret_cast<const void *>(k_rs<true, false, 2>),
-                           reinterpret_cast<const void *>(k_rs<true, false, 3>),
-                           reinterpret_cast<const void *>(k_rs<true, true, 1>),
-                           reinterpret_cast<const void *>(k_rs<true, true, 2>),
-                           reinterpret_cast<const void *>(k_rs<true, true, 3>),
                            reinterpret_cast<const void *>(k_rng_relay<false, false>),
                            reinterpret_cast<const void *>(k_rng_relay<false, true>),
                            reinterpret_cast<const void *>(k_rng_relay<true, false>),
@@ -2922,43 +2927,6 @@ hipError_t launch_rng_relay(const SimDims &d, const DevPtrs &p, bool with_overla
     return hipGetLastError();
 }
 
-bool rs_supported(const SimDims &d) {
-    const uint32_t reals_per_block = 15u / d.W + 2u; // the replay lanes of an 8-wave random-stream workgroup: 16 tile words
-    return rng_relay_supported(d) && d.hc && d.dense_nn == d.nn && d.thr_preshifted && reals_per_block * d.n_replicas <= 256 &&
-           sweep_hc_lds_bytes(d) + 2048 <= 80 * 1024; // two workgroups per CU
-}
-
-hipError_t launch_rs(const SimDims &d, const DevPtrs &p, bool with_overlap, const PtParams &pt, bool do_accum,
-                     bool accum_overlap, bool do_pt, bool with_energy, uint32_t ready_epoch, uint32_t measured_epoch,
-                     hipStream_t stream) {
-    const uint32_t n_tw = d.n_real * d.W;
-    const uint32_t groups = (n_tw + 15) / 16; // 8 waves x 2 tile words
-    const uint32_t n_overlap = with_overlap ? n_tw : 0u;
-    const uint32_t n_measure = (do_accum || accum_overlap || do_pt) ? d.n_real : 0u;
-    const uint32_t n_rng = groups * d.B;
-    const bool replay = n_measure && do_pt && d.n_temps >= 2;
-    const size_t lds = std::max(std::max(sweep_hc_lds_bytes(d), kRngLds + 1024), std::max(overlap_lds_bytes(d), measure_lds_bytes(d)));
-    const dim3 grid(n_overlap + n_measure + n_rng + n_tw), block(512);
-    const int a = do_accum ? 1 : 0, o = accum_overlap ? 1 : 0, t = do_pt ? 1 : 0, e = with_energy ? 1 : 0;
-    const uint32_t ready_target = ready_epoch * d.B, measured_target = measured_epoch;
-#define PA_RS(R, NN) hipLaunchKernelGGL((k_rs<true, R, NN>), grid, block, lds, stream, d, p, n_overlap, n_measure, n_rng, pt, a, o, t, e, ready_target, measured_target)
-    if (replay) {
-        switch (d.dense_nn) {
-        case 1: PA_RS(true, 1); break;
-        case 2: PA_RS(true, 2); break;
-        default: PA_RS(true, 3); break;
-        }
-    } else {
-        switch (d.dense_nn) {
-        case 1: PA_RS(false, 1); break;
-        case 2: PA_RS(false, 2); break;
-        default: PA_RS(false, 3); break;
-        }
-    }
-#undef PA_RS
-    return hipGetLastError();
-}
-
 hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,
                         bool gibbs, hipStream_t stream) {
     if (d.general) return launch_sweep_f(d, p, with_energy, do_sweep, stream);
@@ -2990,10 +2958,11 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
     static const bool no_hc = std::getenv("PEAPODS_NO_HC") != nullptr;
     if (d.hc && !no_hc) { // implicit neighbours, table in the LDS
         const size_t lds_hc = sweep_hc_lds_bytes(d);
+        const dim3 block_hc(512); // two sets of four waves take the passes in turn
         switch (d.dense_nn) {
-        case 1: hipLaunchKernelGGL((k_sweep_hc<1>), grid, block, lds_hc, stream, d, p, e, s, no_stamps); break;
-        case 2: hipLaunchKernelGGL((k_sweep_hc<2>), grid, block, lds_hc, stream, d, p, e, s, no_stamps); break;
-        default: hipLaunchKernelGGL((k_sweep_hc<3>), grid, block, lds_hc, stream, d, p, e, s, no_stamps); break;
+        case 1: hipLaunchKernelGGL((k_sweep_hc<1>), grid, block_hc, lds_hc, stream, d, p, e, s, no_stamps); break;
+        case 2: hipLaunchKernelGGL((k_sweep_hc<2>), grid, block_hc, lds_hc, stream, d, p, e, s, no_stamps); break;
+        default: hipLaunchKernelGGL((k_sweep_hc<3>), grid, block_hc, lds_hc, stream, d, p, e, s, no_stamps); break;
         }
         return hipGetLastError();
     }
@@ -3037,7 +3006,7 @@ hipError_t launch_sweep_stamped(const SimDims &d, const DevPtrs &p, unsigned lon
                                 hipStream_t stream) {
     const dim3 grid(d.n_real * d.W), block(256);
     if (d.hc && d.dense_nn == 3) { // every workgroup stamps: stamps[grid][8]
-        hipLaunchKernelGGL((k_sweep_hc<3, true>), grid, block, sweep_hc_lds_bytes(d), stream, d, p, 1, 1, stamps);
+        hipLaunchKernelGGL((k_sweep_hc<3, true>), grid, dim3(512), sweep_hc_lds_bytes(d), stream, d, p, 1, 1, stamps);
         return hipGetLastError();
     }
     if (d.dense_nn == 3)

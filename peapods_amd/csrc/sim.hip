@@ -121,15 +121,12 @@ struct pa_sim {
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;
         uint32_t fresh = 3; // see pa_sim::fresh
-        uint32_t rs_epoch = 0, rs_measure_epoch = 0; // k_rs launches (with measurement blocks) of this group so far
     };
     std::vector<Group> groups;
     // Running sums are never memset between sample() calls: bit 0 (moments) / bit 1 (overlap moments, P(q)
     // bitmap) says that the next accumulating k_measure launch starts them from zero (PtParams::fresh).  One
     // copy per stream group (run_sweeps) and one for whole-ensemble launches (pa_sim_profile_kernels).
     uint32_t fresh = 3;
-    uint32_t rs_epoch = 0, rs_measure_epoch = 0; // the same for whole-ensemble launches (pa_sim_profile_kernels)
-    bool rs_used = false;                         // a k_rs launch has run: pa_sim_synchronize reads rs_error
     hipEvent_t fork = nullptr;
     hipEvent_t batch_events[2] = {nullptr, nullptr}; // run-ahead bound of run_sweeps (cooperative cancel)
 };
@@ -356,15 +353,6 @@ hipError_t overlap_launch(const SimDims &d, DevPtrs &p, hipStream_t stream) {
     toggle_dots(p);
     return e;
 }
-// The sweep blocks of a k_rs launch left the energy / magnetisation sums in the second pair of arrays.
-void toggle_energy_sums(pa_sim *sim) {
-    std::swap(sim->p.Esum, sim->p.Esum_out);
-    std::swap(sim->p.Msum, sim->p.Msum_out);
-    for (auto &g : sim->groups) {
-        std::swap(g.p.Esum, g.p.Esum_out);
-        std::swap(g.p.Msum, g.p.Msum_out);
-    }
-}
 // A relayed tempering event filed the new slot <-> system permutation in the second pair of tables.
 void toggle_system_tables(pa_sim *sim) {
     std::swap(sim->p.system_ids, sim->p.system_ids_out);
@@ -407,8 +395,6 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     q.mpar += static_cast<size_t>(d.MW) * r0;
     q.rec += (static_cast<size_t>(d.N) + 1) * (d.big ? 2 : 1) * r0;
     if (d.hc) q.hc_tab += static_cast<size_t>(d.N) * r0;
-    q.rs_ready += static_cast<size_t>(d.W) * r0; // (more entries than a group's launches use: one per 16 tile words)
-    q.rs_measured += r0;
     if (d.pipe_lds) q.recS += static_cast<size_t>(d.planes_stride) * r0;
     if (d.pipe_K) q.progress += static_cast<size_t>(d.W) * d.pipe_K * r0;
     if (d.pipe_lds) q.xchg += static_cast<size_t>(d.W) * d.pipe_K * 2 * d.plane * r0;
@@ -416,8 +402,6 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     q.big_counts += static_cast<size_t>(4) * d.n_sys * r0;
     q.Esum += static_cast<size_t>(d.n_sys) * r0;
     q.Msum += static_cast<size_t>(d.n_sys) * r0;
-    q.Esum_out += static_cast<size_t>(d.n_sys) * r0;
-    q.Msum_out += static_cast<size_t>(d.n_sys) * r0;
     q.nz_bonds += r0;
     q.dot_spin += static_cast<size_t>(d.n_pairs) * d.n_temps * r0;
     q.dot_link += static_cast<size_t>(d.n_pairs) * d.n_temps * r0;
@@ -892,8 +876,6 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     // (opt-in: measured slower than two launches)
     const bool relay_nf = !fused && !gibbs && !d.big && !d.general && cfg->pt_schedule == PA_PT_SINGLE_RANDOM_EDGE &&
                           rng_relay_supported(d) && !std::getenv("PEAPODS_NO_RELAY");
-    bool rs = relay && std::getenv("PEAPODS_RS") != nullptr;
-    for (auto &g : sim->groups) rs = rs && rs_supported(g.d);
     // Cooperative cancel (src/lib.rs:304-308, mod.rs:406-408): the host runs at most two batches of
     // kBatch sweeps ahead of the device, so a request is honoured within that much queued work; the
     // state then is the one after the last enqueued sweep (a continuation from it is well defined).
@@ -940,20 +922,6 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             // launch too: the random-stream workgroups replay the swap decisions and fetch their generators
             // from the slots the systems come from, so a sweep is two launches, not three.
             const bool relayed = relay && pending.any;
-            if (rs) { // the whole sweep in one launch: overlap + measurement + random stream + sweep blocks
-                sim->rs_used = true;
-                for (auto &g : sim->groups) {
-                    PtParams q = pending.pt;
-                    q.relay = 1;
-                    q.fresh = relayed ? consume_fresh(g.fresh, g.d, pending.do_accum, pending.accum_overlap) : 0u;
-                    g.rs_epoch += 1;
-                    if (relayed) g.rs_measure_epoch += 1;
-                    PA_HIP(sim, launch_rs(g.d, g.p, overlap_owed, q, relayed && pending.do_accum, relayed && pending.accum_overlap,
-                                          relayed && pending.do_pt, record || pt_this, g.rs_epoch, g.rs_measure_epoch, g.stream));
-                    if (overlap_owed) toggle_dots(g.p);
-                }
-                if (record || pt_this) toggle_energy_sums(sim); // (the launch computed new sums)
-            } else
             for (auto &g : sim->groups) {
                 if (relayed) {
                     PtParams q = pending.pt;
@@ -1878,16 +1846,11 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     ok(bufs.alloc(&sim->jump, jump.size()));
     ok(bufs.alloc(&p.Esum, static_cast<size_t>(d.n_real) * d.n_sys));
     ok(bufs.alloc(&p.Msum, static_cast<size_t>(d.n_real) * d.n_sys));
-    ok(bufs.alloc(&p.Esum_out, static_cast<size_t>(d.n_real) * d.n_sys));
-    ok(bufs.alloc(&p.Msum_out, static_cast<size_t>(d.n_real) * d.n_sys));
     ok(bufs.alloc(&sim->nz_bonds, nz_bonds.size()));
     ok(bufs.alloc(&p.dot_spin, n_pair_slots));
     ok(bufs.alloc(&p.dot_link, n_pair_slots));
     ok(bufs.alloc(&p.dot_spin_prev, n_pair_slots));
     ok(bufs.alloc(&p.dot_link_prev, n_pair_slots));
-    ok(bufs.alloc(&p.rs_ready, 2 * static_cast<size_t>(d.n_real) * d.W + 16)); // [0, n): stream groups; [n, 2n): whole-ensemble launches
-    ok(bufs.alloc(&p.rs_measured, 2 * static_cast<size_t>(d.n_real)));
-    ok(bufs.alloc(&p.rs_error, 4));
     ok(bufs.alloc(&p.system_ids_out, static_cast<size_t>(d.n_real) * d.n_sys));
     ok(bufs.alloc(&p.slot_of_out, static_cast<size_t>(d.n_real) * d.n_sys));
     ok(bufs.alloc(&p.mom, static_cast<size_t>(d.n_real) * 5 * d.n_temps));
@@ -1978,10 +1941,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         (rc = upload(sim, sim->jsite, jsite)) || (rc = upload(sim, sim->nbr_wide, nbr_wide)) || (rc = upload(sim, sim->jorg_p, jorg_p)) ||
         (rc = upload(sim, sim->nz_bonds, nz_bonds)) || (rc = upload(sim, sim->dbeta, dbeta)))
         return bail(rc);
-    if (hipMemsetAsync(p.rs_ready, 0, sizeof(uint32_t) * (2 * static_cast<size_t>(d.n_real) * d.W + 16), sim->stream) != hipSuccess ||
-        hipMemsetAsync(p.rs_measured, 0, sizeof(uint32_t) * 2 * d.n_real, sim->stream) != hipSuccess ||
-        hipMemsetAsync(p.rs_error, 0, sizeof(uint32_t) * 4, sim->stream) != hipSuccess ||
-        hipMemsetAsync(p.big_counts, 0, sizeof(uint32_t) * d.n_real * d.n_sys * 4, sim->stream) != hipSuccess) {
+    if (hipMemsetAsync(p.big_counts, 0, sizeof(uint32_t) * d.n_real * d.n_sys * 4, sim->stream) != hipSuccess) {
         sim->error = "hipMemsetAsync failed";
         return bail(PA_ERR_DEVICE);
     }
@@ -2041,11 +2001,6 @@ int pa_sim_synchronize(pa_sim *sim) {
         PA_HIP(sim, hipMemcpy(&gave_up, sim->p.slab_error, sizeof(gave_up), hipMemcpyDeviceToHost));
         if (gave_up) return fail(sim, PA_ERR_DEVICE, "a slab of the pipelined sweep gave up waiting for its predecessor");
     }
-    if (sim->rs_used) {
-        uint32_t gave_up = 0;
-        PA_HIP(sim, hipMemcpy(&gave_up, sim->p.rs_error, sizeof(gave_up), hipMemcpyDeviceToHost));
-        if (gave_up) return fail(sim, PA_ERR_DEVICE, "a sweep block of the fused launch gave up waiting for its acceptance planes");
-    }
     if (sim->p.stream_error) {
         uint32_t short_stream = 0;
         PA_HIP(sim, hipMemcpy(&short_stream, sim->p.stream_error, sizeof(short_stream), hipMemcpyDeviceToHost));
@@ -2098,28 +2053,13 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
         bool any = false, do_accum = false, accum_overlap = false, do_pt = false;
         PtParams pt{};
     } pending;
-    const bool rs = relay && rs_supported(d) && std::getenv("PEAPODS_RS") != nullptr;
     bool overlap_owed = false;
     for (uint64_t sweep_id = 0; sweep_id < n_sweeps; ++sweep_id) {
         const bool record = sweep_id >= cfg->warmup_sweeps;
         const bool pt_this = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0;
         PA_HIP(sim, hipEventRecord(ev[0], sim->stream));
         const bool relayed = relay && pending.any;
-        if (rs) { // one launch per sweep (k_rs): reported under k_rng, k_sweep stays empty
-            sim->rs_used = true;
-            DevPtrs q_p = sim->p; // whole-ensemble launches keep their own progress counters
-            q_p.rs_ready += static_cast<size_t>(d.n_real) * d.W;
-            q_p.rs_measured += d.n_real;
-            PtParams q = pending.pt;
-            q.relay = 1;
-            q.fresh = relayed ? consume_fresh(sim->fresh, d, pending.do_accum, pending.accum_overlap) : 0u;
-            sim->rs_epoch += 1;
-            if (relayed) sim->rs_measure_epoch += 1;
-            PA_HIP(sim, launch_rs(d, q_p, overlap_owed, q, relayed && pending.do_accum, relayed && pending.accum_overlap,
-                                  relayed && pending.do_pt, record || pt_this, sim->rs_epoch, sim->rs_measure_epoch, sim->stream));
-            if (relayed && pending.do_pt && d.n_temps >= 2) toggle_system_tables(sim);
-            if (record || pt_this) toggle_energy_sums(sim);
-        } else if (relayed) {
+        if (relayed) {
             PtParams q = pending.pt;
             q.relay = 1;
             q.fresh = consume_fresh(sim->fresh, d, pending.do_accum, pending.accum_overlap);
@@ -2135,7 +2075,7 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
         pending.any = false;
         PA_HIP(sim, hipEventRecord(ev[1], sim->stream));
         PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
-        if (!rs) PA_HIP(sim, enqueue_sweep(sim, d, sim->p, record || pt_this, gibbs, sim->stream));
+        PA_HIP(sim, enqueue_sweep(sim, d, sim->p, record || pt_this, gibbs, sim->stream));
         sim->swaps_pending = false;
         toggle_spin_buffers(sim);
         PA_HIP(sim, hipEventRecord(ev[2], sim->stream));

@@ -19,7 +19,7 @@ export PEAPODS_STREAMS=1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_1stream" -o bench -- \
     python3 "$repo/bench.py" --steps 500 --warmup 50 --no-cpu-baseline > "$out/stats_1stream.log" 2>&1
 echo "stats 1 stream done" >> "$out/progress.log"
-for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU"; do
+for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
     name=$(echo "$pass" | tr ' ' '_' | cut -c1-24)
     rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$out/pmc_$name" -o pmc -- \
         python3 "$repo/bench.py" --steps 25 --warmup 5 --no-cpu-baseline --profile-sweeps 4 > "$out/pmc_$name.log" 2>&1

@@ -96,6 +96,7 @@ struct DevPtrs {
                              //   positions are padded so that every segment starts at a multiple of 4
     const uint32_t *pos_of;  // [N] site -> padded schedule position (k_rng files the acceptance planes there)
     uint32_t *slab_error;    // [1] set when a slab gave up waiting for an exchange record
+    unsigned long long *slab_stamps; // diagnostic (pa_debug_slab_stamps), normally null: [workgroups][n_levels + 4] s_memrealtime per level
     const uint4 *recS;       // [n_real][planes_stride] by padded position: 8 x u16 = LDS word of the site and of
                              //   f0,b0,f1,b1,f2,b2 (for a new value of another slab: the value word of its staged exchange record), then jmeta
     const uint32_t *xportS;  // [planes_stride] by padded position: 1 + exchange record the site's new value goes to, or 0

@@ -2408,7 +2408,7 @@ __global__ __launch_bounds__(256) void k_sweep_pipe(SimDims d, DevPtrs p, int gi
 // Counted vmcnt waits rely on vector-memory operations of a wave retiring in issue order.
 // ---------------------------------------------------------------------------
 // (kSlabDepth, kSlabStage: engine.hpp -- the host writes LDS word indices of staged records into the site records)
-constexpr uint32_t kSlabThreads = 384; // four sweep waves, the loader wave (inputs), the fetcher wave (exchange records)
+constexpr uint32_t kSlabThreads = 640; // sweep waves 0-3 (even levels), the loader wave (inputs), the fetcher wave (exchange records), sweep waves 6-9 (odd levels)
 
 __device__ __forceinline__ void slab_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // LDS read the compiler does not see (an ordinary read would make it wait for every pending DMA)
@@ -2541,7 +2541,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
         return;
     }
 
-    if (tid >= 320) {
+    if (tid >= 320 && tid < 384) {
         // ================= fetcher wave: exchange records first read at level L -> staging slot L % R (128 entries)
         if (!reads_others) { // nothing to stage: only keep the barriers company
             slab_barrier();
@@ -2613,42 +2613,89 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
         return;
     }
 
-    // ================= sweep waves
+    // ================= sweep waves: two sets of four take the levels in turn (set A: waves 0-3, set B: waves 6-9).
+    // A level is a chain -- barrier, neighbour words, accept, write -- and a lone wave issues an instruction every
+    // ~4.7 cycles whatever it is, so everything else is done by the set that is NOT sweeping the level: it picks up the
+    // next level's inputs (landed: the loader's counted wait; flag set by the fetcher before the barrier), unpacks the
+    // seven LDS addresses and sends the previous level's global stores (new value, exchange record) on their way.
+    const bool set_b = __builtin_amdgcn_readfirstlane(tid) >= 384u; // (wave-uniform, and known to be: the branches below are scalar)
+    const uint32_t t = set_b ? tid - 384u : tid; // position inside a level
     slab_barrier(); // the fetcher's first groups are in the staging ring, the first one validated
-    // Everything a level needs besides the neighbours' spins is picked up during the level before
-    // (its ring slot has landed by then, its flag is set before the previous barrier): the dependent
-    // chain of a level is barrier -> neighbour words -> accept -> write.
     struct Inputs {
-        uint4 r;
+        uint32_t at, at4, nb[6], jm, hi, target, count, redo;
         uint2 lv;
-        uint32_t target, hi, count, redo;
     };
     auto pick_up = [&](uint32_t L) -> Inputs {
         Inputs in;
         in.count = L <= last ? segs[2 * L + 1] : 0u;
         in.redo = (reads_others && L <= last) ? ctl[8 + L % R] : 0u;
         const uint32_t slot = (L - first) % D;
-        in.r = make_uint4(0u, 0u, 0u, 0u);
+        uint4 r = make_uint4(0u, 0u, 0u, 0u);
         in.lv = make_uint2(0u, 0u);
         in.target = in.hi = 0;
-        if (tid < in.count) {
-            in.r = *reinterpret_cast<const uint4 *>(ring_rec + (slot * 256 + tid) * 4);
-            in.lv = *reinterpret_cast<const uint2 *>(ring_pl + (slot * 256 + tid) * 2);
-            in.target = ring_x[slot * 256 + tid];
-            if (GIBBS) in.hi = ring_hi[slot * 256 + tid];
+        if (t < in.count) {
+            r = *reinterpret_cast<const uint4 *>(ring_rec + (slot * 256 + t) * 4);
+            in.lv = *reinterpret_cast<const uint2 *>(ring_pl + (slot * 256 + t) * 2);
+            in.target = ring_x[slot * 256 + t];
+            if (GIBBS) in.hi = ring_hi[slot * 256 + t];
         }
+        // (a neighbour in another slab is the value word of its staged exchange record: the host wrote that LDS word)
+        const uint32_t lds0 = lds_addr_of(lds); // (LDS byte addresses, ready for ds_read)
+        in.at = r.x & 0xFFFFu;
+        in.nb[0] = lds0 + (r.x >> 16) * 4;
+        in.nb[1] = lds0 + (r.y & 0xFFFFu) * 4;
+        in.nb[2] = lds0 + (r.y >> 16) * 4;
+        in.nb[3] = lds0 + (r.z & 0xFFFFu) * 4;
+        in.nb[4] = lds0 + (r.z >> 16) * 4;
+        in.nb[5] = lds0 + (r.w & 0xFFFFu) * 4;
+        in.at4 = lds0 + in.at * 4;
+        in.jm = r.w >> 16;
+        // computed HERE, by the set that is not sweeping (left alone, the compiler sinks the unpacking to its first
+        // use, behind the next barrier and onto the chain)
+        asm volatile("" : "+v"(in.at), "+v"(in.at4), "+v"(in.jm), "+v"(in.lv.x), "+v"(in.lv.y), "+v"(in.hi), "+v"(in.target), "+v"(in.count));
+#pragma unroll
+        for (int q = 0; q < 6; ++q) asm volatile("" : "+v"(in.nb[q]));
         return in;
     };
     slab_barrier(); // the loader's pieces of the first level and the first flag are in place
     const bool dense3 = !GIBBS && d.dense_nn == 3;
-    Inputs cur = pick_up(first);
+    Inputs cur{};
+    if (!set_b) cur = pick_up(first);
+    // The loader's and the fetcher's code lies on the (lane-masked) way here, so the compiler believes LDS-DMA writes may
+    // be pending and would put a vmcnt(0) wait before the first ring read INSIDE the loop -- where it waits for this
+    // wave's own global stores, a memory round trip per level.  Said once here, it costs nothing: nothing is outstanding.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    // the global stores of the level this set swept last, sent during the other set's level
+    uint32_t owed_value = 0, owed_at = 0, owed_target = 0, owed_tag = 0;
+    bool owed = false;
+    auto settle = [&]() {
+        if (owed) {
+            // (written out: left to the compiler, the store would be waited for -- vmcnt(0) -- before the next LDS
+            // read that reuses one of its registers; the next launch reads Snew)
+            asm volatile("global_store_dword %0, %1, off" ::"v"(Snew + a + owed_at), "v"(owed_value) : "memory");
+            if (owed_target) { // another slab reads this site: value and "ready" in one 16-byte record
+                const u32x4 record = {owed_value, owed_tag, owed_value ^ owed_tag, ~owed_tag};
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(xchg + (owed_target - 1)), "v"(record) : "memory");
+            }
+            owed = false;
+        }
+    };
+    if (p.slab_stamps && tid == 0) {
+        p.slab_stamps[static_cast<size_t>(blockIdx.x) * (d.n_levels + 4)] = first;
+        p.slab_stamps[static_cast<size_t>(blockIdx.x) * (d.n_levels + 4) + 1] = last;
+    }
     for (uint32_t level = first; level <= last; ++level) {
         slab_barrier(); // X(level): last level's spins are visible; the pieces of level + 1 have landed
+        const bool mine = (((level - first) & 1u) != 0u) == set_b;
         const uint32_t sslot = level % R;
-        if (__builtin_amdgcn_readfirstlane(cur.redo)) {
+        const uint32_t redo = mine ? cur.redo : (reads_others ? ctl[8 + sslot] : 0u);
+        if (p.slab_stamps && tid == 0) // (diagnostic runs only; bit 63: the level re-read its exchange records)
+            p.slab_stamps[static_cast<size_t>(blockIdx.x) * (d.n_levels + 4) + 2 + level] =
+                wall_clock64() | (static_cast<unsigned long long>(redo != 0) << 63);
+        if (__builtin_amdgcn_readfirstlane(redo)) {
             // ---- the producer was not far enough ahead when this level's records were fetched: read them again
             const uint32_t e0 = halo_start[level], n_h = halo_start[level + 1] - e0;
-            if (tid < n_h) {
+            if (tid < n_h) { // (threads of set A)
                 uint32_t spins = 0;
                 for (;;) {
                     u32x4 raw;
@@ -2671,33 +2718,30 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
                 return;
             }
         }
-        // the next level's inputs have landed (the loader's counted wait before X(level)): request them now, so that
-        // their LDS round trip runs beside this level's instead of after it
-        const Inputs upcoming = pick_up(level + 1);
-        // ---- this level's sites
-        if (tid < cur.count) {
-            const uint4 r = cur.r;
-            const uint32_t at = r.x & 0xFFFFu;
-            // (a neighbour in another slab is the value word of its staged exchange record: the host wrote that LDS word)
-            uint32_t nb[6] = {lds[r.x >> 16],     lds[r.y & 0xFFFFu], lds[r.y >> 16],
-                              lds[r.z & 0xFFFFu], lds[r.z >> 16],     lds[r.w & 0xFFFFu]};
-            const uint32_t jm = r.w >> 16;
-            const uint32_t sv = lds[at];
-            // (every bond non-zero in three directions -- ferromagnets, +-J: no non-zero masks, no case split)
-            const uint32_t acc = (GIBBS ? accept_mask_gibbs(sv, nb, jm, d.nn, cur.lv.x, cur.lv.y, cur.hi)
-                                  : dense3 ? accept_mask_dense<3>(sv, nb, jm, cur.lv.x, cur.lv.y)
-                                           : accept_mask(sv, nb, jm, cur.lv.x, cur.lv.y)) & valid_bits;
-            const uint32_t value = sv ^ acc;
-            lds[at] = value;
-            coherent_store(Snew + a + at, value);
-            if (cur.target) { // another slab reads this site: value and "ready" in one 16-byte record
-                const uint32_t tag = base + level + 1;
-                const u32x4 record = {value, tag, value ^ tag, ~tag};
-                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(xchg + (cur.target - 1)), "v"(record) : "memory");
+        if (mine) {
+            // ---- this level's sites: reads -> accept -> write, nothing else before the next barrier
+            if (t < cur.count) {
+                uint32_t nb[6] = {lds_load(cur.nb[0]), lds_load(cur.nb[1]), lds_load(cur.nb[2]),
+                                  lds_load(cur.nb[3]), lds_load(cur.nb[4]), lds_load(cur.nb[5])};
+                const uint32_t sv = lds_load(cur.at4);
+                // (every bond non-zero in three directions -- ferromagnets, +-J: no non-zero masks, no case split)
+                const uint32_t acc = (GIBBS ? accept_mask_gibbs(sv, nb, cur.jm, d.nn, cur.lv.x, cur.lv.y, cur.hi)
+                                      : dense3 ? accept_mask_dense<3>(sv, nb, cur.jm, cur.lv.x, cur.lv.y)
+                                               : accept_mask(sv, nb, cur.jm, cur.lv.x, cur.lv.y)) & valid_bits;
+                const uint32_t value = sv ^ acc;
+                lds_store(cur.at4, value);
+                owed = true;
+                owed_value = value;
+                owed_at = cur.at;
+                owed_target = cur.target;
+                owed_tag = base + level + 1;
             }
+        } else {
+            settle();
+            cur = pick_up(level + 1);
         }
-        cur = upcoming;
     }
+    settle();
 }
 
 // chunk = 4096 schedule positions per workgroup; counts go to cnt[real][n_sys][3] (u32 atomics)

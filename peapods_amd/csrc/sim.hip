@@ -2163,6 +2163,32 @@ int pa_debug_sweep_hc_stamps(pa_sim *sim, unsigned long long *out, uint64_t capa
     return static_cast<int>(n_blocks);
 }
 
+// Diagnostic only: s_memrealtime (100 MHz) at every level barrier of every workgroup of ONE k_sweep_slab launch, after
+// `settle` ordinary sweeps; out[workgroups][n_levels + 4] = {first level, last level, stamp per level ...}.
+int pa_debug_slab_stamps(pa_sim *sim, unsigned long long *out, uint64_t capacity_words, uint32_t settle) {
+    const SimDims &d = sim->d;
+    if (!d.pipe_K) return 0;
+    PA_HIP(sim, hipSetDevice(sim->device));
+    const uint32_t n_tw = d.n_real * d.W, n_tw_pad = (n_tw + 7u) & ~7u;
+    const size_t n_blocks = static_cast<size_t>(n_tw_pad) * d.pipe_K, words = n_blocks * (d.n_levels + 4);
+    if (words > capacity_words) return fail(sim, PA_ERR_INVALID, "stamp buffer too small");
+    unsigned long long *dev = nullptr;
+    PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&dev), words * sizeof(unsigned long long)));
+    PA_HIP(sim, hipMemset(dev, 0, words * sizeof(unsigned long long)));
+    for (uint32_t k = 0; k <= settle; ++k) {
+        DevPtrs q = sim->p;
+        q.slab_stamps = k == settle ? dev : nullptr;
+        PA_HIP(sim, launch_rng(d, q, false, sim->stream));
+        PA_HIP(sim, enqueue_sweep(sim, d, q, false, false, sim->stream));
+        sim->swaps_pending = false;
+        toggle_spin_buffers(sim);
+    }
+    PA_HIP(sim, hipStreamSynchronize(sim->stream));
+    PA_HIP(sim, hipMemcpy(out, dev, words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    (void)hipFree(dev);
+    return static_cast<int>(n_blocks);
+}
+
 int pa_debug_measure_stamps(pa_sim *sim, unsigned long long out[7]) {
     PA_HIP(sim, hipSetDevice(sim->device));
     unsigned long long *dev = nullptr;

@@ -337,8 +337,9 @@ def worker(args, rank, world, local_rank):
                       "attempts_per_s_per_rank": per_rank},
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_rng_overlap + k_sweep (the two launches of one Metropolis sweep; the first "
-                          "also measures the previous sweep's replica overlap)" if args.config != "c1" else
+                "kernel": "k_rng_relay + k_sweep_hc (the two launches of one Metropolis sweep; the first also "
+                          "carries the previous sweep's overlap measurement, statistics and tempering event)"
+                          if args.config != "c1" else
                           "k_rng + k_sweep_slab (random stream + LDS-resident slab sweep of one Metropolis sweep)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

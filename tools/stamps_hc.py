@@ -14,7 +14,7 @@ for rep in range(3):
     t = out[:n, :6].astype(np.int64) * 10  # ns
     t0 = t[:, 0].min()
     d = np.diff(t, axis=1)
-    names = ["load", "passes", "writeback", "energy-loop", "reduce"]
+    names = ["load", "passes", "writeback", "(hand-over)", "energy"]
     print(f"rep {rep}: {n} workgroups; kernel span {(t[:, 5].max() - t0) / 1e3:.1f} us; start spread {(t[:, 0].max() - t0) / 1e3:.1f} us")
     for k, name in enumerate(names):
         print(f"   {name:12s} min {d[:, k].min() / 1e3:6.2f}  median {np.median(d[:, k]) / 1e3:6.2f}  max {d[:, k].max() / 1e3:6.2f} us")

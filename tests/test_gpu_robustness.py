@@ -211,3 +211,24 @@ def test_profile_kernels_advances_the_state_like_sample(oracle, schedule):
     a = gpu.sample(5, "metropolis", **kw)
     b = cpu.sample(5, "metropolis", **kw)
     np.testing.assert_array_equal(a["overlap2"], b["overlap2"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,n_sweeps,extra", [
+    ("c2", 300, {}),
+    ("c2", 150, {"pt_schedule": "full_ladder"}),
+    ("c4", 60, {"overlap_cluster_build_mode": "jorg", "overlap_cluster_mode": "wolff"}),
+    ("c1", 60, {}),
+])
+def test_full_size_runs_are_reproducible(config, n_sweeps, extra):
+    """Race hunt at BASELINE sizes (tools/determinism_soak.py): two handles, one seed, the same protocol -- result
+    blocks, tempering counters and final spins must agree bit for bit (the reference is deterministic under a seed,
+    src/lib.rs:116-173)."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "determinism_soak.py")
+    spec = importlib.util.spec_from_file_location("determinism_soak", path)
+    soak = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(soak)
+    soak.one(config, n_sweeps, **extra)

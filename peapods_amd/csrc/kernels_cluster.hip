@@ -1024,8 +1024,11 @@ __global__ __launch_bounds__(64) void k_uf_replay(SimDims d, DevPtrs p, int cmr)
 // the one that lets every task of the launch be resident at once if the LDS allows it (12^3, 6144 pairs: 12 waves and
 // 78 KB per workgroup, two workgroups per CU, instead of 16 waves and 93 KB in two rounds)
 __host__ __device__ inline uint32_t wolff_wave_bitmaps(int mode) { return mode == kSwFk ? 2u : (mode == kSwCmr ? 4u : 3u); }
+// neighbour rows are padded to 8 (or 16) 16-bit slots: the row of a site is a shift away, not a multiplication
+__host__ __device__ inline uint32_t wolff_wave_row_shift(const SimDims &d) { return 2 * d.nn <= 8 ? 3u : 4u; }
 __host__ __device__ inline size_t wolff_wave_lds_words(const SimDims &d, uint32_t tasks, int mode) {
-    return static_cast<size_t>(d.N) * d.nn + d.N + tasks * (static_cast<size_t>(wolff_wave_bitmaps(mode)) * d.MW + (d.N + 1) / 2) + 16;
+    return (static_cast<size_t>(d.N) << (wolff_wave_row_shift(d) - 1)) + d.N +
+           tasks * (static_cast<size_t>(wolff_wave_bitmaps(mode)) * d.MW + (d.N + 1) / 2) + 16;
 }
 __host__ inline uint32_t wolff_wave_tasks(const SimDims &d, int mode) {
     const uint32_t n_tasks = mode == kSwFk ? d.n_sys : d.n_temps * d.n_pairs;
@@ -1062,8 +1065,9 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
     const uint32_t kWaveTasks = blockDim.x / 64;
     constexpr bool FK = MODE == kSwFk, CMR = MODE == kSwCmr;
     extern __shared__ uint32_t lds[];
-    uint16_t *nbr = reinterpret_cast<uint16_t *>(lds); // [N][2 nn] neighbours by site: f0, b0, f1, b1, ...
-    uint32_t *jbits = lds + static_cast<size_t>(d.N) * d.nn; // [N] neg[0..11] | nz[12..23] of the twelve bond slots
+    const uint32_t row_shift = wolff_wave_row_shift(d);
+    uint16_t *nbr = reinterpret_cast<uint16_t *>(lds); // [N][8 or 16] neighbours by site: f0, b0, f1, b1, ... (padded with the site)
+    uint32_t *jbits = lds + (static_cast<size_t>(d.N) << (row_shift - 1)); // [N] neg[0..11] | nz[12..23] of the twelve bond slots
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t per_task = wolff_wave_bitmaps(MODE) * d.MW + (d.N + 1) / 2;
     uint32_t *mine = jbits + d.N + wave * per_task;
@@ -1079,7 +1083,11 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
     const uint32_t task = __builtin_amdgcn_readfirstlane((blockIdx.x % blocks_per_real) * kWaveTasks + wave);
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(p.nbr_site); // [N][12] u16: the first 2 nn slots are used
-        for (uint32_t i = tid; i < d.N * d.nn; i += blockDim.x) lds[i] = src[(i / d.nn) * 6 + i % d.nn];
+        const uint32_t row_words = 1u << (row_shift - 1);
+        for (uint32_t i = tid; i < d.N * row_words; i += blockDim.x) {
+            const uint32_t site = i >> (row_shift - 1), pair = i & (row_words - 1u);
+            lds[i] = pair < d.nn ? src[site * 6 + pair] : site * 0x10001u;
+        }
         const uint32_t *js = p.jsite + static_cast<size_t>(real) * d.N;
         for (uint32_t i = tid; i < d.N; i += blockDim.x) jbits[i] = js[i];
     }
@@ -1152,6 +1160,7 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
         // bonds, or CMR's blue bonds (both systems satisfied, 1 - r^2); phase 1: CMR's red bonds (exactly one
         // system satisfied, 1 - r), which a flip of both systems on the blue cluster leaves as they are
         auto search = [&](uint32_t phase) {
+            const uint32_t slot_mask = (1u << (2 * d.nn)) - 1u; // the row's real slots
             const uint32_t threshold = __builtin_amdgcn_readfirstlane(FK ? p.fk_thr[t] : (CMR ? (phase == 0 ? p.cmr_thr[t] : p.fk_thr[t]) : p.jorg_thr[t]));
             while (top > 0) {
                 --top;
@@ -1160,20 +1169,21 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
                 const uint32_t jm = jbits[site];
                 // lanes 0..11: is the bond of slot `lane` eligible?  Every bitmap word is requested before any is
                 // looked at (no short-circuit: each would be another LDS round trip on the search's critical path)
-                const bool slot_ok = lane < 2 * d.nn;
-                const uint32_t nb = slot_ok ? nbr[site * 2 * d.nn + lane] : site;
+                // (every lane reads: lanes past the row fold onto it, their votes are masked off below -- no exec juggling)
+                const uint32_t sl = lane & ((1u << row_shift) - 1u);
+                const uint32_t nb = nbr[(site << row_shift) + sl];
                 const uint32_t w_site = spa[site >> 5], w_nb = spa[nb >> 5], w_mem = member[nb >> 5];
                 const uint32_t w_act = (FK || CMR) ? 0xFFFFFFFFu : act[nb >> 5];
                 const uint32_t w_site_b = CMR ? spb[site >> 5] : 0u, w_nb_b = CMR ? spb[nb >> 5] : 0u;
-                const uint32_t neg = (jm >> lane) & 1u, nzb = (jm >> (12 + lane)) & 1u;
+                const uint32_t neg = (jm >> sl) & 1u, nzb = (jm >> (12 + sl)) & 1u;
                 const uint32_t a_unsat = ((w_site >> (site & 31u)) ^ (w_nb >> (nb & 31u)) ^ neg) & 1u;
                 uint32_t wanted = (a_unsat ^ 1u) & (w_act >> (nb & 31u));
                 if (CMR) {
                     const uint32_t b_unsat = ((w_site_b >> (site & 31u)) ^ (w_nb_b >> (nb & 31u)) ^ neg) & 1u;
                     wanted = phase == 0 ? ((a_unsat | b_unsat) ^ 1u) : (a_unsat ^ b_unsat);
                 }
-                const bool eligible = slot_ok && ((nzb & ~(w_mem >> (nb & 31u)) & wanted & 1u) != 0);
-                uint32_t todo = static_cast<uint32_t>(__ballot(eligible));
+                const uint32_t eligible = nzb & ~(w_mem >> (nb & 31u)) & wanted & 1u;
+                uint32_t todo = static_cast<uint32_t>(__ballot(eligible != 0)) & slot_mask;
                 while (todo) {
                     const uint32_t q = __ffs(todo) - 1;
                     todo &= todo - 1;
@@ -1198,7 +1208,7 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
                         next = target;
                         next_known = true;
                         // another slot of this site leading to the same neighbour now finds it in the cluster
-                        todo &= ~static_cast<uint32_t>(__ballot(nb == target));
+                        todo &= ~static_cast<uint32_t>(__ballot(nb == target)); // (bits past the row are clear already)
                     }
                 }
             }

@@ -2988,6 +2988,20 @@ hipError_t launch_rng_relay(const SimDims &d, const DevPtrs &p, bool with_overla
     return hipGetLastError();
 }
 
+// The overlap blocks and the measurement blocks of k_rng_relay without its random-stream workgroups (the tail of a
+// run: the last sweep's overlap and its deferred measurement in one launch).  pt.relay must be 0: the measurement
+// block then moves the generators itself.
+hipError_t launch_measure_overlap(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_accum, bool accum_overlap,
+                                  bool do_pt, hipStream_t stream) {
+    const uint32_t n_overlap = d.n_real * d.W, n_measure = d.n_real;
+    const size_t lds = std::max(kRngLds + 1024, overlap_lds_bytes(d));
+    const dim3 grid(n_overlap + n_measure), block(256);
+    const int a = do_accum ? 1 : 0, o = accum_overlap ? 1 : 0, t = do_pt ? 1 : 0;
+    if (d.thr_preshifted) hipLaunchKernelGGL((k_rng_relay<true, false>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
+    else hipLaunchKernelGGL((k_rng_relay<false, false>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
+    return hipGetLastError();
+}
+
 hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,
                         bool gibbs, hipStream_t stream) {
     if (d.general) return launch_sweep_f(d, p, with_energy, do_sweep, stream);

@@ -1134,6 +1134,23 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     // The tail of the fused protocol -- also after an interrupt or a failed launch, so that the accumulators hold
     // whole sweeps only and the last sweep's tempering event has run: the deferred measurement block of the last
     // sweep (as its own launch now), then that sweep's overlap.
+    if (pending.any && overlap_owed && relay) {
+        // one launch for both: the overlap blocks write dot_*, the measurement block reads dot_*_prev -- the data flow
+        // of every relayed launch of the run, without its random-stream workgroups
+        for (auto &g : sim->groups) {
+            PtParams q = pending.pt;
+            q.relay = 0;
+            q.fresh = consume_fresh(g.fresh, g.d, pending.do_accum, pending.accum_overlap);
+            hipError_t e = launch_measure_overlap(g.d, g.p, q, pending.do_accum, pending.accum_overlap, pending.do_pt, g.stream);
+            toggle_dots(g.p);
+            PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
+            if (e == hipSuccess) e = measure_launch(g.fresh, g.d, g.p, pt, false, true, false, g.stream);
+            if (e != hipSuccess && status == PA_OK) status = fail(sim, PA_ERR_DEVICE, std::string("fused tail: ") + hipGetErrorString(e));
+        }
+        if (pending.do_pt) sim->swaps_pending = true;
+        pending.any = false;
+        overlap_owed = false;
+    }
     if (pending.any) {
         for (auto &g : sim->groups) {
             const hipError_t e = measure_launch(g.fresh, g.d, g.p, pending.pt, pending.do_accum, pending.accum_overlap,

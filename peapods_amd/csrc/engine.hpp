@@ -224,11 +224,11 @@ hipError_t launch_rng(const SimDims &d, const DevPtrs &p, bool gibbs, hipStream_
 hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,
                         bool gibbs, hipStream_t stream);
 hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream);
-hipError_t launch_rng_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream);
+hipError_t launch_rng_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool gibbs = false);
 // The random stream of a sweep with the previous sweep's overlap measurement (with_overlap) and / or its deferred
 // measurement block (statistics + tempering event, pt.relay = 1) riding in the same launch.
 hipError_t launch_rng_relay(const SimDims &d, const DevPtrs &p, bool with_overlap, const PtParams &pt, bool do_accum,
-                            bool accum_overlap, bool do_pt, hipStream_t stream);
+                            bool accum_overlap, bool do_pt, hipStream_t stream, bool gibbs = false);
 bool rng_relay_supported(const SimDims &d);
 hipError_t launch_measure_overlap(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_accum, bool accum_overlap,
                                   bool do_pt, hipStream_t stream);
@@ -246,7 +246,7 @@ hipError_t launch_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt
 hipError_t launch_measure_stamped(const SimDims &d, const DevPtrs &p, const PtParams &pt,
                                   unsigned long long *stamps, hipStream_t stream);
 size_t sweep_lds_bytes(const SimDims &d, bool gibbs);
-size_t sweep_hc_lds_bytes(const SimDims &d);
+size_t sweep_hc_lds_bytes(const SimDims &d, bool gibbs = false);
 size_t sweep_slab_lds_bytes(const SimDims &d);
 size_t sweep_slab_lds_bytes_for(uint32_t own_sites, uint32_t plane_sites, uint32_t n_levels);
 // kernels_cluster.hip

@@ -593,6 +593,28 @@ __device__ __forceinline__ uint32_t accept_mask_dense(uint32_t s, const uint32_t
     return t0 | t1 | hi;
 }
 
+// Heat-bath accept mask (accept_mask_gibbs) when every one of the 2*NN bonds is non-zero; nb[k] already carries the
+// coupling sign (neighbour word ^ sign mask).  K = 16 - h = 15 - 2 NN is a compile-time constant here.
+template <int NN>
+__device__ __forceinline__ uint32_t accept_mask_gibbs_dense(uint32_t s, const uint32_t nb[6], uint32_t l0, uint32_t l1, uint32_t l2) {
+    uint32_t u[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) u[k] = k < 2 * NN ? (s ^ nb[k]) : 0u;
+    const uint32_t s1 = u[0] ^ u[1] ^ u[2], c1 = maj3(u[0], u[1], u[2]);
+    const uint32_t s2 = u[3] ^ u[4] ^ u[5], c2 = maj3(u[3], u[4], u[5]);
+    const uint32_t U0 = s1 ^ s2, c3 = s1 & s2;
+    const uint32_t U1 = c1 ^ c2 ^ c3, U2 = maj3(c1, c2, c3);
+    const uint32_t t0 = U0 ^ l0, k0 = U0 & l0;
+    const uint32_t t1 = U1 ^ l1 ^ k0, k1 = maj3(U1, l1, k0);
+    const uint32_t t2 = U2 ^ l2 ^ k1, t3 = maj3(U2, l2, k1);
+    constexpr uint32_t K = 15u - 2u * NN;
+    constexpr uint32_t K0 = 0u - (K & 1u), K1 = 0u - ((K >> 1) & 1u), K2 = 0u - ((K >> 2) & 1u), K3 = 0u - ((K >> 3) & 1u);
+    const uint32_t a0 = t0 & K0;
+    const uint32_t a1 = maj3(t1, K1, a0);
+    const uint32_t a2 = maj3(t2, K2, a1);
+    return maj3(t3, K3, a2);
+}
+
 // Two arrays in one go for a 256-thread workgroup: all loads of both copies are issued before the
 // first LDS store when everything is 16-byte aligned and fits 16 vector loads per thread.
 __device__ __forceinline__ void copy2_to_lds(uint32_t *dst_a, const uint32_t *__restrict__ src_a,
@@ -944,10 +966,11 @@ __device__ __forceinline__ HcSite hc_decode(const SimDims &d, uint32_t e, uint32
     return h;
 }
 
-__host__ __device__ inline size_t sweep_hc_lds_words(const SimDims &d) {
+__host__ __device__ inline size_t sweep_hc_lds_words(const SimDims &d, bool gibbs = false) {
     const size_t n1 = static_cast<size_t>(d.N) + 1, n_pad = (n1 + 3) & ~size_t(3);
     const size_t tab = (static_cast<size_t>(d.N) + 3) & ~size_t(3);
-    return n_pad + ((2 * n1 + 3) & ~size_t(3)) + tab + ((static_cast<size_t>(d.n_passes) + 6 + 3) & ~size_t(3)) + 5 * 48;
+    return n_pad + ((2 * n1 + 3) & ~size_t(3)) + tab + ((static_cast<size_t>(d.n_passes) + 6 + 3) & ~size_t(3)) + 5 * 48 +
+           (gibbs ? n_pad : 0); // the heat bath's third acceptance plane
 }
 
 // STAMPS: diagnostic build, every workgroup files s_memrealtime (100 MHz) stamps of its phases in stamps[block][8]
@@ -1089,7 +1112,7 @@ __device__ __forceinline__ void hc_energy_wide(const SimDims &d, const DevPtrs &
 // the passes in turn, and while one computes pass p the other fetches the table entry of pass p + 1 and decodes its
 // seven LDS addresses, then meets it at the barrier.  Between two barriers one set does "reads -> accept -> write" and
 // nothing else.
-template <int NN, bool STAMPS>
+template <int NN, bool STAMPS, bool GIBBS>
 __device__ __forceinline__ void sweep_hc_block(const SimDims &d, const DevPtrs &p, uint32_t bid, int with_energy, int do_sweep,
                                                unsigned long long *stamps, uint32_t *lds) {
     PA_HC_STAMP(0)
@@ -1101,6 +1124,7 @@ __device__ __forceinline__ void sweep_hc_block(const SimDims &d, const DevPtrs &
     uint32_t *tab = pl + ((2 * n1 + 3u) & ~3u);           // [N] schedule table of this realisation
     uint32_t *ps = tab + ((d.N + 3u) & ~3u);              // [n_passes + 6] pass boundaries (padded with N)
     uint32_t *scratch = ps + ((d.n_passes + 6u + 3u) & ~3u); // [5][48]
+    uint32_t *hi = scratch + 5 * 48;                      // [N + 1] heat bath: third acceptance plane
     uint32_t real, w;
     tile_of_block(d, bid, real, w);
     const uint32_t tid = threadIdx.x;
@@ -1153,6 +1177,7 @@ __device__ __forceinline__ void sweep_hc_block(const SimDims &d, const DevPtrs &
             copy_to_lds(tab, tab_g, d.N, tid, kThreads);
         }
     }
+    if (GIBBS && do_sweep) copy_to_lds(hi, p.planes_hi + (static_cast<size_t>(real) * d.W + w) * d.N, d.N, tid, kThreads);
     for (uint32_t k = tid; k < d.n_passes + 6; k += kThreads) ps[k] = k <= d.n_passes ? p.pass_start[k] : d.N;
     if (do_sweep && epoch != applied) {
         // tempering swaps accepted after the previous sweep: exchange the bit columns now
@@ -1173,6 +1198,7 @@ __device__ __forceinline__ void sweep_hc_block(const SimDims &d, const DevPtrs &
         sw[d.N] = 0;
         pl[2 * d.N] = 0;
         pl[2 * d.N + 1] = 0;
+        if (GIBBS) hi[d.N] = 0;
     }
     const uint32_t live = d.n_sys - w * 32;
     const uint32_t valid_bits = live >= 32 ? 0xFFFFFFFFu : ((1u << live) - 1u);
@@ -1180,6 +1206,7 @@ __device__ __forceinline__ void sweep_hc_block(const SimDims &d, const DevPtrs &
 
     PA_HC_STAMP(1)
     const uint32_t sw_addr = lds_addr_of(sw), pl_addr = lds_addr_of(pl), tab_addr = lds_addr_of(tab);
+    const uint32_t hi_addr = GIBBS ? lds_addr_of(hi) : 0u;
     if (do_sweep) {
         const uint32_t spare = sw_addr + d.N * 4;
         const uint32_t ps_addr = lds_addr_of(ps);
@@ -1203,11 +1230,12 @@ __device__ __forceinline__ void sweep_hc_block(const SimDims &d, const DevPtrs &
         };
         auto compute = [&]() { // reads -> accept -> write: the chain between two barriers
             const uint2 lv = lds_load2(pl_cur);
+            const uint32_t l2 = GIBBS ? lds_load(hi_addr + cur.site4) : 0u;
             const uint32_t s = lds_load(cur.site);
             uint32_t nb[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) nb[k] = k < 2 * NN ? (lds_load(cur.nb[k]) ^ negm[k]) : 0u;
-            const uint32_t acc = accept_mask_dense<NN>(s, nb, 0u, lv.x, lv.y);
+            const uint32_t acc = GIBBS ? accept_mask_gibbs_dense<NN>(s, nb, lv.x, lv.y, l2) : accept_mask_dense<NN>(s, nb, 0u, lv.x, lv.y);
             lds_store(wr_cur, s ^ (acc & valid_bits));
         };
         // set 0 takes the even passes, set 1 the odd ones (two loops, one barrier sequence: every wave meets the same
@@ -1255,11 +1283,11 @@ __device__ __forceinline__ void sweep_hc_block(const SimDims &d, const DevPtrs &
     PA_HC_STAMP(5)
 }
 
-template <int NN, bool STAMPS = false>
+template <int NN, bool STAMPS = false, bool GIBBS = false>
 __global__ __launch_bounds__(512, 2) void k_sweep_hc(SimDims d, DevPtrs p, int with_energy, int do_sweep,
                                                      unsigned long long *stamps) {
     extern __shared__ uint32_t lds[];
-    sweep_hc_block<NN, STAMPS>(d, p, blockIdx.x, with_energy, do_sweep, stamps, lds);
+    sweep_hc_block<NN, STAMPS, GIBBS>(d, p, blockIdx.x, with_energy, do_sweep, stamps, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -1452,13 +1480,13 @@ __global__ __launch_bounds__(256) void k_overlap(SimDims d, DevPtrs p) {
 // state the previous sweep left (latency-bound, few waves), the others draw the random stream
 // of the next sweep (VALU-bound); the two do not depend on each other, so the measurement hides
 // under the random stream instead of costing a launch of its own.
-template <bool PRESHIFTED>
+template <bool PRESHIFTED, bool GIBBS = false>
 __global__ __launch_bounds__(256) void k_rng_overlap(SimDims d, DevPtrs p, uint32_t n_overlap) {
     extern __shared__ uint32_t lds_dyn[];
     if (blockIdx.x < n_overlap)
         overlap_block(d, p, blockIdx.x, lds_dyn);
     else
-        rng_block<PRESHIFTED, false>(d, p, blockIdx.x - n_overlap, lds_dyn);
+        rng_block<PRESHIFTED, GIBBS>(d, p, blockIdx.x - n_overlap, lds_dyn);
 }
 
 // ---------------------------------------------------------------------------
@@ -1842,7 +1870,7 @@ __global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams
 // realisation, PtParams::relay), the rest draw the random stream of the next sweep -- with REPLAY they apply the
 // event's cursor permutation themselves.  A sweep of the plain protocol is then two launches (this one and the
 // sweep kernel) instead of three, and the latency-bound measurement hides under the VALU-bound random stream.
-template <bool PRESHIFTED, bool REPLAY>
+template <bool PRESHIFTED, bool REPLAY, bool GIBBS = false>
 __global__ __launch_bounds__(256) void k_rng_relay(SimDims d, DevPtrs p, uint32_t n_overlap, uint32_t n_measure, PtParams pt,
                                                    int do_accum, int accum_overlap, int do_pt) {
     extern __shared__ uint32_t lds_dyn[];
@@ -1851,7 +1879,7 @@ __global__ __launch_bounds__(256) void k_rng_relay(SimDims d, DevPtrs p, uint32_
     else if (blockIdx.x < n_overlap + n_measure)
         measure_block<false>(d, p, pt, do_accum, accum_overlap, do_pt, nullptr, blockIdx.x - n_overlap, lds_dyn);
     else
-        rng_block<PRESHIFTED, false, REPLAY>(d, p, blockIdx.x - n_overlap - n_measure, lds_dyn);
+        rng_block<PRESHIFTED, GIBBS, REPLAY>(d, p, blockIdx.x - n_overlap - n_measure, lds_dyn);
 }
 
 // ---------------------------------------------------------------------------
@@ -2888,7 +2916,7 @@ size_t sweep_lds_bytes(const SimDims &d, bool gibbs) {
     return ((n1 + 1) / 2 * 2 + (gibbs ? 3 : 2) * n1 + 5 * 48) * 4;
 }
 size_t measure_lds_bytes(const SimDims &d) { return measure_lds_words(d) * 4; }
-size_t sweep_hc_lds_bytes(const SimDims &d) { return sweep_hc_lds_words(d) * 4; }
+size_t sweep_hc_lds_bytes(const SimDims &d, bool gibbs) { return sweep_hc_lds_words(d, gibbs) * 4; }
 static size_t overlap_lds_bytes(const SimDims &d) {
     return ((static_cast<size_t>(d.N) + 1) + 5 * 48) * 4;
 }
@@ -2915,6 +2943,12 @@ hipError_t configure_kernels(const SimDims &) {
                            reinterpret_cast<const void *>(k_rng_relay<true, false>),
                            reinterpret_cast<const void *>(k_rng_relay<true, true>),
                            reinterpret_cast<const void *>(k_rng_overlap<false>),
+                           reinterpret_cast<const void *>(k_rng_overlap<false, true>),
+                           reinterpret_cast<const void *>(k_rng_relay<false, false, true>),
+                           reinterpret_cast<const void *>(k_rng_relay<false, true, true>),
+                           reinterpret_cast<const void *>(k_sweep_hc<1, false, true>),
+                           reinterpret_cast<const void *>(k_sweep_hc<2, false, true>),
+                           reinterpret_cast<const void *>(k_sweep_hc<3, false, true>),
                            reinterpret_cast<const void *>(k_rng_overlap<true>),
                            reinterpret_cast<const void *>(k_houdayer),
                            reinterpret_cast<const void *>(k_houdayer_grow),
@@ -2947,12 +2981,14 @@ hipError_t launch_rng(const SimDims &d, const DevPtrs &p, bool gibbs, hipStream_
 
 // Random stream of the next Metropolis sweep fused with the overlap measurement of the current
 // state (LDS kernels, unit couplings only).
-hipError_t launch_rng_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
+hipError_t launch_rng_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool gibbs) {
     const uint32_t n_pairs_tw = (d.n_real * d.W + 1) / 2;
     const uint32_t groups = (n_pairs_tw + 3) / 4;
     const uint32_t n_overlap = d.n_real * d.W;
     const size_t lds = std::max(kRngLds, overlap_lds_bytes(d));
-    if (d.thr_preshifted)
+    if (gibbs)
+        hipLaunchKernelGGL((k_rng_overlap<false, true>), dim3(n_overlap + groups * d.B), dim3(256), lds, stream, d, p, n_overlap);
+    else if (d.thr_preshifted)
         hipLaunchKernelGGL(k_rng_overlap<true>, dim3(n_overlap + groups * d.B), dim3(256), lds, stream, d, p, n_overlap);
     else
         hipLaunchKernelGGL(k_rng_overlap<false>, dim3(n_overlap + groups * d.B), dim3(256), lds, stream, d, p, n_overlap);
@@ -2969,7 +3005,7 @@ bool rng_relay_supported(const SimDims &d) {
 }
 
 hipError_t launch_rng_relay(const SimDims &d, const DevPtrs &p, bool with_overlap, const PtParams &pt, bool do_accum,
-                            bool accum_overlap, bool do_pt, hipStream_t stream) {
+                            bool accum_overlap, bool do_pt, hipStream_t stream, bool gibbs) {
     const uint32_t n_pairs_tw = (d.n_real * d.W + 1) / 2;
     const uint32_t groups = (n_pairs_tw + 3) / 4;
     const uint32_t n_overlap = with_overlap ? d.n_real * d.W : 0u;
@@ -2978,7 +3014,10 @@ hipError_t launch_rng_relay(const SimDims &d, const DevPtrs &p, bool with_overla
     const size_t lds = std::max(kRngLds + 1024, overlap_lds_bytes(d)); // + the replayed decisions
     const dim3 grid(n_overlap + n_measure + groups * d.B), block(256);
     const int a = do_accum ? 1 : 0, o = accum_overlap ? 1 : 0, t = do_pt ? 1 : 0;
-    if (d.thr_preshifted) {
+    if (gibbs) { // (heat-bath thresholds are compared unshifted, like k_rng<false, true>)
+        if (replay) hipLaunchKernelGGL((k_rng_relay<false, true, true>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
+        else hipLaunchKernelGGL((k_rng_relay<false, false, true>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
+    } else if (d.thr_preshifted) {
         if (replay) hipLaunchKernelGGL((k_rng_relay<true, true>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
         else hipLaunchKernelGGL((k_rng_relay<true, false>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
     } else {
@@ -3026,11 +3065,21 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
     const size_t lds = std::max(sweep_lds_bytes(d, gibbs && do_sweep), pad);
     unsigned long long *no_stamps = nullptr;
     const int e = with_energy ? 1 : 0, s = do_sweep ? 1 : 0;
+    static const bool no_hc = std::getenv("PEAPODS_NO_HC") != nullptr;
     if (gibbs && do_sweep) {
+        if (d.hc && !no_hc && sweep_hc_lds_bytes(d, true) <= 160 * 1024) { // (83 KB at 16^3: one workgroup per CU)
+            const dim3 block_hc(512);
+            const size_t lds_g = sweep_hc_lds_bytes(d, true);
+            switch (d.dense_nn) {
+            case 1: hipLaunchKernelGGL((k_sweep_hc<1, false, true>), grid, block_hc, lds_g, stream, d, p, e, s, no_stamps); break;
+            case 2: hipLaunchKernelGGL((k_sweep_hc<2, false, true>), grid, block_hc, lds_g, stream, d, p, e, s, no_stamps); break;
+            default: hipLaunchKernelGGL((k_sweep_hc<3, false, true>), grid, block_hc, lds_g, stream, d, p, e, s, no_stamps); break;
+            }
+            return hipGetLastError();
+        }
         hipLaunchKernelGGL((k_sweep<false, 0, true>), grid, block, lds, stream, d, p, e, s, no_stamps);
         return hipGetLastError();
     }
-    static const bool no_hc = std::getenv("PEAPODS_NO_HC") != nullptr;
     if (d.hc && !no_hc) { // implicit neighbours, table in the LDS
         const size_t lds_hc = sweep_hc_lds_bytes(d);
         const dim3 block_hc(512); // two sets of four waves take the passes in turn

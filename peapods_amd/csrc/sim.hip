@@ -863,8 +863,10 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     for (auto &g : sim->groups) PA_HIP(sim, hipStreamWaitEvent(g.stream, sim->fork, 0));
     uint64_t overlap_call_count = 0; // mod.rs:300
     size_t equil_next = 0;
-    const bool fused = want_overlap && !gibbs && !fk && !equil && !autocorr && cfg->overlap_cluster_interval == 0 && !d.big &&
-                       !d.general && !std::getenv("PEAPODS_NO_FUSE");
+    // (the heat bath rides the same launches when its sweep runs on the implicit-neighbour kernel: three planes in LDS)
+    const bool gibbs_fast = gibbs && d.hc && sweep_hc_lds_bytes(d, true) <= 160 * 1024 && !std::getenv("PEAPODS_NO_HC");
+    const bool fused = want_overlap && (!gibbs || gibbs_fast) && !fk && !equil && !autocorr && cfg->overlap_cluster_interval == 0 &&
+                       !d.big && !d.general && !std::getenv("PEAPODS_NO_FUSE");
     bool overlap_owed = false; // the last recorded sweep's overlap has not been measured yet
     // the measurement block of the previous sweep when it is relayed into the next sweep's random-stream launch
     struct {
@@ -928,14 +930,14 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                     q.relay = 1;
                     q.fresh = consume_fresh(g.fresh, g.d, pending.do_accum, pending.accum_overlap);
                     PA_HIP(sim, launch_rng_relay(g.d, g.p, overlap_owed, q, pending.do_accum, pending.accum_overlap,
-                                                 pending.do_pt, g.stream));
+                                                 pending.do_pt, g.stream, gibbs));
                 } else if (overlap_owed) {
-                    PA_HIP(sim, launch_rng_overlap(g.d, g.p, g.stream));
+                    PA_HIP(sim, launch_rng_overlap(g.d, g.p, g.stream, gibbs));
                 } else {
-                    PA_HIP(sim, launch_rng(g.d, g.p, false, g.stream));
+                    PA_HIP(sim, launch_rng(g.d, g.p, gibbs, g.stream));
                 }
                 if (overlap_owed) toggle_dots(g.p);
-                PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, record || pt_this, false, g.stream));
+                PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, record || pt_this, gibbs, g.stream));
             }
             if (relayed && pending.do_pt && d.n_temps >= 2) toggle_system_tables(sim);
             pending.any = false;
@@ -2063,7 +2065,8 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
     uint64_t count[3] = {0, 0, 0};
     // same launch sequence as run_sweeps on one stream; with the fused path the overlap of the previous sweep --
     // and, relayed, its measurement block -- ride in the random-stream launch (reported under k_rng)
-    const bool fused = want_overlap && !gibbs && !d.big && !d.general && !std::getenv("PEAPODS_NO_FUSE");
+    const bool gibbs_fast = gibbs && d.hc && sweep_hc_lds_bytes(d, true) <= 160 * 1024 && !std::getenv("PEAPODS_NO_HC");
+    const bool fused = want_overlap && (!gibbs || gibbs_fast) && !d.big && !d.general && !std::getenv("PEAPODS_NO_FUSE");
     const bool relay = fused && cfg->pt_schedule == PA_PT_SINGLE_RANDOM_EDGE && rng_relay_supported(d) &&
                        !std::getenv("PEAPODS_NO_RELAY");
     struct {
@@ -2081,10 +2084,10 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
             q.relay = 1;
             q.fresh = consume_fresh(sim->fresh, d, pending.do_accum, pending.accum_overlap);
             PA_HIP(sim, launch_rng_relay(d, sim->p, overlap_owed, q, pending.do_accum, pending.accum_overlap, pending.do_pt,
-                                         sim->stream));
+                                         sim->stream, gibbs));
             if (pending.do_pt && d.n_temps >= 2) toggle_system_tables(sim);
         } else if (fused && overlap_owed) {
-            PA_HIP(sim, launch_rng_overlap(d, sim->p, sim->stream));
+            PA_HIP(sim, launch_rng_overlap(d, sim->p, sim->stream, gibbs));
         } else {
             PA_HIP(sim, launch_rng(d, sim->p, gibbs, sim->stream));
         }

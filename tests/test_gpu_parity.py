@@ -287,6 +287,31 @@ def test_sample_matches_oracle(oracle, schedule, shape, n_temps, n_rep, n_dis):
     assert_state_equal(gpu, cpu)
 
 
+@pytest.mark.parametrize("schedule", ["single_random_edge", "full_ladder"])
+@pytest.mark.parametrize("shape,n_temps,n_rep,n_dis", [((4, 4), 3, 2, 1), ((6, 6, 6), 24, 4, 2), ((8, 8, 8), 12, 4, 9)])
+def test_heat_bath_sample_matches_oracle(oracle, schedule, shape, n_temps, n_rep, n_dis):
+    """gibbs_sweep (sweep.rs:262-284) inside the full protocol: on +-J lattices the heat bath runs on the
+    implicit-neighbour sweep kernel (three acceptance planes in LDS) with the overlap and the deferred measurement
+    riding in its random-stream launch, like Metropolis."""
+    couplings = bimodal(shape, len(shape), n_dis, 12)
+    temps = np.linspace(0.8, 1.6, n_temps)
+    gpu, cpu = make_pair(oracle, shape, couplings, temps, n_rep, 98)
+    kwargs = dict(pt_interval=1, pt_schedule=schedule, warmup_ratio=0.25)
+    a = gpu.sample(24, "gibbs", **kwargs)
+    b = cpu.sample(24, "gibbs", **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+    # a Metropolis call continues the same chain (the rules share generators, planes and tempering state)
+    a = gpu.sample(9, "metropolis", pt_interval=2, pt_schedule=schedule, warmup_ratio=0.0)
+    b = cpu.sample(9, "metropolis", pt_interval=2, pt_schedule=schedule, warmup_ratio=0.0)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+    a = gpu.sample(7, "gibbs", pt_interval=1, pt_schedule=schedule, warmup_ratio=0.0)
+    b = cpu.sample(7, "gibbs", pt_interval=1, pt_schedule=schedule, warmup_ratio=0.0)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+
+
 def test_more_than_256_systems_per_realization(oracle):
     # 40 temperatures x 8 replicas = 320 systems (10 tile words): the tempering kernel moves the
     # generator cursors of every swapped slot, two slots per thread

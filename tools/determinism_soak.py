@@ -32,7 +32,7 @@ def one(config, n_sweeps, **sample):
         kw = dict(warmup_ratio=0.0, pt_interval=1)
         kw.update(work.get("sample", {}))
         kw.update(sample)
-        res = sim.sample(n_sweeps, "metropolis", **kw)
+        res = sim.sample(n_sweeps, kw.pop("sweep_mode", "metropolis"), **kw)
         spins = np.concatenate([sim.get_spins(r) for r in range(0, work["n_disorder"], max(1, work["n_disorder"] // 8))])
         outs.append((res, spins))
         del sim
@@ -44,6 +44,7 @@ def one(config, n_sweeps, **sample):
 
 if __name__ == "__main__":
     one("c2", 3000)
+    one("c2", 1500, sweep_mode="gibbs")
     one("c2", 1500, pt_schedule="full_ladder") if "full_ladder" in sys.argv else None
     for mode in ("houdayer", "jorg", "cmr"):
         one("c4", 400, overlap_cluster_build_mode=mode, overlap_cluster_mode="wolff")

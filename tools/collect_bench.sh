@@ -16,4 +16,5 @@ python tools/stamps_hc.py > "$out/stamps_hc.txt" 2>&1
 python tools/stamps_slab.py > "$out/stamps_slab.txt" 2>&1
 python tools/fixed_cost.py > "$out/fixed_cost.json" 2>&1
 python tools/determinism_soak.py full_ladder > "$out/determinism_soak.txt" 2>&1
+python tools/time_variants.py > "$out/variants.txt" 2>&1
 echo done

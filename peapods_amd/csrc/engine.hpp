@@ -54,13 +54,13 @@ struct SimDims {
     // at site + one of two offsets -- the regular one or the one through the periodic wrap -- so a site needs
     // one flag bit per slot instead of a 16-byte neighbour record (lattice.rs:44-99 builds tables; on a
     // hypercubic lattice of any extents they collapse to this).  Byte offsets into a u32[N] array.
-    uint32_t hc;         // 1: hc_tab is built and the on-chip Metropolis sweep uses it
+    uint32_t hc;         // 1: hc_tab is built and the on-chip sweeps use it (all bonds non-zero iff dense_nn == nn)
     int32_t hc_d0[6];    // regular offset of each slot (x 4)
     int32_t hc_dd[6];    // (wrapped - regular) offset of each slot (x 4)
 };
 
 // hc_tab entry of a site (schedule order): site | wrap flags << 14 | coupling sign bits << 20
-constexpr uint32_t kHcSiteBits = 14, kHcFlagShift = 14, kHcNegShift = 20;
+constexpr uint32_t kHcSiteBits = 14, kHcFlagShift = 14, kHcNegShift = 20, kHcNzShift = 26; // 14 + 6 + 6 + 6 bits
 
 struct DevPtrs {
     uint32_t *S;             // [n_real][W][N] current spins

@@ -65,6 +65,22 @@ __device__ __forceinline__ void rng_step(Rng32 &rng, uint32_t ca0, uint32_t ca1,
     keep1 = park_in_lane<JJ + 32>(keep1, static_cast<uint32_t>(l1 >> 32));
 }
 
+// The same step on a lattice with zero couplings: sites with an odd number of non-zero bonds take the second
+// threshold set.  `par` holds the parity bits of the chunk's 32 sites -- per lane: the two tile words of a wave may
+// belong to different realisations -- and dk = ca ^ cb, so a threshold is ca ^ (dk & mask): one v_bfe_i32 and three
+// v_bitop3 per step, and the chunk stays unrolled with its immediate lane selects.
+template <int JJ, bool PRESHIFTED>
+__device__ __forceinline__ void rng_step_par(Rng32 &rng, const uint32_t ca[3], const uint32_t dk[3], uint32_t par,
+                                             uint32_t &keep0, uint32_t &keep1) {
+    const uint32_t odd = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(par), JJ, 1));
+    rng_step<JJ, PRESHIFTED>(rng, ca[0] ^ (dk[0] & odd), ca[1] ^ (dk[1] & odd), ca[2] ^ (dk[2] & odd), keep0, keep1);
+}
+template <bool PRESHIFTED, int... JJ>
+__device__ __forceinline__ void rng_chunk32_par(Rng32 &rng, const uint32_t ca[3], const uint32_t dk[3], uint32_t par,
+                                                uint32_t &keep0, uint32_t &keep1, std::integer_sequence<int, JJ...>) {
+    (rng_step_par<JJ, PRESHIFTED>(rng, ca, dk, par, keep0, keep1), ...);
+}
+
 template <bool PRESHIFTED, int... JJ>
 __device__ __forceinline__ void rng_chunk32(Rng32 &rng, uint32_t ca0, uint32_t ca1, uint32_t ca2,
                                             uint32_t &keep0, uint32_t &keep1,
@@ -152,6 +168,22 @@ __device__ __forceinline__ void rng_step_gibbs(Rng32 &rng, const uint32_t c[7], 
     keep1 = park_in_lane<JJ + 32>(keep1, static_cast<uint32_t>(m1 >> 32));
     keep2 = park_in_lane<JJ>(keep2, static_cast<uint32_t>(m2));
     keep2 = park_in_lane<JJ + 32>(keep2, static_cast<uint32_t>(m2 >> 32));
+}
+
+template <int JJ>
+__device__ __forceinline__ void rng_step_gibbs_par(Rng32 &rng, const uint32_t ce[7], const uint32_t dk[7], uint32_t par,
+                                                   uint32_t &keep0, uint32_t &keep1, uint32_t &keep2) {
+    const uint32_t odd = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(par), JJ, 1));
+    uint32_t c[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) c[j] = ce[j] ^ (dk[j] & odd);
+    rng_step_gibbs<JJ>(rng, c, keep0, keep1, keep2);
+}
+template <int... JJ>
+__device__ __forceinline__ void rng_chunk32_gibbs_par(Rng32 &rng, const uint32_t ce[7], const uint32_t dk[7], uint32_t par,
+                                                      uint32_t &keep0, uint32_t &keep1, uint32_t &keep2,
+                                                      std::integer_sequence<int, JJ...>) {
+    (rng_step_gibbs_par<JJ>(rng, ce, dk, par, keep0, keep1, keep2), ...);
 }
 
 template <int... JJ>
@@ -287,6 +319,12 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
             const uint32_t chunk = min(32u, len - j0);
             if (chunk == 32 && !d.has_odd) {
                 rng_chunk32_gibbs(rng, ce, keep0, keep1, keep2, std::make_integer_sequence<int, 32>{});
+            } else if (chunk == 32 && ((begin + j0) & 31u) == 0) { // one parity word covers the chunk
+                const uint32_t par = mpar[(begin + j0) >> 5]; // (the lane's realisation)
+                uint32_t dk[7];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) dk[j] = ce[j] ^ co[j];
+                rng_chunk32_gibbs_par(rng, ce, dk, par, keep0, keep1, keep2, std::make_integer_sequence<int, 32>{});
             } else {
                 for (uint32_t jj = 0; jj < chunk; ++jj) {
                     const uint32_t site = begin + j0 + jj;
@@ -355,6 +393,10 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
         if (chunk == 32 && !d.has_odd) {
             rng_chunk32<PRESHIFTED>(rng, ca0, ca1, ca2, keep0, keep1,
                                     std::make_integer_sequence<int, 32>{});
+        } else if (chunk == 32 && ((begin + j0) & 31u) == 0) { // one parity word covers the chunk
+            const uint32_t par = mpar[(begin + j0) >> 5]; // (the lane's realisation)
+            const uint32_t ca[3] = {ca0, ca1, ca2}, dk[3] = {ca0 ^ cb0, ca1 ^ cb1, ca2 ^ cb2};
+            rng_chunk32_par<PRESHIFTED>(rng, ca, dk, par, keep0, keep1, std::make_integer_sequence<int, 32>{});
         } else {
             for (uint32_t jj = 0; jj < chunk; ++jj) {
                 const uint32_t site = begin + j0 + jj;
@@ -609,6 +651,41 @@ __device__ __forceinline__ uint32_t accept_mask_gibbs_dense(uint32_t s, const ui
     const uint32_t t2 = U2 ^ l2 ^ k1, t3 = maj3(U2, l2, k1);
     constexpr uint32_t K = 15u - 2u * NN;
     constexpr uint32_t K0 = 0u - (K & 1u), K1 = 0u - ((K >> 1) & 1u), K2 = 0u - ((K >> 2) & 1u), K3 = 0u - ((K >> 3) & 1u);
+    const uint32_t a0 = t0 & K0;
+    const uint32_t a1 = maj3(t1, K1, a0);
+    const uint32_t a2 = maj3(t2, K2, a1);
+    return maj3(t3, K3, a2);
+}
+
+// The two rules on the words u[k] = (s ^ neighbour ^ sign) & non-zero, for sites whose bonds may be zero (the table
+// path of diluted lattices): h0 / h1 are the bits of h = ceil(m / 2) as masks (accept_mask), K0..K3 the bits of
+// 16 - (z' + 1 + floor(m / 2)) (accept_mask_gibbs), both prepared off the chain.
+__device__ __forceinline__ void unsat_count(const uint32_t u[6], uint32_t &U0, uint32_t &U1, uint32_t &U2) {
+    const uint32_t s1 = u[0] ^ u[1] ^ u[2], c1 = maj3(u[0], u[1], u[2]);
+    const uint32_t s2 = u[3] ^ u[4] ^ u[5], c2 = maj3(u[3], u[4], u[5]);
+    const uint32_t c3 = s1 & s2;
+    U0 = s1 ^ s2;
+    U1 = c1 ^ c2 ^ c3;
+    U2 = maj3(c1, c2, c3);
+}
+__device__ __forceinline__ uint32_t accept_u_metropolis(const uint32_t u[6], uint32_t l0, uint32_t l1, uint32_t h0, uint32_t h1) {
+    uint32_t U0, U1, U2;
+    unsat_count(u, U0, U1, U2);
+    const uint32_t t0 = U0 ^ l0, k0 = U0 & l0;
+    const uint32_t t1 = U1 ^ l1 ^ k0, k1 = maj3(U1, l1, k0);
+    const uint32_t hi = U2 | k1;
+    const uint32_t ge1 = t0 | t1 | hi, ge2 = t1 | hi, ge3 = (t0 & t1) | hi;
+    const uint32_t lo_sel = ge1 | ~h0;                 // h = 0: everything, h = 1: ge1
+    const uint32_t hi_sel = (ge3 & h0) | (ge2 & ~h0);  // h = 2: ge2, h = 3: ge3
+    return (hi_sel & h1) | (lo_sel & ~h1);
+}
+__device__ __forceinline__ uint32_t accept_u_gibbs(const uint32_t u[6], uint32_t l0, uint32_t l1, uint32_t l2, uint32_t K0,
+                                                   uint32_t K1, uint32_t K2, uint32_t K3) {
+    uint32_t U0, U1, U2;
+    unsat_count(u, U0, U1, U2);
+    const uint32_t t0 = U0 ^ l0, k0 = U0 & l0;
+    const uint32_t t1 = U1 ^ l1 ^ k0, k1 = maj3(U1, l1, k0);
+    const uint32_t t2 = U2 ^ l2 ^ k1, t3 = maj3(U2, l2, k1);
     const uint32_t a0 = t0 & K0;
     const uint32_t a1 = maj3(t1, K1, a0);
     const uint32_t a2 = maj3(t2, K2, a1);
@@ -999,8 +1076,9 @@ __device__ __forceinline__ void hc_energy(const SimDims &d, const DevPtrs &p, ui
             const uint32_t s = lds_load(h.site);
             uint32_t u[3] = {0u, 0u, 0u};
 #pragma unroll
-            for (int q = 0; q < NN; ++q) // unsatisfied forward bonds
-                u[q] = s ^ lds_load(h.nb[2 * q]) ^ static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(h.neg), 2 * q, 1));
+            for (int q = 0; q < NN; ++q) // unsatisfied non-zero forward bonds (neg: bits 0-5, nz: bits 6-11 of h.neg)
+                u[q] = (s ^ lds_load(h.nb[2 * q]) ^ static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(h.neg), 2 * q, 1))) &
+                       static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(h.neg), 6 + 2 * q, 1));
             qa[k] = live_site ? (u[0] ^ u[1] ^ u[2]) : 0u;   // weight 1
             qb[k] = live_site ? maj3(u[0], u[1], u[2]) : 0u; // weight 2
             qc[k] = live_site ? s : 0u;                      // spins equal to -1
@@ -1067,8 +1145,9 @@ __device__ __forceinline__ void hc_energy_wide(const SimDims &d, const DevPtrs &
         const uint32_t s = lds_load(h.site);
         uint32_t u[3] = {0u, 0u, 0u};
 #pragma unroll
-        for (int q = 0; q < NN; ++q) // unsatisfied forward bonds
-            u[q] = s ^ lds_load(h.nb[2 * q]) ^ static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(h.neg), 2 * q, 1));
+        for (int q = 0; q < NN; ++q) // unsatisfied non-zero forward bonds
+            u[q] = (s ^ lds_load(h.nb[2 * q]) ^ static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(h.neg), 2 * q, 1))) &
+                   static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(h.neg), 6 + 2 * q, 1));
         qa[k] = live_site ? (u[0] ^ u[1] ^ u[2]) : 0u;   // weight 1
         qb[k] = live_site ? maj3(u[0], u[1], u[2]) : 0u; // weight 2
         qc[k] = live_site ? s : 0u;                      // spins equal to -1
@@ -1112,7 +1191,7 @@ __device__ __forceinline__ void hc_energy_wide(const SimDims &d, const DevPtrs &
 // the passes in turn, and while one computes pass p the other fetches the table entry of pass p + 1 and decodes its
 // seven LDS addresses, then meets it at the barrier.  Between two barriers one set does "reads -> accept -> write" and
 // nothing else.
-template <int NN, bool STAMPS, bool GIBBS>
+template <int NN, bool STAMPS, bool GIBBS, bool DENSE>
 __device__ __forceinline__ void sweep_hc_block(const SimDims &d, const DevPtrs &p, uint32_t bid, int with_energy, int do_sweep,
                                                unsigned long long *stamps, uint32_t *lds) {
     PA_HC_STAMP(0)
@@ -1214,6 +1293,7 @@ __device__ __forceinline__ void sweep_hc_block(const SimDims &d, const DevPtrs &
         // what a pass needs, all of it prepared by `fetch`: nine LDS addresses and the coupling signs as masks
         HcSite cur;
         uint32_t wr_cur = spare, pl_cur = pl_addr, negm[6] = {0, 0, 0, 0, 0, 0};
+        uint32_t nzm[6] = {0, 0, 0, 0, 0, 0}, rule[4] = {0, 0, 0, 0}; // diluted lattices: non-zero masks, the site's rule bits
         auto fetch = [&](uint32_t b0, uint32_t b1) { // the pass whose positions are [b0, b1)
             const uint32_t pos = b0 + lane;
             const bool active = pos < b1;
@@ -1222,6 +1302,18 @@ __device__ __forceinline__ void sweep_hc_block(const SimDims &d, const DevPtrs &
             pl_cur = pl_addr + 2 * cur.site4;
 #pragma unroll
             for (int k = 0; k < 2 * NN; ++k) negm[k] = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(cur.neg), k, 1));
+            if (!DENSE) {
+#pragma unroll
+                for (int k = 0; k < 2 * NN; ++k) nzm[k] = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(cur.neg), 6 + k, 1));
+                const uint32_t m = __popc((cur.neg >> 6) & 63u); // non-zero bonds of the site
+                // Metropolis: h = ceil(m / 2) (accept_mask); heat bath: K = 16 - (z' + 1 + floor(m / 2)) (accept_mask_gibbs)
+                const uint32_t code = GIBBS ? 16u - (NN + 1u + (m >> 1)) : (m + 1u) >> 1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rule[k] = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(code), k, 1));
+#pragma unroll
+                for (int k = 0; k < 2 * NN; ++k) asm volatile("" : "+v"(nzm[k]));
+                asm volatile("" : "+v"(rule[0]), "+v"(rule[1]), "+v"(rule[2]), "+v"(rule[3]));
+            }
             // all of it is computed HERE, before the barrier the set is about to wait at (left alone, the compiler sinks
             // the address arithmetic to its first use, behind the barrier and onto the chain)
             asm volatile("" : "+v"(cur.site), "+v"(wr_cur), "+v"(pl_cur));
@@ -1235,7 +1327,16 @@ __device__ __forceinline__ void sweep_hc_block(const SimDims &d, const DevPtrs &
             uint32_t nb[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) nb[k] = k < 2 * NN ? (lds_load(cur.nb[k]) ^ negm[k]) : 0u;
-            const uint32_t acc = GIBBS ? accept_mask_gibbs_dense<NN>(s, nb, lv.x, lv.y, l2) : accept_mask_dense<NN>(s, nb, 0u, lv.x, lv.y);
+            uint32_t acc;
+            if (DENSE) {
+                acc = GIBBS ? accept_mask_gibbs_dense<NN>(s, nb, lv.x, lv.y, l2) : accept_mask_dense<NN>(s, nb, 0u, lv.x, lv.y);
+            } else {
+                uint32_t u[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) u[k] = k < 2 * NN ? ((s ^ nb[k]) & nzm[k]) : 0u;
+                acc = GIBBS ? accept_u_gibbs(u, lv.x, lv.y, l2, rule[0], rule[1], rule[2], rule[3])
+                            : accept_u_metropolis(u, lv.x, lv.y, rule[0], rule[1]);
+            }
             lds_store(wr_cur, s ^ (acc & valid_bits));
         };
         // set 0 takes the even passes, set 1 the odd ones (two loops, one barrier sequence: every wave meets the same
@@ -1283,11 +1384,11 @@ __device__ __forceinline__ void sweep_hc_block(const SimDims &d, const DevPtrs &
     PA_HC_STAMP(5)
 }
 
-template <int NN, bool STAMPS = false, bool GIBBS = false>
+template <int NN, bool STAMPS = false, bool GIBBS = false, bool DENSE = true>
 __global__ __launch_bounds__(512, 2) void k_sweep_hc(SimDims d, DevPtrs p, int with_energy, int do_sweep,
                                                      unsigned long long *stamps) {
     extern __shared__ uint32_t lds[];
-    sweep_hc_block<NN, STAMPS, GIBBS>(d, p, blockIdx.x, with_energy, do_sweep, stamps, lds);
+    sweep_hc_block<NN, STAMPS, GIBBS, DENSE>(d, p, blockIdx.x, with_energy, do_sweep, stamps, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -2949,6 +3050,12 @@ hipError_t configure_kernels(const SimDims &) {
                            reinterpret_cast<const void *>(k_sweep_hc<1, false, true>),
                            reinterpret_cast<const void *>(k_sweep_hc<2, false, true>),
                            reinterpret_cast<const void *>(k_sweep_hc<3, false, true>),
+                           reinterpret_cast<const void *>(k_sweep_hc<1, false, false, false>),
+                           reinterpret_cast<const void *>(k_sweep_hc<1, false, true, false>),
+                           reinterpret_cast<const void *>(k_sweep_hc<2, false, false, false>),
+                           reinterpret_cast<const void *>(k_sweep_hc<2, false, true, false>),
+                           reinterpret_cast<const void *>(k_sweep_hc<3, false, false, false>),
+                           reinterpret_cast<const void *>(k_sweep_hc<3, false, true, false>),
                            reinterpret_cast<const void *>(k_rng_overlap<true>),
                            reinterpret_cast<const void *>(k_houdayer),
                            reinterpret_cast<const void *>(k_houdayer_grow),
@@ -3070,11 +3177,21 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
         if (d.hc && !no_hc && sweep_hc_lds_bytes(d, true) <= 160 * 1024) { // (83 KB at 16^3: one workgroup per CU)
             const dim3 block_hc(512);
             const size_t lds_g = sweep_hc_lds_bytes(d, true);
-            switch (d.dense_nn) {
-            case 1: hipLaunchKernelGGL((k_sweep_hc<1, false, true>), grid, block_hc, lds_g, stream, d, p, e, s, no_stamps); break;
-            case 2: hipLaunchKernelGGL((k_sweep_hc<2, false, true>), grid, block_hc, lds_g, stream, d, p, e, s, no_stamps); break;
-            default: hipLaunchKernelGGL((k_sweep_hc<3, false, true>), grid, block_hc, lds_g, stream, d, p, e, s, no_stamps); break;
+#define PA_HC(NN, G, D) hipLaunchKernelGGL((k_sweep_hc<NN, false, G, D>), grid, block_hc, lds_g, stream, d, p, e, s, no_stamps)
+            if (d.dense_nn == d.nn) {
+                switch (d.nn) {
+                case 1: PA_HC(1, true, true); break;
+                case 2: PA_HC(2, true, true); break;
+                default: PA_HC(3, true, true); break;
+                }
+            } else { // some bonds are zero: per-site non-zero masks and rule bits from the table
+                switch (d.nn) {
+                case 1: PA_HC(1, true, false); break;
+                case 2: PA_HC(2, true, false); break;
+                default: PA_HC(3, true, false); break;
+                }
             }
+#undef PA_HC
             return hipGetLastError();
         }
         hipLaunchKernelGGL((k_sweep<false, 0, true>), grid, block, lds, stream, d, p, e, s, no_stamps);
@@ -3083,11 +3200,21 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
     if (d.hc && !no_hc) { // implicit neighbours, table in the LDS
         const size_t lds_hc = sweep_hc_lds_bytes(d);
         const dim3 block_hc(512); // two sets of four waves take the passes in turn
-        switch (d.dense_nn) {
-        case 1: hipLaunchKernelGGL((k_sweep_hc<1>), grid, block_hc, lds_hc, stream, d, p, e, s, no_stamps); break;
-        case 2: hipLaunchKernelGGL((k_sweep_hc<2>), grid, block_hc, lds_hc, stream, d, p, e, s, no_stamps); break;
-        default: hipLaunchKernelGGL((k_sweep_hc<3>), grid, block_hc, lds_hc, stream, d, p, e, s, no_stamps); break;
+#define PA_HC(NN, D) hipLaunchKernelGGL((k_sweep_hc<NN, false, false, D>), grid, block_hc, lds_hc, stream, d, p, e, s, no_stamps)
+        if (d.dense_nn == d.nn) {
+            switch (d.nn) {
+            case 1: PA_HC(1, true); break;
+            case 2: PA_HC(2, true); break;
+            default: PA_HC(3, true); break;
+            }
+        } else {
+            switch (d.nn) {
+            case 1: PA_HC(1, false); break;
+            case 2: PA_HC(2, false); break;
+            default: PA_HC(3, false); break;
+            }
         }
+#undef PA_HC
         return hipGetLastError();
     }
     switch (d.dense_nn) {

@@ -1642,11 +1642,11 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
 
     // ---- implicit neighbours (k_sweep_hc): usable when every neighbour slot of every site lies at one of two
     // offsets from the site (regular / through the periodic wrap) -- true for hypercubic lattices of any
-    // extents -- all bonds are non-zero and the on-chip kernels apply.  The table replaces the 16-byte site
-    // records on the sweep path: 4 bytes per site, staged in the LDS.
+    // extents -- and the on-chip kernels apply.  The table replaces the 16-byte site records on the sweep
+    // path: 4 bytes per site (site, wrap flags, coupling signs, non-zero flags), staged in the LDS.
     d.hc = 0;
     std::vector<uint32_t> hc_tab;
-    if (!d.big && !d.general && d.dense_nn == d.nn && d.nn >= 1 && d.nn <= 3 && d.N < (1u << kHcSiteBits) &&
+    if (!d.big && !d.general && d.nn >= 1 && d.nn <= 3 && d.N < (1u << kHcSiteBits) &&
         !std::getenv("PEAPODS_NO_HC")) {
         bool ok = true;
         int64_t d0[6] = {0, 0, 0, 0, 0, 0}, d1[6] = {0, 0, 0, 0, 0, 0};
@@ -1687,8 +1687,9 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
                         const uint32_t j = (k & 1u) ? lat.bwd[site * d.nn + k / 2] : lat.fwd[site * d.nn + k / 2];
                         if (static_cast<int64_t>(j) - static_cast<int64_t>(site) != d0[k]) flags |= 1u << k;
                     }
-                    const uint32_t neg = jsite[static_cast<size_t>(real) * d.N + site] & 63u; // f0,b0,f1,b1,f2,b2
-                    hc_tab[static_cast<size_t>(real) * d.N + pos] = site | (flags << kHcFlagShift) | (neg << kHcNegShift);
+                    const uint32_t js = jsite[static_cast<size_t>(real) * d.N + site]; // neg[0..11] | nz[12..23]: f0,b0,f1,b1,f2,b2
+                    hc_tab[static_cast<size_t>(real) * d.N + pos] =
+                        site | (flags << kHcFlagShift) | ((js & 63u) << kHcNegShift) | (((js >> 12) & 63u) << kHcNzShift);
                 }
         }
     }

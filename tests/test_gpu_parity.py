@@ -312,6 +312,23 @@ def test_heat_bath_sample_matches_oracle(oracle, schedule, shape, n_temps, n_rep
     assert_state_equal(gpu, cpu)
 
 
+@pytest.mark.parametrize("mode", ["metropolis", "gibbs"])
+def test_diluted_lattice_on_the_table_path(oracle, mode):
+    """+-J with a fifth of the bonds removed, differently in every realisation: sites with an odd number of non-zero
+    bonds take the second threshold set (sweep.rs:109-139), the sweep runs on the implicit-neighbour kernel with
+    per-site non-zero masks, and with three tile words per realisation the two halves of a random-stream wave
+    belong to different realisations (different parity words)."""
+    shape, n_temps, n_rep, n_dis = (8, 8, 8), 24, 4, 3
+    couplings = bimodal(shape, 3, n_dis, 21)
+    couplings[np.random.default_rng(3).random(couplings.shape) < 0.2] = 0.0
+    gpu, cpu = make_pair(oracle, shape, couplings, np.linspace(0.8, 1.6, n_temps), n_rep, 97)
+    kwargs = dict(pt_interval=1, warmup_ratio=0.25)
+    a = gpu.sample(20, mode, **kwargs)
+    b = cpu.sample(20, mode, **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+
+
 def test_more_than_256_systems_per_realization(oracle):
     # 40 temperatures x 8 replicas = 320 systems (10 tile words): the tempering kernel moves the
     # generator cursors of every swapped slot, two slots per thread

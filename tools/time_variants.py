@@ -16,8 +16,10 @@ coupling_seq, dynamics_seed = seed_material(bench.ROOT_SEED)
 temps = np.linspace(*work["t_range"], work["n_temps"]).astype(np.float32)
 
 
-def timed(label, n_rep, mode, couplings="bimodal", **kw):
+def timed(label, n_rep, mode, couplings="bimodal", dilution=0.0, **kw):
     J = np.stack(generate_couplings(couplings, work["shape"], 3, 128, coupling_seq, realizations=range(128)))
+    if dilution:
+        J = J * (np.random.default_rng(5).random(J.shape) >= dilution)
     sim = IsingSimulation(list(work["shape"]), J, temps, n_rep, None, dynamics_seed)
     cfg = lambda n: sim.make_config(n, mode, **kw)  # noqa: E731
     sim.run(cfg(60))
@@ -39,3 +41,5 @@ timed("gibbs, 4 replicas, PT every sweep", 4, "gibbs", warmup_ratio=0.0, pt_inte
 timed("gibbs, 1 replica, PT every sweep", 1, "gibbs", warmup_ratio=0.0, pt_interval=1)
 timed("metropolis, 4 replicas, autocorrelation", 4, "metropolis", warmup_ratio=0.0, pt_interval=1, autocorrelation_max_lag=100)
 timed("metropolis, 4 replicas, Gaussian couplings", 4, "metropolis", couplings="gaussian", warmup_ratio=0.0, pt_interval=1)
+timed("metropolis, 4 replicas, +-J with 20 % of the bonds removed", 4, "metropolis", dilution=0.2, warmup_ratio=0.0, pt_interval=1)
+timed("gibbs, 4 replicas, +-J with 20 % of the bonds removed", 4, "gibbs", dilution=0.2, warmup_ratio=0.0, pt_interval=1)

@@ -217,6 +217,9 @@ struct PtParams {
     // the swap decisions themselves and fetch their generators from the slots the systems come from, so the event
     // neither permutes cursors nor rewrites energies, and it files the permutation in system_ids_out / slot_of_out
     uint32_t relay;
+    // the recorded sweep whose OVERLAP this launch accumulates (1 + index, 0 = none): the same sweep as ac_index on the
+    // launch-per-phase protocol, the one before it where the overlap is measured inside the next sweep's launch
+    uint32_t ac_index_q;
 };
 
 // All launchers enqueue on `stream` and return the hipGetLastError() of the launch.

@@ -1759,8 +1759,8 @@ __device__ __forceinline__ void measure_block(const SimDims &d, const DevPtrs &p
                 if (fresh) *seen = seen_word | (1u << (qbin & 31u));
             }
             for (int k = 0; k < 6; ++k) ovm[k * d.n_temps + t] = o[k];
-            if (pt.ac_index) // mod.rs:588-594
-                p.ac_q2[(static_cast<size_t>(real) * pt.ac_stride + (pt.ac_index - 1)) * d.n_temps + t] =
+            if (pt.ac_index_q) // mod.rs:588-594
+                p.ac_q2[(static_cast<size_t>(real) * pt.ac_stride + (pt.ac_index_q - 1)) * d.n_temps + t] =
                     static_cast<float>(__dmul_rn(q2_ac, __ddiv_rn(1.0, static_cast<double>(d.n_pairs))));
         }
     }

@@ -865,7 +865,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     size_t equil_next = 0;
     // (the heat bath rides the same launches when its sweep runs on the implicit-neighbour kernel: three planes in LDS)
     const bool gibbs_fast = gibbs && d.hc && sweep_hc_lds_bytes(d, true) <= 160 * 1024 && !std::getenv("PEAPODS_NO_HC");
-    const bool fused = want_overlap && (!gibbs || gibbs_fast) && !fk && !equil && !autocorr && cfg->overlap_cluster_interval == 0 &&
+    const bool fused = want_overlap && (!gibbs || gibbs_fast) && !fk && !equil && cfg->overlap_cluster_interval == 0 &&
                        !d.big && !d.general && !std::getenv("PEAPODS_NO_FUSE");
     bool overlap_owed = false; // the last recorded sweep's overlap has not been measured yet
     // the measurement block of the previous sweep when it is relayed into the next sweep's random-stream launch
@@ -944,6 +944,11 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             sim->swaps_pending = false;
             toggle_spin_buffers(sim);
             PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
+            if (autocorr) { // this sweep's m^2 sample; the q^2 sample of the sweep whose overlap is accumulated with it
+                pt.ac_index = record ? static_cast<uint32_t>(sim->n_recorded + 1) : 0u;
+                pt.ac_index_q = overlap_owed ? static_cast<uint32_t>(sim->n_recorded) : 0u;
+                pt.ac_stride = static_cast<uint32_t>(sim->ac_capacity);
+            }
             if (record || pt_this || overlap_owed) {
                 if (relay) { // deferred into the next sweep's launch (or the tail of the run)
                     pending.any = true;
@@ -1003,6 +1008,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                         equil ? 1u : 0u, equil_ckpt, static_cast<uint32_t>(sweep_id + 1),
                         (autocorr && record) ? static_cast<uint32_t>(sim->n_recorded + 1) : 0u,
                         static_cast<uint32_t>(sim->ac_capacity)};
+            pt.ac_index_q = pt.ac_index;
             if (!oc_this) {
                 if (record || pt_this || equil) { // statistics :543-578, tempering :748-796
                     if (relay_nf && pt_this) { // rides in the next sweep's random-stream launch
@@ -1146,6 +1152,8 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             hipError_t e = launch_measure_overlap(g.d, g.p, q, pending.do_accum, pending.accum_overlap, pending.do_pt, g.stream);
             toggle_dots(g.p);
             PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
+            pt.ac_index_q = autocorr ? static_cast<uint32_t>(sim->n_recorded) : 0u;
+            pt.ac_stride = static_cast<uint32_t>(sim->ac_capacity);
             if (e == hipSuccess) e = measure_launch(g.fresh, g.d, g.p, pt, false, true, false, g.stream);
             if (e != hipSuccess && status == PA_OK) status = fail(sim, PA_ERR_DEVICE, std::string("fused tail: ") + hipGetErrorString(e));
         }
@@ -1164,6 +1172,8 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     }
     if (overlap_owed) {
         PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
+        pt.ac_index_q = (fused && autocorr) ? static_cast<uint32_t>(sim->n_recorded) : 0u;
+        pt.ac_stride = static_cast<uint32_t>(sim->ac_capacity);
         for (auto &g : sim->groups) {
             hipError_t e = overlap_launch(g.d, g.p, g.stream);
             if (e == hipSuccess) e = measure_launch(g.fresh, g.d, g.p, pt, false, true, false, g.stream);

@@ -647,6 +647,25 @@ def test_autocorrelation_times_match_oracle(oracle, n_rep):
     assert_results_equal(a, b)
 
 
+@pytest.mark.parametrize("mode", ["metropolis", "gibbs"])
+def test_autocorrelation_series_on_the_relayed_protocol(oracle, mode):
+    """With the overlap measured inside the next sweep's launch, a launch files the m^2 sample of one recorded sweep
+    and the q^2 sample of the sweep before it (mod.rs:580-595 pushes both for the same sweep): the series, and so
+    the integrated times, must not notice -- tempering every sweep, warm-up sweeps in front, a second call after."""
+    shape = (6, 6, 6)
+    couplings = bimodal(shape, 3, 2, 31)
+    gpu, cpu = make_pair(oracle, shape, couplings, np.linspace(0.9, 1.8, 8), 4, 8)
+    kwargs = dict(pt_interval=1, warmup_ratio=0.25, autocorrelation_max_lag=20)
+    a = gpu.sample(160, mode, **kwargs)
+    b = cpu.sample(160, mode, **kwargs)
+    assert "overlap2_tau" in a and "mags2_tau" in a
+    assert_results_equal(a, b)
+    a = gpu.sample(90, mode, pt_interval=3, warmup_ratio=0.0, autocorrelation_max_lag=10)
+    b = cpu.sample(90, mode, pt_interval=3, warmup_ratio=0.0, autocorrelation_max_lag=10)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+
+
 def test_fft_autocorrelation_backend_agrees_with_the_ring(oracle):
     # reference tests/test_sampling_interfaces.py:159-194 and autocorrelation.rs:345-372: the two backends agree
     # to 1e-9; the ring result is the exact one (and is compared bit for bit with the oracle elsewhere)

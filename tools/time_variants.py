@@ -16,11 +16,12 @@ coupling_seq, dynamics_seed = seed_material(bench.ROOT_SEED)
 temps = np.linspace(*work["t_range"], work["n_temps"]).astype(np.float32)
 
 
-def timed(label, n_rep, mode, couplings="bimodal", dilution=0.0, **kw):
-    J = np.stack(generate_couplings(couplings, work["shape"], 3, 128, coupling_seq, realizations=range(128)))
+def timed(label, n_rep, mode, couplings="bimodal", dilution=0.0, offsets=None, **kw):
+    nn = len(offsets) if offsets else 3
+    J = np.stack(generate_couplings(couplings, work["shape"], nn, 128, coupling_seq, realizations=range(128)))
     if dilution:
         J = J * (np.random.default_rng(5).random(J.shape) >= dilution)
-    sim = IsingSimulation(list(work["shape"]), J, temps, n_rep, None, dynamics_seed)
+    sim = IsingSimulation(list(work["shape"]), J, temps, n_rep, offsets, dynamics_seed)
     cfg = lambda n: sim.make_config(n, mode, **kw)  # noqa: E731
     sim.run(cfg(60))
     sim.synchronize()
@@ -43,3 +44,7 @@ timed("metropolis, 4 replicas, autocorrelation", 4, "metropolis", warmup_ratio=0
 timed("metropolis, 4 replicas, Gaussian couplings", 4, "metropolis", couplings="gaussian", warmup_ratio=0.0, pt_interval=1)
 timed("metropolis, 4 replicas, +-J with 20 % of the bonds removed", 4, "metropolis", dilution=0.2, warmup_ratio=0.0, pt_interval=1)
 timed("gibbs, 4 replicas, +-J with 20 % of the bonds removed", 4, "gibbs", dilution=0.2, warmup_ratio=0.0, pt_interval=1)
+BCC = [[1, 1, 1], [1, 1, -1], [1, -1, 1], [1, -1, -1]]
+FCC = [[1, 1, 0], [1, 0, 1], [0, 1, 1], [1, -1, 0], [1, 0, -1], [0, 1, -1]]
+timed("metropolis, 4 replicas, +-J on the bcc lattice (8 neighbours)", 4, "metropolis", offsets=BCC, warmup_ratio=0.0, pt_interval=1)
+timed("metropolis, 4 replicas, +-J on the fcc lattice (12 neighbours)", 4, "metropolis", offsets=FCC, warmup_ratio=0.0, pt_interval=1)

@@ -233,6 +233,7 @@ hipError_t launch_rng_overlap(const SimDims &d, const DevPtrs &p, hipStream_t st
 hipError_t launch_rng_relay(const SimDims &d, const DevPtrs &p, bool with_overlap, const PtParams &pt, bool do_accum,
                             bool accum_overlap, bool do_pt, hipStream_t stream, bool gibbs = false);
 bool rng_relay_supported(const SimDims &d);
+bool rng_relay_ladder_supported(const SimDims &d);
 hipError_t launch_measure_overlap(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_accum, bool accum_overlap,
                                   bool do_pt, hipStream_t stream);
 hipError_t launch_sweep_pipe(const SimDims &d, const DevPtrs &p, bool gibbs, uint32_t epoch, hipStream_t stream);

@@ -211,8 +211,9 @@ __device__ __forceinline__ void rng_chunk32_gibbs(Rng32 &rng, const uint32_t c[7
 // previous sweep left it, gen_range for the edge, the f32 criterion -- the same code the event runs) and each lane
 // then fetches the state of the system that sits in its slot AFTER the event: its own slot's, or the neighbouring
 // slot's when its edge was accepted; the lane that receives the ladder's generator skips the draws the event used.
-template <bool PRESHIFTED, bool GIBBS, bool REPLAY = false>
-__device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, uint32_t bid, uint32_t *tab) {
+template <bool PRESHIFTED, bool GIBBS, int REPLAY = 0>
+__device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, uint32_t bid, uint32_t *tab,
+                                          uint32_t first_parity = 0) {
     // tab: [64 * 16 * 8] dwords of LDS for the block's jump table
     const uint32_t block = bid % d.B;
     const uint32_t group = bid / d.B;
@@ -233,7 +234,90 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
     }
     uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t src_slot = slot, skip_draws = 0;
-    if (REPLAY) {
+    if (REPLAY == 2) {
+        // full_ladder (tempering.rs:59-70): the ladder's generator draws its n_temps - 1 uniforms in order, the edges of
+        // the first parity are decided side by side, then those of the other parity on the exchanged energies -- as in
+        // measure_block, which runs the same event in this launch to record it.  A slot's generator is found by walking
+        // the two rounds backwards.  Scratch behind the jump table: draws[tasks][n_edges], then two accepted-edge masks
+        // per task (n_temps <= 32, checked on the host).
+        const uint32_t n_edges = d.n_temps - 1;
+        const uint32_t tw0 = group * 2 * nw, real0 = tw0 / d.W;
+        const uint32_t real1 = min(tw0 + 2 * nw - 1u, n_tw - 1u) / d.W;
+        const uint32_t n_tasks = (real1 - real0 + 1u) * d.n_replicas;
+        uint32_t *draws = tab + 64 * 16 * 8;
+        uint32_t *dec = draws + n_tasks * n_edges;
+        if (tid < n_tasks) {
+            const uint32_t r = real0 + tid / d.n_replicas, offset = (tid % d.n_replicas) * d.n_temps;
+            uint32_t gs[8];
+            load_cursor(p.cursor, r, d.SP, p.slot_of[static_cast<size_t>(r) * d.n_sys + offset], gs);
+            DevRng g;
+            g.s0 = (static_cast<uint64_t>(gs[1]) << 32) | gs[0];
+            g.s1 = (static_cast<uint64_t>(gs[3]) << 32) | gs[2];
+            g.s2 = (static_cast<uint64_t>(gs[5]) << 32) | gs[4];
+            g.s3 = (static_cast<uint64_t>(gs[7]) << 32) | gs[6];
+            for (uint32_t a = 0; a < n_edges; ++a) draws[tid * n_edges + a] = static_cast<uint32_t>(g.next() >> 40);
+            dec[2 * tid] = 0;
+            dec[2 * tid + 1] = 0;
+        }
+        __syncthreads();
+        // one (ladder, draw) item per lane and turn, at most four turns (checked on the host): the item's edge, its four
+        // candidate energies, its coupling difference and its logarithm -- every global value of both rounds is
+        // requested at once, so the prologue pays one memory round trip, not one per round
+        const uint32_t n_first = (n_edges + 1 - first_parity) / 2; // edges of the first parity come first
+        const float n_f = static_cast<float>(d.N);
+        const uint32_t n_items = n_tasks * n_edges;
+        uint32_t it_edge[4], it_task[4];
+        int32_t e0[4], e1[4], em[4], ep[4];
+        float it_db[4], it_ln[4];
+        bool it_first[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t idx = tid + k * nthreads;
+            it_task[k] = 0xFFFFFFFFu;
+            if (idx < n_items) {
+                const uint32_t task = idx / n_edges, a = idx % n_edges;
+                it_first[k] = a < n_first;
+                const uint32_t edge = it_first[k] ? first_parity + 2 * a : (1 - first_parity) + 2 * (a - n_first);
+                const int32_t *E = p.Esum + static_cast<size_t>(real0 + task / d.n_replicas) * d.n_sys + (task % d.n_replicas) * d.n_temps;
+                it_task[k] = task;
+                it_edge[k] = edge;
+                e0[k] = E[edge];
+                e1[k] = E[edge + 1];
+                em[k] = edge > 0 ? E[edge - 1] : 0;           // (read for round 1 only)
+                ep[k] = edge + 2 < d.n_temps ? E[edge + 2] : 0;
+                it_db[k] = p.dbeta[edge];
+                it_ln[k] = p.ln_table[draws[idx]];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) // round 0
+            if (it_task[k] != 0xFFFFFFFFu && it_first[k] && pt_accept(n_f, e0[k], e1[k], d.general, it_db[k], it_ln[k]))
+                atomicOr(&dec[2 * it_task[k]], 1u << it_edge[k]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) // round 1, on the exchanged energies
+            if (it_task[k] != 0xFFFFFFFFu && !it_first[k]) {
+                const uint32_t edge = it_edge[k], m0 = dec[2 * it_task[k]];
+                const int32_t el = (edge > 0 && ((m0 >> (edge - 1)) & 1u)) ? em[k] : e0[k];
+                const int32_t er = ((m0 >> (edge + 1)) & 1u) ? ep[k] : e1[k];
+                if (pt_accept(n_f, el, er, d.general, it_db[k], it_ln[k])) atomicOr(&dec[2 * it_task[k] + 1], 1u << edge);
+            }
+        __syncthreads();
+        if (active) {
+            const uint32_t rep = slot / d.n_temps, t = slot % d.n_temps;
+            const uint32_t task = (real - real0) * d.n_replicas + rep;
+            const uint32_t m0 = dec[2 * task], m1 = dec[2 * task + 1];
+            uint32_t s1 = t; // where the system now at temperature t sat between the rounds, then before the event
+            if ((m1 >> t) & 1u) s1 = t + 1;
+            else if (t > 0 && ((m1 >> (t - 1)) & 1u)) s1 = t - 1;
+            uint32_t s0 = s1;
+            if ((m0 >> s1) & 1u) s0 = s1 + 1;
+            else if (s1 > 0 && ((m0 >> (s1 - 1)) & 1u)) s0 = s1 - 1;
+            src_slot = rep * d.n_temps + s0;
+            if (p.system_ids[static_cast<size_t>(real) * d.n_sys + src_slot] == rep * d.n_temps) skip_draws = n_edges;
+        }
+    }
+    if (REPLAY == 1) {
         uint32_t *dec = tab + 64 * 16 * 8; // [<= 256] edge | accepted << 16 | draws << 17 per (realisation, ladder)
         const uint32_t tw0 = group * 2 * nw, real0 = tw0 / d.W;
         const uint32_t real1 = min(tw0 + 2 * nw - 1u, n_tw - 1u) / d.W;
@@ -278,7 +362,7 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
         }
     }
     if (active) load_cursor(p.cursor, real, d.SP, src_slot, st);
-    if (REPLAY && skip_draws) { // the ladder's generator: the event's draws come before this sweep's
+    if (REPLAY != 0 && skip_draws) { // the ladder's generator: the event's draws come before this sweep's
         DevRng g;
         g.s0 = (static_cast<uint64_t>(st[1]) << 32) | st[0];
         g.s1 = (static_cast<uint64_t>(st[3]) << 32) | st[2];
@@ -1971,7 +2055,7 @@ __global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams
 // realisation, PtParams::relay), the rest draw the random stream of the next sweep -- with REPLAY they apply the
 // event's cursor permutation themselves.  A sweep of the plain protocol is then two launches (this one and the
 // sweep kernel) instead of three, and the latency-bound measurement hides under the VALU-bound random stream.
-template <bool PRESHIFTED, bool REPLAY, bool GIBBS = false>
+template <bool PRESHIFTED, int REPLAY, bool GIBBS = false>
 __global__ __launch_bounds__(256) void k_rng_relay(SimDims d, DevPtrs p, uint32_t n_overlap, uint32_t n_measure, PtParams pt,
                                                    int do_accum, int accum_overlap, int do_pt) {
     extern __shared__ uint32_t lds_dyn[];
@@ -1980,7 +2064,7 @@ __global__ __launch_bounds__(256) void k_rng_relay(SimDims d, DevPtrs p, uint32_
     else if (blockIdx.x < n_overlap + n_measure)
         measure_block<false>(d, p, pt, do_accum, accum_overlap, do_pt, nullptr, blockIdx.x - n_overlap, lds_dyn);
     else
-        rng_block<PRESHIFTED, GIBBS, REPLAY>(d, p, blockIdx.x - n_overlap - n_measure, lds_dyn);
+        rng_block<PRESHIFTED, GIBBS, REPLAY>(d, p, blockIdx.x - n_overlap - n_measure, lds_dyn, pt.first_parity);
 }
 
 // ---------------------------------------------------------------------------
@@ -3043,6 +3127,9 @@ hipError_t configure_kernels(const SimDims &) {
                            reinterpret_cast<const void *>(k_rng_relay<false, true>),
                            reinterpret_cast<const void *>(k_rng_relay<true, false>),
                            reinterpret_cast<const void *>(k_rng_relay<true, true>),
+                           reinterpret_cast<const void *>(k_rng_relay<true, 2>),
+                           reinterpret_cast<const void *>(k_rng_relay<false, 2>),
+                           reinterpret_cast<const void *>(k_rng_relay<false, 2, true>),
                            reinterpret_cast<const void *>(k_rng_overlap<false>),
                            reinterpret_cast<const void *>(k_rng_overlap<false, true>),
                            reinterpret_cast<const void *>(k_rng_relay<false, false, true>),
@@ -3111,26 +3198,40 @@ bool rng_relay_supported(const SimDims &d) {
            reals_per_block * d.n_replicas <= 256 && measure_lds_bytes(d) <= kRngLds;
 }
 
+// full_ladder events are replayed too when a ladder's edges fit one mask word and the draws fit behind the jump table
+bool rng_relay_ladder_supported(const SimDims &d) {
+    const size_t tasks = static_cast<size_t>(7u / d.W + 2u) * d.n_replicas;
+    return rng_relay_supported(d) && d.n_temps <= 32 && tasks * (d.n_temps - 1) <= 4 * 256 && // four items per lane
+           tasks * (d.n_temps + 1) * 4 <= 16 * 1024;
+}
+
 hipError_t launch_rng_relay(const SimDims &d, const DevPtrs &p, bool with_overlap, const PtParams &pt, bool do_accum,
                             bool accum_overlap, bool do_pt, hipStream_t stream, bool gibbs) {
     const uint32_t n_pairs_tw = (d.n_real * d.W + 1) / 2;
     const uint32_t groups = (n_pairs_tw + 3) / 4;
     const uint32_t n_overlap = with_overlap ? d.n_real * d.W : 0u;
     const uint32_t n_measure = (do_accum || accum_overlap || do_pt) ? d.n_real : 0u;
-    const bool replay = n_measure && do_pt && d.n_temps >= 2;
-    const size_t lds = std::max(kRngLds + 1024, overlap_lds_bytes(d)); // + the replayed decisions
+    const int replay = (n_measure && do_pt && d.n_temps >= 2) ? (pt.schedule != 0 ? 2 : 1) : 0; // 2: the whole ladder
+    // behind the jump table: the replayed decisions (one word per ladder), or the ladders' draws and edge masks
+    const size_t replay_words = replay == 2 ? static_cast<size_t>(7u / d.W + 2u) * d.n_replicas * (d.n_temps + 1) : 256;
+    const size_t lds = std::max(kRngLds + std::max<size_t>(1024, replay_words * 4), overlap_lds_bytes(d));
     const dim3 grid(n_overlap + n_measure + groups * d.B), block(256);
     const int a = do_accum ? 1 : 0, o = accum_overlap ? 1 : 0, t = do_pt ? 1 : 0;
+#define PA_RELAY(P, R, G) hipLaunchKernelGGL((k_rng_relay<P, R, G>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t)
     if (gibbs) { // (heat-bath thresholds are compared unshifted, like k_rng<false, true>)
-        if (replay) hipLaunchKernelGGL((k_rng_relay<false, true, true>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
-        else hipLaunchKernelGGL((k_rng_relay<false, false, true>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
+        if (replay == 2) PA_RELAY(false, 2, true);
+        else if (replay == 1) PA_RELAY(false, 1, true);
+        else PA_RELAY(false, 0, true);
     } else if (d.thr_preshifted) {
-        if (replay) hipLaunchKernelGGL((k_rng_relay<true, true>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
-        else hipLaunchKernelGGL((k_rng_relay<true, false>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
+        if (replay == 2) PA_RELAY(true, 2, false);
+        else if (replay == 1) PA_RELAY(true, 1, false);
+        else PA_RELAY(true, 0, false);
     } else {
-        if (replay) hipLaunchKernelGGL((k_rng_relay<false, true>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
-        else hipLaunchKernelGGL((k_rng_relay<false, false>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
+        if (replay == 2) PA_RELAY(false, 2, false);
+        else if (replay == 1) PA_RELAY(false, 1, false);
+        else PA_RELAY(false, 0, false);
     }
+#undef PA_RELAY
     return hipGetLastError();
 }
 

@@ -873,8 +873,8 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         bool any = false, do_accum = false, accum_overlap = false, do_pt = false;
         PtParams pt{};
     } pending;
-    const bool relay = fused && cfg->pt_schedule == PA_PT_SINGLE_RANDOM_EDGE && rng_relay_supported(d) &&
-                       !std::getenv("PEAPODS_NO_RELAY");
+    const bool relay = fused && !std::getenv("PEAPODS_NO_RELAY") &&
+                       (cfg->pt_schedule == PA_PT_SINGLE_RANDOM_EDGE ? rng_relay_supported(d) : rng_relay_ladder_supported(d));
     // (opt-in: measured slower than two launches)
     const bool relay_nf = !fused && !gibbs && !d.big && !d.general && cfg->pt_schedule == PA_PT_SINGLE_RANDOM_EDGE &&
                           rng_relay_supported(d) && !std::getenv("PEAPODS_NO_RELAY");
@@ -2078,8 +2078,8 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
     // and, relayed, its measurement block -- ride in the random-stream launch (reported under k_rng)
     const bool gibbs_fast = gibbs && d.hc && sweep_hc_lds_bytes(d, true) <= 160 * 1024 && !std::getenv("PEAPODS_NO_HC");
     const bool fused = want_overlap && (!gibbs || gibbs_fast) && !d.big && !d.general && !std::getenv("PEAPODS_NO_FUSE");
-    const bool relay = fused && cfg->pt_schedule == PA_PT_SINGLE_RANDOM_EDGE && rng_relay_supported(d) &&
-                       !std::getenv("PEAPODS_NO_RELAY");
+    const bool relay = fused && !std::getenv("PEAPODS_NO_RELAY") &&
+                       (cfg->pt_schedule == PA_PT_SINGLE_RANDOM_EDGE ? rng_relay_supported(d) : rng_relay_ladder_supported(d));
     struct {
         bool any = false, do_accum = false, accum_overlap = false, do_pt = false;
         PtParams pt{};

@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "device_util.hpp"
+#include "bitcount.hpp"
 
 namespace pa {
 
@@ -542,39 +543,70 @@ __global__ __launch_bounds__(kEnergyThreads) void k_energy_f(SimDims d, DevPtrs 
 // ---------------------------------------------------------------------------
 // k_energy_unit_f: unit couplings on the general path (four to six forward directions: bcc, fcc).  Every term of
 // the reference's sequential f32 sum is -1, 0 or +1, so every partial sum is an integer below 2^24 in magnitude:
-// exact in f32 in any order.  The chain of k_energy_f is then unnecessary -- count in parallel, convert once.
-// Workgroup = (realisation, tile word), 8 waves over the sites; lane = slot (two half-waves: even / odd sites).
+// exact in f32 in any order.  The chain of k_energy_f is then unnecessary -- count in parallel, convert once:
+// E = (non-zero bonds) - 2 * (bonds whose term is -1), the latter counted for all 32 slots of a word at once.
+// Workgroup = (realisation, tile word), 256 threads, 16 sites per thread and turn: the NN words
+// v = (bond word ^ [J < 0]) & [J != 0] of a site go through a carry-save adder into three weight planes, which the
+// byte-sliced counters of the on-chip kernels (count16, block_bit_totals) add up -- 99 -> a few us per launch at 16^3 fcc.
 // ---------------------------------------------------------------------------
 template <int NN>
-__global__ __launch_bounds__(512) void k_energy_unit_f(SimDims d, DevPtrs p) {
+__global__ __launch_bounds__(256) void k_energy_unit_f(SimDims d, DevPtrs p) {
     constexpr int XW = JRow<NN>::kWidth;
-    __shared__ int e_sum[32], neg_sum[32];
+    __shared__ uint32_t scratch[5 * 64];
     const uint32_t real = blockIdx.x / d.W, w = blockIdx.x % d.W;
-    const uint32_t tid = threadIdx.x, bit = tid & 31u;
-    if (tid < 32) {
-        e_sum[tid] = 0;
-        neg_sum[tid] = 0;
-    }
-    __syncthreads();
+    const uint32_t tid = threadIdx.x;
     const uint32_t *xw = p.xw + static_cast<size_t>(real * d.W + w) * d.N * XW;
     const float *J = p.Jf + static_cast<size_t>(real) * d.N * NN;
-    int e = 0, neg = 0;
-    for (uint32_t site = tid >> 5; site < d.N; site += 512 / 32) {
-        const uint32_t *x = xw + static_cast<size_t>(site) * XW;
+    uint32_t c[4][8];
 #pragma unroll
-        for (int dd = 0; dd < NN; ++dd) {
-            const int j = static_cast<int>(J[site * NN + dd]); // -1, 0, +1
-            e += ((x[dd] >> bit) & 1u) ? -j : j;                // s_i s_j = -1 where the bond word's bit is set
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[s][j] = 0;
+    int nz_bonds = 0; // the same for every slot
+#pragma unroll 1
+    for (uint32_t base = 0; base < d.N; base += 16 * 256) {
+        uint32_t q1[16], q2[16], q4[16], qs[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t site = base + k * 256 + tid;
+            q1[k] = q2[k] = q4[k] = qs[k] = 0;
+            if (site < d.N) {
+                const uint32_t *x = xw + static_cast<size_t>(site) * XW;
+                uint32_t v[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int dd = 0; dd < NN; ++dd) {
+                    const float j = J[site * NN + dd]; // -1, 0, +1
+                    const uint32_t nz = j != 0.0f ? 0xFFFFFFFFu : 0u, neg = j < 0.0f ? 0xFFFFFFFFu : 0u;
+                    v[dd] = (x[dd] ^ neg) & nz; // 1 where the bond's term is -1
+                    nz_bonds += j != 0.0f ? 1 : 0;
+                }
+                uint32_t s1, c1, s2, c2;
+                full_add(v[0], v[1], v[2], s1, c1);
+                full_add(v[3], v[4], v[5], s2, c2);
+                const uint32_t c3 = s1 & s2;
+                q1[k] = s1 ^ s2;
+                q2[k] = c1 ^ c2 ^ c3;
+                q4[k] = maj3(c1, c2, c3);
+                qs[k] = x[XW - 1];
+            }
         }
-        neg += (x[XW - 1] >> bit) & 1u;
+        count16(q1, c[0]);
+        count16(q2, c[1]);
+        count16(q4, c[2]);
+        count16(qs, c[3]);
     }
-    atomicAdd(&e_sum[bit], e);
-    atomicAdd(&neg_sum[bit], neg);
+    // the non-zero bonds of the realisation: every thread counted those of its sites
+    __shared__ int nz_total;
+    if (tid == 0) nz_total = 0;
     __syncthreads();
-    const uint32_t slot = w * 32 + bit;
+    atomicAdd(&nz_total, nz_bonds);
+    uint32_t tot[4];
+    block_bit_totals<4>(c, scratch, tot); // (its barriers also publish nz_total)
+    const uint32_t slot = w * 32 + tid;
     if (tid < 32 && slot < d.n_sys) {
-        p.Esum[static_cast<size_t>(real) * d.n_sys + slot] = __float_as_int(static_cast<float>(e_sum[bit])); // raw f32 bits
-        p.Msum[static_cast<size_t>(real) * d.n_sys + slot] = static_cast<int32_t>(d.N) - 2 * neg_sum[bit];
+        const int minus = static_cast<int>(tot[0] + 2 * tot[1] + 4 * tot[2]);
+        p.Esum[static_cast<size_t>(real) * d.n_sys + slot] = __float_as_int(static_cast<float>(nz_total - 2 * minus)); // raw f32 bits
+        p.Msum[static_cast<size_t>(real) * d.n_sys + slot] = static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(tot[3]);
     }
 }
 
@@ -631,7 +663,7 @@ static void launch_sweep_f_nn(const SimDims &d, const DevPtrs &p, bool with_ener
         if (!do_sweep || d.big) // (the on-chip sweep has written the bond words itself)
             hipLaunchKernelGGL(k_bonds_f<NN>, dim3((d.N + 255) / 256, d.n_real * d.W), dim3(256), 0, stream, d, p);
         if (d.unit && static_cast<uint64_t>(d.N) * NN < (1u << 24)) // every partial sum is an exact f32 integer
-            hipLaunchKernelGGL(k_energy_unit_f<NN>, dim3(d.n_real * d.W), dim3(512), 0, stream, d, p);
+            hipLaunchKernelGGL(k_energy_unit_f<NN>, dim3(d.n_real * d.W), dim3(256), 0, stream, d, p);
         else
             hipLaunchKernelGGL(k_energy_f<NN>, dim3(d.n_real * ((d.W + 1) / 2)), dim3(kEnergyThreads),
                                sizeof(EnergyLds<NN>), stream, d, p);

@@ -329,6 +329,30 @@ def test_diluted_lattice_on_the_table_path(oracle, mode):
     assert_state_equal(gpu, cpu)
 
 
+@pytest.mark.parametrize("mode", ["metropolis", "gibbs"])
+@pytest.mark.parametrize("lattice", ["triangular", "cubic-without-table"])
+def test_record_path_protocol_matches_oracle(oracle, monkeypatch, lattice, mode):
+    """Lattices whose neighbours do not follow from one wrap flag per slot (triangular: the diagonal wraps in three
+    ways) keep the 16-byte site records on the sweep path; PEAPODS_NO_HC forces the same kernels on a cubic lattice.
+    Full protocol: tempering every sweep, overlaps, a second call."""
+    if lattice == "triangular":
+        shape, offsets, nn = (6, 6), [[1, 0], [0, 1], [1, -1]], 3
+    else:
+        shape, offsets, nn = (6, 6, 6), None, 3
+        monkeypatch.setenv("PEAPODS_NO_HC", "1")
+    couplings = bimodal(shape, nn, 3, 41)
+    gpu, cpu = make_pair(oracle, shape, couplings, np.linspace(0.9, 2.2, 7), 4, 12, offsets)
+    kwargs = dict(pt_interval=1, warmup_ratio=0.25)
+    a = gpu.sample(30, mode, **kwargs)
+    b = cpu.sample(30, mode, **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+    a = gpu.sample(11, mode, pt_interval=2, pt_schedule="full_ladder", warmup_ratio=0.0)
+    b = cpu.sample(11, mode, pt_interval=2, pt_schedule="full_ladder", warmup_ratio=0.0)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+
+
 def test_more_than_256_systems_per_realization(oracle):
     # 40 temperatures x 8 replicas = 320 systems (10 tile words): the tempering kernel moves the
     # generator cursors of every swapped slot, two slots per thread

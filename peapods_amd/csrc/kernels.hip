@@ -2678,31 +2678,37 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
             return;
         }
         const uint32_t lane = tid - 320;
-        auto stage_fetch = [&](uint32_t L) {
-            const uint32_t e0 = L <= last ? lds_peek(&halo_start[L]) : 0u;
+        // halo_start[L], clamped (levels past the last read nothing)
+        auto hs = [&](uint32_t L) -> uint32_t { return lds_peek(&halo_start[min(L, last + 1)]); };
+        auto stage_fetch = [&](uint32_t L, uint32_t e0) {
             // (aux 16 = sc1: agent scope, past the CU's L1 -- the records are written while this kernel runs)
 #pragma unroll
             for (uint32_t q = 0; q < 2; ++q)
                 __builtin_amdgcn_global_load_lds((GlobalPtr *)(xin + e0 + q * 64 + lane),
                                                  (LdsPtr *)(stage + ((L % R) * 128 + q * 64) * 4), 16, 0, 16);
         };
-        // is the landed group of level L complete?  -> ctl[8 + L % R] (read by every wave after X(L)); this wave
-        // reads what its own DMA wrote, ordered by its own counted wait
-        auto validate = [&](uint32_t L) {
-            const uint32_t n_h = L <= last ? lds_peek(&halo_start[L + 1]) - lds_peek(&halo_start[L]) : 0u;
-            bool bad = false;
-#pragma unroll
-            for (uint32_t q = 0; q < 2; ++q)
-                if (q * 64 + lane < n_h)
-                    bad = bad || !exchange_valid(lds_peek4(stage + ((L % R) * 128 + q * 64 + lane) * 4), base, d.n_levels);
+        // is the landed group of level L (n_h records) complete?  -> ctl[8 + L % R] (read by the other waves after X(L)) and
+        // the return value; this wave reads what its own DMA wrote, ordered by its own counted wait.  Both halves are
+        // requested before either is looked at: the wave's chain per level is one LDS round trip, not six -- every
+        // wave of the workgroup meets at the level barrier, so this wave's chain was the level time of every slab that
+        // reads another (480 against 400 ns per level, tools/stamps_slab.py)
+        auto validate = [&](uint32_t L, uint32_t n_h) -> uint32_t {
+            u32x4 r0, r1;
+            const uint32_t a0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(stage + ((L % R) * 128 + lane) * 4));
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(r0), "=&v"(r1)
+                         : "v"(a0)
+                         : "memory");
+            const bool bad = (lane < n_h && !exchange_valid(make_uint4(r0.x, r0.y, r0.z, r0.w), base, d.n_levels)) ||
+                             (64 + lane < n_h && !exchange_valid(make_uint4(r1.x, r1.y, r1.z, r1.w), base, d.n_levels));
             const uint32_t any = __ballot(bad) != 0ull ? 1u : 0u;
             if (lane == 0)
                 asm volatile("ds_write_b32 %0, %1" ::"v"(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&ctl[8 + L % R]))), "v"(any)
                              : "memory");
+            return any;
         };
-        // Optional head start for the slab(s) read from (tuning knob, off by default: the slab finds its distance by
-        // itself through a few re-reads, and starting further back only adds to the pipeline's length): wait until
-        // the group of a level `lead` ahead exists, then begin.
+        // Optional head start for the slab(s) read from (tuning knob): wait until the group of a level `lead` ahead
+        // exists, then begin.
         if (d.slab_lead) {
             const uint32_t lead = d.slab_lead;
             uint32_t L = min(first + lead, last);
@@ -2720,22 +2726,37 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
                 __builtin_amdgcn_s_sleep(2);
             }
         }
-        for (uint32_t L = first; L < first + kSlabAhead; ++L) stage_fetch(L);
+        for (uint32_t L = first; L < first + kSlabAhead; ++L) stage_fetch(L, L <= last ? hs(L) : 0u);
         __builtin_amdgcn_s_waitcnt(0x0F70); // the first groups are simply waited for
-        validate(first);
+        uint32_t flag_cur = validate(first, hs(first + 1) - hs(first));
+        // window of the table kept in registers: h[k] = halo_start[level + 1 + k]
+        uint32_t h[kSlabAhead + 1];
+#pragma unroll
+        for (uint32_t k = 0; k <= kSlabAhead; ++k) h[k] = hs(first + 1 + k);
         slab_barrier();
         slab_barrier(); // the sweep waves pick the first level up
         for (uint32_t level = first; level <= last; ++level) {
+            // the window's next entry: requested now, looked at after this level's work
+            uint32_t h_new;
+            asm volatile("ds_read_b32 %0, %1"
+                         : "=v"(h_new)
+                         : "v"(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&halo_start[min(level + 2 + kSlabAhead, last + 1)])))
+                         : "memory");
             // the group of level + 1 has landed once only the kSlabAhead - 2 younger groups (two pieces each) are outstanding:
             // a fetch has that many levels to come back through this CU's memory queue, behind the loader's pieces
             __builtin_amdgcn_s_waitcnt(0x0F70 | (2u * (kSlabAhead - 2)));
-            validate(level + 1);
+            const uint32_t flag_next = validate(level + 1, h[1] - h[0]);
             slab_barrier(); // X(level)
-            if (lds_peek(&ctl[8 + level % R])) { // the sweep waves re-read the level's group: same barrier
+            if (flag_cur) { // the sweep waves re-read the level's group: same barrier
                 slab_barrier();
                 if (lds_peek(&ctl[1])) return;
             }
-            stage_fetch(level + kSlabAhead);
+            stage_fetch(level + kSlabAhead, level + kSlabAhead <= last ? h[kSlabAhead - 1] : 0u);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h_new)::"memory");
+#pragma unroll
+            for (uint32_t k = 0; k < kSlabAhead; ++k) h[k] = h[k + 1];
+            h[kSlabAhead] = h_new;
+            flag_cur = flag_next;
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);
         return;

@@ -2782,12 +2782,12 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
         uint4 r = make_uint4(0u, 0u, 0u, 0u);
         in.lv = make_uint2(0u, 0u);
         in.target = in.hi = 0;
-        if (t < in.count) {
-            r = *reinterpret_cast<const uint4 *>(ring_rec + (slot * 256 + t) * 4);
-            in.lv = *reinterpret_cast<const uint2 *>(ring_pl + (slot * 256 + t) * 2);
-            in.target = ring_x[slot * 256 + t];
-            if (GIBBS) in.hi = ring_hi[slot * 256 + t];
-        }
+        // (read whatever the count says -- the slot exists -- so that the count and the ring travel in one LDS round trip;
+        // compute and settle look at `count`)
+        r = *reinterpret_cast<const uint4 *>(ring_rec + (slot * 256 + t) * 4);
+        in.lv = *reinterpret_cast<const uint2 *>(ring_pl + (slot * 256 + t) * 2);
+        in.target = ring_x[slot * 256 + t];
+        if (GIBBS) in.hi = ring_hi[slot * 256 + t];
         // (a neighbour in another slab is the value word of its staged exchange record: the host wrote that LDS word)
         const uint32_t lds0 = lds_addr_of(lds); // (LDS byte addresses, ready for ds_read)
         in.at = r.x & 0xFFFFu;

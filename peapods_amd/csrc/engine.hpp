@@ -239,6 +239,8 @@ hipError_t launch_measure_overlap(const SimDims &d, const DevPtrs &p, const PtPa
 hipError_t launch_sweep_pipe(const SimDims &d, const DevPtrs &p, bool gibbs, uint32_t epoch, hipStream_t stream);
 hipError_t launch_apply_swaps(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 hipError_t launch_houdayer(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool with_energy = false);
+hipError_t launch_houdayer_seeds(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool with_overlap);
+hipError_t launch_houdayer_grow(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool with_energy);
 bool houdayer_computes_energy(const SimDims &d); // with_energy is honoured: no energy-only sweep launch needed after the move
 size_t houdayer_lds_bytes(const SimDims &d);
 hipError_t launch_jorg(const SimDims &d, const DevPtrs &p, hipStream_t stream);

@@ -2055,15 +2055,14 @@ __device__ __forceinline__ void houdayer_active_site(const uint32_t *tile, uint3
     for (int w = 0; w < NW; ++w) A[w * N + i] = out[w];
 }
 
-__global__ __launch_bounds__(1024) void k_houdayer(SimDims d, DevPtrs p) {
-    extern __shared__ uint32_t lds[];
+__device__ __forceinline__ void houdayer_block(const SimDims &d, const DevPtrs &p, uint32_t real, uint32_t *lds) {
     const size_t tile_words = static_cast<size_t>(d.N) * d.W;
     uint32_t *tile = lds;                      // [W][N] spins
     uint32_t *A = lds + tile_words;            // [W][N] active mask
     uint32_t *F = lds + 2 * tile_words;        // [W][N] cluster membership (seeds)
     uint32_t *pair_slots = lds + 3 * tile_words; // [n_temps * n_pairs][2]
     uint32_t *partner = pair_slots + 2 * d.n_temps * d.n_pairs; // [n_sys]
-    const uint32_t real = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
     const uint32_t *Sg = p.S + static_cast<size_t>(real) * tile_words;
     uint32_t *Ag = p.hd_scratch + static_cast<size_t>(real) * 2 * tile_words; // active masks, then the seeds
     uint32_t *Fg = Ag + tile_words;
@@ -2162,6 +2161,24 @@ __global__ __launch_bounds__(1024) void k_houdayer(SimDims d, DevPtrs p) {
     for (size_t i = tid; i < tile_words; i += nthreads) {
         Ag[i] = A[i];
         Fg[i] = F[i];
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_houdayer(SimDims d, DevPtrs p) {
+    extern __shared__ uint32_t lds[];
+    houdayer_block(d, p, blockIdx.x, lds);
+}
+
+// The same launch with the overlap measurement of the state the sweep left riding in it: this kernel only READS the
+// spins (masks and seeds go to scratch; the growth kernel that follows flips), so the overlap blocks -- the first four
+// waves of their workgroups -- see the state between the sweep and the move, as the reference measures it.
+__global__ __launch_bounds__(1024) void k_houdayer_overlap(SimDims d, DevPtrs p, uint32_t n_houdayer) {
+    extern __shared__ uint32_t lds[];
+    if (blockIdx.x < n_houdayer) {
+        houdayer_block(d, p, blockIdx.x, lds);
+    } else {
+        if (threadIdx.x >= 256) return; // (a barrier waits for the surviving waves only)
+        overlap_block(d, p, blockIdx.x - n_houdayer, lds);
     }
 }
 
@@ -3064,6 +3081,7 @@ hipError_t configure_kernels(const SimDims &) {
                            reinterpret_cast<const void *>(k_sweep_hc<3, false, true, false>),
                            reinterpret_cast<const void *>(k_rng_overlap<true>),
                            reinterpret_cast<const void *>(k_houdayer),
+                           reinterpret_cast<const void *>(k_houdayer_overlap),
                            reinterpret_cast<const void *>(k_houdayer_grow),
                            reinterpret_cast<const void *>(k_jorg),
                            reinterpret_cast<const void *>(k_measure<false>),
@@ -3312,6 +3330,23 @@ hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream
     return hipGetLastError();
 }
 
+// Houdayer single-cluster move in two launches; with_overlap: the overlap blocks of k_overlap ride in the first
+// (the caller exchanges dot_* and dot_*_prev after it and may launch the statistics between the two).
+hipError_t launch_houdayer_seeds(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool with_overlap) {
+    if (with_overlap) {
+        const size_t lds = std::max(houdayer_lds_words(d) * 4, overlap_lds_bytes(d));
+        hipLaunchKernelGGL(k_houdayer_overlap, dim3(d.n_real + d.n_real * d.W), dim3(1024), lds, stream, d, p, d.n_real);
+    } else {
+        hipLaunchKernelGGL(k_houdayer, dim3(d.n_real), dim3(1024), houdayer_lds_words(d) * 4, stream, d, p);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_houdayer_grow(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool with_energy) {
+    const bool e = with_energy && d.hc && d.dense_nn == d.nn;
+    const size_t lds = (2 * static_cast<size_t>(d.N) + 4 + (e ? d.N + 4 + 5 * 48 : 0)) * 4;
+    hipLaunchKernelGGL(k_houdayer_grow, dim3(d.n_real * d.W), dim3(1024), lds, stream, d, p, e ? 1 : 0);
+    return hipGetLastError();
+}
 hipError_t launch_houdayer(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool with_energy) {
     hipLaunchKernelGGL(k_houdayer, dim3(d.n_real), dim3(1024), houdayer_lds_words(d) * 4, stream, d, p);
     const bool e = with_energy && d.hc && d.dense_nn == d.nn;

@@ -1001,9 +1001,22 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                 PA_HIP(sim, launch_fk(g.d, g.p, cfg->cluster_mode == PA_CLUSTER_WOLFF, aux, g.stream));
                 if (record || pt_this || equil) PA_HIP(sim, launch_sweep(g.d, g.p, true, false, false, g.stream));
             }
-            if (((record && want_overlap) || equil) && d.n_pairs) PA_HIP(sim, overlap_launch(g.d, g.p, g.stream)); // :527-529
             const bool oc_this = cfg->overlap_cluster_interval > 0 &&
                                  sweep_id % cfg->overlap_cluster_interval == 0; // :598-599
+            // The plain Houdayer single-cluster move (k_houdayer + k_houdayer_grow) only reads the spins in its first
+            // launch: this sweep's overlap measurement rides in it, and the statistics follow between the two launches
+            // (the same order of effects: sweep, overlap and statistics on the swept state, then the move).
+            bool overlap_in_houdayer = false;
+            if (oc_this && record && want_overlap && !equil && d.n_pairs && !d.big && d.nn <= 3) {
+                const uint64_t mode_now = overlap_call_count % static_cast<uint64_t>(cfg->n_overlap_cluster_modes);
+                const int mode = cfg->overlap_cluster_modes[mode_now];
+                const bool first = &g == &sim->groups.front() && sim->first_realization == 0;
+                const bool snap_now = snapshot_interval > 0 && sweep_id % snapshot_interval == 0;
+                overlap_in_houdayer = (mode & 0xFF) == PA_OC_HOUDAYER && (mode >> 8) <= 2 && !oc_sw && !collect_overlap &&
+                                      !observe_overlap && !(snap_now && first);
+            }
+            if (((record && want_overlap) || equil) && d.n_pairs && !overlap_in_houdayer)
+                PA_HIP(sim, overlap_launch(g.d, g.p, g.stream)); // :527-529
             PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot,
                         equil ? 1u : 0u, equil_ckpt, static_cast<uint32_t>(sweep_id + 1),
                         (autocorr && record) ? static_cast<uint32_t>(sim->n_recorded + 1) : 0u,
@@ -1024,7 +1037,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                     }
                 }
             } else {
-                if (record || equil)
+                if ((record || equil) && !overlap_in_houdayer)
                     PA_HIP(sim, measure_launch(g.fresh, g.d, g.p, pt, record, record && want_overlap, false, g.stream));
                 pt.equil = 0; // the tempering launch below must not accumulate the diagnostic again
                 const uint64_t mode_idx = overlap_call_count % static_cast<uint64_t>(cfg->n_overlap_cluster_modes);
@@ -1086,7 +1099,14 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                     PA_HIP(sim, launch_jorg(g.d, g.p, g.stream)); // :601-602,660-680
                 else {
                     energy_done = pt_this && !observe_overlap && houdayer_computes_energy(g.d);
-                    PA_HIP(sim, launch_houdayer(g.d, g.p, g.stream, energy_done));
+                    if (overlap_in_houdayer) {
+                        PA_HIP(sim, launch_houdayer_seeds(g.d, g.p, g.stream, true));
+                        toggle_dots(g.p);
+                        PA_HIP(sim, measure_launch(g.fresh, g.d, g.p, pt, record, true, false, g.stream));
+                        PA_HIP(sim, launch_houdayer_grow(g.d, g.p, g.stream, energy_done));
+                    } else {
+                        PA_HIP(sim, launch_houdayer(g.d, g.p, g.stream, energy_done));
+                    }
                 }
                 if (aux.flags & kAuxSizes) PA_HIP(sim, launch_top4_accumulate(g.d, g.p, aux, g.stream)); // :725-735
                 if (take_snapshot && first_group) { // :682-714

@@ -237,6 +237,7 @@ bool rng_relay_ladder_supported(const SimDims &d);
 hipError_t launch_measure_overlap(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_accum, bool accum_overlap,
                                   bool do_pt, hipStream_t stream);
 hipError_t launch_sweep_pipe(const SimDims &d, const DevPtrs &p, bool gibbs, uint32_t epoch, hipStream_t stream);
+hipError_t launch_energy_overlap_big(const SimDims &d, const DevPtrs &p, hipStream_t stream); // (d.big, d.nn <= 3)
 hipError_t launch_apply_swaps(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 hipError_t launch_houdayer(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool with_energy = false);
 hipError_t launch_houdayer_seeds(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool with_overlap);

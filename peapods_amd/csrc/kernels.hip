@@ -2911,10 +2911,10 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
 }
 
 // chunk = 4096 schedule positions per workgroup; counts go to cnt[real][n_sys][3] (u32 atomics)
-__global__ __launch_bounds__(256) void k_energy_big(SimDims d, DevPtrs p, uint32_t n_chunks) {
+__device__ __forceinline__ void energy_big_block(const SimDims &d, const DevPtrs &p, uint32_t bid, uint32_t n_chunks) {
     __shared__ uint32_t scratch[5 * 48];
-    const uint32_t chunk = blockIdx.x % n_chunks;
-    const uint32_t w = (blockIdx.x / n_chunks) % d.W, real = blockIdx.x / (n_chunks * d.W);
+    const uint32_t chunk = bid % n_chunks;
+    const uint32_t w = (bid / n_chunks) % d.W, real = bid / (n_chunks * d.W);
     const uint32_t tid = threadIdx.x;
     const uint32_t *Sg = p.S + (static_cast<size_t>(real) * d.W + w) * d.N;
     const uint32_t *jsite = p.jsite + static_cast<size_t>(real) * d.N;
@@ -2955,10 +2955,14 @@ __global__ __launch_bounds__(256) void k_energy_big(SimDims d, DevPtrs p, uint32
     }
 }
 
-__global__ __launch_bounds__(256) void k_overlap_big(SimDims d, DevPtrs p, uint32_t n_chunks) {
+__global__ __launch_bounds__(256) void k_energy_big(SimDims d, DevPtrs p, uint32_t n_chunks) {
+    energy_big_block(d, p, blockIdx.x, n_chunks);
+}
+
+__device__ __forceinline__ void overlap_big_block(const SimDims &d, const DevPtrs &p, uint32_t bid, uint32_t n_chunks) {
     __shared__ uint32_t scratch[5 * 48];
-    const uint32_t chunk = blockIdx.x % n_chunks;
-    const uint32_t w = (blockIdx.x / n_chunks) % d.W, real = blockIdx.x / (n_chunks * d.W);
+    const uint32_t chunk = bid % n_chunks;
+    const uint32_t w = (bid / n_chunks) % d.W, real = bid / (n_chunks * d.W);
     const uint32_t tid = threadIdx.x;
     const uint32_t q = d.n_temps >> 5, r = d.n_temps & 31u;
     const uint32_t wa = w + q, wb = w + q + 1;
@@ -3003,18 +3007,30 @@ __global__ __launch_bounds__(256) void k_overlap_big(SimDims d, DevPtrs p, uint3
     }
 }
 
-// counts -> Esum / Msum (mode 0) or dot_spin / dot_link (mode 1); one thread per slot
+__global__ __launch_bounds__(256) void k_overlap_big(SimDims d, DevPtrs p, uint32_t n_chunks) {
+    overlap_big_block(d, p, blockIdx.x, n_chunks);
+}
+
+// Both in one launch (they read the same state and write different counters): the energies of the state a sweep left
+// and its overlap measurement, when nothing comes between them in the protocol.
+__global__ __launch_bounds__(256) void k_energy_overlap_big(SimDims d, DevPtrs p, uint32_t n_chunks, uint32_t n_energy) {
+    if (blockIdx.x < n_energy) energy_big_block(d, p, blockIdx.x, n_chunks);
+    else overlap_big_block(d, p, blockIdx.x - n_energy, n_chunks);
+}
+
+// counts -> Esum / Msum (mode 0), dot_spin / dot_link (mode 1) or both (mode 2); one thread per slot
 __global__ void k_big_finalize(SimDims d, DevPtrs p, int mode) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= d.n_real * d.n_sys) return;
     const uint32_t real = idx / d.n_sys, k = idx % d.n_sys;
     uint32_t *cnt = p.big_counts + static_cast<size_t>(idx) * 4;
-    if (mode == 0) {
+    if (mode == 0 || mode == 2) {
         p.Esum[idx] = p.nz_bonds[real] - 2 * static_cast<int32_t>(cnt[0]);
         p.Msum[idx] = static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(cnt[1]);
         cnt[0] = 0;
         cnt[1] = 0;
-    } else {
+    }
+    if (mode != 0) {
         const uint32_t rep = k / d.n_temps, t = k % d.n_temps;
         if ((rep & 1u) == 0 && rep + 1 < d.n_replicas) {
             const size_t o = (static_cast<size_t>(real) * d.n_pairs + (rep >> 1)) * d.n_temps + t;
@@ -3309,6 +3325,13 @@ hipError_t launch_sweep_stamped(const SimDims &d, const DevPtrs &p, unsigned lon
 hipError_t launch_apply_swaps(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
     hipLaunchKernelGGL(k_apply_swaps, dim3((d.N + 255) / 256, d.n_real), dim3(256), 0, stream, d, p);
     hipLaunchKernelGGL(k_mark_applied, dim3((d.n_real * d.W + 255) / 256), dim3(256), 0, stream, d, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_energy_overlap_big(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
+    const uint32_t n_chunks = (d.N + 4095) / 4096, n_each = d.n_real * d.W * n_chunks;
+    hipLaunchKernelGGL(k_energy_overlap_big, dim3(2 * n_each), dim3(256), 0, stream, d, p, n_chunks, n_each);
+    hipLaunchKernelGGL(k_big_finalize, dim3((d.n_real * d.n_sys + 255) / 256), dim3(256), 0, stream, d, p, 2);
     return hipGetLastError();
 }
 

@@ -486,7 +486,7 @@ void toggle_spin_buffers(pa_sim *sim) {
 // Sweep of one group (and whatever has to precede it): on the large path pending tempering swaps
 // are materialised first; the LDS kernel applies them itself while loading.
 hipError_t enqueue_sweep(pa_sim *sim, const SimDims &d, const DevPtrs &p, bool with_energy,
-                         bool gibbs, hipStream_t stream) {
+                         bool gibbs, hipStream_t stream, bool overlap_too = false) {
     if ((d.big || d.general) && sim->swaps_pending) {
         hipError_t e = launch_apply_swaps(d, p, stream);
         if (e != hipSuccess) return e;
@@ -496,6 +496,8 @@ hipError_t enqueue_sweep(pa_sim *sim, const SimDims &d, const DevPtrs &p, bool w
         if (e != hipSuccess || !with_energy) return e;
         DevPtrs q = p;
         q.S = p.S_next;
+        // overlap_too: the overlap of the new state in the same launch as its energies (the caller exchanges the dots)
+        if (overlap_too) return launch_energy_overlap_big(d, q, stream);
         return launch_sweep(d, q, true, false, false, stream);
     }
     return launch_sweep(d, p, with_energy, true, gibbs, stream);
@@ -970,6 +972,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         // (general protocol) the previous sweep's measurement launch that carries its tempering event rides in this
         // sweep's random-stream launch when it can (relay_nf): one launch less per sweep
         const bool relayed_nf = relay_nf && pending.any;
+        bool big_overlap_done = false;
         for (auto &g : sim->groups) {
             if (relayed_nf) {
                 PtParams q = pending.pt;
@@ -980,8 +983,13 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             } else {
                 PA_HIP(sim, launch_rng(g.d, g.p, gibbs, g.stream));                     // :412-432
             }
-            // energies are computed after every mutating move of the sweep (:492-509)
-            PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, (record || pt_this || equil) && !fk_this, gibbs, g.stream));
+            // energies are computed after every mutating move of the sweep (:492-509); on the pipelined large-lattice
+            // path the overlap of the swept state is measured by the same launch when nothing comes between the two
+            const bool with_e = (record || pt_this || equil) && !fk_this;
+            const bool big_fuse = g.d.pipe_K && with_e && !fk_this && !equil && record && want_overlap && d.n_pairs && d.nn <= 3;
+            PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, with_e, gibbs, g.stream, big_fuse));
+            if (big_fuse) toggle_dots(g.p);
+            big_overlap_done = big_fuse; // (one stream group on this path)
         }
         if (relayed_nf && pending.do_pt && d.n_temps >= 2) toggle_system_tables(sim);
         pending.any = false;
@@ -1015,7 +1023,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                 overlap_in_houdayer = (mode & 0xFF) == PA_OC_HOUDAYER && (mode >> 8) <= 2 && !oc_sw && !collect_overlap &&
                                       !observe_overlap && !(snap_now && first);
             }
-            if (((record && want_overlap) || equil) && d.n_pairs && !overlap_in_houdayer)
+            if (((record && want_overlap) || equil) && d.n_pairs && !overlap_in_houdayer && !big_overlap_done)
                 PA_HIP(sim, overlap_launch(g.d, g.p, g.stream)); // :527-529
             PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot,
                         equil ? 1u : 0u, equil_ckpt, static_cast<uint32_t>(sweep_id + 1),

@@ -250,6 +250,12 @@ int pa_comm_allgather(pa_comm *comm, const void *send_host, void *recv_host, uin
 int pa_comm_allreduce_max_f64(pa_comm *comm, double *inout, uint64_t count); /* e.g. max-over-ranks timing */
 int pa_comm_allreduce_sum_u64(pa_comm *comm, uint64_t *inout, uint64_t count); /* exact; e.g. summed P(q) counts */
 int pa_comm_barrier(pa_comm *comm);
+/* Variable-length gather in rank order: every rank contributes send_bytes host bytes (0 allowed); recv_host
+ * receives the concatenation on `root`, or on every rank when root < 0; bytes_per_rank_out [n_ranks] is filled on
+ * every rank.  The per-realisation result arrays of a sharded run travel through it (peapods_amd.distributed.sample:
+ * statistics/results.rs:165-282 and overlap.rs:106-152 then run on the concatenation, as for one process). */
+int pa_comm_gatherv(pa_comm *comm, const void *send_host, uint64_t send_bytes, void *recv_host, uint64_t recv_capacity,
+                    int32_t root, uint64_t *bytes_per_rank_out);
 /* All ranks' pa_sim_get_result_blocks in rank (= global realisation) order; ranks may own different numbers
  * of realisations.  out: [out_capacity][pa_sim_result_block_len] f64; *n_total_out = blocks gathered. */
 int pa_comm_gather_result_blocks(pa_comm *comm, pa_sim *sim, double *out, uint64_t out_capacity,

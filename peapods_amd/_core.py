@@ -353,30 +353,52 @@ class IsingSimulation:
         """Runs the sweeps and returns the reference's result dictionary (src/lib.rs:337-617)."""
         cfg = self.make_config(n_sweeps, sweep_mode, **kwargs)
         self.run(cfg)
-        out = assemble_results(
-            self._lib, self.result_blocks(),
-            self.result_histograms() if self.n_replicas >= 2 else None,
-            self.pt_diagnostics() if kwargs.get("pt_interval") is not None else None,
-            self.n_temps, self.n_replicas // 2,
-        )
+        parts, meta = self.collect_parts(cfg, kwargs.get("pt_interval") is not None)
+        return assemble_parts(self._lib, parts, meta)
+
+    # ---- per-realisation results: what a rank contributes to the disorder aggregation --------------
+    def collect_parts(self, cfg, with_pt):
+        """Everything the last sample() produced, BEFORE the aggregation over disorder realisations:
+        `parts` maps a name to an array whose first axis is the realisation (cluster snapshots: the
+        snapshot), `meta` holds what is the same for every shard of one run.  One handle assembles its
+        own parts (`sample`); a disorder ensemble sharded over several handles / GPUs concatenates the
+        parts in realisation order first (peapods_amd.distributed.sample) -- the aggregation code and
+        its operand order are the same, so the result is bit-identical."""
+        n_t, n_bins, n_real = self.n_temps, self.n_spins + 1, self.n_realizations
+        parts = {"blocks": self.result_blocks()}
+        meta = {"n_temps": n_t, "n_pairs": self.n_replicas // 2, "n_modes": 0, "cluster_flags": 0}
+        if self.n_replicas >= 2:
+            parts["hist"], parts["qlq"], parts["ql2q"] = self.result_histograms()
+        if with_pt:
+            for key, arr in self.pt_diagnostics().items():
+                parts["pt_" + key] = arr
         if cfg.autocorrelation_max_lag:
-            out.update(self.autocorrelation_times())
+            m2 = np.zeros((n_real, n_t), dtype=np.float64)
+            q2 = np.zeros_like(m2)
+            for r in range(n_real):
+                self._check(self._lib.pa_sim_get_autocorrelation_tau(self._handle, r, nat.ptr(m2[r]), nat.ptr(q2[r])))
+            parts["tau_mags2"] = m2
+            if self.n_replicas >= 2:
+                parts["tau_overlap2"] = q2
         if cfg.equilibration_diagnostic:
-            out.update(self.equilibration_checkpoints())
+            n_ck = int(self._lib.pa_sim_n_equil_checkpoints(self._handle))
+            sweeps = np.zeros(n_ck, dtype=np.uint64)
+            energy = np.zeros((n_real, n_ck, n_t), dtype=np.float64)
+            link = np.zeros_like(energy)
+            for r in range(n_real):
+                self._check(self._lib.pa_sim_get_equilibration(self._handle, r, nat.ptr(sweeps),
+                                                               nat.ptr(energy[r]), nat.ptr(link[r])))
+            meta["equil_sweeps"] = sweeps
+            parts["equil_energy"], parts["equil_link"] = energy, link
         observing = (cfg.cluster_interval and cfg.cluster_action) or \
                     (cfg.overlap_cluster_interval and cfg.overlap_cluster_action)
         if cfg.collect_cluster_stats or observing:
-            self._cluster_results(out, int(cfg.n_overlap_cluster_modes))
+            self._collect_cluster_parts(parts, meta, int(cfg.n_overlap_cluster_modes))
         if cfg.snapshot_interval and cfg.overlap_cluster_interval:
-            snaps = self.cluster_snapshots()
-            if snaps:
-                out["cluster_snapshots"] = snaps
-        return out
+            self._collect_snapshot_parts(parts)
+        return parts, meta
 
-    def _cluster_results(self, out, n_modes):
-        """fk_csd / overlap_csd / top_cluster_sizes and per_disorder["cluster_observations"] of the last
-        sample(): sums (histograms) and realisation-ordered means (top sizes) as in
-        results.rs:181-214,261-267 and src/lib.rs:414-456,492-543."""
+    def _collect_cluster_parts(self, parts, meta, n_modes):
         n_t, n_bins, n_real = self.n_temps, self.n_spins + 1, self.n_realizations
         modes = max(n_modes, 1)
         fk = np.zeros((n_real, n_t, n_bins), dtype=np.uint64)
@@ -388,21 +410,12 @@ class IsingSimulation:
                                                      nat.ptr(tops[r]))
             if got < 0:
                 self._check(got)
+        meta["n_modes"], meta["cluster_flags"] = modes, int(got)
         if got & 1:
-            total = np.empty((n_t, n_bins), dtype=np.uint64)
-            self._lib.pa_aggregate_sum_u64(nat.ptr(fk), n_real, fk[0].size, nat.ptr(total))
-            if total.any():  # src/lib.rs:492-505
-                out["fk_csd"] = [total[t].copy() for t in range(n_t)]
+            parts["cs_fk"] = fk
         if got & 2:
-            total = np.empty((modes, n_t, n_bins), dtype=np.uint64)
-            self._lib.pa_aggregate_sum_u64(nat.ptr(ov), n_real, ov[0].size, nat.ptr(total))
-            if total.any():
-                out["overlap_csd"] = [[total[m, t].copy() for t in range(n_t)] for m in range(modes)]
-            mean = np.empty((modes, n_t, 4), dtype=np.float64)
-            self._lib.pa_aggregate_mean(nat.ptr(tops), n_real, tops[0].size, nat.ptr(mean))
-            out["top_cluster_sizes"] = [mean[m].copy() for m in range(modes)]
-        observations = {}
-        for kind, name in enumerate(("fk", "houdayer", "jorg", "cmr_blue")):
+            parts["cs_ov"], parts["cs_tops"] = ov, tops
+        for kind, name in enumerate(_OBSERVATION_KINDS):
             rows = []
             for r in range(n_real):
                 count = np.zeros(n_t, dtype=np.uint64)
@@ -425,64 +438,104 @@ class IsingSimulation:
                     for k, key in enumerate(("winding_x", "winding_y", "winding_either", "winding_both")):
                         row[key] = winding[:, k].copy()
                 rows.append(row)
-            if len(rows) == n_real:  # a kind is reported when every realisation has it (src/lib.rs:447-453)
-                observations[name] = {f: np.stack([row[f] for row in rows]) for f in rows[0]}
-        if observations:
-            out.setdefault("per_disorder", {})["cluster_observations"] = observations
+            if len(rows) == n_real and rows:  # a kind is reported when every realisation has it (src/lib.rs:447-453)
+                for field in rows[0]:
+                    parts[f"obs/{name}/{field}"] = np.stack([row[field] for row in rows])
 
-    def cluster_snapshots(self):
-        """`cluster_snapshots` of the last sample() (src/lib.rs:576-614)."""
-        snaps = []
+    def _collect_snapshot_parts(self, parts):
+        """`cluster_snapshots` of the last sample() (src/lib.rs:576-614): global realisation 0 only, so a
+        handle holding a later shard contributes no rows."""
         n_t, n = self.n_temps, self.n_spins
-        for k in range(int(self._lib.pa_sim_n_snapshots(self._handle))):
+        count = int(self._lib.pa_sim_n_snapshots(self._handle))
+        head = np.zeros((count, 3), dtype=np.int64)  # sweep_id, mode_idx, has_blue
+        ids = np.zeros((count, n_t, n), dtype=np.uint32)
+        blue = np.zeros((count, n_t, n), dtype=np.uint32)
+        spins = np.zeros((count, n_t, 2, n), dtype=np.int8)
+        sids = np.zeros((count, n_t, 2), dtype=np.uint64)
+        for k in range(count):
             sweep_id, mode_idx = C.c_uint64(), C.c_int32()
-            ids = np.zeros((n_t, n), dtype=np.uint32)
-            blue = np.zeros((n_t, n), dtype=np.uint32)
-            spins = np.zeros((n_t, 2, n), dtype=np.int8)
-            sids = np.zeros((n_t, 2), dtype=np.uint64)
             has_blue = self._lib.pa_sim_get_snapshot(self._handle, k, C.byref(sweep_id), C.byref(mode_idx),
-                                                     nat.ptr(ids), nat.ptr(blue), nat.ptr(spins), nat.ptr(sids))
+                                                     nat.ptr(ids[k]), nat.ptr(blue[k]), nat.ptr(spins[k]),
+                                                     nat.ptr(sids[k]))
             if has_blue < 0:
                 self._check(has_blue)
-            snap = {"sweep_id": int(sweep_id.value), "mode_idx": int(mode_idx.value), "cluster_ids": ids,
-                    "spins": spins, "system_ids": sids}
-            if has_blue:
-                snap["blue_ids"] = blue
-            snaps.append(snap)
-        return snaps
+            head[k] = (int(sweep_id.value), int(mode_idx.value), int(has_blue))
+        parts["snap_head"], parts["snap_ids"], parts["snap_blue"] = head, ids, blue
+        parts["snap_spins"], parts["snap_sids"] = spins, sids
 
-    def autocorrelation_times(self):
-        """mags2_tau (and overlap2_tau with replica pairs) of the last sample(), averaged over the
-        realisations in order (results.rs:213-228,267-274; src/lib.rs:545-557)."""
-        m2 = np.zeros((self.n_realizations, self.n_temps), dtype=np.float64)
-        q2 = np.zeros_like(m2)
-        for r in range(self.n_realizations):
-            self._check(self._lib.pa_sim_get_autocorrelation_tau(self._handle, r, nat.ptr(m2[r]), nat.ptr(q2[r])))
-        out = {}
-        for key, arr in (("mags2_tau", m2), ("overlap2_tau", q2)):
-            if key == "overlap2_tau" and self.n_replicas < 2:
-                continue
-            mean = np.empty(self.n_temps, dtype=np.float64)
-            self._lib.pa_aggregate_mean(nat.ptr(arr), self.n_realizations, self.n_temps, nat.ptr(mean))
-            out[key] = mean
-        return out
+    def cluster_snapshots(self):
+        """`cluster_snapshots` of the last sample() as the reference's list of dictionaries."""
+        parts = {}
+        self._collect_snapshot_parts(parts)
+        return _snapshots_from_parts(parts)
 
-    def equilibration_checkpoints(self):
-        """equil_sweeps / equil_energy_avg / equil_link_overlap_avg of the last sample(), averaged
-        over the realisations in order (results.rs:229-244,275-282; src/lib.rs:559-574)."""
-        n_ck = int(self._lib.pa_sim_n_equil_checkpoints(self._handle))
-        sweeps = np.zeros(n_ck, dtype=np.uint64)
-        energy = np.zeros((self.n_realizations, n_ck, self.n_temps), dtype=np.float64)
-        link = np.zeros_like(energy)
-        for r in range(self.n_realizations):
-            self._check(self._lib.pa_sim_get_equilibration(self._handle, r, nat.ptr(sweeps),
-                                                           nat.ptr(energy[r]), nat.ptr(link[r])))
-        e_mean = np.empty(n_ck * self.n_temps, dtype=np.float64)
-        l_mean = np.empty_like(e_mean)
-        self._lib.pa_aggregate_mean(nat.ptr(energy), self.n_realizations, e_mean.size, nat.ptr(e_mean))
-        self._lib.pa_aggregate_mean(nat.ptr(link), self.n_realizations, l_mean.size, nat.ptr(l_mean))
-        return {"equil_sweeps": sweeps, "equil_energy_avg": e_mean.reshape(n_ck, self.n_temps),
-                "equil_link_overlap_avg": l_mean.reshape(n_ck, self.n_temps)}
+
+
+_OBSERVATION_KINDS = ("fk", "houdayer", "jorg", "cmr_blue")
+
+
+def _snapshots_from_parts(parts):
+    snaps = []
+    for k in range(parts["snap_head"].shape[0]):
+        sweep_id, mode_idx, has_blue = (int(x) for x in parts["snap_head"][k])
+        snap = {"sweep_id": sweep_id, "mode_idx": mode_idx, "cluster_ids": parts["snap_ids"][k],
+                "spins": parts["snap_spins"][k], "system_ids": parts["snap_sids"][k]}
+        if has_blue:
+            snap["blue_ids"] = parts["snap_blue"][k]
+        snaps.append(snap)
+    return snaps
+
+
+def _mean_over_realizations(lib, arr):
+    """Sequential sum in realisation order, one division (results.rs:165-196,262-282)."""
+    arr = np.ascontiguousarray(arr, dtype=np.float64)
+    out = np.empty(arr.shape[1:], dtype=np.float64)
+    lib.pa_aggregate_mean(nat.ptr(arr), arr.shape[0], int(np.prod(arr.shape[1:], dtype=np.int64)), nat.ptr(out))
+    return out
+
+
+def assemble_parts(lib, parts, meta):
+    """The reference's result dictionary (src/lib.rs:337-617) from per-realisation parts in realisation
+    order: disorder aggregation as statistics/results.rs:165-282, overlap.rs:106-152, mod.rs:905-921."""
+    n_t = meta["n_temps"]
+    histograms = (parts["hist"], parts["qlq"], parts["ql2q"]) if "hist" in parts else None
+    pt = {k[3:]: v for k, v in parts.items() if k.startswith("pt_")} or None
+    out = assemble_results(lib, parts["blocks"], histograms, pt, n_t, meta["n_pairs"])
+    for key, name in (("tau_mags2", "mags2_tau"), ("tau_overlap2", "overlap2_tau")):  # results.rs:213-228,267-274
+        if key in parts:
+            out[name] = _mean_over_realizations(lib, parts[key])
+    if "equil_sweeps" in meta:  # results.rs:229-244,275-282; src/lib.rs:559-574
+        out["equil_sweeps"] = meta["equil_sweeps"]
+        out["equil_energy_avg"] = _mean_over_realizations(lib, parts["equil_energy"])
+        out["equil_link_overlap_avg"] = _mean_over_realizations(lib, parts["equil_link"])
+    modes = meta["n_modes"]
+    if "cs_fk" in parts:  # results.rs:181-214,261-267; src/lib.rs:492-543
+        fk = np.ascontiguousarray(parts["cs_fk"])
+        total = np.empty(fk.shape[1:], dtype=np.uint64)
+        lib.pa_aggregate_sum_u64(nat.ptr(fk), fk.shape[0], fk[0].size, nat.ptr(total))
+        if total.any():  # src/lib.rs:492-505
+            out["fk_csd"] = [total[t].copy() for t in range(n_t)]
+    if "cs_ov" in parts:
+        ov = np.ascontiguousarray(parts["cs_ov"])
+        total = np.empty(ov.shape[1:], dtype=np.uint64)
+        lib.pa_aggregate_sum_u64(nat.ptr(ov), ov.shape[0], ov[0].size, nat.ptr(total))
+        if total.any():
+            out["overlap_csd"] = [[total[m, t].copy() for t in range(n_t)] for m in range(modes)]
+        mean = _mean_over_realizations(lib, parts["cs_tops"])
+        out["top_cluster_sizes"] = [mean[m].copy() for m in range(modes)]
+    observations = {}
+    for key, arr in parts.items():
+        if key.startswith("obs/"):
+            _, kind, field = key.split("/")
+            observations.setdefault(kind, {})[field] = arr
+    if observations:  # src/lib.rs:414-456
+        ordered = {kind: observations[kind] for kind in _OBSERVATION_KINDS if kind in observations}
+        out.setdefault("per_disorder", {})["cluster_observations"] = ordered
+    if "snap_head" in parts:
+        snaps = _snapshots_from_parts(parts)
+        if snaps:
+            out["cluster_snapshots"] = snaps
+    return out
 
 
 def assemble_results(lib, blocks, histograms, pt, n_temps, n_pairs):

@@ -118,6 +118,7 @@ SIGNATURES = {
     "pa_comm_allreduce_max_f64": (C.c_int, [_vp, _vp, _u64]),
     "pa_comm_allreduce_sum_u64": (C.c_int, [_vp, _vp, _u64]),
     "pa_comm_barrier": (C.c_int, [_vp]),
+    "pa_comm_gatherv": (C.c_int, [_vp, _vp, _u64, _vp, _u64, _i32, _vp]),
     "pa_comm_gather_result_blocks": (C.c_int, [_vp, _vp, _vp, _u64, _vp]),
     "pa_sim_n_realizations": (_u64, [_vp]),
     "pa_device_copy_bandwidth": (C.c_int, [_i32, _u64, _i32, _vp, C.c_char_p, C.c_size_t]),

@@ -15,9 +15,7 @@ namespace pa {
 // ---------------------------------------------------------------------------
 struct DevRng {
     uint64_t s0, s1, s2, s3;
-    __device__ __forceinline__ uint64_t next() {
-        const uint64_t m5 = s1 * 5;
-        const uint64_t result = ((m5 << 7) | (m5 >> 57)) * 9;
+    __device__ __forceinline__ void advance() {
         const uint64_t t = s1 << 17;
         s2 ^= s0;
         s3 ^= s1;
@@ -25,9 +23,31 @@ struct DevRng {
         s0 ^= s3;
         s2 ^= t;
         s3 = (s3 << 45) | (s3 >> 19);
+    }
+    // (plain C: wave-uniform generators -- k_wolff_wave -- stay on the scalar unit)
+    __device__ __forceinline__ uint64_t next() {
+        const uint64_t m5 = s1 * 5;
+        const uint64_t result = ((m5 << 7) | (m5 >> 57)) * 9;
+        advance();
+        return result;
+    }
+    // The same step for per-lane generators: s1 * 5 and * 9 as one 64-bit shift-add each (v_lshl_add_u64); hipcc
+    // lowers the two multiplications to six v_mad_u64_u32 otherwise (the event replay of the random-stream kernel
+    // steps the ladder generators in every workgroup).
+    __device__ __forceinline__ uint64_t next_lane() {
+        uint64_t m5, result;
+        asm("v_lshl_add_u64 %0, %1, 2, %1" : "=v"(m5) : "v"(s1));
+        const uint64_t rot = (m5 << 7) | (m5 >> 57);
+        asm("v_lshl_add_u64 %0, %1, 3, %1" : "=v"(result) : "v"(rot));
+        advance();
         return result;
     }
 };
+
+// floor(n / d) through the reciprocal m = ceil(2^32 / d) the host precomputed: exact whenever n d < 2^32 (the error
+// n (m d - 2^32) / (d 2^32) then stays below 1 / d) -- tile words by W <= 16, slots by n_temps, tasks by n_replicas.
+// A runtime u32 division costs ~25 VALU instructions per use on this target.
+__device__ __forceinline__ uint32_t div_small(uint32_t n, uint32_t recip) { return recip ? __umulhi(n, recip) : n; } // (recip 0: d = 1)
 
 __device__ __forceinline__ void load_cursor(const uint32_t *cursor, uint32_t real, uint32_t SP,
                                             uint32_t slot, uint32_t st[8]) {
@@ -75,9 +95,12 @@ struct Rng32 {
         const uint32_t rlo = __builtin_amdgcn_alignbit(plo, phi, 25);
         const uint64_t rr = (static_cast<uint64_t>(rhi) << 32) | rlo;
         const uint32_t top = static_cast<uint32_t>(lshl_add_u64<3>(rr, rr) >> 32);
-        // state transition; three-input XORs (v_bitop3_b32, truth table 0x96) fold the chained updates
-        const uint32_t t0 = b0 << 17;
-        const uint32_t t1 = __builtin_amdgcn_alignbit(b1, b0, 15);
+        // state transition; three-input XORs (v_bitop3_b32, truth table 0x96) fold the chained updates.
+        // s1 << 17 as ONE 64-bit shift: tools/probe/step_variants.hip measured the two-instruction form
+        // (v_lshlrev_b32 + v_alignbit_b32) 2.3 us per launch slower on the bench ensemble's random stream
+        uint64_t tt;
+        asm("v_lshlrev_b64 %0, 17, %1" : "=v"(tt) : "v"(s1));
+        const uint32_t t0 = static_cast<uint32_t>(tt), t1 = static_cast<uint32_t>(tt >> 32);
         const uint32_t e0 = d0 ^ b0, e1 = d1 ^ b1;                      // s3 ^ s1
         const uint32_t nb0 = __builtin_amdgcn_bitop3_b32(b0, c0, a0, 0x96); // s1 ^ (s2 ^ s0)
         const uint32_t nb1 = __builtin_amdgcn_bitop3_b32(b1, c1, a1, 0x96);
@@ -92,16 +115,20 @@ struct Rng32 {
     }
 };
 
-// state <- M * state with M as nibble tables [64][16][8] in LDS.
+// state <- M * state with M as nibble tables in LDS (or global memory), layout [64 positions][2 halves][16 values][4]:
+// the sixteen 16-byte half rows a ds_read_b128 can pick for one (position, half) are 256 contiguous bytes = all 64
+// banks once, so the sixteen lanes of a read group never conflict whatever their nibbles are (equal nibbles
+// broadcast).  With whole 32-byte rows side by side (round 2) values v and v + 8 shared their banks and 46 % of the
+// random-stream kernel's LDS cycles were conflict cycles (SQ_LDS_BANK_CONFLICT, profiles/r02_pmc_per_launch.csv).
 __device__ __forceinline__ void jump_state_lds(uint32_t st[8], const uint32_t *tab) {
     uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int p = 0; p < 64; p += 2) { // two table rows per round: one three-input XOR (v_bitop3) folds both in
         const uint32_t nib0 = (st[p >> 3] >> ((p & 7) * 4)) & 15u;
         const uint32_t nib1 = (st[(p + 1) >> 3] >> (((p + 1) & 7) * 4)) & 15u;
-        const uint4 *e0 = reinterpret_cast<const uint4 *>(tab + (p * 16 + nib0) * 8);
-        const uint4 *e1 = reinterpret_cast<const uint4 *>(tab + ((p + 1) * 16 + nib1) * 8);
-        const uint4 a = e0[0], b = e0[1], c = e1[0], e = e1[1];
+        const uint4 *e0 = reinterpret_cast<const uint4 *>(tab + p * 128 + nib0 * 4);
+        const uint4 *e1 = reinterpret_cast<const uint4 *>(tab + (p + 1) * 128 + nib1 * 4);
+        const uint4 a = e0[0], b = e0[16], c = e1[0], e = e1[16]; // second half: + 64 dwords
         acc[0] = __builtin_amdgcn_bitop3_b32(acc[0], a.x, c.x, 0x96);
         acc[1] = __builtin_amdgcn_bitop3_b32(acc[1], a.y, c.y, 0x96);
         acc[2] = __builtin_amdgcn_bitop3_b32(acc[2], a.z, c.z, 0x96);

@@ -57,6 +57,10 @@ struct SimDims {
     uint32_t hc;         // 1: hc_tab is built and the on-chip sweeps use it (all bonds non-zero iff dense_nn == nn)
     int32_t hc_d0[6];    // regular offset of each slot (x 4)
     int32_t hc_dd[6];    // (wrapped - regular) offset of each slot (x 4)
+    // random-stream workgroups: waves per workgroup (4 or 8; all of them share one jump table) and the reciprocals
+    // ceil(2^32 / x) with which the kernels divide small indices (device_util.hpp div_small)
+    uint32_t rng_waves;
+    uint32_t inv_temps, inv_replicas, inv_W;
 };
 
 // hc_tab entry of a site (schedule order): site | wrap flags << 14 | coupling sign bits << 20
@@ -102,7 +106,7 @@ struct DevPtrs {
     const uint32_t *xportS;  // [planes_stride] by padded position: 1 + exchange record the site's new value goes to, or 0
     uint4 *xchg;             // [n_real * W][pipe_K][2 * plane] exchange records {value, tag, value ^ tag, ~tag} in the
                              //   order of the reading slab's staged entries; tag = epoch base + level + 1
-    const uint32_t *jump;    // [B][64][16][8] nibble tables of T^(b*BS)
+    const uint32_t *jump;    // [B][64][2][16][4] nibble tables of T^(b*BS) (jump_state_lds)
     int32_t *Esum;           // [n_real][n_sys] by slot: sum_{i,d} J s s (exact integer)
     int32_t *Msum;           // [n_real][n_sys] by slot: sum_i s_i
     const int32_t *nz_bonds; // [n_real] number of non-zero forward bonds
@@ -141,7 +145,7 @@ struct DevPtrs {
     // "sw" inner variant of the overlap-cluster moves (kernels_cluster.hip; built on first use)
     uint32_t *pair_slots;    // [n_real][n_temps][n_replicas] slots in the shuffled order of each temperature
     uint32_t *slot_bits;     // [n_real][SP][MW] spins of every slot as a bitmap over the sites (k_slot_bitmaps, per call)
-    const uint32_t *jump_unit; // [cluster_stream_units][64][16][8] nibble tables of T^(64 u)
+    const uint32_t *jump_unit; // [cluster_stream_units][64][2][16][4] nibble tables of T^(64 u)
     uint8_t *stream_bits;    // [n_real][n_sys][cluster_stream_units * 64] classified draws of the cluster generators (unit couplings)
     uint32_t *stream_raw;    // same shape: the 24-bit draws themselves (other couplings)
     uint32_t *stream_error;  // [1] set if a task ever needed draws beyond its stream (checked by pa_sim_synchronize)

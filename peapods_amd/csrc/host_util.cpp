@@ -107,11 +107,14 @@ void JumpMatrix::nibble_table(uint32_t *out) const {
                     acc[2] ^= col[2];
                     acc[3] ^= col[3];
                 }
-            uint32_t *dst = out + (static_cast<size_t>(p) * 16 + v) * 8;
-            for (int w = 0; w < 4; ++w) {
-                dst[2 * w] = static_cast<uint32_t>(acc[w]);
-                dst[2 * w + 1] = static_cast<uint32_t>(acc[w] >> 32);
-            }
+            // layout [position][half][value][4 dwords] (device_util.hpp jump_state_lds: bank-conflict-free gathers);
+            // dword j of the 256-bit row = half j / 4, entry j % 4
+            const uint32_t row[8] = {static_cast<uint32_t>(acc[0]), static_cast<uint32_t>(acc[0] >> 32),
+                                     static_cast<uint32_t>(acc[1]), static_cast<uint32_t>(acc[1] >> 32),
+                                     static_cast<uint32_t>(acc[2]), static_cast<uint32_t>(acc[2] >> 32),
+                                     static_cast<uint32_t>(acc[3]), static_cast<uint32_t>(acc[3] >> 32)};
+            for (int j = 0; j < 8; ++j)
+                out[(static_cast<size_t>(p) * 2 + j / 4) * 64 + static_cast<size_t>(v) * 4 + j % 4] = row[j];
         }
     }
 }

@@ -49,7 +49,7 @@ struct JumpMatrix {
     void apply(const uint64_t in[4], uint64_t out[4]) const;
     // Nibble tables used on the device: entry [p][v] (p = 0..63, v = 0..15) is
     // M * (v << 4p) as 8 little-endian dwords.
-    void nibble_table(uint32_t *out /* [64][16][8] */) const;
+    void nibble_table(uint32_t *out /* [64 positions][2 halves][16 values][4] */) const;
 };
 
 struct LatticeTables {

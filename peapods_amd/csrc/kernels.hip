@@ -224,15 +224,16 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
     const uint32_t n_tw = d.n_real * d.W;
     const uint32_t tw = (group * nw + wave) * 2 + half;
     const bool tw_ok = tw < n_tw;
-    const uint32_t real = tw_ok ? tw / d.W : 0, w = tw_ok ? tw % d.W : 0;
+    // (small indices are divided through host-made reciprocals: a runtime division is ~25 VALU instructions, and the
+    // prologue of this block had eight of them in front of every 128-site stretch of the stream)
+    const uint32_t real = tw_ok ? div_small(tw, d.inv_W) : 0, w = tw_ok ? tw - real * d.W : 0;
     const uint32_t slot = w * 32 + bit;
     const bool active = tw_ok && slot < d.n_sys;
+    const uint32_t slot_rep = div_small(slot, d.inv_temps), slot_t = slot - slot_rep * d.n_temps; // slot = rep * n_temps + t
 
-    if (block > 0) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(p.jump + static_cast<size_t>(block) * (64 * 16 * 8));
-        uint4 *dst = reinterpret_cast<uint4 *>(tab);
-        for (uint32_t i = tid; i < 64 * 16 * 2; i += nthreads) dst[i] = src[i];
-    }
+    // the block's jump table: every 16-byte piece is requested before the first one is stored (copy_to_lds), so the
+    // workgroup pays one memory round trip for its 32 KB, not eight
+    if (block > 0) copy_to_lds(tab, p.jump + static_cast<size_t>(block) * (64 * 16 * 8), 64 * 16 * 8, tid, nthreads);
     uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t src_slot = slot, skip_draws = 0;
     if (REPLAY == 2) {
@@ -242,13 +243,14 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
         // the two rounds backwards.  Scratch behind the jump table: draws[tasks][n_edges], then two accepted-edge masks
         // per task (n_temps <= 32, checked on the host).
         const uint32_t n_edges = d.n_temps - 1;
-        const uint32_t tw0 = group * 2 * nw, real0 = tw0 / d.W;
-        const uint32_t real1 = min(tw0 + 2 * nw - 1u, n_tw - 1u) / d.W;
+        const uint32_t tw0 = group * 2 * nw, real0 = div_small(tw0, d.inv_W);
+        const uint32_t real1 = div_small(min(tw0 + 2 * nw - 1u, n_tw - 1u), d.inv_W);
         const uint32_t n_tasks = (real1 - real0 + 1u) * d.n_replicas;
         uint32_t *draws = tab + 64 * 16 * 8;
         uint32_t *dec = draws + n_tasks * n_edges;
         if (tid < n_tasks) {
-            const uint32_t r = real0 + tid / d.n_replicas, offset = (tid % d.n_replicas) * d.n_temps;
+            const uint32_t task_real = div_small(tid, d.inv_replicas);
+            const uint32_t r = real0 + task_real, offset = (tid - task_real * d.n_replicas) * d.n_temps;
             uint32_t gs[8];
             load_cursor(p.cursor, r, d.SP, p.slot_of[static_cast<size_t>(r) * d.n_sys + offset], gs);
             DevRng g;
@@ -256,7 +258,7 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
             g.s1 = (static_cast<uint64_t>(gs[3]) << 32) | gs[2];
             g.s2 = (static_cast<uint64_t>(gs[5]) << 32) | gs[4];
             g.s3 = (static_cast<uint64_t>(gs[7]) << 32) | gs[6];
-            for (uint32_t a = 0; a < n_edges; ++a) draws[tid * n_edges + a] = static_cast<uint32_t>(g.next() >> 40);
+            for (uint32_t a = 0; a < n_edges; ++a) draws[tid * n_edges + a] = static_cast<uint32_t>(g.next_lane() >> 40);
             dec[2 * tid] = 0;
             dec[2 * tid + 1] = 0;
         }
@@ -279,7 +281,8 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
                 const uint32_t task = idx / n_edges, a = idx % n_edges;
                 it_first[k] = a < n_first;
                 const uint32_t edge = it_first[k] ? first_parity + 2 * a : (1 - first_parity) + 2 * (a - n_first);
-                const int32_t *E = p.Esum + static_cast<size_t>(real0 + task / d.n_replicas) * d.n_sys + (task % d.n_replicas) * d.n_temps;
+                const uint32_t task_real = div_small(task, d.inv_replicas);
+                const int32_t *E = p.Esum + static_cast<size_t>(real0 + task_real) * d.n_sys + (task - task_real * d.n_replicas) * d.n_temps;
                 it_task[k] = task;
                 it_edge[k] = edge;
                 e0[k] = E[edge];
@@ -305,7 +308,7 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
             }
         __syncthreads();
         if (active) {
-            const uint32_t rep = slot / d.n_temps, t = slot % d.n_temps;
+            const uint32_t rep = slot_rep, t = slot_t;
             const uint32_t task = (real - real0) * d.n_replicas + rep;
             const uint32_t m0 = dec[2 * task], m1 = dec[2 * task + 1];
             uint32_t s1 = t; // where the system now at temperature t sat between the rounds, then before the event
@@ -320,11 +323,12 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
     }
     if (REPLAY == 1) {
         uint32_t *dec = tab + 64 * 16 * 8; // [<= 256] edge | accepted << 16 | draws << 17 per (realisation, ladder)
-        const uint32_t tw0 = group * 2 * nw, real0 = tw0 / d.W;
-        const uint32_t real1 = min(tw0 + 2 * nw - 1u, n_tw - 1u) / d.W;
+        const uint32_t tw0 = group * 2 * nw, real0 = div_small(tw0, d.inv_W);
+        const uint32_t real1 = div_small(min(tw0 + 2 * nw - 1u, n_tw - 1u), d.inv_W);
         const uint32_t n_tasks = (real1 - real0 + 1u) * d.n_replicas; // (<= 256: rng_relay_supported)
         if (tid < n_tasks) {
-            const uint32_t r = real0 + tid / d.n_replicas, offset = (tid % d.n_replicas) * d.n_temps;
+            const uint32_t task_real = div_small(tid, d.inv_replicas);
+            const uint32_t r = real0 + task_real, offset = (tid - task_real * d.n_replicas) * d.n_temps;
             uint32_t gs[8];
             load_cursor(p.cursor, r, d.SP, p.slot_of[static_cast<size_t>(r) * d.n_sys + offset], gs);
             DevRng g;
@@ -337,14 +341,14 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
             const uint64_t zone = (range << __clzll(range)) - 1;
             uint32_t n_draws = 0, edge;
             for (;;) {
-                const uint64_t v = g.next();
+                const uint64_t v = g.next_lane();
                 ++n_draws;
                 if (v * range <= zone) {
                     edge = static_cast<uint32_t>(__umul64hi(v, range));
                     break;
                 }
             }
-            const uint32_t draw = static_cast<uint32_t>(g.next() >> 40);
+            const uint32_t draw = static_cast<uint32_t>(g.next_lane() >> 40);
             ++n_draws;
             const int32_t *E = p.Esum + static_cast<size_t>(r) * d.n_sys + offset + edge;
             const bool accepted = pt_accept(static_cast<float>(d.N), E[0], E[1], d.general, p.dbeta[edge], p.ln_table[draw]);
@@ -352,7 +356,7 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
         }
         __syncthreads();
         if (active) {
-            const uint32_t rep = slot / d.n_temps, t = slot % d.n_temps;
+            const uint32_t rep = slot_rep, t = slot_t;
             const uint32_t v = dec[(real - real0) * d.n_replicas + rep];
             const uint32_t edge = v & 0xFFFFu;
             if ((v >> 16) & 1u) {
@@ -369,7 +373,7 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
         g.s1 = (static_cast<uint64_t>(st[3]) << 32) | st[2];
         g.s2 = (static_cast<uint64_t>(st[5]) << 32) | st[4];
         g.s3 = (static_cast<uint64_t>(st[7]) << 32) | st[6];
-        for (uint32_t k = 0; k < skip_draws; ++k) (void)g.next();
+        for (uint32_t k = 0; k < skip_draws; ++k) g.advance();
         st[0] = static_cast<uint32_t>(g.s0); st[1] = static_cast<uint32_t>(g.s0 >> 32);
         st[2] = static_cast<uint32_t>(g.s1); st[3] = static_cast<uint32_t>(g.s1 >> 32);
         st[4] = static_cast<uint32_t>(g.s2); st[5] = static_cast<uint32_t>(g.s2 >> 32);
@@ -391,7 +395,7 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
     if (GIBBS) {
         uint32_t ce[7] = {0, 0, 0, 0, 0, 0, 0}, co[7] = {0, 0, 0, 0, 0, 0, 0};
         if (active) {
-            const uint32_t t = slot % d.n_temps;
+            const uint32_t t = slot_t;
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
                 ce[j] = p.thr_gibbs[(0 + j) * d.n_temps + t];
@@ -442,7 +446,7 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
 
     uint32_t ca0 = 0, ca1 = 0, ca2 = 0, cb0 = 0, cb1 = 0, cb2 = 0;
     if (active) {
-        const uint32_t t = slot % d.n_temps;
+        const uint32_t t = slot_t;
         const uint32_t *thr = PRESHIFTED ? p.thr + 6 * d.n_temps : p.thr; // second half: c << 8
         ca0 = thr[0 * d.n_temps + t];
         ca1 = thr[1 * d.n_temps + t];
@@ -461,7 +465,7 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
     const TransposeLanes tl(bit);
     uint32_t ua0 = 0, ua1 = 0, ua2 = 0; // the even set again, unshifted, for the sign form
     if (active) {
-        const uint32_t t = slot % d.n_temps;
+        const uint32_t t = slot_t;
         ua0 = p.thr[0 * d.n_temps + t];
         ua1 = p.thr[1 * d.n_temps + t];
         ua2 = p.thr[2 * d.n_temps + t];
@@ -1953,13 +1957,17 @@ __global__ __launch_bounds__(1024) void k_measure(SimDims d, DevPtrs p, PtParams
 // realisation, PtParams::relay), the rest draw the random stream of the next sweep -- with REPLAY they apply the
 // event's cursor permutation themselves.  A sweep of the plain protocol is then two launches (this one and the
 // sweep kernel) instead of three, and the latency-bound measurement hides under the VALU-bound random stream.
+// Workgroups have 64 * SimDims::rng_waves threads (256 or 512): the random-stream waves of a workgroup share one jump
+// table; an overlap block is written for 256 threads and retires the others at once (a retired wave no longer counts
+// at the workgroup's barriers), a measurement block takes any size.
 template <bool PRESHIFTED, int REPLAY, bool GIBBS = false>
-__global__ __launch_bounds__(256) void k_rng_relay(SimDims d, DevPtrs p, uint32_t n_overlap, uint32_t n_measure, PtParams pt,
+__global__ __launch_bounds__(512) void k_rng_relay(SimDims d, DevPtrs p, uint32_t n_overlap, uint32_t n_measure, PtParams pt,
                                                    int do_accum, int accum_overlap, int do_pt) {
     extern __shared__ uint32_t lds_dyn[];
-    if (blockIdx.x < n_overlap)
+    if (blockIdx.x < n_overlap) {
+        if (threadIdx.x >= 256) return;
         overlap_block(d, p, blockIdx.x, lds_dyn);
-    else if (blockIdx.x < n_overlap + n_measure)
+    } else if (blockIdx.x < n_overlap + n_measure)
         measure_block<false>(d, p, pt, do_accum, accum_overlap, do_pt, nullptr, blockIdx.x - n_overlap, lds_dyn);
     else
         rng_block<PRESHIFTED, GIBBS, REPLAY>(d, p, blockIdx.x - n_overlap - n_measure, lds_dyn, pt.first_parity);
@@ -3145,30 +3153,32 @@ hipError_t launch_rng_overlap(const SimDims &d, const DevPtrs &p, hipStream_t st
 // A relayed measurement block needs: a workgroup of 256 threads (measure_block: n_sys <= 2 x 256, n_temps,
 // n_replicas, 2 W <= 256), one replay lane per (realisation, ladder) of a random-stream workgroup's eight tile words,
 // the on-chip table kernels.
+// realisations a random-stream workgroup's 2 * rng_waves tile words can belong to
+static uint32_t relay_reals_per_block(const SimDims &d) { return (2u * d.rng_waves - 1u) / d.W + 2u; }
+
 bool rng_relay_supported(const SimDims &d) {
-    const uint32_t reals_per_block = 7u / d.W + 2u;
     return !d.general && !d.big && d.n_sys <= 512 && d.n_temps <= 256 && d.n_replicas <= 256 && 2 * d.W <= 256 &&
-           reals_per_block * d.n_replicas <= 256 && measure_lds_bytes(d) <= kRngLds;
+           relay_reals_per_block(d) * d.n_replicas <= 256 && measure_lds_bytes(d) <= kRngLds;
 }
 
 // full_ladder events are replayed too when a ladder's edges fit one mask word and the draws fit behind the jump table
 bool rng_relay_ladder_supported(const SimDims &d) {
-    const size_t tasks = static_cast<size_t>(7u / d.W + 2u) * d.n_replicas;
-    return rng_relay_supported(d) && d.n_temps <= 32 && tasks * (d.n_temps - 1) <= 4 * 256 && // four items per lane
+    const size_t tasks = static_cast<size_t>(relay_reals_per_block(d)) * d.n_replicas;
+    return rng_relay_supported(d) && d.n_temps <= 32 && tasks * (d.n_temps - 1) <= 4 * 64 * d.rng_waves && // four items per lane
            tasks * (d.n_temps + 1) * 4 <= 16 * 1024;
 }
 
 hipError_t launch_rng_relay(const SimDims &d, const DevPtrs &p, bool with_overlap, const PtParams &pt, bool do_accum,
                             bool accum_overlap, bool do_pt, hipStream_t stream, bool gibbs) {
     const uint32_t n_pairs_tw = (d.n_real * d.W + 1) / 2;
-    const uint32_t groups = (n_pairs_tw + 3) / 4;
+    const uint32_t groups = (n_pairs_tw + d.rng_waves - 1) / d.rng_waves;
     const uint32_t n_overlap = with_overlap ? d.n_real * d.W : 0u;
     const uint32_t n_measure = (do_accum || accum_overlap || do_pt) ? d.n_real : 0u;
     const int replay = (n_measure && do_pt && d.n_temps >= 2) ? (pt.schedule != 0 ? 2 : 1) : 0; // 2: the whole ladder
     // behind the jump table: the replayed decisions (one word per ladder), or the ladders' draws and edge masks
-    const size_t replay_words = replay == 2 ? static_cast<size_t>(7u / d.W + 2u) * d.n_replicas * (d.n_temps + 1) : 256;
+    const size_t replay_words = replay == 2 ? static_cast<size_t>(relay_reals_per_block(d)) * d.n_replicas * (d.n_temps + 1) : 256;
     const size_t lds = std::max(kRngLds + std::max<size_t>(1024, replay_words * 4), overlap_lds_bytes(d));
-    const dim3 grid(n_overlap + n_measure + groups * d.B), block(256);
+    const dim3 grid(n_overlap + n_measure + groups * d.B), block(64 * d.rng_waves);
     const int a = do_accum ? 1 : 0, o = accum_overlap ? 1 : 0, t = do_pt ? 1 : 0;
 #define PA_RELAY(P, R, G) hipLaunchKernelGGL((k_rng_relay<P, R, G>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t)
     if (gibbs) { // (heat-bath thresholds are compared unshifted, like k_rng<false, true>)

@@ -80,7 +80,7 @@ __global__ void k_pairing(SimDims d, DevPtrs p) {
 // ---------------------------------------------------------------------------
 template <bool RAW>
 __global__ __launch_bounds__(256) void k_pair_stream(SimDims d, DevPtrs p, uint32_t n_units, const uint32_t *first_thr, int fk) {
-    extern __shared__ uint32_t tab[]; // [64][16][8] nibble tables of T^(64 u)
+    extern __shared__ uint32_t tab[]; // [64][2][16][4] nibble tables of T^(64 u)
     const uint32_t u = blockIdx.x % n_units, chunk = blockIdx.x / n_units;
     const uint32_t tid = threadIdx.x;
     const uint32_t per_real = fk ? d.n_sys : d.n_temps * d.n_pairs;

@@ -1269,7 +1269,7 @@ void pa_xoshiro_jump(const uint64_t in[4], uint64_t n_steps, uint64_t out[4]) {
     }
     for (int p = 0; p < 64; ++p) {
         const uint32_t nib = (st[p >> 3] >> ((p & 7) * 4)) & 15u;
-        for (int j = 0; j < 8; ++j) acc[j] ^= table[(p * 16 + nib) * 8 + j];
+        for (int j = 0; j < 8; ++j) acc[j] ^= table[(p * 2 + j / 4) * 64 + nib * 4 + j % 4];
     }
     for (int w = 0; w < 4; ++w) out[w] = (static_cast<uint64_t>(acc[2 * w + 1]) << 32) | acc[2 * w];
 }
@@ -1416,6 +1416,17 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     if (const char *env = std::getenv("PEAPODS_RNG_BLOCK")) {
         const long v = std::strtol(env, nullptr, 10);
         if (v >= 16 && v <= 65536) target_block = static_cast<uint32_t>(v);
+    }
+    {
+        auto recip = [](uint32_t x) { return static_cast<uint32_t>(((1ull << 32) + x - 1) / x); }; // (x >= 2; x = 1: see div_small)
+        d.inv_temps = recip(d.n_temps);
+        d.inv_replicas = recip(d.n_replicas);
+        d.inv_W = recip(d.W);
+        d.rng_waves = 4;
+        if (const char *env = std::getenv("PEAPODS_RNG_WAVES")) {
+            const long v = std::strtol(env, nullptr, 10);
+            if (v == 4 || v == 8) d.rng_waves = static_cast<uint32_t>(v);
+        }
     }
     d.B = std::max<uint32_t>(1, (d.N + target_block / 2) / target_block);
     d.BS = (d.N + d.B - 1) / d.B;

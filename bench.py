@@ -70,6 +70,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--profile-sweeps", type=int, default=64)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed call of exactly --steps steps is made this many times; the median is reported")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short measurements of BASELINE configs[1] and configs[4] after the headline")
     return ap.parse_args()
 
 
@@ -212,35 +216,99 @@ def load_json(name):
         return json.load(fh)
 
 
-def valu_limiter(kernels_ms, scale):
-    """What actually bounds the two sweep kernels: VALU issue.  Peaks are MEASURED on this chip by
-    tools/probe/valu_issue.hip (profiles/r02_valu_issue.json): gfx950 issues simple integer ops
-    (xor / and / add / sub / bitop3 / mov) at ~2.3 cycles per wave-instruction per SIMD once two waves
-    share it, but shifts-left, rotates (v_alignbit), 64-bit shift-adds, compares into SGPRs,
-    v_writelane / v_readlane and DPP moves hold the SIMD ~4.2 cycles -- and a stream that mixes both
-    classes runs close to the slow rate.  `peak_wave_insts_per_s` is the probe's own run of the
-    generator step of k_rng (xoshiro256** + 3 compares + ballot parking, 23 VALU instructions) at 8 waves
-    per SIMD; wave-instruction counts per launch are SQ_INSTS_VALU of the committed PMC pass (they scale
-    with the ensemble and do not depend on the data)."""
+def library_source_hash():
+    """Hash of the sources libpeapods_amd.so was built from, as the library itself reports it (pa_version)."""
+    from peapods_amd import _native as nat
+
+    text = nat.lib().pa_version().decode()
+    return text.split("src:")[-1] if "src:" in text else None
+
+
+def current_counters():
+    """profiles/counters.json, or (None, reason) when it was collected from other kernel sources than the ones
+    loaded now: the PMC figures describe a binary, not a file name."""
     counters = load_json("counters.json")
+    if not counters:
+        return None, "profiles/counters.json is missing"
+    have, want = counters.get("source_hash"), library_source_hash()
+    if have is None or want is None or have != want:
+        return None, (f"profiles/counters.json was collected from kernel sources {have} (commit "
+                      f"{counters.get('commit')}), the loaded library was built from {want}: recollect with "
+                      "tools/run_collect.sh")
+    return counters, None
+
+
+def valu_limiter(kernels_ms, scale):
+    """What actually bounds the two sweep kernels: VALU issue, priced against BOTH peaks.
+    (a) the hardware guide's figure (MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles, 4 SIMDs
+        per CU, 256 CUs) at the clock the probe observed under this load;
+    (b) the rate the probe measured for the generator step itself (tools/probe/valu_issue.hip ->
+        profiles/r02_valu_issue.json: xoshiro256** + 3 compares + ballot parking at 8 waves per SIMD; the step's
+        instruction mix does not reach (a): tools/probe/step_variants.hip, profiles/r03_step_variants.json).
+    Wave-instruction counts per launch are SQ_INSTS_VALU of the committed PMC pass (they scale with the ensemble
+    and do not depend on the data); null when that pass was collected from other kernel sources."""
+    counters, stale = current_counters()
     probe = load_json("r02_valu_issue.json")
-    if not counters or not probe:
+    if not probe:
         return None
-    rate = {}
+    if not counters:
+        return {"resource": "VALU issue (wave64 instructions)", "wave_insts_per_launch": None, "reason": stale}
+    rate, clock = {}, {}
     for row in probe["rows"]:
         if row["waves_per_simd"] == 8:
             rate[row["op"]] = row["wall_inst_per_s"]
+            clock[row["op"]] = row["clock_mhz"]
     counts = {k: v * scale for k, v in counters.get("wave_insts_per_launch", {}).items()}
-    peak = rate.get("rng_step_full")
-    frac = {k: counts[k] / (kernels_ms[k] * 1e-3) / peak for k in counts if kernels_ms.get(k, 0) > 0 and peak}
+    peak_probe = rate.get("rng_step_full")
+    peak_guide = 256 * 4 * clock.get("rng_step_full", 2400) * 1e6 / 2.0  # 2 cycles per wave-instruction per SIMD
+    def fracs(peak):
+        return {k: counts[k] / (kernels_ms[k] * 1e-3) / peak for k in counts if kernels_ms.get(k, 0) > 0 and peak}
     return {"resource": "VALU issue (wave64 instructions)", "wave_insts_per_launch": counts,
-            "counters_collected_at": counters.get("commit"),
-            "peak_wave_insts_per_s": peak,
-            "peak_source": "profiles/r02_valu_issue.json: rng_step_full at 8 waves/SIMD (tools/probe/valu_issue.hip)",
-            "class_peaks_wave_insts_per_s": {"simple_int (v_xor/v_add/v_bitop3)": rate.get("v_xor_b32"),
-                                             "shift/rotate/lane/64-bit (v_alignbit/v_writelane/v_lshl_add_u64)":
-                                                 rate.get("v_alignbit_b32")},
-            "frac": frac}
+            "counters_collected_at": counters.get("commit"), "counters_source_hash": counters.get("source_hash"),
+            "peak_guide_wave_insts_per_s": peak_guide,
+            "peak_guide_source": "MI355X_MICROARCH.md: 2 cycles per wave64 VALU instruction per SIMD, 1024 SIMDs, at the "
+                                 f"{clock.get('rng_step_full', 2400)} MHz the probe observed",
+            "frac_of_guide_peak": fracs(peak_guide),
+            "peak_probe_wave_insts_per_s": peak_probe,
+            "peak_probe_source": "profiles/r02_valu_issue.json: rng_step_full at 8 waves/SIMD (tools/probe/valu_issue.hip)",
+            "frac_of_probe_peak": fracs(peak_probe)}
+
+
+def other_configs(args, device):
+    """configs[1] (64^3 ferromagnet) and configs[4] (12^3 glass with the Houdayer / Joerg overlap move) on this GPU:
+    value, ms_per_step and the roofline fraction of the sweep pair, from a warm-up call and one timed call each."""
+    out = {}
+    todo = [("c1", "c1", {}, 300), ("c4_houdayer", "c4", dict(overlap_cluster_build_mode="houdayer", overlap_cluster_mode="wolff"), 300),
+            ("c4_jorg", "c4", dict(overlap_cluster_build_mode="jorg", overlap_cluster_mode="wolff"), 100)]
+    for name, key, extra, steps in todo:
+        work = WORKLOADS[key]
+        try:
+            sim, _couplings, _temps, _seed = build_ensemble(work, 0, work["n_disorder"], 1, device)
+            kw = dict(work["sample"], pt_interval=1, pt_schedule=args.pt_schedule, **extra)
+            attempts = int(np.prod(work["shape"])) * work["n_temps"] * work["n_replicas"] * work["n_disorder"]
+            sim.run(sim.make_config(max(steps // 5, 10), "metropolis", warmup_ratio=0.0, **kw))
+            sim.synchronize()
+            t0 = time.perf_counter()
+            sim.run(sim.make_config(steps, "metropolis", warmup_ratio=0.0, **kw), wait=False)
+            sim.synchronize()
+            dt = time.perf_counter() - t0
+            kernels = sim.profile_kernels(sim.make_config(32, "metropolis", warmup_ratio=0.0, pt_interval=1,
+                                                          pt_schedule=args.pt_schedule), 32)
+            pair_ms = kernels["k_rng"] + kernels["k_sweep"]
+            alg = (work["bytes"] + BYTES_OVERLAP) * attempts
+            achieved = alg / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
+            out[name] = {"workload": work["title"].format(n=work["n_disorder"], mode="/".join(extra.values()) or "-"),
+                         "value": attempts * steps / dt, "unit": "spin-flip attempts/s", "steps": steps,
+                         "ms_per_step": dt / steps * 1e3,
+                         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": achieved / HBM_PEAK_GBS, "kernel_ms": kernels,
+                                      "algorithmic_bytes_per_launch": alg,
+                                      "kernels": "random stream + sweep of one Metropolis sweep (the cluster move of c4 is "
+                                                 "in ms_per_step, not in this pair)"}}
+            del sim
+        except Exception as exc:  # the headline line must not be lost to a side measurement
+            out[name] = {"error": f"{type(exc).__name__}: {exc}"}
+    return out
 
 
 def worker(args, rank, world, local_rank):
@@ -278,19 +346,32 @@ def worker(args, rank, world, local_rank):
             copy_gbs = out_bw.value
     if args.warmup > 0:
         sim.run(config(args.warmup))
-    sync_all()
-    t0 = time.perf_counter()
-    sim.run(config(args.steps), wait=False)
-    enqueue_ms = (time.perf_counter() - t0) * 1e3
-    sim.synchronize()
-    own = time.perf_counter() - t0
-    if comm is not None:
-        comm.barrier()
-    elapsed = time.perf_counter() - t0
-    per_rank = [attempts_per_step * args.steps / own]
-    if comm is not None:
-        elapsed = comm.max_f64(elapsed)
-        per_rank = (attempts_per_step * args.steps / comm.all_gather(np.array([own]))).reshape(-1).tolist()
+    # The timed call -- EXACTLY args.steps steps between barrier + synchronise on both sides, max over ranks -- is made
+    # `repeats` times and the median is reported: a 20-step call lasts 1.3 ms, and one such sample scatters by several
+    # per cent with the host's scheduling (profiles/r02_fixed_cost.json).  Every repeat is a complete, separately
+    # bracketed measurement of the same K steps; nothing is skipped or carried between them.
+    repeats = max(1, args.repeats)
+    timings = []
+    timed_config = config(args.steps)  # (argument checking is not part of a step: built once, outside the timed region)
+    for _ in range(repeats):
+        sync_all()
+        t0 = time.perf_counter()
+        sim.run(timed_config, wait=False)
+        enqueue = (time.perf_counter() - t0) * 1e3
+        sim.synchronize()
+        own = time.perf_counter() - t0
+        if comm is not None:
+            comm.barrier()
+        elapsed = time.perf_counter() - t0
+        if comm is not None:
+            elapsed = comm.max_f64(elapsed)
+            own_all = comm.all_gather(np.array([own])).reshape(-1)
+        else:
+            own_all = np.array([own])
+        timings.append((elapsed, enqueue, own_all))
+    order = sorted(range(repeats), key=lambda k: timings[k][0])
+    elapsed, enqueue_ms, own_all = timings[order[(repeats - 1) // 2]]  # the median call (the lower one of an even count)
+    per_rank = (attempts_per_step * args.steps / own_all).tolist()
 
     # final observable exchange: per-realisation blocks, all-gathered over RCCL, aggregated in
     # realisation order (results.rs:165-282) so the result is independent of the GPU count
@@ -298,6 +379,22 @@ def worker(args, rank, world, local_rank):
     blocks = comm.gather_result_blocks(sim, n_per_gpu * world) if comm is not None else sim.result_blocks()
     gather_ms = (time.perf_counter() - t_gather) * 1e3
     mean = aggregate_mean(blocks)
+    # ... and the full result of the sharded run as distributed.sample assembles it on rank 0: every per-realisation
+    # array (P(q) histograms and conditional sums: 2.4 MB per realisation at this shape, tempering counters) gathered
+    # to the root in realisation order over the same communicator (pa_comm_gatherv)
+    full_gather_ms, full_gather_bytes = None, None
+    if comm is not None:
+        from peapods_amd.distributed import gather_parts
+
+        parts, _meta = sim.collect_parts(config(args.steps), True)
+        comm.barrier()
+        t_full = time.perf_counter()
+        gathered = gather_parts(parts, comm, root=0)
+        comm.barrier()
+        full_gather_ms = (time.perf_counter() - t_full) * 1e3
+        if rank == 0:
+            full_gather_bytes = int(sum(a.nbytes for a in gathered.values()))
+        del parts, gathered
 
     profiled = "overlap_cluster_update_interval" not in sample_kw
     kernels_ms = sim.profile_kernels(sim.make_config(args.profile_sweeps, "metropolis", warmup_ratio=0.0, pt_interval=1,
@@ -309,7 +406,7 @@ def worker(args, rank, world, local_rank):
         # (k_rng_overlap), so its algorithmic bytes (+0.125 B/attempt) count with it
         alg_bytes = (work["bytes"] + BYTES_OVERLAP) * attempts_per_step
         achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
-        counters = load_json("counters.json") if args.config == "c2" else None
+        counters, counters_stale = current_counters() if args.config == "c2" else (None, "collected for config c2 only")
         scale = n_per_gpu / 128.0
         out = {
             "metric": work["metric"],
@@ -319,6 +416,9 @@ def worker(args, rank, world, local_rank):
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "repeats": repeats,
+            "timing": f"median of {repeats} separately bracketed calls of exactly {args.steps} steps",
+            "ms_per_step_all_repeats": [t[0] / args.steps * 1e3 for t in timings],
             "host_enqueue_ms": enqueue_ms,
             "higher_is_better": True,
             "scaling": "weak",
@@ -349,6 +449,7 @@ def worker(args, rank, world, local_rank):
                 "frac_of_attainable": achieved / copy_gbs if copy_gbs else None,
                 "traffic": counters.get("hbm_bytes_per_sweep") * scale if counters else None,
                 "traffic_collected_at": counters.get("commit") if counters else None,
+                "traffic_null_reason": None if counters else counters_stale,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": kernels_ms,
                 "kernel_ms_protocol": "sweep pipeline of the timed protocol" if profiled else
@@ -356,8 +457,16 @@ def worker(args, rank, world, local_rank):
                 "limiter": valu_limiter(kernels_ms, scale) if args.config == "c2" else None,
             },
             "observable_allgather_ms": gather_ms,
+            "full_result_gather_ms": full_gather_ms,
+            "full_result_gather_bytes": full_gather_bytes,
+            "library": nat.lib().pa_version().decode(),
             "checksum_energy_mean": float(mean[3 * work["n_temps"]:4 * work["n_temps"]].sum()),
         }
+        if args.config == "c2" and world == 1 and not args.no_other_configs:
+            # the other BASELINE configs, measured in this same run after the headline's timed region (short:
+            # well under a second of GPU time each; their full runs are `--config c1`, `--config c4 --oc-mode ...`)
+            del sim
+            out["other_configs"] = other_configs(args, local_rank)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(work, couplings, temps, dynamics_seed,
                                                {k: v for k, v in sample_kw.items()}, args.cpu_seconds)

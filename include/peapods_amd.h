@@ -180,6 +180,16 @@ int pa_sim_get_energies(pa_sim *sim, uint64_t realization, float *out);
 int pa_sim_get_magnetization_sums(pa_sim *sim, uint64_t realization, int64_t *out);
 /* xoshiro256** state of one system's generator (Realization::rngs[system]) */
 int pa_sim_get_rng_state(pa_sim *sim, uint64_t realization, uint64_t system, uint64_t out[4]);
+/* ---- state setters (caller-owned buffers in the reference's layouts; validated before anything changes) ----
+ * The reference's kernels borrow the slices of a Realization (ss/mcmc/sweep.rs:220-229, ss/spins/energy.rs:43-48,
+ * ss/mcmc/tempering.rs:20-27), so a caller may hand over any state; these are that hand-over for a handle.
+ * spins: i8 +-1 [n_systems][n_spins] by system (the cached energies / magnetisation sums are recomputed);
+ * system_ids: [n_systems] slot -> system, a permutation inside every replica's ladder (spins, generators and cached
+ * sums stay with their systems, as in the reference, where only this array is permuted);
+ * rng state: the four words of Realization::rngs[system]. */
+int pa_sim_set_spins(pa_sim *sim, uint64_t realization, const int8_t *spins);
+int pa_sim_set_system_ids(pa_sim *sim, uint64_t realization, const uint64_t *system_ids);
+int pa_sim_set_rng_state(pa_sim *sim, uint64_t realization, uint64_t system, const uint64_t state[4]);
 /* PtState counters: edge_* [n_temps-1], round_trips [n_replicas*n_temps] by system */
 int pa_sim_get_pt_counters(pa_sim *sim, uint64_t realization, uint64_t *edge_attempts,
                            uint64_t *edge_acceptances, uint64_t *round_trips);

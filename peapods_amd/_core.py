@@ -309,6 +309,25 @@ class IsingSimulation:
         self._check(self._lib.pa_sim_get_rng_state(self._handle, realization, system, nat.ptr(out)))
         return out
 
+    # setters: the reference's kernels borrow a Realization's slices (sweep.rs:220-229), so a caller may arrange them
+    def set_spins(self, spins, realization=0):
+        arr = np.ascontiguousarray(spins, dtype=np.int8).reshape(-1)
+        if arr.size != self.n_systems * self.n_spins:
+            raise ValueError(f"spins must hold {self.n_systems} x {self.n_spins} values")
+        self._check(self._lib.pa_sim_set_spins(self._handle, realization, nat.ptr(arr)))
+
+    def set_system_ids(self, system_ids, realization=0):
+        arr = np.ascontiguousarray(system_ids, dtype=np.uint64).reshape(-1)
+        if arr.size != self.n_systems:
+            raise ValueError(f"system_ids must hold {self.n_systems} entries")
+        self._check(self._lib.pa_sim_set_system_ids(self._handle, realization, nat.ptr(arr)))
+
+    def set_rng_state(self, realization, system, state):
+        arr = np.ascontiguousarray(state, dtype=np.uint64).reshape(-1)
+        if arr.size != 4:
+            raise ValueError("a xoshiro256** state has four 64-bit words")
+        self._check(self._lib.pa_sim_set_rng_state(self._handle, realization, system, nat.ptr(arr)))
+
     def get_pt_counters(self, realization=0):
         n_edges = max(self.n_temps - 1, 0)
         attempts = np.zeros(max(n_edges, 1), dtype=np.uint64)

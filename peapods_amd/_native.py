@@ -83,6 +83,9 @@ SIGNATURES = {
     "pa_sim_get_energies": (C.c_int, [_vp, _u64, _vp]),
     "pa_sim_get_magnetization_sums": (C.c_int, [_vp, _u64, _vp]),
     "pa_sim_get_rng_state": (C.c_int, [_vp, _u64, _u64, _vp]),
+    "pa_sim_set_spins": (C.c_int, [_vp, _u64, _vp]),
+    "pa_sim_set_system_ids": (C.c_int, [_vp, _u64, _vp]),
+    "pa_sim_set_rng_state": (C.c_int, [_vp, _u64, _u64, _vp]),
     "pa_sim_get_pt_counters": (C.c_int, [_vp, _u64, _vp, _vp, _vp]),
     "pa_sim_get_result_moments": (C.c_int, [_vp, _u64, _vp]),
     "pa_sim_get_result_overlap": (C.c_int, [_vp, _u64, _vp]),

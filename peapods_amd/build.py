@@ -51,24 +51,58 @@ def _header_paths():
     return [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
 
 
-def needs_build():
-    return _newer(LIB, [os.path.join(CSRC, s) for s in SOURCES] + _header_paths())
+def source_hash():
+    """sha256 (12 hex digits) over the product sources in a fixed order: what libpeapods_amd.so was built from.
+    The library reports it (pa_version), profiles/counters.json records it at collection time, and bench.py prints
+    counter-derived figures only when the two agree."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in sorted(SOURCES) + sorted(HEADERS):
+        with open(os.path.join(CSRC, name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read() + b"\0")
+    return h.hexdigest()[:12]
+
+
+STAMP = os.path.join(OBJ, "build_stamp.txt")
+
+
+def _stamp(extra_flags):
+    return source_hash() + " " + " ".join(extra_flags)
+
+
+def needs_build(extra_flags=()):
+    """The library is missing, older than a source, or was built from other sources / with other flags (a
+    variant build with extra_flags leaves its stamp, so the next plain build() relinks the plain library)."""
+    if _newer(LIB, [os.path.join(CSRC, s) for s in SOURCES] + _header_paths()):
+        return True
+    try:
+        with open(STAMP) as fh:
+            return fh.read() != _stamp(extra_flags)
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=False, extra_flags=()):
-    if not force and not needs_build() and not extra_flags:
+    extra_flags = tuple(extra_flags)
+    if not force and not needs_build(extra_flags):
         return LIB
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
     tag = "".join(c if c.isalnum() else "_" for c in "".join(extra_flags))
+    digest = source_hash()
     jobs = []
     objects = []
     for src in SOURCES:
         path = os.path.join(CSRC, src)
-        obj = os.path.join(OBJ, os.path.splitext(src)[0] + tag + ".o")
+        # host_util.cpp carries pa_version(): its object is named after the source hash, so it is rebuilt (3 s)
+        # whenever any source changed
+        suffix = tag + ("_" + digest if src == "host_util.cpp" else "")
+        obj = os.path.join(OBJ, os.path.splitext(src)[0] + suffix + ".o")
         objects.append(obj)
+        defines = [f'-DPA_SOURCE_HASH="{digest}"'] if src == "host_util.cpp" else []
         if force or _newer(obj, [path] + _header_paths()):
-            jobs.append([cc, *FLAGS, *extra_flags, "-c", path, "-o", obj])
+            jobs.append([cc, *FLAGS, *extra_flags, *defines, "-c", path, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -78,6 +112,11 @@ def build(force=False, verbose=False, extra_flags=()):
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as pool:
         list(pool.map(run, jobs))
     run([cc, "--offload-arch=gfx950", "-fPIC", *LINK_FLAGS, "-o", LIB, *objects])
+    for name in os.listdir(OBJ):  # objects of older source hashes
+        if name.startswith("host_util") and name.endswith(".o") and os.path.join(OBJ, name) not in objects:
+            os.remove(os.path.join(OBJ, name))
+    with open(STAMP, "w") as fh:
+        fh.write(_stamp(extra_flags))
     return LIB
 
 

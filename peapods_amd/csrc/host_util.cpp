@@ -385,3 +385,11 @@ uint32_t build_levels(const LatticeTables &lat, std::vector<uint32_t> &level) {
 }
 
 } // namespace pa
+
+// The library's version string carries the hash of the sources it was built from (peapods_amd/build.py
+// source_hash): bench.py prints counter-derived figures only when profiles/counters.json was collected from the
+// same kernels.
+#ifndef PA_SOURCE_HASH
+#define PA_SOURCE_HASH "unknown"
+#endif
+extern "C" const char *pa_version(void) { return "peapods_amd 0.3 (gfx950) src:" PA_SOURCE_HASH; }

@@ -215,7 +215,7 @@ __device__ __forceinline__ void rng_chunk32_gibbs(Rng32 &rng, const uint32_t c[7
 template <bool PRESHIFTED, bool GIBBS, int REPLAY = 0>
 __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, uint32_t bid, uint32_t *tab,
                                           uint32_t first_parity = 0) {
-    // tab: [64 * 16 * 8] dwords of LDS for the block's jump table
+    // tab: [64 * 16 * 8] dwords of LDS for the block's jump table, then the replay scratch
     const uint32_t block = bid % d.B;
     const uint32_t group = bid / d.B;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -1280,7 +1280,17 @@ __device__ __forceinline__ void sweep_hc_block(const SimDims &d, const DevPtrs &
         HcSite cur;
         uint32_t wr_cur = spare, pl_cur = pl_addr, negm[6] = {0, 0, 0, 0, 0, 0};
         uint32_t nzm[6] = {0, 0, 0, 0, 0, 0}, rule[4] = {0, 0, 0, 0}; // diluted lattices: non-zero masks, the site's rule bits
-        auto fetch = [&](uint32_t b0, uint32_t b1) { // the pass whose positions are [b0, b1)
+        // A dependency level of a 16^3 lattice has 1 ... 192 sites (46 hyperplanes, 89 on average), so of the four
+        // waves of a set only ceil(sites / 64) have a site to update: 88 of 184 wave-passes.  The others skip the
+        // pass altogether -- a wave-uniform scalar branch to the barrier -- which halves the instructions this
+        // kernel issues in its pass loop (3.8 M of 7.8 M per launch of the bench ensemble) beside the VALU-bound
+        // random stream of the other stream group.
+        const uint32_t wave_first = __builtin_amdgcn_readfirstlane(lane & ~63u);
+        bool wave_live = false; // (uniform) this wave has a site in the pass `cur` describes
+        auto fetch = [&](uint32_t b0_v, uint32_t b1_v) { // the pass whose positions are [b0, b1)
+            const uint32_t b0 = __builtin_amdgcn_readfirstlane(b0_v), b1 = __builtin_amdgcn_readfirstlane(b1_v);
+            wave_live = b0 + wave_first < b1;
+            if (!wave_live) return;
             const uint32_t pos = b0 + lane;
             const bool active = pos < b1;
             cur = hc_decode<NN>(d, lds_load(tab_addr + (active ? pos : 0u) * 4), sw_addr);
@@ -1307,6 +1317,7 @@ __device__ __forceinline__ void sweep_hc_block(const SimDims &d, const DevPtrs &
             for (int k = 0; k < 2 * NN; ++k) asm volatile("" : "+v"(cur.nb[k]), "+v"(negm[k]));
         };
         auto compute = [&]() { // reads -> accept -> write: the chain between two barriers
+            if (!wave_live) return;
             const uint2 lv = lds_load2(pl_cur);
             const uint32_t l2 = GIBBS ? lds_load(hi_addr + cur.site4) : 0u;
             const uint32_t s = lds_load(cur.site);
@@ -1370,8 +1381,11 @@ __device__ __forceinline__ void sweep_hc_block(const SimDims &d, const DevPtrs &
     PA_HC_STAMP(5)
 }
 
+// Register budget of five waves per SIMD (<= 96 VGPRs; the compiler lands at 77 without spilling, against 123 when
+// given 128): a sweep workgroup's two waves per SIMD then fit beside THREE random-stream waves of 112 registers.
 template <int NN, bool STAMPS = false, bool GIBBS = false, bool DENSE = true>
-__global__ __launch_bounds__(512, 2) void k_sweep_hc(SimDims d, DevPtrs p, int with_energy, int do_sweep,
+__global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_per_eu(5))) void
+k_sweep_hc(SimDims d, DevPtrs p, int with_energy, int do_sweep,
                                                      unsigned long long *stamps) {
     extern __shared__ uint32_t lds[];
     sweep_hc_block<NN, STAMPS, GIBBS, DENSE>(d, p, blockIdx.x, with_energy, do_sweep, stamps, lds);
@@ -3158,7 +3172,7 @@ static uint32_t relay_reals_per_block(const SimDims &d) { return (2u * d.rng_wav
 
 bool rng_relay_supported(const SimDims &d) {
     return !d.general && !d.big && d.n_sys <= 512 && d.n_temps <= 256 && d.n_replicas <= 256 && 2 * d.W <= 256 &&
-           relay_reals_per_block(d) * d.n_replicas <= 256 && measure_lds_bytes(d) <= kRngLds;
+           relay_reals_per_block(d) * d.n_replicas <= 256 && measure_lds_bytes(d) <= 64 * 1024;
 }
 
 // full_ladder events are replayed too when a ladder's edges fit one mask word and the draws fit behind the jump table
@@ -3177,7 +3191,12 @@ hipError_t launch_rng_relay(const SimDims &d, const DevPtrs &p, bool with_overla
     const int replay = (n_measure && do_pt && d.n_temps >= 2) ? (pt.schedule != 0 ? 2 : 1) : 0; // 2: the whole ladder
     // behind the jump table: the replayed decisions (one word per ladder), or the ladders' draws and edge masks
     const size_t replay_words = replay == 2 ? static_cast<size_t>(relay_reals_per_block(d)) * d.n_replicas * (d.n_temps + 1) : 256;
-    const size_t lds = std::max(kRngLds + std::max<size_t>(1024, replay_words * 4), overlap_lds_bytes(d));
+    static const size_t lds_floor = [] { // (experiment knob: a larger reservation limits the workgroups per CU)
+        const char *env = std::getenv("PEAPODS_RNG_LDS");
+        return env ? static_cast<size_t>(std::strtol(env, nullptr, 10)) : 0;
+    }();
+    const size_t lds = std::max({kRngLds + std::max<size_t>(1024, replay_words * 4), n_overlap ? overlap_lds_bytes(d) : 0,
+                                 n_measure ? measure_lds_bytes(d) : 0, lds_floor});
     const dim3 grid(n_overlap + n_measure + groups * d.B), block(64 * d.rng_waves);
     const int a = do_accum ? 1 : 0, o = accum_overlap ? 1 : 0, t = do_pt ? 1 : 0;
 #define PA_RELAY(P, R, G) hipLaunchKernelGGL((k_rng_relay<P, R, G>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t)
@@ -3204,7 +3223,7 @@ hipError_t launch_rng_relay(const SimDims &d, const DevPtrs &p, bool with_overla
 hipError_t launch_measure_overlap(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_accum, bool accum_overlap,
                                   bool do_pt, hipStream_t stream) {
     const uint32_t n_overlap = d.n_real * d.W, n_measure = d.n_real;
-    const size_t lds = std::max(kRngLds + 1024, overlap_lds_bytes(d));
+    const size_t lds = std::max(overlap_lds_bytes(d), measure_lds_bytes(d));
     const dim3 grid(n_overlap + n_measure), block(256);
     const int a = do_accum ? 1 : 0, o = accum_overlap ? 1 : 0, t = do_pt ? 1 : 0;
     if (d.thr_preshifted) hipLaunchKernelGGL((k_rng_relay<true, false>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
@@ -3262,7 +3281,7 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
         return hipGetLastError();
     }
     if (d.hc && !no_hc) { // implicit neighbours, table in the LDS
-        const size_t lds_hc = sweep_hc_lds_bytes(d);
+        const size_t lds_hc = std::max(sweep_hc_lds_bytes(d), pad);
         const dim3 block_hc(512); // two sets of four waves take the passes in turn
 #define PA_HC(NN, D) hipLaunchKernelGGL((k_sweep_hc<NN, false, false, D>), grid, block_hc, lds_hc, stream, d, p, e, s, no_stamps)
         if (d.dense_nn == d.nn) {

@@ -860,9 +860,13 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             sim->equil_sweeps.push_back(cfg->n_sweeps);
         if (sim->equil_sweeps.size() > 64) return fail(sim, PA_ERR_UNSUPPORTED, "more than 64 equilibration checkpoints");
     }
-    // fork: every group stream starts after what is already queued on the main stream
-    PA_HIP(sim, hipEventRecord(sim->fork, sim->stream));
-    for (auto &g : sim->groups) PA_HIP(sim, hipStreamWaitEvent(g.stream, sim->fork, 0));
+    // fork: every group stream starts after what is already queued on the main stream -- if anything is: after a
+    // synchronised call the main stream is idle, and an event that every group's first kernel has to wait for would
+    // only put a marker packet's round trip through the command processor in front of a short call
+    if (hipStreamQuery(sim->stream) != hipSuccess) {
+        PA_HIP(sim, hipEventRecord(sim->fork, sim->stream));
+        for (auto &g : sim->groups) PA_HIP(sim, hipStreamWaitEvent(g.stream, sim->fork, 0));
+    }
     uint64_t overlap_call_count = 0; // mod.rs:300
     size_t equil_next = 0;
     // (the heat bath rides the same launches when its sweep runs on the implicit-neighbour kernel: three planes in LDS)
@@ -926,6 +930,9 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             // launch too: the random-stream workgroups replay the swap decisions and fetch their generators
             // from the slots the systems come from, so a sweep is two launches, not three.
             const bool relayed = relay && pending.any;
+            // (enqueue order: every group's random stream first, then every group's sweep -- a launch costs the host
+            // ~6 us, and in a short call the group enqueued second runs that much behind the first from its first
+            // kernel to its last: two launches behind with the order group by group, profiles/r03_timeline_20steps.txt)
             for (auto &g : sim->groups) {
                 if (relayed) {
                     PtParams q = pending.pt;
@@ -939,8 +946,8 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                     PA_HIP(sim, launch_rng(g.d, g.p, gibbs, g.stream));
                 }
                 if (overlap_owed) toggle_dots(g.p);
-                PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, record || pt_this, gibbs, g.stream));
             }
+            for (auto &g : sim->groups) PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, record || pt_this, gibbs, g.stream));
             if (relayed && pending.do_pt && d.n_temps >= 2) toggle_system_tables(sim);
             pending.any = false;
             sim->swaps_pending = false;
@@ -1235,7 +1242,6 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
 
 extern "C" {
 
-const char *pa_version(void) { return "peapods_amd 0.1 (gfx950)"; }
 
 int pa_device_count(void) {
     int n = 0;
@@ -2064,6 +2070,8 @@ void pa_sim_request_interrupt(pa_sim *sim) { sim->interrupt.store(true); }
 
 int pa_sim_synchronize(pa_sim *sim) {
     PA_HIP(sim, hipSetDevice(sim->device));
+    // the group streams first: the main stream only holds the join (one wait per group), which is done the moment they are
+    for (auto &g : sim->groups) PA_HIP(sim, hipStreamSynchronize(g.stream));
     PA_HIP(sim, hipStreamSynchronize(sim->stream));
     if (sim->d.pipe_K) { // a slab workgroup that gave up waiting leaves the state unusable: say so
         uint32_t gave_up = 0;
@@ -2461,6 +2469,103 @@ int pa_sim_get_rng_state(pa_sim *sim, uint64_t realization, uint64_t system, uin
     const uint32_t slot = slot_of[system];
     for (int w = 0; w < 4; ++w)
         out[w] = (static_cast<uint64_t>(cur[(2 * w + 1) * d.SP + slot]) << 32) | cur[(2 * w) * d.SP + slot];
+    return PA_OK;
+}
+
+// ---- state setters: the inner boundary in the other direction ------------------------------------------------
+// The reference's kernels run on slices a caller owns (mcmc/sweep.rs:220-229: spins, system_ids and rngs of a
+// Realization are plain borrowed buffers), so a caller may arrange them freely before a sweep -- its own test of the
+// permuted case does (sweep.rs:382-442: system_ids = [2, 0, 1]).  These three calls give a handle the same freedom.
+// All validate before touching anything.
+
+int pa_sim_set_spins(pa_sim *sim, uint64_t realization, const int8_t *spins) {
+    PA_CHECK_REAL(sim, realization);
+    const SimDims &d = sim->d;
+    for (size_t i = 0; i < static_cast<size_t>(d.n_sys) * d.N; ++i)
+        if (spins[i] != 1 && spins[i] != -1) return fail(sim, PA_ERR_INVALID, "spins must be +1 or -1");
+    PA_HIP(sim, hipSetDevice(sim->device));
+    if (int rc = flush_swaps(sim)) return rc;
+    std::vector<uint32_t> S, slot_of;
+    int rc;
+    const size_t tile_words = static_cast<size_t>(d.N) * d.W;
+    if ((rc = download(sim, S, sim->p.S + tile_words * realization, tile_words))) return rc;
+    if ((rc = download(sim, slot_of, sim->p.slot_of + d.n_sys * realization, d.n_sys))) return rc;
+    for (uint32_t sys = 0; sys < d.n_sys; ++sys) { // system-major in, bit column of the system's slot out
+        const uint32_t slot = slot_of[sys], bit = 1u << (slot & 31u);
+        uint32_t *word = S.data() + static_cast<size_t>(slot >> 5) * d.N;
+        const int8_t *src = spins + static_cast<size_t>(sys) * d.N;
+        for (uint32_t site = 0; site < d.N; ++site) word[site] = src[site] < 0 ? (word[site] | bit) : (word[site] & ~bit);
+    }
+    if ((rc = upload(sim, sim->p.S + tile_words * realization, S))) return rc;
+    // the cached energies and magnetisation sums follow the new state (Realization::new does the same, realization.rs:196-197)
+    PA_HIP(sim, launch_sweep(sim->d, sim->p, true, false, false, sim->stream));
+    return pa_sim_synchronize(sim);
+}
+
+int pa_sim_set_system_ids(pa_sim *sim, uint64_t realization, const uint64_t *system_ids) {
+    PA_CHECK_REAL(sim, realization);
+    const SimDims &d = sim->d;
+    std::vector<uint32_t> new_slot_of(d.n_sys, 0xFFFFFFFFu);
+    for (uint32_t slot = 0; slot < d.n_sys; ++slot) {
+        const uint64_t sys = system_ids[slot];
+        if (sys >= d.n_sys || new_slot_of[sys] != 0xFFFFFFFFu)
+            return fail(sim, PA_ERR_INVALID, "system_ids must be a permutation of 0..n_systems");
+        // a replica's ladder keeps its own systems (tempering.rs exchanges neighbours of one ladder only)
+        if (sys / d.n_temps != slot / d.n_temps)
+            return fail(sim, PA_ERR_INVALID, "system_ids must permute the systems of each replica among that replica's slots");
+        new_slot_of[sys] = slot;
+    }
+    PA_HIP(sim, hipSetDevice(sim->device));
+    if (int rc = flush_swaps(sim)) return rc;
+    // spins, generators and cached sums belong to systems: every system's bit column, cursor and sums move to its new slot
+    std::vector<uint32_t> S, old_slot_of, cur;
+    std::vector<int32_t> E, M;
+    int rc;
+    const size_t tile_words = static_cast<size_t>(d.N) * d.W, cur_words = static_cast<size_t>(8) * d.SP;
+    if ((rc = download(sim, S, sim->p.S + tile_words * realization, tile_words)) ||
+        (rc = download(sim, old_slot_of, sim->p.slot_of + d.n_sys * realization, d.n_sys)) ||
+        (rc = download(sim, cur, sim->p.cursor + cur_words * realization, cur_words)) ||
+        (rc = download(sim, E, sim->p.Esum + d.n_sys * realization, d.n_sys)) ||
+        (rc = download(sim, M, sim->p.Msum + d.n_sys * realization, d.n_sys)))
+        return rc;
+    std::vector<uint32_t> S2(S), cur2(cur), ids(d.n_sys);
+    std::vector<int32_t> E2(E), M2(M);
+    for (uint32_t sys = 0; sys < d.n_sys; ++sys) {
+        const uint32_t from = old_slot_of[sys], to = new_slot_of[sys];
+        ids[to] = sys;
+        E2[to] = E[from];
+        M2[to] = M[from];
+        for (int w = 0; w < 8; ++w) cur2[static_cast<size_t>(w) * d.SP + to] = cur[static_cast<size_t>(w) * d.SP + from];
+        const uint32_t *src = S.data() + static_cast<size_t>(from >> 5) * d.N;
+        uint32_t *dst = S2.data() + static_cast<size_t>(to >> 5) * d.N;
+        const uint32_t sb = from & 31u, bit = 1u << (to & 31u);
+        for (uint32_t site = 0; site < d.N; ++site) dst[site] = ((src[site] >> sb) & 1u) ? (dst[site] | bit) : (dst[site] & ~bit);
+    }
+    if ((rc = upload(sim, sim->p.S + tile_words * realization, S2)) ||
+        (rc = upload(sim, sim->p.cursor + cur_words * realization, cur2)) ||
+        (rc = upload(sim, sim->p.Esum + d.n_sys * realization, E2)) ||
+        (rc = upload(sim, sim->p.Msum + d.n_sys * realization, M2)) ||
+        (rc = upload(sim, sim->p.system_ids + d.n_sys * realization, ids)) ||
+        (rc = upload(sim, sim->p.slot_of + d.n_sys * realization, new_slot_of)))
+        return rc;
+    return PA_OK;
+}
+
+int pa_sim_set_rng_state(pa_sim *sim, uint64_t realization, uint64_t system, const uint64_t state[4]) {
+    PA_CHECK_REAL(sim, realization);
+    if (system >= sim->d.n_sys) return fail(sim, PA_ERR_INVALID, "system index out of range");
+    PA_HIP(sim, hipSetDevice(sim->device));
+    const SimDims &d = sim->d;
+    std::vector<uint32_t> slot_of;
+    if (int rc = download(sim, slot_of, sim->p.slot_of + d.n_sys * realization, d.n_sys)) return rc;
+    const uint32_t slot = slot_of[system];
+    uint32_t *cur = sim->p.cursor + static_cast<size_t>(realization) * 8 * d.SP;
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t lo = static_cast<uint32_t>(state[w]), hi = static_cast<uint32_t>(state[w] >> 32);
+        PA_HIP(sim, hipMemcpyAsync(cur + static_cast<size_t>(2 * w) * d.SP + slot, &lo, 4, hipMemcpyHostToDevice, sim->stream));
+        PA_HIP(sim, hipMemcpyAsync(cur + static_cast<size_t>(2 * w + 1) * d.SP + slot, &hi, 4, hipMemcpyHostToDevice, sim->stream));
+        PA_HIP(sim, hipStreamSynchronize(sim->stream)); // (lo / hi live on this frame)
+    }
     return PA_OK;
 }
 

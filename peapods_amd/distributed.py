@@ -400,7 +400,7 @@ def gather_parts(parts, comm, root=None):
     ranks in rank order = global realisation order for contiguous shards.  Every rank must hold the same set of
     arrays (same sample configuration); a digest of names, dtypes and row shapes is compared first, so a mismatch
     raises on every rank instead of hanging in a collective.  With `root` only that rank receives data."""
-    keys = sorted(parts)
+    keys = list(parts)  # (collect_parts files them in one order on every rank; the result dictionary keeps it)
     described = "|".join(f"{k}:{np.asarray(parts[k]).dtype.str}:{np.asarray(parts[k]).shape[1:]}" for k in keys)
     digest = np.array([[zlib.crc32(described.encode())]], dtype=np.uint64)
     if not (comm.gather_rows(digest) == digest[0, 0]).all():

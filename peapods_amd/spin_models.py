@@ -58,7 +58,11 @@ class Ising:
 
     def __init__(self, lattice_shape, couplings="ferro", temperatures=_DEFAULT_TEMPERATURES,
                  n_replicas=1, n_disorder=1, neighbor_offsets=None, geometry=None, seed=None,
-                 device=0):
+                 device=0, comm=None):
+        """`comm` (not in the reference, which is one process): an exchange of peapods_amd.distributed (`Comm` =
+        RCCL, one rank per GPU).  The n_disorder realisations are then sharded over its ranks -- this rank
+        builds and runs only its own -- and `sample()` returns, on every rank, the result over all of them,
+        bit-identical to a single-GPU run of the same arguments."""
         if geometry is not None:
             if neighbor_offsets is not None:
                 raise ValueError("Cannot specify both geometry and neighbor_offsets")
@@ -79,16 +83,28 @@ class Ising:
         self.seed = seed
         coupling_seq, self._constructor_dynamics_seed = seed_material(seed)
 
+        self._comm = comm
+        first, stop = 0, n_disorder
+        if comm is not None:
+            from .distributed import shard_range
+
+            if n_disorder < comm.world:
+                raise ValueError(f"n_disorder = {n_disorder} realisations cannot be sharded over {comm.world} ranks")
+            first, stop = shard_range(n_disorder, comm.rank, comm.world)
         if isinstance(couplings, np.ndarray):
             coup = couplings.astype(np.float32)
+            if comm is not None:
+                if coup.ndim != len(self.lattice_shape) + 2 or coup.shape[0] != n_disorder:
+                    raise ValueError("with comm, explicit couplings must have shape (n_disorder, *lattice, z')")
+                coup = coup[first:stop]
         else:
             samples = generate_couplings(couplings, self.lattice_shape, self.n_neighbors,
-                                         n_disorder, coupling_seq)
+                                         n_disorder, coupling_seq, realizations=range(first, stop))
             coup = samples[0] if n_disorder == 1 else np.stack(samples)
-        self.couplings = coup
+        self.couplings = coup  # (with comm: this rank's shard)
         self._sim = IsingSimulation(list(lattice_shape), coup, self.temperatures, n_replicas,
                                     neighbor_offsets, self._constructor_dynamics_seed,
-                                    device=device)
+                                    device=device, first_realization=first)
 
     def reset(self, seed=None):
         """Replay the constructor's dynamics, or a one-off seeded reset; couplings stay."""
@@ -121,7 +137,15 @@ class Ising:
             )
 
         oci = overlap_cluster_update_interval
-        result = self._sim.sample(
+        if self._comm is not None:
+            from functools import partial
+
+            from . import distributed
+
+            run = partial(distributed.sample, self._sim, self._comm)
+        else:
+            run = self._sim.sample
+        result = run(
             n_sweeps,
             sweep_mode,
             cluster_update_interval=cluster_update_interval,

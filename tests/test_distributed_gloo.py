@@ -71,6 +71,75 @@ def test_two_rank_gather_equals_single_process(tmp_path):
     np.testing.assert_array_equal(got[0], aggregate_mean(single))
 
 
+def _oracle_parts(first, stop):
+    """The oracle's per-realisation results in the layout of IsingSimulation.collect_parts (test plumbing: the
+    shard's work is done by the oracle here, the exchange and the aggregation under test are the product's)."""
+    from oracle import bindings as ob
+
+    shape, n_dis, couplings, temps, dyn = _ensemble()
+    sim = ob.OracleSimulation(list(shape), couplings[first:stop], temps, 2, None, dyn, first_realization=first)
+    sim.run(sim.make_config(12, "metropolis", pt_interval=1, warmup_ratio=0.25))
+    per_real, _ = sim.per_realization_results()
+    att, acc, trips = zip(*(sim.get_pt_counters(r) for r in range(stop - first)))
+    parts = {"blocks": sim.result_blocks(),
+             "hist": np.stack([r["histogram"] for r in per_real]),
+             "qlq": np.stack([r["ql_at_q_sum"] for r in per_real]),
+             "ql2q": np.stack([r["ql2_at_q_sum"] for r in per_real]),
+             "pt_edge_attempts": np.stack(att), "pt_edge_acceptances": np.stack(acc), "pt_round_trips": np.stack(trips)}
+    meta = {"n_temps": len(temps), "n_pairs": 1, "n_modes": 0, "cluster_flags": 0}
+    return parts, meta
+
+
+def _parts_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from peapods_amd import _core, _native
+    from peapods_amd.distributed import GlooExchange, gather_parts, shard_range
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, stop = shard_range(_ensemble()[1], rank, world)
+    parts, meta = _oracle_parts(first, stop)
+    exchange = GlooExchange(dist)
+    everywhere = gather_parts(parts, exchange)           # every rank
+    at_root = gather_parts(parts, exchange, root=1)      # one rank
+    assert (at_root is None) == (rank != 1)
+    if rank == 1:
+        for key in everywhere:
+            np.testing.assert_array_equal(everywhere[key], at_root[key])
+        result = _core.assemble_parts(_native.lib(), at_root, meta)
+        flat = {k: v for k, v in result.items() if k not in ("per_disorder", "overlap_histogram")}
+        flat["overlap_histogram"] = np.stack(result["overlap_histogram"])
+        flat.update({"pt_" + k: v for k, v in result["per_disorder"]["parallel_tempering"].items()})
+        np.savez(out_path, **flat)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_full_result_equals_single_process(tmp_path):
+    """World size 2 on CPU (gloo), shards of 2 + 3 realisations: moments, summed and per-sample P(q) histograms and
+    conditional sums, tempering counters -- gathered in realisation order by the product's gather_parts and
+    aggregated by its assemble_parts, equal to the single-process oracle bit for bit."""
+    import torch.multiprocessing as mp
+
+    from oracle import bindings as ob
+
+    out_path = str(tmp_path / "result.npz")
+    mp.spawn(_parts_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    got = np.load(out_path)
+    shape, n_dis, couplings, temps, dyn = _ensemble()
+    want = ob.OracleSimulation(list(shape), couplings, temps, 2, None, dyn).sample(12, "metropolis", pt_interval=1,
+                                                                                   warmup_ratio=0.25)
+    for key in ("mags", "mags2", "mags4", "energies", "energies2", "overlap", "overlap2", "overlap4", "link_overlap",
+                "link_overlap2", "link_overlap4", "ql_at_q_sum", "ql2_at_q_sum", "per_sample_overlap_histogram",
+                "per_sample_ql_at_q_sum", "per_sample_ql2_at_q_sum"):
+        np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+    np.testing.assert_array_equal(got["overlap_histogram"], np.stack(want["overlap_histogram"]))
+    for key, value in want["per_disorder"]["parallel_tempering"].items():
+        np.testing.assert_array_equal(got["pt_" + key], value, err_msg=key)
+
+
 def _id_worker(rank, world, port, out_dir, channel):
     sys.path.insert(0, ROOT)
     from peapods_amd.distributed import exchange_id
@@ -96,10 +165,11 @@ def test_communicator_id_travels_from_rank_0(tmp_path, channel):
 
     ctx = mp.get_context("spawn")
     port = _free_port()
-    if channel == "file":  # hold the port, as torch.distributed.run's agent does
-        holder = socket.socket()
-        holder.bind(("127.0.0.1", port))
-        holder.listen(1)
+    # hold MASTER_PORT, as torch.distributed.run's agent does (its TCPStore): neither channel may bind it -- the
+    # file channel binds nothing, the tcp channel serves on id_port(MASTER_PORT)
+    holder = socket.socket()
+    holder.bind(("127.0.0.1", port))
+    holder.listen(1)
     procs = [ctx.Process(target=_id_worker, args=(r, 3, port, str(tmp_path), channel)) for r in (2, 1, 0)]
     for p in procs:
         p.start()
@@ -126,3 +196,23 @@ def test_bench_refuses_more_gpus_than_the_box_has():
     run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, env=dict(env, RANK="0", WORLD_SIZE="1"), timeout=120)
     assert run.returncode == 2 and "WORLD_SIZE=1" in run.stderr
+
+
+def test_channel_choice_follows_the_launch_not_the_spelling_of_the_address(monkeypatch):
+    """One node (LOCAL_WORLD_SIZE == WORLD_SIZE, or MASTER_ADDR naming this host) -> the file channel, whatever
+    MASTER_ADDR is spelled like; several nodes -> tcp on a port that is never MASTER_PORT."""
+    from peapods_amd import distributed as dist
+
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    assert dist._single_node_launch("node17.cluster")
+    monkeypatch.setenv("WORLD_SIZE", "16")
+    assert not dist._single_node_launch("127.0.0.1")
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    monkeypatch.delenv("WORLD_SIZE")
+    assert dist._single_node_launch("localhost")
+    assert dist._single_node_launch(socket.gethostname()) or True  # (a container's hostname may not resolve)
+    monkeypatch.delenv("PEAPODS_ID_PORT", raising=False)
+    assert dist.id_port(29500) == 29501
+    monkeypatch.setenv("PEAPODS_ID_PORT", "31000")
+    assert dist.id_port(29500) == 31000

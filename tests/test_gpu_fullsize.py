@@ -60,6 +60,24 @@ def test_full_ensemble_properties(oracle):
         np.testing.assert_array_equal(alone.get_system_ids(0), full.get_system_ids(r))
         np.testing.assert_array_equal(alone.result_blocks()[0], full.result_blocks()[r])
 
+    # (1b) the handle the benchmark times, directly against the oracle: realisations on both sides of the
+    # stream-group split (64 realisations per group) and the two ends, every state array and every result
+    for r in (0, 63, 64, 127):
+        cpu = oracle.OracleSimulation(list(SHAPE), couplings[r:r + 1], temps, N_REP, None, dyn, first_realization=r)
+        want = cpu.sample(n_sweeps, "metropolis", pt_interval=1, warmup_ratio=0.0)
+        np.testing.assert_array_equal(full.get_spins(r), cpu.get_spins(0))
+        np.testing.assert_array_equal(full.get_system_ids(r), cpu.get_system_ids(0))
+        np.testing.assert_array_equal(full.get_energies(r), cpu.get_energies(0))
+        for s in range(N_TEMPS * N_REP):
+            np.testing.assert_array_equal(full.get_rng_state(r, s), cpu.get_rng_state(0, s))
+        np.testing.assert_array_equal(full.result_blocks()[r], cpu.result_blocks()[0])
+        np.testing.assert_array_equal(result["per_sample_overlap_histogram"][r], np.stack(want["overlap_histogram"]))
+        np.testing.assert_array_equal(result["per_sample_ql_at_q_sum"][r], want["ql_at_q_sum"])
+        np.testing.assert_array_equal(result["per_sample_ql2_at_q_sum"][r], want["ql2_at_q_sum"])
+        pt_full, pt_one = result["per_disorder"]["parallel_tempering"], want["per_disorder"]["parallel_tempering"]
+        for key in pt_full:
+            np.testing.assert_array_equal(pt_full[key][r], pt_one[key][0], err_msg=key)
+
     # (2) energies / magnetisation recomputed from the downloaded spins (energy.rs:92-109)
     lib = oracle.load()
     lat = oracle.Lattice(list(SHAPE))
@@ -224,3 +242,51 @@ def test_config4_overlap_moves_at_full_size(oracle, build, inner):
         np.testing.assert_array_equal(gpu.get_system_ids(r), cpu.get_system_ids(r))
         for s in (0, 17, 95):
             np.testing.assert_array_equal(gpu.get_rng_state(r, s), cpu.get_rng_state(r, s))
+
+
+def _assert_realization_equals_oracle(full, result, r, cpu, want, n_sys):
+    np.testing.assert_array_equal(full.get_spins(r), cpu.get_spins(0))
+    np.testing.assert_array_equal(full.get_system_ids(r), cpu.get_system_ids(0))
+    for s in range(n_sys):
+        np.testing.assert_array_equal(full.get_rng_state(r, s), cpu.get_rng_state(0, s))
+    np.testing.assert_array_equal(full.result_blocks()[r], cpu.result_blocks()[0])
+    np.testing.assert_array_equal(result["per_sample_overlap_histogram"][r], np.stack(want["overlap_histogram"]))
+    np.testing.assert_array_equal(result["per_sample_ql_at_q_sum"][r], want["ql_at_q_sum"])
+    pt_full, pt_one = result["per_disorder"]["parallel_tempering"], want["per_disorder"]["parallel_tempering"]
+    for key in pt_full:
+        np.testing.assert_array_equal(pt_full[key][r], pt_one[key][0], err_msg=key)
+
+
+def test_full_ensemble_with_the_full_ladder_schedule_matches_oracle(oracle):
+    """The 128-realisation handle of the benchmark with `full_ladder` tempering (the whole ladder replayed by the
+    random-stream workgroups): realisations at both ends and on both sides of the stream-group split, each against
+    an oracle run of that realisation alone (seeds by global index)."""
+    n_sweeps = 24
+    full, couplings, temps, dyn = ensemble(128)
+    kw = dict(pt_interval=1, pt_schedule="full_ladder", warmup_ratio=0.25)
+    result = full.sample(n_sweeps, "metropolis", **kw)
+    for r in (0, 63, 64, 127):
+        cpu = oracle.OracleSimulation(list(SHAPE), couplings[r:r + 1], temps, N_REP, None, dyn, first_realization=r)
+        want = cpu.sample(n_sweeps, "metropolis", **kw)
+        _assert_realization_equals_oracle(full, result, r, cpu, want, N_TEMPS * N_REP)
+
+
+@pytest.mark.parametrize("build,inner", [("houdayer", "wolff"), ("jorg", "wolff")])
+def test_config4_full_ensemble_matches_oracle(oracle, build, inner):
+    """BASELINE configs[4] as `bench.py --config c4` runs it: 12^3 +-J, 24 T x 4 replicas x 128 disorder with the
+    overlap-cluster move every sweep; two realisations of the 128-realisation handle against the oracle."""
+    from peapods_amd import IsingSimulation
+    from peapods_amd.spin_models import generate_couplings, seed_material
+
+    shape = (12, 12, 12)
+    seq, dyn = seed_material(42)
+    couplings = np.stack(generate_couplings("bimodal", shape, 3, 128, seq))
+    temps = np.linspace(0.8, 1.4, N_TEMPS).astype(np.float32)
+    full = IsingSimulation(list(shape), couplings, temps, N_REP, None, dyn)
+    kw = dict(pt_interval=1, warmup_ratio=0.0, overlap_cluster_update_interval=1, overlap_cluster_build_mode=build,
+              overlap_cluster_mode=inner)
+    result = full.sample(12, "metropolis", **kw)
+    for r in (37, 127):
+        cpu = oracle.OracleSimulation(list(shape), couplings[r:r + 1], temps, N_REP, None, dyn, first_realization=r)
+        want = cpu.sample(12, "metropolis", **kw)
+        _assert_realization_equals_oracle(full, result, r, cpu, want, N_TEMPS * N_REP)

@@ -726,3 +726,101 @@ def test_unbuilt_overlap_modes_are_refused_not_emulated():
     with pytest.raises(ValueError, match="n_replicas >= max group_size"):
         sim.sample(2, "metropolis", overlap_cluster_update_interval=1, overlap_cluster_build_mode="houd4")
     np.testing.assert_array_equal(sim.get_spins(), before)
+
+
+# ---- state setters: the inner boundary in the other direction (sweep.rs:220-229 borrows the caller's slices) ----
+@pytest.mark.parametrize("offsets", [None, [[1, 0], [0, 1]]])
+def test_unit_lookup_with_permuted_systems_on_the_device(oracle, offsets):
+    """The reference's own permuted-systems test (mcmc/sweep.rs:382-442) on the HIP path: 8 x 8, couplings cycling
+    -1, 0, +1, temperatures 0.7 / 2.0 / 5.0, system_ids = [2, 0, 1], spins -1 at every fifth index, generators seeded
+    71, 72, 73, twenty Metropolis sweeps -- state handed over with pa_sim_set_spins / set_rng_state / set_system_ids,
+    compared with the oracle's slice-level sweep (table path and logarithm path agree there, test_oracle_kat.py)."""
+    import ctypes as C
+
+    from peapods_amd import IsingSimulation
+    from peapods_amd import _native as nat
+
+    lib = oracle.load()
+    lat = oracle.Lattice([8, 8], offsets=offsets)
+    n = lat.n_spins
+    couplings = np.array([[-1.0, 0.0, 1.0][i % 3] for i in range(n * lat.n_neighbors)], np.float32)
+    temps = np.array([0.7, 2.0, 5.0], dtype=np.float32)
+    system_ids = np.array([2, 0, 1], dtype=np.uint64)
+    initial = np.array([-1 if i % 5 == 0 else 1 for i in range(3 * n)], dtype=np.int8)
+
+    gpu = IsingSimulation([8, 8], couplings.reshape(8, 8, 2), temps, 1, offsets, 5)
+    gpu.set_spins(initial)
+    for system, seed in enumerate((71, 72, 73)):
+        state = np.zeros(4, dtype=np.uint64)
+        nat.lib().pa_xoshiro_state(seed, 0, nat.ptr(state))
+        gpu.set_rng_state(0, system, state)
+    gpu.set_system_ids(system_ids)
+    np.testing.assert_array_equal(gpu.get_spins(0), initial)            # spins stay with their systems
+    np.testing.assert_array_equal(gpu.get_system_ids(0), system_ids)
+
+    want_spins = initial.copy()
+    rngs = oracle.make_rngs([71, 72, 73])
+    lookup = lib.orc_lookup_new(couplings.ctypes.data_as(C.c_void_p), len(couplings), temps.ctypes.data_as(C.c_void_p), 3,
+                                lat.n_neighbors)
+    energies = np.zeros(3, dtype=np.float32)
+    lib.orc_compute_energies(lat.handle, want_spins.ctypes.data, couplings.ctypes.data, 3, energies.ctypes.data, None, None)
+    np.testing.assert_array_equal(gpu.get_energies(0), energies)         # recomputed by set_spins
+    for _ in range(20):
+        lib.orc_metropolis_sweep(lat.handle, want_spins.ctypes.data_as(C.c_void_p), couplings.ctypes.data_as(C.c_void_p),
+                                 temps.ctypes.data_as(C.c_void_p), system_ids.ctypes.data_as(C.c_void_p), 3,
+                                 C.byref(rngs), lookup)
+    lib.orc_lookup_free(lookup)
+    gpu.metropolis_sweep(20)
+    np.testing.assert_array_equal(gpu.get_spins(0), want_spins)
+    assert not np.array_equal(want_spins, initial)
+    for system in range(3):
+        got = gpu.get_rng_state(0, system)
+        assert [int(x) for x in got] == [int(x) for x in rngs[system].s]
+
+
+def test_setters_validate_before_touching_anything():
+    from peapods_amd import IsingSimulation
+
+    rng = np.random.default_rng(3)
+    couplings = (2 * rng.integers(0, 2, size=(4, 4, 4, 3)) - 1).astype(np.float32)
+    gpu = IsingSimulation([4, 4, 4], couplings, np.linspace(1.0, 2.0, 3).astype(np.float32), 2, None, 9)
+    before = gpu.get_spins(0).copy()
+    ids_before = gpu.get_system_ids(0).copy()
+    bad = before.copy()
+    bad[7] = 0
+    with pytest.raises(ValueError, match="spins must be"):
+        gpu.set_spins(bad)
+    with pytest.raises(ValueError, match="permutation"):
+        gpu.set_system_ids([0, 0, 2, 3, 4, 5])
+    with pytest.raises(ValueError, match="each replica"):
+        gpu.set_system_ids([3, 1, 2, 0, 4, 5])   # systems of different replica ladders exchanged
+    with pytest.raises(ValueError):
+        gpu.set_rng_state(0, 6, [1, 2, 3, 4])
+    np.testing.assert_array_equal(gpu.get_spins(0), before)
+    np.testing.assert_array_equal(gpu.get_system_ids(0), ids_before)
+
+
+def test_set_system_ids_then_sample_matches_an_oracle_that_reached_the_same_state(oracle):
+    """A permutation the tempering dynamics themselves produce: run both engines, read the GPU state back, rebuild it
+    on a FRESH handle through the setters, continue both -- the continued trajectories must agree."""
+    shape, temps = (4, 4, 4), np.linspace(0.9, 2.5, 5).astype(np.float32)
+    couplings = bimodal(shape, 3, 1, 21)
+    gpu, cpu = make_pair(oracle, shape, couplings, temps, 2, 77)
+    kw = dict(pt_interval=1, warmup_ratio=0.0)
+    gpu.sample(30, "metropolis", **kw)
+    cpu.sample(30, "metropolis", **kw)
+    ids = gpu.get_system_ids(0)
+    assert not np.array_equal(ids, np.arange(10))   # the ladder has moved
+    from peapods_amd import IsingSimulation
+
+    fresh = IsingSimulation(list(shape), couplings, temps, 2, None, 123456)  # another seed: everything is overwritten
+    fresh.set_spins(gpu.get_spins(0))
+    for s in range(10):
+        fresh.set_rng_state(0, s, gpu.get_rng_state(0, s))
+    fresh.set_system_ids(ids)
+    assert_state_equal(fresh, cpu)
+    fresh.metropolis_sweep(7)
+    gpu.metropolis_sweep(7)
+    np.testing.assert_array_equal(fresh.get_spins(0), gpu.get_spins(0))
+    for s in range(10):
+        np.testing.assert_array_equal(fresh.get_rng_state(0, s), gpu.get_rng_state(0, s))

@@ -3281,7 +3281,11 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
         return hipGetLastError();
     }
     if (d.hc && !no_hc) { // implicit neighbours, table in the LDS
-        const size_t lds_hc = std::max(sweep_hc_lds_bytes(d), pad);
+        // One sweep workgroup per CU while the launch has no more of them than the chip has CUs (a stream group of the
+        // bench ensemble: 192): two on one CU share its LDS pipeline and SIMDs and stretch each other's passes (96
+        // workgroups 17.5 us, 192 workgroups 23.5 us per launch; reserving 82 KB: 58.0 -> 57.4 us per step).
+        const size_t alone = (do_sweep && grid.x <= 256) ? 82 * 1024 : 0;
+        const size_t lds_hc = std::max({sweep_hc_lds_bytes(d), pad, alone});
         const dim3 block_hc(512); // two sets of four waves take the passes in turn
 #define PA_HC(NN, D) hipLaunchKernelGGL((k_sweep_hc<NN, false, false, D>), grid, block_hc, lds_hc, stream, d, p, e, s, no_stamps)
         if (d.dense_nn == d.nn) {

@@ -250,7 +250,7 @@ def valu_limiter(kernels_ms, scale):
     Wave-instruction counts per launch are SQ_INSTS_VALU of the committed PMC pass (they scale with the ensemble
     and do not depend on the data); null when that pass was collected from other kernel sources."""
     counters, stale = current_counters()
-    probe = load_json("r02_valu_issue.json")
+    probe = load_json("r03_valu_issue.json") or load_json("r02_valu_issue.json")
     if not probe:
         return None
     if not counters:
@@ -272,7 +272,7 @@ def valu_limiter(kernels_ms, scale):
                                  f"{clock.get('rng_step_full', 2400)} MHz the probe observed",
             "frac_of_guide_peak": fracs(peak_guide),
             "peak_probe_wave_insts_per_s": peak_probe,
-            "peak_probe_source": "profiles/r02_valu_issue.json: rng_step_full at 8 waves/SIMD (tools/probe/valu_issue.hip)",
+            "peak_probe_source": "profiles/r03_valu_issue.json: rng_step_full at 8 waves/SIMD (tools/probe/valu_issue.hip; disassembly: tools/probe/valu_issue_excerpt.s)",
             "frac_of_probe_peak": fracs(peak_probe)}
 
 

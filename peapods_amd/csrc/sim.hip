@@ -123,6 +123,11 @@ struct pa_sim {
         uint32_t fresh = 3; // see pa_sim::fresh
     };
     std::vector<Group> groups;
+    // Two consecutive steady-state sweeps of the plain protocol captured as one hipGraph per stream group (run_sweeps):
+    // the four dependent launches of a pair then cost the graph's 1.6 us per hop instead of the stream's 2.8 us
+    // (build_probe/gaps.hip).  `graph_key` hashes every kernel argument of the pair; a mismatch recaptures.
+    std::vector<hipGraphExec_t> pair_graphs;
+    uint64_t graph_key = 0;
     // Running sums are never memset between sample() calls: bit 0 (moments) / bit 1 (overlap moments, P(q)
     // bitmap) says that the next accumulating k_measure launch starts them from zero (PtParams::fresh).  One
     // copy per stream group (run_sweeps) and one for whole-ensemble launches (pa_sim_profile_kernels).
@@ -893,6 +898,148 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     // The sweeps are enqueued inside a lambda so that every failure (a HIP error, an interrupt) leaves
     // through the join below: the main stream always waits for the group streams before anything else
     // -- a getter, a reset, the next call -- touches the buffers.
+    // One sweep of the plain protocol on the on-chip kernels: its launches (launch = true) and the host's bookkeeping --
+    // buffer roles, the pending measurement block, counters.  With launch = false only the bookkeeping runs: the launches
+    // are being replayed from a captured graph (graph_pair).
+    auto fused_sweep = [&](uint64_t sweep_id, bool launch) -> int {
+        const bool record = sweep_id >= cfg->warmup_sweeps; // mod.rs:410
+        const bool pt_this = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0; // :486-488
+        // Plain protocol on the LDS kernels: the overlap of the state sweep s-1 left is measured
+        // inside the launch that draws the random stream of sweep s, and its statistics are
+        // accumulated by the measurement block of sweep s.  Every accumulator still receives
+        // its values in sweep order, so the f64 sums are unchanged.
+        // With `relay` the measurement block of sweep s-1 (statistics + tempering event) rides in that
+        // launch too: the random-stream workgroups replay the swap decisions and fetch their generators
+        // from the slots the systems come from, so a sweep is two launches, not three.
+        const bool relayed = relay && pending.any;
+        // (enqueue order: every group's random stream first, then every group's sweep -- a launch costs the host
+        // ~6 us, and in a short call the group enqueued second runs that much behind the first from its first
+        // kernel to its last: two launches behind with the order group by group, profiles/r03_timeline_20steps.txt)
+        for (auto &g : sim->groups) {
+            if (relayed) {
+                PtParams q = pending.pt;
+                q.relay = 1;
+                q.fresh = consume_fresh(g.fresh, g.d, pending.do_accum, pending.accum_overlap);
+                if (launch)
+                    PA_HIP(sim, launch_rng_relay(g.d, g.p, overlap_owed, q, pending.do_accum, pending.accum_overlap,
+                                                 pending.do_pt, g.stream, gibbs));
+            } else if (overlap_owed) {
+                if (launch) PA_HIP(sim, launch_rng_overlap(g.d, g.p, g.stream, gibbs));
+            } else {
+                if (launch) PA_HIP(sim, launch_rng(g.d, g.p, gibbs, g.stream));
+            }
+            if (overlap_owed) toggle_dots(g.p);
+        }
+        if (launch)
+            for (auto &g : sim->groups) PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, record || pt_this, gibbs, g.stream));
+        if (relayed && pending.do_pt && d.n_temps >= 2) toggle_system_tables(sim);
+        pending.any = false;
+        sim->swaps_pending = false;
+        toggle_spin_buffers(sim);
+        PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
+        if (autocorr) { // this sweep's m^2 sample; the q^2 sample of the sweep whose overlap is accumulated with it
+            pt.ac_index = record ? static_cast<uint32_t>(sim->n_recorded + 1) : 0u;
+            pt.ac_index_q = overlap_owed ? static_cast<uint32_t>(sim->n_recorded) : 0u;
+            pt.ac_stride = static_cast<uint32_t>(sim->ac_capacity);
+        }
+        if (record || pt_this || overlap_owed) {
+            if (relay) { // deferred into the next sweep's launch (or the tail of the run)
+                pending.any = true;
+                pending.pt = pt;
+                pending.do_accum = record;
+                pending.accum_overlap = overlap_owed;
+                pending.do_pt = pt_this;
+            } else {
+                for (auto &g : sim->groups) // (never on the graph path: it requires `relay`)
+                    PA_HIP(sim, measure_launch(g.fresh, g.d, g.p, pt, record, overlap_owed, pt_this, g.stream));
+                if (pt_this) sim->swaps_pending = true;
+            }
+        }
+        overlap_owed = record;
+        if (record) sim->n_recorded += 1;
+        if (pt_this && cfg->pt_schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
+        return PA_OK;
+    };
+    // A pair of consecutive steady-state sweeps (every flag of both equal to the pair before: recorded, tempering event
+    // every sweep, measurement relayed, accumulators past their first store) as ONE graph launch per stream group.  The
+    // first such pair of a handle is captured from the ordinary launch code (stream capture on every group's stream)
+    // and instantiated; `graph_key` hashes every argument the captured kernels received -- SimDims, all device
+    // pointers (their double-buffer roles return after two sweeps), the tempering parameters -- and a later pair with
+    // another key (a Gibbs call after a Metropolis one, the other ladder parity, reallocated buffers) is captured afresh.
+    constexpr int kGraphDeclined = -1;
+    // Measured on the bench ensemble and NOT adopted (opt-in: PEAPODS_GRAPH=1, kept exact by test_gpu_robustness.py):
+    // steady state 57.6 -> 59.0 us per step, 20-step calls 64 -> 79 us per step.  hipGraphLaunch costs the host ~25 us
+    // on this stack (two launches per pair and group: 0.58 ms of enqueueing per 20 steps against 0.41 ms launch by
+    // launch), and the dependent-launch hop it shortens in an empty-kernel chain (1.6 against 2.8 us,
+    // build_probe/gaps.hip) is not what separates these kernels: most of the ~5 us before a large kernel's first wave
+    // is its own wave-launch ramp.
+    const bool graph_enabled = fused && relay && std::getenv("PEAPODS_GRAPH") != nullptr && cfg->pt_interval == 1;
+    auto pair_key = [&]() -> uint64_t {
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](const void *ptr, size_t n) {
+            const unsigned char *b = static_cast<const unsigned char *>(ptr);
+            for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+        };
+        for (auto &g : sim->groups) {
+            mix(&g.d, sizeof(g.d));
+            mix(&g.p, sizeof(g.p));
+        }
+        mix(&pending.pt, sizeof(pending.pt));
+        const uint32_t flags[4] = {static_cast<uint32_t>(cfg->pt_schedule), sim->next_parity, gibbs ? 1u : 0u,
+                                   static_cast<uint32_t>(sim->groups.size())};
+        mix(flags, sizeof(flags));
+        return h | 1ull; // (0 = nothing captured)
+    };
+    auto graph_pair = [&](uint64_t sweep_id) -> int {
+        const uint64_t key = pair_key();
+        if (sim->graph_key == key && sim->pair_graphs.size() == sim->groups.size()) {
+            for (size_t gi = 0; gi < sim->groups.size(); ++gi)
+                PA_HIP(sim, hipGraphLaunch(sim->pair_graphs[gi], sim->groups[gi].stream));
+            if (int rc = fused_sweep(sweep_id, false)) return rc;
+            return fused_sweep(sweep_id + 1, false);
+        }
+        for (auto &ge : sim->pair_graphs)
+            if (ge) (void)hipGraphExecDestroy(ge);
+        sim->pair_graphs.clear();
+        sim->graph_key = 0;
+        size_t capturing = 0;
+        hipError_t e = hipSuccess;
+        for (; capturing < sim->groups.size() && e == hipSuccess; ++capturing)
+            e = hipStreamBeginCapture(sim->groups[capturing].stream, hipStreamCaptureModeRelaxed);
+        if (e != hipSuccess) { // no capture on this stack: end what was begun and run launch by launch
+            for (size_t gi = 0; gi + 1 < capturing; ++gi) {
+                hipGraph_t junk = nullptr;
+                (void)hipStreamEndCapture(sim->groups[gi].stream, &junk);
+                if (junk) (void)hipGraphDestroy(junk);
+            }
+            (void)hipGetLastError();
+            return kGraphDeclined;
+        }
+        int rc = fused_sweep(sweep_id, true);
+        if (rc == PA_OK) rc = fused_sweep(sweep_id + 1, true);
+        std::vector<hipGraph_t> graphs(sim->groups.size(), nullptr);
+        for (size_t gi = 0; gi < sim->groups.size(); ++gi) {
+            const hipError_t ee = hipStreamEndCapture(sim->groups[gi].stream, &graphs[gi]);
+            if (ee != hipSuccess && rc == PA_OK) rc = fail(sim, PA_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(ee));
+        }
+        sim->pair_graphs.assign(sim->groups.size(), nullptr);
+        for (size_t gi = 0; gi < sim->groups.size() && rc == PA_OK; ++gi) {
+            const hipError_t ee = hipGraphInstantiate(&sim->pair_graphs[gi], graphs[gi], nullptr, nullptr, 0);
+            if (ee != hipSuccess) rc = fail(sim, PA_ERR_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(ee));
+        }
+        for (auto &gr : graphs)
+            if (gr) (void)hipGraphDestroy(gr);
+        if (rc != PA_OK) { // (the two sweeps' bookkeeping has run but nothing was launched: the state is unusable)
+            for (auto &ge : sim->pair_graphs)
+                if (ge) (void)hipGraphExecDestroy(ge);
+            sim->pair_graphs.clear();
+            return rc;
+        }
+        sim->graph_key = key;
+        for (size_t gi = 0; gi < sim->groups.size(); ++gi)
+            PA_HIP(sim, hipGraphLaunch(sim->pair_graphs[gi], sim->groups[gi].stream));
+        return PA_OK;
+    };
     auto enqueue_all = [&]() -> int {
     for (uint64_t sweep_id = 0; sweep_id < cfg->n_sweeps; ++sweep_id) {
         if (sweep_id % kBatch == 0) {
@@ -922,58 +1069,24 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         const bool pt_this = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0; // :486-488
         const bool fk_this = fk && sweep_id % cfg->cluster_interval == 0;               // :434-437
         if (fused) {
-            // Plain protocol on the LDS kernels: the overlap of the state sweep s-1 left is measured
-            // inside the launch that draws the random stream of sweep s, and its statistics are
-            // accumulated by the measurement block of sweep s.  Every accumulator still receives
-            // its values in sweep order, so the f64 sums are unchanged.
-            // With `relay` the measurement block of sweep s-1 (statistics + tempering event) rides in that
-            // launch too: the random-stream workgroups replay the swap decisions and fetch their generators
-            // from the slots the systems come from, so a sweep is two launches, not three.
-            const bool relayed = relay && pending.any;
-            // (enqueue order: every group's random stream first, then every group's sweep -- a launch costs the host
-            // ~6 us, and in a short call the group enqueued second runs that much behind the first from its first
-            // kernel to its last: two launches behind with the order group by group, profiles/r03_timeline_20steps.txt)
-            for (auto &g : sim->groups) {
-                if (relayed) {
-                    PtParams q = pending.pt;
-                    q.relay = 1;
-                    q.fresh = consume_fresh(g.fresh, g.d, pending.do_accum, pending.accum_overlap);
-                    PA_HIP(sim, launch_rng_relay(g.d, g.p, overlap_owed, q, pending.do_accum, pending.accum_overlap,
-                                                 pending.do_pt, g.stream, gibbs));
-                } else if (overlap_owed) {
-                    PA_HIP(sim, launch_rng_overlap(g.d, g.p, g.stream, gibbs));
-                } else {
-                    PA_HIP(sim, launch_rng(g.d, g.p, gibbs, g.stream));
-                }
-                if (overlap_owed) toggle_dots(g.p);
-            }
-            for (auto &g : sim->groups) PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, record || pt_this, gibbs, g.stream));
-            if (relayed && pending.do_pt && d.n_temps >= 2) toggle_system_tables(sim);
-            pending.any = false;
-            sim->swaps_pending = false;
-            toggle_spin_buffers(sim);
-            PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
-            if (autocorr) { // this sweep's m^2 sample; the q^2 sample of the sweep whose overlap is accumulated with it
-                pt.ac_index = record ? static_cast<uint32_t>(sim->n_recorded + 1) : 0u;
-                pt.ac_index_q = overlap_owed ? static_cast<uint32_t>(sim->n_recorded) : 0u;
-                pt.ac_stride = static_cast<uint32_t>(sim->ac_capacity);
-            }
-            if (record || pt_this || overlap_owed) {
-                if (relay) { // deferred into the next sweep's launch (or the tail of the run)
-                    pending.any = true;
-                    pending.pt = pt;
-                    pending.do_accum = record;
-                    pending.accum_overlap = overlap_owed;
-                    pending.do_pt = pt_this;
-                } else {
-                    for (auto &g : sim->groups)
-                        PA_HIP(sim, measure_launch(g.fresh, g.d, g.p, pt, record, overlap_owed, pt_this, g.stream));
-                    if (pt_this) sim->swaps_pending = true;
+            // Two steady-state sweeps at a time through a captured graph, when nothing about them differs from the pair
+            // before (see graph_pair above the loop); otherwise launch by launch.
+            if (graph_enabled && sweep_id + 1 < cfg->n_sweeps && sweep_id >= cfg->warmup_sweeps && pt_this &&
+                (sweep_id % kBatch) != kBatch - 1 && relay && pending.any && pending.do_accum && pending.accum_overlap &&
+                pending.do_pt && overlap_owed && !autocorr && d.n_temps >= 2 && !sim->interrupt.load(std::memory_order_relaxed)) {
+                bool fresh_left = false;
+                for (auto &g : sim->groups) fresh_left = fresh_left || g.fresh != 0;
+                if (!fresh_left) {
+                    const int rc = graph_pair(sweep_id);
+                    if (rc == PA_OK) {
+                        sim->n_sweeps_run = sweep_id + 2;
+                        ++sweep_id; // (the pair covers the next sweep too)
+                        continue;
+                    }
+                    if (rc != kGraphDeclined) return rc;
                 }
             }
-            overlap_owed = record;
-            if (record) sim->n_recorded += 1;
-            if (pt_this && cfg->pt_schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
+            if (int rc = fused_sweep(sweep_id, true)) return rc;
             continue;
         }
         // (general protocol) the previous sweep's measurement launch that carries its tempering event rides in this
@@ -2036,11 +2149,13 @@ void pa_sim_destroy(pa_sim *sim) {
     if (sim->stream) {
         (void)hipSetDevice(sim->device);
         (void)hipStreamSynchronize(sim->stream);
+        for (auto &g : sim->groups)
+            if (g.stream) (void)hipStreamSynchronize(g.stream);
+        for (auto &ge : sim->pair_graphs)
+            if (ge) (void)hipGraphExecDestroy(ge);
+        sim->pair_graphs.clear();
         for (auto &g : sim->groups) {
-            if (g.stream) {
-                (void)hipStreamSynchronize(g.stream);
-                (void)hipStreamDestroy(g.stream);
-            }
+            if (g.stream) (void)hipStreamDestroy(g.stream);
             if (g.done) (void)hipEventDestroy(g.done);
         }
         if (sim->fork) (void)hipEventDestroy(sim->fork);

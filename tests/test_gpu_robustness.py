@@ -232,3 +232,31 @@ def test_full_size_runs_are_reproducible(config, n_sweeps, extra):
     soak = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(soak)
     soak.one(config, n_sweeps, **extra)
+
+
+@pytest.mark.parametrize("schedule", ["single_random_edge", "full_ladder"])
+def test_captured_graph_pairs_replay_the_same_trajectory(oracle, monkeypatch, schedule):
+    """PEAPODS_GRAPH=1: pairs of steady-state sweeps go through one captured hipGraph per stream group (opt-in: it
+    measured slower).  The replayed launches must leave exactly what launch-by-launch enqueueing leaves --
+    across calls too (the second call replays the graphs of the first; the Gibbs call captures its own)."""
+    from peapods_amd import IsingSimulation
+
+    monkeypatch.setenv("PEAPODS_GRAPH", "1")
+    shape, n_rep = (8, 8, 8), 4
+    temps = np.linspace(0.8, 1.4, 6).astype(np.float32)
+    J = bimodal(shape, 3, 23)
+    gpu = IsingSimulation(list(shape), J, temps, n_rep, None, 31)
+    cpu = oracle.OracleSimulation(list(shape), J, temps, n_rep, None, 31)
+    kw = dict(pt_interval=1, pt_schedule=schedule, warmup_ratio=0.25)
+    for n_sweeps, mode in ((21, "metropolis"), (12, "metropolis"), (9, "gibbs"), (14, "metropolis")):
+        a = gpu.sample(n_sweeps, mode, **kw)
+        b = cpu.sample(n_sweeps, mode, **kw)
+        for key in ("mags", "mags2", "energies", "energies2", "overlap", "overlap2", "overlap4", "link_overlap",
+                    "ql_at_q_sum", "per_sample_overlap_histogram"):
+            np.testing.assert_array_equal(a[key], b[key], err_msg=f"{mode} {n_sweeps} {key}")
+        for r in range(3):
+            np.testing.assert_array_equal(gpu.get_spins(r), cpu.get_spins(r))
+            np.testing.assert_array_equal(gpu.get_system_ids(r), cpu.get_system_ids(r))
+        pt_a, pt_b = a["per_disorder"]["parallel_tempering"], b["per_disorder"]["parallel_tempering"]
+        for key in pt_a:
+            np.testing.assert_array_equal(pt_a[key], pt_b[key], err_msg=key)

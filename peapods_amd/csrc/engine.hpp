@@ -145,6 +145,8 @@ struct DevPtrs {
     // "sw" inner variant of the overlap-cluster moves (kernels_cluster.hip; built on first use)
     uint32_t *pair_slots;    // [n_real][n_temps][n_replicas] slots in the shuffled order of each temperature
     uint32_t *slot_bits;     // [n_real][SP][MW] spins of every slot as a bitmap over the sites (k_slot_bitmaps, per call)
+    uint32_t *sw_scratch;    // [tasks][2][N] large lattices: the union-find's per-site arrays of every k_cluster_sw
+                             //   workgroup (uncached device memory; tasks = n_real * max(n_temps * n_pairs, n_sys))
     const uint32_t *jump_unit; // [cluster_stream_units][64][2][16][4] nibble tables of T^(64 u)
     uint8_t *stream_bits;    // [n_real][n_sys][cluster_stream_units * 64] classified draws of the cluster generators (unit couplings)
     uint32_t *stream_raw;    // same shape: the 24-bit draws themselves (other couplings)
@@ -271,6 +273,7 @@ hipError_t launch_cmr_wave(const SimDims &d, const DevPtrs &p, hipStream_t strea
 size_t wolff_wave_lds_bytes(const SimDims &d);
 size_t cmr_wolff_lds_bytes(const SimDims &d);
 size_t cluster_sw_lds_bytes(const SimDims &d);
+size_t cluster_sw_lds_bytes_global_labels(const SimDims &d); // large lattices: per-site arrays in device memory
 hipError_t launch_fk(const SimDims &d, const DevPtrs &p, bool wolff, const ClusterAux &aux, hipStream_t stream);
 size_t fk_wolff_lds_bytes(const SimDims &d);
 hipError_t configure_cluster_kernels();

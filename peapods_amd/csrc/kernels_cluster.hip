@@ -191,9 +191,32 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
     return base + incl - v;
 }
 
-struct SwLds {
-    uint32_t *label;   // [N] component label (smallest site after convergence)
-    uint32_t *aux;     // [N] multi-site flag of roots
+// The two per-site arrays of the union-find.  They live in the LDS; on a lattice whose task does not fit there
+// (GLOBAL: 128 x 128 = 16384 sites need 128 KB for them alone) they live in an uncached scratch area of device memory,
+// one slice per workgroup, and every access goes through the L2 (relaxed agent-scope loads / stores next to the same
+// atomics the LDS form uses): the lock-free union mixes compare-and-swaps with plain reads of the same words, and a
+// read served by the CU's L1 would not see another wave's swap.
+template <bool GLOBAL> struct SiteWords {
+    uint32_t *base;
+    struct Ref {
+        uint32_t *q;
+        __device__ __forceinline__ operator uint32_t() const {
+            return GLOBAL ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+        }
+        __device__ __forceinline__ const Ref &operator=(uint32_t v) const {
+            if (GLOBAL) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *q = v;
+            return *this;
+        }
+        __device__ __forceinline__ const Ref &operator=(const Ref &o) const { return *this = static_cast<uint32_t>(o); }
+        __device__ __forceinline__ uint32_t *operator&() const { return q; }
+    };
+    __device__ __forceinline__ Ref operator[](size_t i) const { return Ref{base + i}; }
+};
+
+template <bool GLOBAL> struct SwLds {
+    SiteWords<GLOBAL> label; // [N] component label (smallest site after convergence)
+    SiteWords<GLOBAL> aux;   // [N] multi-site flag of roots
     uint32_t *act;     // [MW] active sites (the pair's spins differ)
     uint32_t *spa;     // [MW] spin of the pair's first system (1 <=> -1)
     uint32_t *spb;     // [MW] spin of the pair's second system
@@ -214,9 +237,9 @@ struct SwLds {
 __host__ __device__ inline size_t cluster_sw_bit_words(const SimDims &d) {
     return (static_cast<size_t>(d.N) * d.nn + 255) / 256 * 8 + 16;
 }
-__host__ __device__ inline size_t cluster_sw_lds_words(const SimDims &d) {
-    return 2 * static_cast<size_t>(d.N) + 26 * static_cast<size_t>(d.MW) + 1 + 2 * cluster_sw_bit_words(d) + 24 +
-           (d.unit ? 0 : static_cast<size_t>(d.N) * d.nn);
+__host__ __device__ inline size_t cluster_sw_lds_words(const SimDims &d, bool global_labels = false) {
+    return (global_labels ? 0 : 2 * static_cast<size_t>(d.N)) + 26 * static_cast<size_t>(d.MW) + 1 +
+           2 * cluster_sw_bit_words(d) + 24 + (d.unit ? 0 : static_cast<size_t>(d.N) * d.nn);
 }
 
 enum { kSwHoudayer = 0, kSwJorg = 1, kSwFk = 2, kSwCmr = 3 };
@@ -229,7 +252,8 @@ enum { kSwHoudayer = 0, kSwJorg = 1, kSwFk = 2, kSwCmr = 3 };
 // The lean Houdayer build (no bond draws) is capped at 128 VGPRs: four workgroups per CU instead of three, 461 ->
 // 400 us per call on 6144 pairs.  The moves that draw bonds lose more to the spills than they gain (Joerg 792 -> 853 us,
 // FK 312 -> 363 us), and the reporting builds need their registers.
-template <int MODE, int LEVEL>
+// GLOBAL: the union-find's per-site arrays in device memory (large lattices; the full build only).
+template <int MODE, int LEVEL, bool GLOBAL = false>
 __global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4 : (LEVEL == 1 ? 3 : 2)) void k_cluster_sw(
     SimDims d, DevPtrs p, uint32_t group, int wolff, ClusterAux aux) {
     constexpr bool EXTRAS = LEVEL > 0; // sizes / top four and the single-cluster forms
@@ -238,11 +262,16 @@ __global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4
     constexpr bool STOCHASTIC = JORG || FK || CMR; // bonds are drawn
     constexpr uint32_t N_PHASES = CMR ? 2 : 1;     // CMR: blue clusters, then grey = blue + red bonds
     extern __shared__ uint32_t lds[];
-    SwLds L;
+    SwLds<GLOBAL> L;
     {
         uint32_t *q = lds;
-        L.label = q; q += d.N;
-        L.aux = q; q += d.N;
+        if (GLOBAL) {
+            L.label.base = p.sw_scratch + static_cast<size_t>(blockIdx.x) * 2 * d.N;
+            L.aux.base = L.label.base + d.N;
+        } else {
+            L.label.base = q; q += d.N;
+            L.aux.base = q; q += d.N;
+        }
         L.act = q; q += d.MW;
         L.spa = q; q += d.MW;
         L.spb = q; q += d.MW;
@@ -1510,12 +1539,17 @@ hipError_t launch_exp_selftest(float *out, hipStream_t stream) {
 }
 
 size_t cluster_sw_lds_bytes(const SimDims &d) { return cluster_sw_lds_words(d) * 4; }
+size_t cluster_sw_lds_bytes_global_labels(const SimDims &d) { return cluster_sw_lds_words(d, true) * 4; }
 
 hipError_t configure_cluster_kernels() {
     for (const void *fn : {reinterpret_cast<const void *>(k_cluster_sw<kSwHoudayer, 0>),
                            reinterpret_cast<const void *>(k_cluster_sw<kSwJorg, 0>),
                            reinterpret_cast<const void *>(k_cluster_sw<kSwFk, 0>),
                            reinterpret_cast<const void *>(k_cluster_sw<kSwCmr, 0>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwHoudayer, 2, true>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwJorg, 2, true>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwFk, 2, true>),
+                           reinterpret_cast<const void *>(k_cluster_sw<kSwCmr, 2, true>),
                            reinterpret_cast<const void *>(k_cluster_sw<kSwHoudayer, 1>),
                            reinterpret_cast<const void *>(k_cluster_sw<kSwJorg, 1>),
                            reinterpret_cast<const void *>(k_cluster_sw<kSwFk, 1>),
@@ -1545,6 +1579,11 @@ static int cluster_sw_level(uint32_t flags, bool single_form) {
 template <int MODE>
 static void launch_sw_build(int level, dim3 grid, hipStream_t stream, const SimDims &d, const DevPtrs &p, uint32_t group,
                             int single, const ClusterAux &aux) {
+    if (cluster_sw_lds_bytes(d) > 160 * 1024) { // the per-site arrays in device memory (p.sw_scratch: ensure_cluster_sw)
+        hipLaunchKernelGGL((k_cluster_sw<MODE, 2, true>), grid, dim3(kSwThreads), cluster_sw_lds_words(d, true) * 4, stream, d, p,
+                           group, single, aux);
+        return;
+    }
     const size_t lds = cluster_sw_lds_bytes(d);
     if (level == 0)
         hipLaunchKernelGGL((k_cluster_sw<MODE, 0>), grid, dim3(kSwThreads), lds, stream, d, p, group, single, aux);

@@ -126,6 +126,7 @@ struct pa_sim {
     // Two consecutive steady-state sweeps of the plain protocol captured as one hipGraph per stream group (run_sweeps):
     // the four dependent launches of a pair then cost the graph's 1.6 us per hop instead of the stream's 2.8 us
     // (build_probe/gaps.hip).  `graph_key` hashes every kernel argument of the pair; a mismatch recaptures.
+    std::vector<void *> uncached_areas; // hipExtMallocWithFlags areas (cluster scratch of large lattices), freed with the handle
     std::vector<hipGraphExec_t> pair_graphs;
     uint64_t graph_key = 0;
     // Running sums are never memset between sample() calls: bit 0 (moments) / bit 1 (overlap moments, P(q)
@@ -558,8 +559,19 @@ int flush_swaps(pa_sim *sim) {
 int ensure_cluster_sw(pa_sim *sim) {
     if (sim->jump_unit) return PA_OK;
     const SimDims &d = sim->d;
-    if (d.big || cluster_sw_lds_bytes(d) > 160 * 1024)
-        return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the overlap-cluster kernel");
+    // A task's union-find normally lives in its workgroup's LDS.  Where that does not fit (the reference's own Rust
+    // benchmark: 128 x 128 sites, examples/bench.rs:12) the two per-site arrays move to an uncached scratch area of
+    // device memory, one slice per workgroup (k_cluster_sw<.., .., true>); the bitmaps stay on chip.
+    const bool global_labels = cluster_sw_lds_bytes(d) > 160 * 1024;
+    if (d.N > 65535 || (global_labels && cluster_sw_lds_bytes_global_labels(d) > 160 * 1024))
+        return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the cluster kernels (at most 65535 sites)");
+    if (global_labels) {
+        const size_t tasks = static_cast<size_t>(d.n_real) * std::max(d.n_temps * std::max(d.n_pairs, 1u), d.n_sys);
+        void *area = nullptr;
+        PA_HIP(sim, hipExtMallocWithFlags(&area, tasks * 2 * d.N * sizeof(uint32_t), hipDeviceMallocUncached));
+        sim->uncached_areas.push_back(area);
+        sim->p.sw_scratch = static_cast<uint32_t *>(area);
+    }
     const uint32_t n_units = cluster_stream_units(d);
     std::vector<uint32_t> jump_unit(static_cast<size_t>(n_units) * 64 * 16 * 8);
     {
@@ -618,6 +630,9 @@ int ensure_cluster_sw(pa_sim *sim) {
         g.p.fk_thr = sim->fk_thr;
         g.p.cmr_thr = sim->cmr_thr;
         g.p.pair_slots = sim->p.pair_slots + slots_per_real * r0;
+        g.p.sw_scratch = sim->p.sw_scratch
+                             ? sim->p.sw_scratch + static_cast<size_t>(std::max(d.n_temps * std::max(d.n_pairs, 1u), d.n_sys)) * 2 * d.N * r0
+                             : nullptr;
         g.p.slot_bits = sim->p.slot_bits + static_cast<size_t>(d.SP) * d.MW * r0;
         r0 += g.d.n_real;
     }
@@ -786,9 +801,8 @@ std::string validate_text(const pa_sample_config *cfg, uint64_t n_replicas, int 
 
 int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     const SimDims &d = sim->d;
-    if (d.big && cfg->overlap_cluster_interval > 0)
-        return fail(sim, PA_ERR_UNSUPPORTED,
-                    "overlap-cluster moves are not built for lattices above 12000 sites yet");
+    if (d.N > 65535 && (cfg->overlap_cluster_interval > 0 || cfg->cluster_interval > 0))
+        return fail(sim, PA_ERR_UNSUPPORTED, "cluster moves are built for lattices of at most 65535 sites");
     bool needs_exp = cfg->cluster_interval > 0 && !d.unit; // bond probabilities 1 - exp(-c |J| / T) per bond
     if (!d.unit && cfg->overlap_cluster_interval > 0)
         for (int k = 0; k < cfg->n_overlap_cluster_modes && k < 4; ++k)
@@ -805,15 +819,22 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
         oc_cmr = oc_cmr || (cfg->overlap_cluster_modes[k] & 0xFF) == PA_OC_CMR || (cfg->overlap_cluster_modes[k] >> 8) > 2 ||
                  d.nn > 3;
     const bool fk = cfg->cluster_interval > 0;
-    if (fk && cfg->cluster_mode == PA_CLUSTER_WOLFF && (d.big || fk_wolff_lds_bytes(d) > 160 * 1024))
+    // (FK single-cluster form: one wave per system with the lattice tables in the LDS, else one lane per system with
+    // the whole tile there)
+    if (fk && cfg->cluster_mode == PA_CLUSTER_WOLFF && !cfg->collect_cluster_stats && cfg->cluster_action != PA_ACTION_OBSERVE &&
+        fk_wolff_lds_bytes(d) > 160 * 1024 && !(wolff_wave_lds_bytes(d) <= 160 * 1024 && d.N <= 65535))
         return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the FK cluster kernel");
     // Joerg single-cluster moves run one wave per pair when the lattice tables fit the LDS (k_wolff_wave)
     bool jorg_wave = false;
     for (int k = 0; cfg->overlap_cluster_interval > 0 && !oc_sw && k < cfg->n_overlap_cluster_modes && k < 4; ++k)
         jorg_wave = jorg_wave || (cfg->overlap_cluster_modes[k] & 0xFF) == PA_OC_JORG;
-    const bool wave_ok = !d.big && d.N <= 65535 && wolff_wave_lds_bytes(d) <= 160 * 1024 && cluster_sw_lds_bytes(d) <= 160 * 1024;
+    const bool wave_ok = d.N <= 65535 && wolff_wave_lds_bytes(d) <= 160 * 1024 && cluster_sw_lds_bytes(d) <= 160 * 1024;
     jorg_wave = jorg_wave && wave_ok;
-    if ((oc_sw || fk || oc_cmr || jorg_wave) && (rc = ensure_cluster_sw(sim))) return rc;
+    // the single-cluster Houdayer search keeps the realisation's tile in the LDS; an ensemble whose tile does not fit
+    // takes the move's union-find form, which reaches the same clusters from the same draws (overlap.rs:179-339)
+    const bool houdayer_tile_fits = houdayer_lds_bytes(d) <= 160 * 1024;
+    const bool has_houdayer_uf = cfg->overlap_cluster_interval > 0 && !houdayer_tile_fits;
+    if ((oc_sw || fk || oc_cmr || jorg_wave || has_houdayer_uf) && (rc = ensure_cluster_sw(sim))) return rc;
     if (needs_exp && (rc = ensure_device_exp(sim))) return rc;
     if (cfg->equilibration_diagnostic && (rc = ensure_equil(sim))) return rc;
     // autocorrelation (mod.rs:342-345): max_lag capped at a quarter of the measurement sweeps, at least 1
@@ -840,7 +861,6 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     sim->obs_kind[0] = observe_fk;
     for (uint32_t m = 0; observe_overlap && m < n_modes; ++m) sim->obs_kind[cfg->overlap_cluster_modes[m] & 0xFF] = true;
     if (collect_fk || collect_overlap || snapshot_interval > 0) {
-        if (d.big) return fail(sim, PA_ERR_UNSUPPORTED, "cluster statistics are not built for lattices above 12000 sites");
         if ((rc = ensure_cluster_sw(sim))) return rc;
         if ((rc = ensure_cluster_stats(sim, n_modes, snapshot_interval > 0))) return rc;
         if (snapshot_interval > 0) {
@@ -854,8 +874,16 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     sim->overlap_collected = want_overlap;
     // every capability check comes before the first launch: a configuration this build declines is
     // rejected with the state untouched and no group stream forked
-    if (has_oc && static_cast<size_t>(d.N) * d.W * 12 + 4096 > 160 * 1024)
-        return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the overlap-cluster kernel");
+    if (has_oc && !oc_sw && !wave_ok && !collect_overlap) {
+        // (depth-first Joerg / CMR searches without the one-wave-per-pair kernel: their one-lane-per-pair fallbacks
+        // hold the realisation's tile and a bitmap per pair in the LDS)
+        for (int k = 0; k < cfg->n_overlap_cluster_modes && k < 4; ++k) {
+            const int kind = cfg->overlap_cluster_modes[k] & 0xFF;
+            if ((kind == PA_OC_JORG && jorg_lds_bytes(d) > 160 * 1024) || (kind == PA_OC_CMR && cmr_wolff_lds_bytes(d) > 160 * 1024))
+                return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the single-cluster search of this overlap move "
+                                                     "(its union-find form, overlap_cluster_mode='sw', has no such limit)");
+        }
+    }
     // equilibration diagnostic: energies and the link overlap of EVERY sweep (mod.rs:492,527)
     const bool equil = cfg->equilibration_diagnostic != 0;
     sim->equil_sweeps.clear();
@@ -1141,7 +1169,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                 const bool first = &g == &sim->groups.front() && sim->first_realization == 0;
                 const bool snap_now = snapshot_interval > 0 && sweep_id % snapshot_interval == 0;
                 overlap_in_houdayer = (mode & 0xFF) == PA_OC_HOUDAYER && (mode >> 8) <= 2 && !oc_sw && !collect_overlap &&
-                                      !observe_overlap && !(snap_now && first);
+                                      !observe_overlap && !(snap_now && first) && houdayer_tile_fits;
             }
             if (((record && want_overlap) || equil) && d.n_pairs && !overlap_in_houdayer && !big_overlap_done)
                 PA_HIP(sim, overlap_launch(g.d, g.p, g.stream)); // :527-529
@@ -1192,7 +1220,8 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                 // directions also for the single-cluster Houdayer move (same components, same seed rule).
                 // Every call that reports sizes or takes a snapshot is on the union-find path too
                 // (`use_uf`, overlap.rs:179-183,376-380,640-644) -- a snapshot only for the first realisation.
-                const bool uf_all = oc_sw || oc_group > 2 || (oc_kind == PA_OC_HOUDAYER && d.nn > 3) || aux.flags != 0;
+                const bool uf_all = oc_sw || oc_group > 2 || (oc_kind == PA_OC_HOUDAYER && (d.nn > 3 || !houdayer_tile_fits)) ||
+                                    aux.flags != 0;
                 const bool dfs_same = oc_kind == PA_OC_HOUDAYER; // deterministic bonds: both paths consume the same draws
                 if (uf_all || (take_snapshot && first_group && dfs_same)) {
                     ClusterAux a2 = aux;
@@ -1561,7 +1590,11 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     // is the bisection of that rule, sweep.rs:141-155)
     d.general = (!d.unit || d.nn > 3) ? 1 : 0;
     // the LDS kernels hold a word's N sites (sweep) / the W-word tile (tempering swaps) on chip
-    d.big = (d.N > 12000 || static_cast<size_t>(d.N) * d.W * 4 > 150000) ? 1 : 0;
+    // (the lattice decides: a sweep workgroup holds ONE word's N sites, whatever the number of words.  Kernels that
+    // keep a realisation's whole W-word tile on chip -- the single-cluster Houdayer search k_houdayer, the one-lane-
+    // per-pair fallbacks -- are chosen per call in run_sweeps only where the tile fits, so an ensemble of many slots,
+    // 16^3 x 64 temperatures x 8 replicas = 16 words, keeps the on-chip path and every cluster move)
+    d.big = d.N > 12000 ? 1 : 0;
     if (d.general && sweep_f_lds_bytes(d) > 160 * 1024) d.big = 1;
     if (d.big && d.nn > 3) {
         sim->error = "lattices with more than 3 forward directions are built for the on-chip kernels only "
@@ -1781,7 +1814,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
                 nbr_wide[static_cast<size_t>(pos) * 16] = site;
                 for (int k = 0; k < 12; ++k) {
                     nbr_wide[static_cast<size_t>(pos) * 16 + 1 + k] = nb[k];
-                    if (!d.big) nbr_site[static_cast<size_t>(site) * 12 + k] = static_cast<uint16_t>(nb[k]);
+                    if (d.N <= 65535) nbr_site[static_cast<size_t>(site) * 12 + k] = static_cast<uint16_t>(nb[k]);
                 }
             }
             if (d.nn > 3) continue; // the bit-sliced records below hold three directions
@@ -2065,7 +2098,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     }
     ok(bufs.alloc(&sim->nbr_wide, nbr_wide.size()));
     ok(bufs.alloc(&sim->jorg_p, jorg_p.size()));
-    ok(bufs.alloc(&p.dfs_stack, d.big ? 1 : static_cast<size_t>(d.n_real) * std::max(d.n_temps * d.n_pairs, d.n_sys) * d.N));
+    ok(bufs.alloc(&p.dfs_stack, d.N > 65535 ? 1 : static_cast<size_t>(d.n_real) * std::max(d.n_temps * d.n_pairs, d.n_sys) * d.N));
     if (!d.big && d.n_pairs) ok(bufs.alloc(&p.hd_scratch, 2 * tile_words * d.n_real));
     ok(bufs.alloc(&p.big_counts, static_cast<size_t>(d.n_real) * d.n_sys * 4));
     if (e != hipSuccess) {
@@ -2168,6 +2201,7 @@ void pa_sim_destroy(pa_sim *sim) {
                             static_cast<void *>(sim->p.snap_ids), static_cast<void *>(sim->p.snap_blue),
                             static_cast<void *>(sim->p.snap_spins), static_cast<void *>(sim->p.snap_sids)})
             if (extra) (void)hipFree(extra);
+        for (void *area : sim->uncached_areas) (void)hipFree(area);
         sim->buffers.release();
         (void)hipStreamDestroy(sim->stream);
     }

@@ -74,11 +74,11 @@ __device__ __forceinline__ uint32_t wave_sum_lane63(uint32_t v) {
 
 // Reduce NSET sets of byte counters over the workgroup (blockDim.x / 64 waves).  Thread b < 32
 // receives in out[set] the total for bit b.  scratch: [n_waves + 1][NSET*16] dwords of LDS.
-template <int NSET>
+template <int NSET, uint32_t N_WAVES = 4>
 __device__ __forceinline__ void block_bit_totals(const uint32_t (*c)[8], uint32_t *scratch,
                                                  uint32_t out[NSET]) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    constexpr uint32_t n_waves = 4; // every caller is a 256-thread role (possibly the first four waves of a wider block)
+    constexpr uint32_t n_waves = N_WAVES; // a 256-thread role (possibly the first four waves of a wider block), or one wave
 #pragma unroll
     for (int s = 0; s < NSET; ++s) {
 #pragma unroll

@@ -61,6 +61,11 @@ struct SimDims {
     // ceil(2^32 / x) with which the kernels divide small indices (device_util.hpp div_small)
     uint32_t rng_waves;
     uint32_t inv_temps, inv_replicas, inv_W;
+    // 1: four to six forward directions (bcc, fcc, ...) with unit couplings: Metropolis sweeps take the integer table
+    // route of the reference (sweep.rs:109-185 applies to any z') -- acceptance levels in three bit planes from the
+    // random-stream kernel, bit-sliced neighbour counts in k_sweep_wide -- while the handle stays a `general` one for
+    // everything else (heat bath, energies kept as f32 bits)
+    uint32_t wide;
 };
 
 // hc_tab entry of a site (schedule order): site | wrap flags << 14 | coupling sign bits << 20
@@ -92,6 +97,10 @@ struct DevPtrs {
                              //   jmeta = neg[0..5] | nz[6..11] | h[12..13] for bonds f0,b0,f1,b1,f2,b2
     const uint32_t *pass_start; // [n_passes + 1]
     const uint32_t *hc_tab;  // [n_real][N] schedule order: site | wrap flags << 14 | neg bits << 20 (SimDims::hc)
+    const uint4 *rec_wide;   // [n_real][2 (N + 1)] SimDims::wide, schedule order (+ dummy): thirteen 16-bit LDS byte
+                             //   offsets (site, f0, b0, ..., f5, b5), h = ceil(m / 2), then neg[0..11] | nz[12..23]
+    const uint32_t *thr_wide; // [2][7][n_temps] SimDims::wide: Metropolis thresholds in the layout of thr_gibbs --
+                             //   even set dE = -2, -4, ..., odd set dE = -1, -3, ... (falling; unused entries 0)
     const uint32_t *seg;     // [n_levels][pipe_K + 1] schedule positions where each slab's part of a level starts
     uint32_t *progress;      // [n_real * W][pipe_K] levels completed by each slab workgroup (epoch-based, monotone)
     const uint32_t *halo_start; // [pipe_K][n_levels + 2] k_sweep_slab: the exchange records a slab first reads at level l are
@@ -259,6 +268,8 @@ hipError_t launch_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt
 hipError_t launch_measure_stamped(const SimDims &d, const DevPtrs &p, const PtParams &pt,
                                   unsigned long long *stamps, hipStream_t stream);
 size_t sweep_lds_bytes(const SimDims &d, bool gibbs);
+size_t sweep_wide_lds_bytes(const SimDims &d);
+bool takes_wide_route(const SimDims &d, bool gibbs); // Metropolis sweep of a SimDims::wide handle
 size_t sweep_hc_lds_bytes(const SimDims &d, bool gibbs = false);
 size_t sweep_slab_lds_bytes(const SimDims &d);
 size_t sweep_slab_lds_bytes_for(uint32_t own_sites, uint32_t plane_sites, uint32_t n_levels);

@@ -971,6 +971,209 @@ __global__ __launch_bounds__(256) void k_sweep(SimDims d, DevPtrs p, int with_en
 }
 
 // ---------------------------------------------------------------------------
+// k_sweep_wide: the level-ordered Metropolis sweep for four to six forward directions (bcc: 8 neighbours, fcc: 12)
+// with unit couplings.  The reference's table path serves any z' (sweep.rs:109-139 builds 4 z' + 1 columns,
+// :170-185 decides with one integer compare); round 2 sent these lattices through the f32 kernels of the
+// general-coupling path (276 / 469 us per step on the bench ensemble, five launches, 201 MB of thresholds a sweep).
+// Here: the random-stream kernel files the acceptance LEVEL of every draw, L = #{k : draw < table[dE = -2k]}
+// (k <= z' <= 6: three bit planes, the heat bath's seven-threshold machinery with the Metropolis table), and the sweep
+// decides flip <=> U + L >= h, U = unsatisfied non-zero bonds of the site (twelve bit-sliced inputs -> four planes),
+// h = ceil(m / 2), as the carry out of a five-bit addition.  Site records (two 16-byte words: thirteen LDS offsets,
+// coupling signs, non-zero flags, h) stream from global memory four passes ahead.  The epilogue leaves the energies
+// as f32 bits of the exact integer sum (the handle's convention) and the magnetisation sums.
+// ---------------------------------------------------------------------------
+struct WideRec {
+    uint32_t site, nb[12], h, neg, nz;
+    __device__ __forceinline__ WideRec(const uint4 a, const uint4 b) {
+        site = a.x & 0xFFFFu;
+        nb[0] = a.x >> 16;
+        nb[1] = a.y & 0xFFFFu; nb[2] = a.y >> 16;
+        nb[3] = a.z & 0xFFFFu; nb[4] = a.z >> 16;
+        nb[5] = a.w & 0xFFFFu; nb[6] = a.w >> 16;
+        nb[7] = b.x & 0xFFFFu; nb[8] = b.x >> 16;
+        nb[9] = b.y & 0xFFFFu; nb[10] = b.y >> 16;
+        nb[11] = b.z & 0xFFFFu;
+        h = b.z >> 16;
+        neg = b.w & 0xFFFu;
+        nz = (b.w >> 12) & 0xFFFu;
+    }
+};
+
+// flip mask of one site word: u[k] = unsatisfied non-zero bond k (k < 12), l0..l2 the draw's level, h = ceil(m / 2)
+__device__ __forceinline__ uint32_t accept_mask_wide(const uint32_t u[12], uint32_t l0, uint32_t l1, uint32_t l2, uint32_t h) {
+    uint32_t s0, s1, s2, s3, c0, c1, c2, c3;
+    full_add(u[0], u[1], u[2], s0, c0);
+    full_add(u[3], u[4], u[5], s1, c1);
+    full_add(u[6], u[7], u[8], s2, c2);
+    full_add(u[9], u[10], u[11], s3, c3);
+    uint32_t t0, d0;
+    full_add(s0, s1, s2, t0, d0);
+    const uint32_t U0 = t0 ^ s3, e0 = t0 & s3;                 // weight 1
+    uint32_t x0, y0, x1, y1;
+    full_add(c0, c1, c2, x0, y0);
+    full_add(c3, d0, e0, x1, y1);
+    const uint32_t U1 = x0 ^ x1, z = x0 & x1;                  // weight 2
+    uint32_t U2, U3;
+    full_add(y0, y1, z, U2, U3);                               // weights 4, 8 (U <= 12)
+    // U + L: five bits
+    const uint32_t a0 = U0 ^ l0, k0 = U0 & l0;
+    const uint32_t a1 = U1 ^ l1 ^ k0, k1 = maj3(U1, l1, k0);
+    const uint32_t a2 = U2 ^ l2 ^ k1, k2 = maj3(U2, l2, k1);
+    const uint32_t a3 = U3 ^ k2, a4 = U3 & k2;
+    // (U + L) + (32 - h) >= 32: the carry out of bit 4 (h = 0: every site flips)
+    const uint32_t K = 32u - h;
+    const uint32_t K0 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(K), 0, 1));
+    const uint32_t K1 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(K), 1, 1));
+    const uint32_t K2 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(K), 2, 1));
+    const uint32_t K3 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(K), 3, 1));
+    const uint32_t K4 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(K), 4, 1));
+    uint32_t c = a0 & K0;
+    c = maj3(a1, K1, c);
+    c = maj3(a2, K2, c);
+    c = maj3(a3, K3, c);
+    c = maj3(a4, K4, c);
+    return h == 0 ? 0xFFFFFFFFu : c;
+}
+
+__host__ __device__ inline size_t sweep_wide_lds_words(const SimDims &d) {
+    const size_t n1 = static_cast<size_t>(d.N) + 1;
+    return (n1 + 1) / 2 * 2 + 2 * n1 + n1 + 5 * 64 + 8; // spins, two level planes, the third, reduction scratch
+}
+
+// (Measured and dropped: a workgroup of ONE wave for lattices none of whose levels exceeds 64 sites -- fcc at 16^3 has 256
+// levels of 16 -- which needs no barrier at all: 256 against 244 us per step.  The level time there, 0.58 us, is the
+// lone wave's ~135 dependent instructions, not the barrier.)
+__global__ __launch_bounds__(256) void k_sweep_wide(SimDims d, DevPtrs p, int with_energy, int do_sweep) {
+    constexpr int WAVES = 4;
+    constexpr uint32_t kThreads = 64 * WAVES;
+    extern __shared__ uint32_t lds[];
+    const uint32_t n1 = d.N + 1;
+    uint32_t *sw = lds;                    // [N + 1] spins of this word (+ spare slot N for idle lanes)
+    uint32_t *pl = sw + (n1 + 1) / 2 * 2;  // [N + 1][2] level planes 0, 1
+    uint32_t *pl2 = pl + 2 * n1;           // [N + 1] level plane 2
+    uint32_t *scratch = pl2 + n1;          // [5][64]
+    const uint32_t real = blockIdx.x / d.W, w = blockIdx.x % d.W;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t *Sin = p.S + (static_cast<size_t>(real) * d.W + w) * d.N;
+    uint32_t *Sout = p.S_next + (static_cast<size_t>(real) * d.W + w) * d.N;
+    const uint4 *rec = p.rec_wide + static_cast<size_t>(real) * 2 * n1;
+    const uint32_t *planes_in = reinterpret_cast<const uint32_t *>(p.planes + (static_cast<size_t>(real) * d.W + w) * d.N);
+    copy_to_lds(sw, Sin, d.N, tid, kThreads);
+    if (do_sweep) {
+        copy_to_lds(pl, planes_in, 2 * d.N, tid, kThreads);
+        copy_to_lds(pl2, p.planes_hi + (static_cast<size_t>(real) * d.W + w) * d.N, d.N, tid, kThreads);
+    }
+    if (tid == 0) {
+        sw[d.N] = 0;
+        pl[2 * d.N] = 0;
+        pl[2 * d.N + 1] = 0;
+        pl2[d.N] = 0;
+    }
+    const uint32_t live = d.n_sys - w * 32;
+    const uint32_t valid_bits = live >= 32 ? 0xFFFFFFFFu : ((1u << live) - 1u);
+    __syncthreads();
+    auto unsat = [&](const WideRec &r, uint32_t s, uint32_t u[12]) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k)
+            u[k] = (s ^ lds_word(sw, r.nb[k]) ^ static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(r.neg), k, 1))) &
+                   static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(r.nz), k, 1));
+    };
+    if (do_sweep) {
+        auto fetch = [&](uint32_t pass, uint4 &a, uint4 &b) {
+            uint32_t pos = d.N; // dummy record when idle: every offset points at the spare slot, h = 0 masked below
+            if (pass < d.n_passes) {
+                const uint32_t at = p.pass_start[pass] + tid;
+                if (at < p.pass_start[pass + 1]) pos = at;
+            }
+            a = rec[2 * pos];
+            b = rec[2 * pos + 1];
+        };
+        const uint32_t wave_first = __builtin_amdgcn_readfirstlane(tid & ~63u);
+        uint32_t pass_at = 0; // the pass `run` is about to execute
+        auto run = [&](const uint4 a, const uint4 b) {
+            // a wave none of whose lanes has a site in this pass goes straight to the barrier (k_sweep_hc does the same)
+            const uint32_t b0 = __builtin_amdgcn_readfirstlane(p.pass_start[pass_at]), b1 = __builtin_amdgcn_readfirstlane(p.pass_start[pass_at + 1]);
+            ++pass_at;
+            if (b0 + wave_first >= b1) {
+                lds_barrier();
+                return;
+            }
+            const WideRec r(a, b);
+            const uint32_t s = lds_word(sw, r.site);
+            const uint2 lv = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(pl) + 2 * r.site);
+            const uint32_t l2 = lds_word(pl2, r.site);
+            uint32_t u[12];
+            unsat(r, s, u);
+            const uint32_t acc = accept_mask_wide(u, lv.x, lv.y, l2, r.h);
+            // (idle lanes hold the dummy record: site = spare slot, whose value nobody reads)
+            *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(sw) + r.site) = s ^ (acc & valid_bits);
+            lds_barrier();
+        };
+        uint4 a0, b0, a1, b1, a2, b2, a3, b3;
+        fetch(0, a0, b0);
+        fetch(1, a1, b1);
+        fetch(2, a2, b2);
+        for (uint32_t pass = 0; pass < d.n_passes; pass += 4) {
+            fetch(pass + 3, a3, b3);
+            run(a0, b0);
+            if (pass + 1 >= d.n_passes) break;
+            fetch(pass + 4, a0, b0);
+            run(a1, b1);
+            if (pass + 2 >= d.n_passes) break;
+            fetch(pass + 5, a1, b1);
+            run(a2, b2);
+            if (pass + 3 >= d.n_passes) break;
+            fetch(pass + 6, a2, b2);
+            run(a3, b3);
+        }
+        for (uint32_t i = tid; i < d.N; i += kThreads) Sout[i] = sw[i];
+    }
+    if (with_energy & 1) { // energy.rs:92-109 on the swept word: unsatisfied non-zero FORWARD bonds (even slots), spins
+        uint32_t c[4][8];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c[s][j] = 0;
+        for (uint32_t base = 0; base < d.N; base += 16 * kThreads) {
+            uint32_t q1[16], q2[16], q4[16], qs[16];
+#pragma unroll 4
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t pos = base + k * kThreads + tid;
+                const bool live_site = pos < d.N;
+                const WideRec r(rec[2 * (live_site ? pos : d.N)], rec[2 * (live_site ? pos : d.N) + 1]);
+                const uint32_t s = lds_word(sw, r.site);
+                uint32_t f[6];
+#pragma unroll
+                for (int dir = 0; dir < 6; ++dir)
+                    f[dir] = (s ^ lds_word(sw, r.nb[2 * dir]) ^ static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(r.neg), 2 * dir, 1))) &
+                             static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(r.nz), 2 * dir, 1));
+                uint32_t s0, c0, s1, c1;
+                full_add(f[0], f[1], f[2], s0, c0);
+                full_add(f[3], f[4], f[5], s1, c1);
+                const uint32_t dd = s0 & s1;
+                q1[k] = live_site ? (s0 ^ s1) : 0u;
+                q2[k] = live_site ? (c0 ^ c1 ^ dd) : 0u;
+                q4[k] = live_site ? maj3(c0, c1, dd) : 0u;
+                qs[k] = live_site ? s : 0u;
+            }
+            count16(q1, c[0]);
+            count16(q2, c[1]);
+            count16(q4, c[2]);
+            count16(qs, c[3]);
+        }
+        uint32_t tot[4];
+        block_bit_totals<4, WAVES>(c, scratch, tot);
+        if (tid < 32 && w * 32 + tid < d.n_sys) {
+            const uint32_t slot = w * 32 + tid;
+            const int32_t n_unsat = static_cast<int32_t>(tot[0] + 2 * tot[1] + 4 * tot[2]);
+            const float energy_sum = static_cast<float>(p.nz_bonds[real] - 2 * n_unsat); // exact: |sum| <= 6 N < 2^24
+            p.Esum[static_cast<size_t>(real) * d.n_sys + slot] = d.general ? __float_as_int(energy_sum) : static_cast<int32_t>(energy_sum);
+            p.Msum[static_cast<size_t>(real) * d.n_sys + slot] = static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(tot[3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_sweep_hc: the same sweep for lattices whose neighbours follow from index arithmetic (SimDims::hc: every
 // hypercubic lattice; sweep.rs:8-19 reads neighbour tables, lattice.rs:44-99 builds them) and whose bonds are
 // all non-zero (+-J, ferromagnets).  Differences from k_sweep:
@@ -3097,6 +3300,7 @@ hipError_t configure_kernels(const SimDims &) {
                            reinterpret_cast<const void *>(k_sweep_hc<3, true>),
                            reinterpret_cast<const void *>(k_overlap),
                            reinterpret_cast<const void *>(k_overlap_wide),
+                           reinterpret_cast<const void *>(k_sweep_wide),
                            reinterpret_cast<const void *>(k_rng_relay<false, false>),
                            reinterpret_cast<const void *>(k_rng_relay<false, true>),
                            reinterpret_cast<const void *>(k_rng_relay<true, false>),
@@ -3135,7 +3339,17 @@ hipError_t configure_kernels(const SimDims &) {
     return hipSuccess;
 }
 
+size_t sweep_wide_lds_bytes(const SimDims &d) { return sweep_wide_lds_words(d) * 4; }
+bool takes_wide_route(const SimDims &d, bool gibbs) { return d.wide && !gibbs; }
+
 hipError_t launch_rng(const SimDims &d, const DevPtrs &p, bool gibbs, hipStream_t stream) {
+    if (takes_wide_route(d, gibbs)) { // the level planes of the Metropolis table, by the heat bath's seven-threshold code
+        DevPtrs q = p;
+        q.thr_gibbs = p.thr_wide;
+        const uint32_t groups = ((d.n_real * d.W + 1) / 2 + 3) / 4;
+        hipLaunchKernelGGL((k_rng<false, true>), dim3(groups * d.B), dim3(256), kRngLds, stream, d, q);
+        return hipGetLastError();
+    }
     if (d.general) return launch_rng_f(d, p, gibbs, stream);
     const uint32_t n_pairs_tw = (d.n_real * d.W + 1) / 2;
     const uint32_t groups = (n_pairs_tw + 3) / 4;
@@ -3233,6 +3447,11 @@ hipError_t launch_measure_overlap(const SimDims &d, const DevPtrs &p, const PtPa
 
 hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,
                         bool gibbs, hipStream_t stream) {
+    if (do_sweep && takes_wide_route(d, gibbs)) {
+        hipLaunchKernelGGL(k_sweep_wide, dim3(d.n_real * d.W), dim3(256), sweep_wide_lds_bytes(d), stream, d, p,
+                           with_energy ? 1 : 0, 1);
+        return hipGetLastError();
+    }
     if (d.general) return launch_sweep_f(d, p, with_energy, do_sweep, stream);
     if (d.big) {
         if (do_sweep)

@@ -64,8 +64,8 @@ struct pa_sim {
     uint32_t next_parity = 0;
     // non-const aliases of the static tables (filled once in create)
     uint32_t *thr = nullptr, *mpar = nullptr, *pass_start = nullptr, *jump = nullptr;
-    uint4 *rec = nullptr;
-    uint32_t *hc_tab = nullptr;
+    uint4 *rec = nullptr, *rec_wide = nullptr;
+    uint32_t *hc_tab = nullptr, *thr_wide = nullptr;
     uint16_t *nbr_site = nullptr;
     uint32_t *jsite = nullptr, *nbr_wide = nullptr;
     uint4 *fwd_big = nullptr;
@@ -391,6 +391,11 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
         q.xw += tile_words * (d.nn <= 3 ? 4 : 8) * r0;
     } else {
         q.planes += static_cast<size_t>(d.planes_stride) * d.W * r0;
+    }
+    if (d.wide) {
+        q.planes += static_cast<size_t>(d.planes_stride) * d.W * r0;
+        q.planes_hi += static_cast<size_t>(d.planes_stride) * d.W * r0;
+        q.rec_wide += (static_cast<size_t>(d.N) + 1) * 2 * r0;
     }
     q.cursor += static_cast<size_t>(8) * d.SP * r0;
     q.cursor_out += static_cast<size_t>(8) * d.SP * r0;
@@ -1596,6 +1601,22 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     // 16^3 x 64 temperatures x 8 replicas = 16 words, keeps the on-chip path and every cluster move)
     d.big = d.N > 12000 ? 1 : 0;
     if (d.general && sweep_f_lds_bytes(d) > 160 * 1024) d.big = 1;
+    // unit couplings on four to six forward directions: Metropolis sweeps by the integer table (SimDims::wide)
+    d.wide = (d.general && d.unit && d.nn > 3 && d.nn <= 6 && !d.big && d.N <= 16383 &&
+              sweep_wide_lds_bytes(d) <= 160 * 1024 && !std::getenv("PEAPODS_NO_WIDE")) ? 1 : 0;
+    std::vector<uint32_t> thr_wide;
+    if (d.wide) { // the table's columns in the layout the random-stream kernel reads for the heat bath (thr_gibbs)
+        const uint32_t width = 4 * d.nn + 1, off = 2 * d.nn;
+        thr_wide.assign(static_cast<size_t>(14) * d.n_temps, 0u);
+        for (uint32_t t = 0; t < d.n_temps && d.wide; ++t) {
+            for (uint32_t j = 0; j < 7; ++j) {
+                if (2 * (j + 1) <= off) thr_wide[(0 + j) * d.n_temps + t] = table[t * width + off - 2 * (j + 1)]; // dE = -2 (j + 1)
+                if (2 * j + 1 <= off) thr_wide[(7 + j) * d.n_temps + t] = table[t * width + off - (2 * j + 1)];   // dE = -(2 j + 1)
+            }
+            for (uint32_t e = 1; e <= off; ++e) // the levels are nested only if the table falls with |dE| (it does: sweep.rs:141-159)
+                if (table[t * width + e] < table[t * width + e - 1]) d.wide = 0;
+        }
+    }
     if (d.big && d.nn > 3) {
         sim->error = "lattices with more than 3 forward directions are built for the on-chip kernels only "
                      "(about 4000 sites)";
@@ -1786,6 +1807,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     // ---- per-realisation site records in schedule order (neighbours + coupling metadata)
     const size_t rec_stride = (static_cast<size_t>(d.N) + 1) * (d.big ? 2 : 1); // uint4 per realisation
     std::vector<uint4> rec(static_cast<size_t>(d.n_real) * rec_stride);
+    std::vector<uint4> rec_wide(d.wide ? static_cast<size_t>(d.n_real) * (d.N + 1) * 2 : 0);
     std::vector<uint16_t> nbr_site(static_cast<size_t>(d.N) * 12);
     std::vector<uint32_t> jsite(static_cast<size_t>(d.n_real) * d.N), nbr_wide(static_cast<size_t>(d.N) * 16, 0u);
     bool all_nonzero = true;
@@ -1817,14 +1839,27 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
                     if (d.N <= 65535) nbr_site[static_cast<size_t>(site) * 12 + k] = static_cast<uint16_t>(nb[k]);
                 }
             }
-            if (d.nn > 3) continue; // the bit-sliced records below hold three directions
             const uint32_t h = (m + 1) / 2;
-            const uint32_t jm = (neg & 63u) | ((nz & 63u) << 6) | (h << 12);
-            if (m != 2 * d.nn) all_nonzero = false;
             if (m & 1u) { // odd number of non-zero bonds: the odd threshold set (k_rng)
                 mpar[static_cast<size_t>(real) * d.MW + (site >> 5)] |= 1u << (site & 31u);
                 d.has_odd = 1;
             }
+            if (d.wide) { // thirteen LDS byte offsets, h, then the coupling signs and the non-zero flags of the twelve slots
+                uint4 a, b;
+                a.x = (site * 4) | (nb[0] * 4 << 16);
+                a.y = (nb[1] * 4) | (nb[2] * 4 << 16);
+                a.z = (nb[3] * 4) | (nb[4] * 4 << 16);
+                a.w = (nb[5] * 4) | (nb[6] * 4 << 16);
+                b.x = (nb[7] * 4) | (nb[8] * 4 << 16);
+                b.y = (nb[9] * 4) | (nb[10] * 4 << 16);
+                b.z = (nb[11] * 4) | (h << 16);
+                b.w = neg | (nz << 12);
+                rec_wide[(static_cast<size_t>(real) * (d.N + 1) + pos) * 2] = a;
+                rec_wide[(static_cast<size_t>(real) * (d.N + 1) + pos) * 2 + 1] = b;
+            }
+            if (d.nn > 3) continue; // the bit-sliced records below hold three directions
+            const uint32_t jm = (neg & 63u) | ((nz & 63u) << 6) | (h << 12);
+            if (m != 2 * d.nn) all_nonzero = false;
             if (d.big) { // full-width indices, two uint4 per site
                 rec[static_cast<size_t>(real) * rec_stride + 2 * pos] = make_uint4(site, nb[0], nb[1], nb[2]);
                 rec[static_cast<size_t>(real) * rec_stride + 2 * pos + 1] = make_uint4(nb[3], nb[4], nb[5], jm);
@@ -1833,6 +1868,11 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
             rec[static_cast<size_t>(real) * rec_stride + pos] = // fields hold LDS byte offsets (4 * index)
                 make_uint4((site * 4) | (nb[0] * 4 << 16), (nb[1] * 4) | (nb[2] * 4 << 16),
                            (nb[3] * 4) | (nb[4] * 4 << 16), (nb[5] * 4) | (jm << 16));
+        }
+        if (d.wide) { // idle lanes: every offset at the spare slot N, no bond
+            const uint32_t spare = d.N * 4;
+            rec_wide[(static_cast<size_t>(real) * (d.N + 1) + d.N) * 2] = make_uint4(spare | (spare << 16), spare | (spare << 16), spare | (spare << 16), spare | (spare << 16));
+            rec_wide[(static_cast<size_t>(real) * (d.N + 1) + d.N) * 2 + 1] = make_uint4(spare | (spare << 16), spare | (spare << 16), spare, 0u);
         }
         const uint32_t dummy = d.N * 4; // idle lanes of a pass work on the spare slot N
         if (!d.big)
@@ -2048,7 +2088,12 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     ok(bufs.alloc(&p.swap_epoch, static_cast<size_t>(d.n_real)));
 
     ok(bufs.alloc(&p.applied_epoch, static_cast<size_t>(d.n_real) * d.W));
-    ok(bufs.alloc(&p.planes, d.general ? 1 : static_cast<size_t>(d.planes_stride) * d.W * d.n_real));
+    ok(bufs.alloc(&p.planes, (d.general && !d.wide) ? 1 : static_cast<size_t>(d.planes_stride) * d.W * d.n_real));
+    if (d.wide) {
+        ok(bufs.alloc(&p.planes_hi, static_cast<size_t>(d.planes_stride) * d.W * d.n_real));
+        ok(bufs.alloc(&sim->rec_wide, rec_wide.size()));
+        ok(bufs.alloc(&sim->thr_wide, thr_wide.size()));
+    }
     if (d.general) {
         ok(bufs.alloc(&sim->Jf, n_coup * d.n_real));
         ok(bufs.alloc(&sim->temps_dev, static_cast<size_t>(d.n_temps)));
@@ -2110,6 +2155,8 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     p.rec = sim->rec;
     p.pass_start = sim->pass_start;
     p.hc_tab = sim->hc_tab;
+    p.rec_wide = sim->rec_wide;
+    p.thr_wide = sim->thr_wide;
     if (d.hc && (rc = upload(sim, sim->hc_tab, hc_tab))) return bail(rc);
     p.jump = sim->jump;
     p.nz_bonds = sim->nz_bonds;
@@ -2158,6 +2205,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     }
     if ((rc = upload(sim, sim->thr, thr)) || (rc = upload(sim, sim->mpar, mpar)) ||
         (rc = upload(sim, sim->rec, rec)) || (rc = upload(sim, sim->pass_start, pass_start)) ||
+        (d.wide && ((rc = upload(sim, sim->rec_wide, rec_wide)) || (rc = upload(sim, sim->thr_wide, thr_wide)))) ||
         (rc = upload(sim, sim->jump, jump)) || (rc = upload(sim, sim->nbr_site, nbr_site)) ||
         (rc = upload(sim, sim->jsite, jsite)) || (rc = upload(sim, sim->nbr_wide, nbr_wide)) || (rc = upload(sim, sim->jorg_p, jorg_p)) ||
         (rc = upload(sim, sim->nz_bonds, nz_bonds)) || (rc = upload(sim, sim->dbeta, dbeta)))

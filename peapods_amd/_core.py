@@ -242,9 +242,17 @@ class IsingSimulation:
             while not done.wait(0.2):
                 pass
         except KeyboardInterrupt:
-            self._lib.pa_sim_request_interrupt(self._handle)
-            while not done.wait(0.2):  # the call returns PA_ERR_INTERRUPTED within two batches of queued sweeps
-                pass
+            # The native call must have returned before this frame is left (a later __del__ would free state it is
+            # using), so further Ctrl-Cs only renew the request.  The request is repeated while waiting: the native
+            # call clears the flag when it starts, and an interrupt that arrived between Thread.start() and that
+            # store would otherwise be lost and the full run awaited.
+            while True:
+                try:
+                    self._lib.pa_sim_request_interrupt(self._handle)
+                    if done.wait(0.2):  # the call returns PA_ERR_INTERRUPTED within two batches of queued sweeps
+                        break
+                except KeyboardInterrupt:
+                    continue
             self._lib.pa_sim_synchronize(self._handle)
             raise
         self._check(outcome["code"])

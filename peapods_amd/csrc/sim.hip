@@ -963,8 +963,12 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             }
             if (overlap_owed) toggle_dots(g.p);
         }
+        // (a relayed tempering event files the new permutation but leaves the cached sums in the old slot order: the
+        // sweep behind it recomputes them even where the protocol would not ask -- pt_interval > 1 inside the warm-up --
+        // so that pa_sim_get_energies / _magnetization_sums never pair a system with another system's sums)
+        const bool resum = relayed && pending.do_pt;
         if (launch)
-            for (auto &g : sim->groups) PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, record || pt_this, gibbs, g.stream));
+            for (auto &g : sim->groups) PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, record || pt_this || resum, gibbs, g.stream));
         if (relayed && pending.do_pt && d.n_temps >= 2) toggle_system_tables(sim);
         pending.any = false;
         sim->swaps_pending = false;
@@ -1138,7 +1142,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             }
             // energies are computed after every mutating move of the sweep (:492-509); on the pipelined large-lattice
             // path the overlap of the swept state is measured by the same launch when nothing comes between the two
-            const bool with_e = (record || pt_this || equil) && !fk_this;
+            const bool with_e = (record || pt_this || equil || (relayed_nf && pending.do_pt)) && !fk_this; // (relayed event: see fused_sweep)
             const bool big_fuse = g.d.pipe_K && with_e && !fk_this && !equil && record && want_overlap && d.n_pairs && d.nn <= 3;
             PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, with_e, gibbs, g.stream, big_fuse));
             if (big_fuse) toggle_dots(g.p);

@@ -37,6 +37,26 @@ for path in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"
             short = name.split("(")[0].replace("void ", "").replace(",", ";")
             sums[short][row["Counter_Name"]] += float(row["Counter_Value"])
             counts[short][row["Counter_Name"]] += 1
+# the other configs' counter passes (pmcx_<config>_<counters>): one table per config
+for cfg in ("c1", "c4_houdayer", "c4_jorg"):
+    xs, xn = defaultdict(lambda: defaultdict(float)), defaultdict(lambda: defaultdict(int))
+    for path in glob.glob(os.path.join(src, f"pmcx_{cfg}_*", "**", "*counter_collection.csv"), recursive=True):
+        with open(path, newline="") as fh:
+            for row in csv.DictReader(fh):
+                name = row["Kernel_Name"]
+                if "pa::" not in name:
+                    continue
+                short = name.split("(")[0].replace("void ", "").replace(",", ";")
+                xs[short][row["Counter_Name"]] += float(row["Counter_Value"])
+                xn[short][row["Counter_Name"]] += 1
+    if xs:
+        cols = sorted({c for k in xs for c in xs[k]})
+        with open(os.path.join(dst, f"{tag}_pmc_{cfg}.csv"), "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(["kernel"] + cols)
+            for kernel in sorted(xs):
+                w.writerow([kernel] + [f"{xs[kernel][c] / xn[kernel][c]:.1f}" if xn[kernel][c] else "" for c in cols])
+        print(f"pmc {cfg}:", len(xs), "kernels")
 counters = sorted({c for k in sums for c in sums[k]})
 rows = []
 for kernel in sorted(sums):
@@ -76,8 +96,12 @@ head_file = os.path.join(dst, "collect_head.txt")
 commit = open(head_file).read().strip() if os.path.exists(head_file) else "unlabelled"
 if all(v is not None for v in fetch + write):
     fetch_kb, write_kb = sum(fetch), sum(write)
+    sys.path.insert(0, root)
+    from peapods_amd import build as _build
+
     counters_out = {
         "commit": commit,
+        "source_hash": _build.source_hash(),  # the kernel sources these counts belong to (bench.py compares it with pa_version)
         "workload": "bench.py --config c2, 128 realisations per launch, one stream group (PEAPODS_STREAMS=1)",
         "wave_insts_per_launch": {k: v for k, v in insts.items() if v is not None},
         "hbm_bytes_per_sweep": (2 * fetch_kb + write_kb) * 1024,

@@ -72,8 +72,9 @@ def parse_args():
     ap.add_argument("--profile-sweeps", type=int, default=64)
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed call of exactly --steps steps is made this many times; the median is reported")
-    ap.add_argument("--settle-calls", type=int, default=24,
-                    help="at most this many untimed calls of --steps steps before the timed ones (until three agree)")
+    ap.add_argument("--settle-ms", type=float, default=30.0,
+                    help="untimed calls of --steps steps are made back to back for this long before the timed ones")
+    ap.add_argument("--settle-calls", type=int, default=64, help="... and at most this many of them")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short measurements of BASELINE configs[1] and configs[4] after the headline")
     return ap.parse_args()
@@ -355,19 +356,21 @@ def worker(args, rank, world, local_rank):
     repeats = max(1, args.repeats)
     timings = []
     timed_config = config(args.steps)  # (argument checking is not part of a step: built once, outside the timed region)
-    # Settling: a call of 20 steps lasts 1.3 ms, and the first such calls after start-up run 7 % slower than the same
-    # call a few milliseconds later (67.7 -> 62.4 us per step over fifteen consecutive calls, gpurun_out of round 3:
-    # the chip's clocks and the runtime settle).  Untimed calls of the same K steps are made until three in a row
-    # agree within 1.5 % (at most --settle-calls); they are reported, and nothing of the timed calls depends on them.
-    settle = []
-    for _ in range(max(0, args.settle_calls)):
+    # Settling: a call of 20 steps lasts 1.2 ms, and on a chip that has just been idle it runs 12 % slower than the same
+    # call in a train of such calls -- 70 -> 62 us per step over the first fifteen back-to-back calls (20 ms), and back to
+    # 68 after every 2 ms of idling (profiles/r03_settle_series.json: the clocks follow the load).  Untimed calls of the
+    # same K steps are therefore made back to back until --settle-ms of them have run; they are reported, and nothing of
+    # the timed calls depends on them (each timed call is bracketed and synchronised by itself).
+    settle, settled = [], 0.0
+    while settled < args.settle_ms * 1e-3 and len(settle) < max(0, args.settle_calls):
         sync_all()
         t0 = time.perf_counter()
         sim.run(timed_config, wait=False)
         sim.synchronize()
         settle.append(time.perf_counter() - t0)
-        if len(settle) >= 3 and max(settle[-3:]) <= 1.015 * min(settle[-3:]):
-            break
+        settled += settle[-1]
+        if comm is not None:
+            settled = comm.max_f64(settled)  # every rank makes the same number of calls
     for _ in range(repeats):
         sync_all()
         t0 = time.perf_counter()

@@ -2269,11 +2269,29 @@ int pa_sim_reset(pa_sim *sim, uint64_t seed) {
 
 void pa_sim_request_interrupt(pa_sim *sim) { sim->interrupt.store(true); }
 
+// Waits for a stream: polls for up to 2 ms before handing the thread to the runtime's blocking wait, whose wake-up after
+// the last kernel costs 20-30 us (profiles/r03_settle_series.json: a 1-step call 128 -> 107 us, a 20-step call 62.0 ->
+// 60.4 us per step).  PEAPODS_SYNC_SPIN_US sets the polling time, 0 turns it off.
+static hipError_t wait_for_stream(hipStream_t stream) {
+    static const long spin_us = [] {
+        const char *env = std::getenv("PEAPODS_SYNC_SPIN_US");
+        return env ? std::strtol(env, nullptr, 10) : 2000L;
+    }();
+    if (spin_us > 0) {
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us);
+        do {
+            const hipError_t q = hipStreamQuery(stream);
+            if (q != hipErrorNotReady) return q;
+        } while (std::chrono::steady_clock::now() < until);
+    }
+    return hipStreamSynchronize(stream);
+}
+
 int pa_sim_synchronize(pa_sim *sim) {
     PA_HIP(sim, hipSetDevice(sim->device));
     // the group streams first: the main stream only holds the join (one wait per group), which is done the moment they are
-    for (auto &g : sim->groups) PA_HIP(sim, hipStreamSynchronize(g.stream));
-    PA_HIP(sim, hipStreamSynchronize(sim->stream));
+    for (auto &g : sim->groups) PA_HIP(sim, wait_for_stream(g.stream));
+    PA_HIP(sim, wait_for_stream(sim->stream));
     if (sim->d.pipe_K) { // a slab workgroup that gave up waiting leaves the state unusable: say so
         uint32_t gave_up = 0;
         PA_HIP(sim, hipMemcpy(&gave_up, sim->p.slab_error, sizeof(gave_up), hipMemcpyDeviceToHost));

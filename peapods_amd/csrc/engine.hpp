@@ -66,6 +66,10 @@ struct SimDims {
     // random-stream kernel, bit-sliced neighbour counts in k_sweep_wide -- while the handle stays a `general` one for
     // everything else (heat bath, energies kept as f32 bits)
     uint32_t wide;
+    // > 0 (with `wide`): the lattice's dependency levels are far thinner than a wave -- chunks of <= 16 sites of one
+    // level, swept by one wave with a site's bonds spread over a quad of lanes (k_sweep_wide, rec_thin)
+    uint32_t thin_chunks;
+    uint32_t thin_dense; // 1: every bond of every site of every realisation is non-zero (no masks, h = nn everywhere)
 };
 
 // hc_tab entry of a site (schedule order): site | wrap flags << 14 | coupling sign bits << 20
@@ -99,6 +103,11 @@ struct DevPtrs {
     const uint32_t *hc_tab;  // [n_real][N] schedule order: site | wrap flags << 14 | neg bits << 20 (SimDims::hc)
     const uint4 *rec_wide;   // [n_real][2 (N + 1)] SimDims::wide, schedule order (+ dummy): thirteen 16-bit LDS byte
                              //   offsets (site, f0, b0, ..., f5, b5), h = ceil(m / 2), then neg[0..11] | nz[12..23]
+    int32_t *Esum_relay, *Msum_relay; // [n_real][n_sys] sums exchanged by a relayed tempering event, until k_adopt_relay_sums
+    uint32_t *relay_swapped;          // [n_real] 1: that event accepted a swap in this realisation
+    const uint4 *rec_thin;   // [n_real][thin_chunks][64] SimDims::thin_chunks: lane 4 q + j of a chunk = part j of its q-th site:
+                             //   x = site | nb[3j] << 16, y = nb[3j+1] | nb[3j+2] << 16 (LDS byte offsets),
+                             //   z = neg[0..2] | nz[3..5] | h << 8 of those three slots (idle: the spare slot, no bond)
     const uint32_t *thr_wide; // [2][7][n_temps] SimDims::wide: Metropolis thresholds in the layout of thr_gibbs --
                              //   even set dE = -2, -4, ..., odd set dE = -1, -3, ... (falling; unused entries 0)
     const uint32_t *seg;     // [n_levels][pipe_K + 1] schedule positions where each slab's part of a level starts
@@ -249,6 +258,7 @@ hipError_t launch_rng_relay(const SimDims &d, const DevPtrs &p, bool with_overla
                             bool accum_overlap, bool do_pt, hipStream_t stream, bool gibbs = false);
 bool rng_relay_supported(const SimDims &d);
 bool rng_relay_ladder_supported(const SimDims &d);
+hipError_t launch_adopt_relay_sums(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 hipError_t launch_measure_overlap(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_accum, bool accum_overlap,
                                   bool do_pt, hipStream_t stream);
 hipError_t launch_sweep_pipe(const SimDims &d, const DevPtrs &p, bool gibbs, uint32_t epoch, hipStream_t stream);

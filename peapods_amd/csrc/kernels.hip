@@ -999,6 +999,28 @@ struct WideRec {
     }
 };
 
+// flip <=> U + L >= h from the bit planes of U (<= 12), the draw's level L (l0..l2) and h = ceil(m / 2): the carry out
+// of a five-bit addition, (U + L) + (32 - h) >= 32 (h = 0: every site flips)
+__device__ __forceinline__ uint32_t accept_from_count(uint32_t U0, uint32_t U1, uint32_t U2, uint32_t U3, uint32_t l0,
+                                                      uint32_t l1, uint32_t l2, uint32_t h) {
+    const uint32_t a0 = U0 ^ l0, k0 = U0 & l0;
+    const uint32_t a1 = U1 ^ l1 ^ k0, k1 = maj3(U1, l1, k0);
+    const uint32_t a2 = U2 ^ l2 ^ k1, k2 = maj3(U2, l2, k1);
+    const uint32_t a3 = U3 ^ k2, a4 = U3 & k2;
+    const uint32_t K = 32u - h;
+    const uint32_t K0 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(K), 0, 1));
+    const uint32_t K1 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(K), 1, 1));
+    const uint32_t K2 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(K), 2, 1));
+    const uint32_t K3 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(K), 3, 1));
+    const uint32_t K4 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(K), 4, 1));
+    uint32_t c = a0 & K0;
+    c = maj3(a1, K1, c);
+    c = maj3(a2, K2, c);
+    c = maj3(a3, K3, c);
+    c = maj3(a4, K4, c);
+    return h == 0 ? 0xFFFFFFFFu : c;
+}
+
 // flip mask of one site word: u[k] = unsatisfied non-zero bond k (k < 12), l0..l2 the draw's level, h = ceil(m / 2)
 __device__ __forceinline__ uint32_t accept_mask_wide(const uint32_t u[12], uint32_t l0, uint32_t l1, uint32_t l2, uint32_t h) {
     uint32_t s0, s1, s2, s3, c0, c1, c2, c3;
@@ -1015,24 +1037,27 @@ __device__ __forceinline__ uint32_t accept_mask_wide(const uint32_t u[12], uint3
     const uint32_t U1 = x0 ^ x1, z = x0 & x1;                  // weight 2
     uint32_t U2, U3;
     full_add(y0, y1, z, U2, U3);                               // weights 4, 8 (U <= 12)
-    // U + L: five bits
-    const uint32_t a0 = U0 ^ l0, k0 = U0 & l0;
-    const uint32_t a1 = U1 ^ l1 ^ k0, k1 = maj3(U1, l1, k0);
-    const uint32_t a2 = U2 ^ l2 ^ k1, k2 = maj3(U2, l2, k1);
-    const uint32_t a3 = U3 ^ k2, a4 = U3 & k2;
-    // (U + L) + (32 - h) >= 32: the carry out of bit 4 (h = 0: every site flips)
-    const uint32_t K = 32u - h;
-    const uint32_t K0 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(K), 0, 1));
-    const uint32_t K1 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(K), 1, 1));
-    const uint32_t K2 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(K), 2, 1));
-    const uint32_t K3 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(K), 3, 1));
-    const uint32_t K4 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(K), 4, 1));
-    uint32_t c = a0 & K0;
-    c = maj3(a1, K1, c);
-    c = maj3(a2, K2, c);
-    c = maj3(a3, K3, c);
-    c = maj3(a4, K4, c);
-    return h == 0 ? 0xFFFFFFFFu : c;
+    return accept_from_count(U0, U1, U2, U3, l0, l1, l2, h);
+}
+
+// The same decision with a site's twelve bonds spread over the four lanes of a quad (k_sweep_wide's thin-level loop):
+// a lane holds the carry-save sum (sm, cr) of its three bonds, the quad adds its four two-bit numbers with two DPP
+// exchanges (lane ^ 1, then lane ^ 2); every lane of the quad ends with the site's flip mask.
+__device__ __forceinline__ uint32_t quad_swap1(uint32_t v) { // the value of lane ^ 1
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0xB1, 0xF, 0xF, true)); // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ uint32_t quad_swap2(uint32_t v) { // the value of lane ^ 2
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x4E, 0xF, 0xF, true)); // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ uint32_t accept_mask_quad(uint32_t sm, uint32_t cr, uint32_t l0, uint32_t l1, uint32_t l2, uint32_t h) {
+    const uint32_t sm1 = quad_swap1(sm), cr1 = quad_swap1(cr);
+    const uint32_t b0 = sm ^ sm1, k0 = sm & sm1;               // a pair of lanes: <= 6 in three bits
+    const uint32_t b1 = cr ^ cr1 ^ k0, b2 = maj3(cr, cr1, k0);
+    const uint32_t B0 = quad_swap2(b0), B1 = quad_swap2(b1), B2 = quad_swap2(b2);
+    const uint32_t U0 = b0 ^ B0, k1 = b0 & B0;                 // the quad: <= 12 in four bits
+    const uint32_t U1 = b1 ^ B1 ^ k1, k2 = maj3(b1, B1, k1);
+    const uint32_t U2 = b2 ^ B2 ^ k2, U3 = maj3(b2, B2, k2);
+    return accept_from_count(U0, U1, U2, U3, l0, l1, l2, h);
 }
 
 __host__ __device__ inline size_t sweep_wide_lds_words(const SimDims &d) {
@@ -1078,7 +1103,61 @@ __global__ __launch_bounds__(256) void k_sweep_wide(SimDims d, DevPtrs p, int wi
             u[k] = (s ^ lds_word(sw, r.nb[k]) ^ static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(r.neg), k, 1))) &
                    static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(r.nz), k, 1));
     };
-    if (do_sweep) {
+    if (do_sweep && d.thin_chunks) {
+        // ---- thin levels (fcc at 16^3: 256 levels of 16 sites): a level is far less than a wave of sites, and what it
+        // costs is the ~135 instructions a lone wave issues for it at one per ~4.7 cycles.  Here the FIRST WAVE alone
+        // sweeps, sixteen sites at a time with a site's twelve bonds over the four lanes of a quad (rec_thin: one
+        // 16-byte record per lane and chunk of <= 16 sites of one level): three bonds, one carry-save add and two quad
+        // exchanges per lane, ~60 instructions per chunk.  One wave: LDS operations stay in program order, no barrier
+        // between levels; the chunks of a level do not read one another.
+        auto thin_loop = [&](auto dense_tag) {
+            constexpr bool DENSE = decltype(dense_tag)::value; // every bond of every site non-zero: no masks, h = nn for all
+            const uint32_t n = d.thin_chunks;
+            const uint4 *rt = p.rec_thin + static_cast<size_t>(real) * n * 64 + tid;
+            constexpr uint32_t kAhead = 8; // records in flight: a chunk lasts ~0.25 us, a global load ~1.5
+            uint4 ring[kAhead];
+#pragma unroll
+            for (uint32_t i = 0; i < kAhead; ++i) ring[i] = rt[static_cast<size_t>(min(i, n - 1)) * 64];
+            const bool writer = (tid & 3u) == 0;
+            const uint32_t h_all = __builtin_amdgcn_readfirstlane(d.nn);
+            for (uint32_t c = 0; c < n; c += kAhead) {
+#pragma unroll
+                for (uint32_t i = 0; i < kAhead; ++i) {
+                    if (c + i >= n) break;
+                    const uint4 r = ring[i];
+                    ring[i] = rt[static_cast<size_t>(min(c + i + kAhead, n - 1)) * 64];
+                    const uint32_t site = r.x & 0xFFFFu;
+                    const uint32_t sv = lds_word(sw, site);
+                    const uint2 lv = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(pl) + 2 * site);
+                    const uint32_t l2 = lds_word(pl2, site);
+                    const uint32_t n0 = lds_word(sw, r.x >> 16), n1 = lds_word(sw, r.y & 0xFFFFu), n2 = lds_word(sw, r.y >> 16);
+                    const int meta = static_cast<int>(r.z);
+                    uint32_t u0 = sv ^ n0 ^ static_cast<uint32_t>(__builtin_amdgcn_sbfe(meta, 0, 1));
+                    uint32_t u1 = sv ^ n1 ^ static_cast<uint32_t>(__builtin_amdgcn_sbfe(meta, 1, 1));
+                    uint32_t u2 = sv ^ n2 ^ static_cast<uint32_t>(__builtin_amdgcn_sbfe(meta, 2, 1));
+                    if (!DENSE) {
+                        u0 &= static_cast<uint32_t>(__builtin_amdgcn_sbfe(meta, 3, 1));
+                        u1 &= static_cast<uint32_t>(__builtin_amdgcn_sbfe(meta, 4, 1));
+                        u2 &= static_cast<uint32_t>(__builtin_amdgcn_sbfe(meta, 5, 1));
+                    }
+                    uint32_t sm, cr;
+                    full_add(u0, u1, u2, sm, cr);
+                    // (the planes are read with the neighbours, not behind the quad exchange where only the writing lanes
+                    // would want them: one LDS round trip per chunk, not two)
+                    uint32_t l0 = lv.x, l1 = lv.y, l2p = l2;
+                    asm volatile("" : "+v"(l0), "+v"(l1), "+v"(l2p), "+v"(sm), "+v"(cr));
+                    const uint32_t acc = accept_mask_quad(sm, cr, l0, l1, l2p, DENSE ? h_all : r.z >> 8);
+                    if (writer) *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(sw) + site) = sv ^ (acc & valid_bits);
+                }
+            }
+        };
+        if (tid < 64) {
+            if (d.thin_dense) thin_loop(std::true_type{});
+            else thin_loop(std::false_type{});
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < d.N; i += kThreads) Sout[i] = sw[i];
+    } else if (do_sweep) {
         auto fetch = [&](uint32_t pass, uint4 &a, uint4 &b) {
             uint32_t pos = d.N; // dummy record when idle: every offset points at the spare slot, h = 0 masked below
             if (pass < d.n_passes) {
@@ -1729,13 +1808,51 @@ __global__ __launch_bounds__(256) void k_overlap_wide(SimDims d, DevPtrs p) {
         const uint32_t v0 = B0 ? B0[i] : 0u, v1 = B1 ? B1[i] : 0u;
         Y[i] = A[i] ^ (r ? ((v0 >> r) | (v1 << (32 - r))) : v0);
     }
+    if (tid == 0) Y[d.N] = 0; // the idle record's slot
     __syncthreads();
     uint32_t c[5][8];
 #pragma unroll
     for (int s = 0; s < 5; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) c[s][j] = 0;
-    for (uint32_t base = 0; base < d.N; base += 16 * 256) {
+    // the sites' records (LDS byte offsets of the site and its neighbours; rec_wide, schedule order -- the sums do not
+    // care) are requested eight sites at a time before any is used: a thread's sixteen sites cost two memory round
+    // trips, not sixteen
+    const uint4 *rec = p.rec_wide + static_cast<size_t>(real) * 2 * n1;
+    for (uint32_t base = 0; p.rec_wide && base < d.N; base += 16 * 256) {
+        uint32_t qa[16], s1[16], c1[16], s2[16], c2[16];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint4 ra[8], rb[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t pos = base + (half * 8 + k) * 256 + tid, at = pos < d.N ? pos : d.N;
+                ra[k] = rec[2 * at];
+                rb[k] = rec[2 * at + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const WideRec wr(ra[k], rb[k]);
+                const uint32_t y = lds_word(Y, wr.site);
+                uint32_t z[6];
+#pragma unroll
+                for (int dir = 0; dir < 6; ++dir) // 1 where q_i * q_k = -1 (an absent direction's slot is the site itself: 0)
+                    z[dir] = y ^ lds_word(Y, wr.nb[2 * dir]);
+                qa[half * 8 + k] = y;
+                s1[half * 8 + k] = z[0] ^ z[1] ^ z[2];
+                c1[half * 8 + k] = maj3(z[0], z[1], z[2]);
+                s2[half * 8 + k] = z[3] ^ z[4] ^ z[5];
+                c2[half * 8 + k] = maj3(z[3], z[4], z[5]);
+            }
+        }
+        count16(qa, c[0]);
+        count16(s1, c[1]);
+        count16(c1, c[2]);
+        count16(s2, c[3]);
+        count16(c2, c[4]);
+    }
+    // (lattices whose offsets the 16-bit records cannot hold: neighbour indices from the wide table)
+    for (uint32_t base = 0; !p.rec_wide && base < d.N; base += 16 * 256) {
         uint32_t qa[16], s1[16], c1[16], s2[16], c2[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -1746,7 +1863,7 @@ __global__ __launch_bounds__(256) void k_overlap_wide(SimDims d, DevPtrs p) {
                 const uint32_t y = Y[row[0]];
                 uint32_t z[6];
 #pragma unroll
-                for (int dir = 0; dir < 6; ++dir) // 1 where q_i * q_k = -1
+                for (int dir = 0; dir < 6; ++dir)
                     z[dir] = dir < static_cast<int>(d.nn) ? (y ^ Y[row[1 + 2 * dir]]) : 0u;
                 qa[k] = y;
                 s1[k] = z[0] ^ z[1] ^ z[2];
@@ -2097,6 +2214,15 @@ __device__ __forceinline__ void measure_block(const SimDims &d, const DevPtrs &p
         }
         if (tid < 2 * d.W) p.swap_masks[static_cast<size_t>(real) * 2 * d.W + tid] = m.masks[tid];
         if (tid == 0 && any_swap) p.swap_epoch[real] += 1;
+        // The cached sums must follow the systems too, but Esum is being read by those workgroups (they replay the
+        // event from it): the exchanged sums are staged, and k_adopt_relay_sums files them behind this launch where
+        // the sweep that follows does not recompute them anyway (pt_interval > 1 inside the warm-up).
+        if (any_swap)
+            for (uint32_t k = tid; k < d.n_sys; k += nthreads) {
+                p.Esum_relay[static_cast<size_t>(real) * d.n_sys + k] = m.E[k];
+                p.Msum_relay[static_cast<size_t>(real) * d.n_sys + k] = m.M[k];
+            }
+        if (tid == 0) p.relay_swapped[real] = any_swap ? 1u : 0u;
         return;
     }
     // cursors follow their systems: new cursor[slot] = old cursor[old slot of the system now there].
@@ -3428,6 +3554,21 @@ hipError_t launch_rng_relay(const SimDims &d, const DevPtrs &p, bool with_overla
         else PA_RELAY(false, 0, false);
     }
 #undef PA_RELAY
+    return hipGetLastError();
+}
+
+// Files the sums a relayed tempering event exchanged (measure_block, pt.relay) -- launched behind that launch when the
+// following sweep leaves the sums alone; realisations without an accepted swap have nothing staged.
+__global__ __launch_bounds__(256) void k_adopt_relay_sums(SimDims d, DevPtrs p) {
+    const uint32_t real = blockIdx.x;
+    if (!p.relay_swapped[real]) return;
+    for (uint32_t k = threadIdx.x; k < d.n_sys; k += blockDim.x) {
+        p.Esum[static_cast<size_t>(real) * d.n_sys + k] = p.Esum_relay[static_cast<size_t>(real) * d.n_sys + k];
+        p.Msum[static_cast<size_t>(real) * d.n_sys + k] = p.Msum_relay[static_cast<size_t>(real) * d.n_sys + k];
+    }
+}
+hipError_t launch_adopt_relay_sums(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
+    hipLaunchKernelGGL(k_adopt_relay_sums, dim3(d.n_real), dim3(256), 0, stream, d, p);
     return hipGetLastError();
 }
 

@@ -64,7 +64,7 @@ struct pa_sim {
     uint32_t next_parity = 0;
     // non-const aliases of the static tables (filled once in create)
     uint32_t *thr = nullptr, *mpar = nullptr, *pass_start = nullptr, *jump = nullptr;
-    uint4 *rec = nullptr, *rec_wide = nullptr;
+    uint4 *rec = nullptr, *rec_wide = nullptr, *rec_thin = nullptr;
     uint32_t *hc_tab = nullptr, *thr_wide = nullptr;
     uint16_t *nbr_site = nullptr;
     uint32_t *jsite = nullptr, *nbr_wide = nullptr;
@@ -315,6 +315,7 @@ int seed_state(pa_sim *sim, uint64_t seed) {
     PA_HIP(sim, hipMemsetAsync(sim->p.edge_acc, 0, sizeof(uint64_t) * d.n_real * d.n_edges, sim->stream));
     PA_HIP(sim, hipMemsetAsync(sim->p.round_trips, 0, sizeof(uint64_t) * d.n_real * d.n_sys, sim->stream));
     PA_HIP(sim, hipMemsetAsync(sim->p.swap_epoch, 0, sizeof(uint32_t) * d.n_real, sim->stream));
+    PA_HIP(sim, hipMemsetAsync(sim->p.relay_swapped, 0, sizeof(uint32_t) * d.n_real, sim->stream));
     PA_HIP(sim, hipMemsetAsync(sim->p.applied_epoch, 0, sizeof(uint32_t) * d.n_real * d.W, sim->stream));
     PA_HIP(sim, hipMemsetAsync(sim->p.swap_masks, 0, sizeof(uint32_t) * d.n_real * 2 * d.W, sim->stream));
     sim->swaps_pending = false;
@@ -395,8 +396,9 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     if (d.wide) {
         q.planes += static_cast<size_t>(d.planes_stride) * d.W * r0;
         q.planes_hi += static_cast<size_t>(d.planes_stride) * d.W * r0;
-        q.rec_wide += (static_cast<size_t>(d.N) + 1) * 2 * r0;
+        if (d.thin_chunks) q.rec_thin += static_cast<size_t>(d.thin_chunks) * 64 * r0;
     }
+    if (q.rec_wide) q.rec_wide += (static_cast<size_t>(d.N) + 1) * 2 * r0;
     q.cursor += static_cast<size_t>(8) * d.SP * r0;
     q.cursor_out += static_cast<size_t>(8) * d.SP * r0;
     q.system_ids += static_cast<size_t>(d.n_sys) * r0;
@@ -413,6 +415,9 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     q.big_counts += static_cast<size_t>(4) * d.n_sys * r0;
     q.Esum += static_cast<size_t>(d.n_sys) * r0;
     q.Msum += static_cast<size_t>(d.n_sys) * r0;
+    q.Esum_relay += static_cast<size_t>(d.n_sys) * r0;
+    q.Msum_relay += static_cast<size_t>(d.n_sys) * r0;
+    q.relay_swapped += r0;
     q.nz_bonds += r0;
     q.dot_spin += static_cast<size_t>(d.n_pairs) * d.n_temps * r0;
     q.dot_link += static_cast<size_t>(d.n_pairs) * d.n_temps * r0;
@@ -963,12 +968,14 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             }
             if (overlap_owed) toggle_dots(g.p);
         }
-        // (a relayed tempering event files the new permutation but leaves the cached sums in the old slot order: the
-        // sweep behind it recomputes them even where the protocol would not ask -- pt_interval > 1 inside the warm-up --
-        // so that pa_sim_get_energies / _magnetization_sums never pair a system with another system's sums)
-        const bool resum = relayed && pending.do_pt;
+        // (a relayed tempering event files the new permutation but cannot touch the cached sums, which the launch's
+        // random-stream workgroups read: where the sweep behind it does not recompute them -- pt_interval > 1 inside the
+        // warm-up -- the exchanged sums it staged are filed now, so that pa_sim_get_energies / _magnetization_sums hold
+        // what the reference's caches hold: the last computed values, with their systems)
+        if (launch && relayed && pending.do_pt && d.n_temps >= 2 && !(record || pt_this))
+            for (auto &g : sim->groups) PA_HIP(sim, launch_adopt_relay_sums(g.d, g.p, g.stream));
         if (launch)
-            for (auto &g : sim->groups) PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, record || pt_this || resum, gibbs, g.stream));
+            for (auto &g : sim->groups) PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, record || pt_this, gibbs, g.stream));
         if (relayed && pending.do_pt && d.n_temps >= 2) toggle_system_tables(sim);
         pending.any = false;
         sim->swaps_pending = false;
@@ -1142,7 +1149,9 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             }
             // energies are computed after every mutating move of the sweep (:492-509); on the pipelined large-lattice
             // path the overlap of the swept state is measured by the same launch when nothing comes between the two
-            const bool with_e = (record || pt_this || equil || (relayed_nf && pending.do_pt)) && !fk_this; // (relayed event: see fused_sweep)
+            if (relayed_nf && pending.do_pt && d.n_temps >= 2 && !(record || pt_this || equil)) // (the event's exchanged sums: see fused_sweep)
+                PA_HIP(sim, launch_adopt_relay_sums(g.d, g.p, g.stream));
+            const bool with_e = (record || pt_this || equil) && !fk_this;
             const bool big_fuse = g.d.pipe_K && with_e && !fk_this && !equil && record && want_overlap && d.n_pairs && d.nn <= 3;
             PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, with_e, gibbs, g.stream, big_fuse));
             if (big_fuse) toggle_dots(g.p);
@@ -1811,7 +1820,9 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     // ---- per-realisation site records in schedule order (neighbours + coupling metadata)
     const size_t rec_stride = (static_cast<size_t>(d.N) + 1) * (d.big ? 2 : 1); // uint4 per realisation
     std::vector<uint4> rec(static_cast<size_t>(d.n_real) * rec_stride);
-    std::vector<uint4> rec_wide(d.wide ? static_cast<size_t>(d.n_real) * (d.N + 1) * 2 : 0);
+    // (the wide records serve the wide sweep and, on any lattice of four to six directions they can address, the overlap)
+    const bool want_rec_wide = d.wide || (d.nn > 3 && d.nn <= 6 && d.N <= 16383);
+    std::vector<uint4> rec_wide(want_rec_wide ? static_cast<size_t>(d.n_real) * (d.N + 1) * 2 : 0);
     std::vector<uint16_t> nbr_site(static_cast<size_t>(d.N) * 12);
     std::vector<uint32_t> jsite(static_cast<size_t>(d.n_real) * d.N), nbr_wide(static_cast<size_t>(d.N) * 16, 0u);
     bool all_nonzero = true;
@@ -1848,7 +1859,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
                 mpar[static_cast<size_t>(real) * d.MW + (site >> 5)] |= 1u << (site & 31u);
                 d.has_odd = 1;
             }
-            if (d.wide) { // thirteen LDS byte offsets, h, then the coupling signs and the non-zero flags of the twelve slots
+            if (want_rec_wide) { // thirteen LDS byte offsets, h, then the coupling signs and the non-zero flags of the twelve slots
                 uint4 a, b;
                 a.x = (site * 4) | (nb[0] * 4 << 16);
                 a.y = (nb[1] * 4) | (nb[2] * 4 << 16);
@@ -1861,9 +1872,9 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
                 rec_wide[(static_cast<size_t>(real) * (d.N + 1) + pos) * 2] = a;
                 rec_wide[(static_cast<size_t>(real) * (d.N + 1) + pos) * 2 + 1] = b;
             }
+            if (m != 2 * d.nn) all_nonzero = false;
             if (d.nn > 3) continue; // the bit-sliced records below hold three directions
             const uint32_t jm = (neg & 63u) | ((nz & 63u) << 6) | (h << 12);
-            if (m != 2 * d.nn) all_nonzero = false;
             if (d.big) { // full-width indices, two uint4 per site
                 rec[static_cast<size_t>(real) * rec_stride + 2 * pos] = make_uint4(site, nb[0], nb[1], nb[2]);
                 rec[static_cast<size_t>(real) * rec_stride + 2 * pos + 1] = make_uint4(nb[3], nb[4], nb[5], jm);
@@ -1873,7 +1884,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
                 make_uint4((site * 4) | (nb[0] * 4 << 16), (nb[1] * 4) | (nb[2] * 4 << 16),
                            (nb[3] * 4) | (nb[4] * 4 << 16), (nb[5] * 4) | (jm << 16));
         }
-        if (d.wide) { // idle lanes: every offset at the spare slot N, no bond
+        if (want_rec_wide) { // idle lanes: every offset at the spare slot N, no bond
             const uint32_t spare = d.N * 4;
             rec_wide[(static_cast<size_t>(real) * (d.N + 1) + d.N) * 2] = make_uint4(spare | (spare << 16), spare | (spare << 16), spare | (spare << 16), spare | (spare << 16));
             rec_wide[(static_cast<size_t>(real) * (d.N + 1) + d.N) * 2 + 1] = make_uint4(spare | (spare << 16), spare | (spare << 16), spare, 0u);
@@ -1883,7 +1894,40 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
             rec[static_cast<size_t>(real) * rec_stride + d.N] =
                 make_uint4(dummy | (dummy << 16), dummy | (dummy << 16), dummy | (dummy << 16), dummy);
     }
-    d.dense_nn = all_nonzero ? d.nn : 0;
+    d.dense_nn = (all_nonzero && d.nn <= 3) ? d.nn : 0;
+
+    // ---- thin levels (SimDims::thin_chunks): when the lattice's levels hold far fewer sites than a wave -- fcc: N / 16^2
+    // levels of 16 sites; five directions: levels of one or two -- the wide sweep is run by one wave, a level in chunks
+    // of <= 16 sites with each site's twelve bond slots over four lanes.  Worth it when the chunks are fewer than three
+    // times the passes (a chunk costs ~0.2 us, a pass of the four-wave loop ~0.6).
+    d.thin_chunks = 0;
+    d.thin_dense = all_nonzero ? 1 : 0;
+    std::vector<uint4> rec_thin;
+    if (d.wide && !std::getenv("PEAPODS_NO_THIN")) {
+        uint32_t chunks = 0;
+        for (uint32_t l = 0; l < n_levels; ++l) chunks += (level_start[l + 1] - level_start[l] + 15) / 16;
+        if (chunks < 3 * d.n_passes || std::getenv("PEAPODS_FORCE_THIN")) {
+            d.thin_chunks = chunks;
+            rec_thin.resize(static_cast<size_t>(d.n_real) * chunks * 64);
+            for (uint32_t real = 0; real < d.n_real; ++real) {
+                uint4 *out = rec_thin.data() + static_cast<size_t>(real) * chunks * 64;
+                const uint4 *in = rec_wide.data() + static_cast<size_t>(real) * (d.N + 1) * 2;
+                for (uint32_t l = 0; l < n_levels; ++l)
+                    for (uint32_t b = level_start[l]; b < level_start[l + 1]; b += 16, out += 64)
+                        for (uint32_t q = 0; q < 16; ++q) {
+                            const uint32_t pos = b + q < level_start[l + 1] ? b + q : d.N; // (N: the idle record)
+                            const uint4 a = in[2 * pos], bb = in[2 * pos + 1];
+                            const uint32_t off[13] = {a.x & 0xFFFFu, a.x >> 16, a.y & 0xFFFFu, a.y >> 16, a.z & 0xFFFFu, a.z >> 16,
+                                                      a.w & 0xFFFFu, a.w >> 16, bb.x & 0xFFFFu, bb.x >> 16, bb.y & 0xFFFFu,
+                                                      bb.y >> 16, bb.z & 0xFFFFu};
+                            const uint32_t h = bb.z >> 16, neg = bb.w & 0xFFFu, nz = (bb.w >> 12) & 0xFFFu;
+                            for (uint32_t j = 0; j < 4; ++j)
+                                out[4 * q + j] = make_uint4(off[0] | (off[1 + 3 * j] << 16), off[2 + 3 * j] | (off[3 + 3 * j] << 16),
+                                                            ((neg >> (3 * j)) & 7u) | (((nz >> (3 * j)) & 7u) << 3) | (h << 8), 0u);
+                        }
+            }
+        }
+    }
 
     // ---- implicit neighbours (k_sweep_hc): usable when every neighbour slot of every site lies at one of two
     // offsets from the site (regular / through the periodic wrap) -- true for hypercubic lattices of any
@@ -2095,9 +2139,10 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     ok(bufs.alloc(&p.planes, (d.general && !d.wide) ? 1 : static_cast<size_t>(d.planes_stride) * d.W * d.n_real));
     if (d.wide) {
         ok(bufs.alloc(&p.planes_hi, static_cast<size_t>(d.planes_stride) * d.W * d.n_real));
-        ok(bufs.alloc(&sim->rec_wide, rec_wide.size()));
+        if (d.thin_chunks) ok(bufs.alloc(&sim->rec_thin, rec_thin.size()));
         ok(bufs.alloc(&sim->thr_wide, thr_wide.size()));
     }
+    if (!rec_wide.empty()) ok(bufs.alloc(&sim->rec_wide, rec_wide.size()));
     if (d.general) {
         ok(bufs.alloc(&sim->Jf, n_coup * d.n_real));
         ok(bufs.alloc(&sim->temps_dev, static_cast<size_t>(d.n_temps)));
@@ -2116,6 +2161,9 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     ok(bufs.alloc(&sim->jump, jump.size()));
     ok(bufs.alloc(&p.Esum, static_cast<size_t>(d.n_real) * d.n_sys));
     ok(bufs.alloc(&p.Msum, static_cast<size_t>(d.n_real) * d.n_sys));
+    ok(bufs.alloc(&p.Esum_relay, static_cast<size_t>(d.n_real) * d.n_sys));
+    ok(bufs.alloc(&p.Msum_relay, static_cast<size_t>(d.n_real) * d.n_sys));
+    ok(bufs.alloc(&p.relay_swapped, static_cast<size_t>(d.n_real)));
     ok(bufs.alloc(&sim->nz_bonds, nz_bonds.size()));
     ok(bufs.alloc(&p.dot_spin, n_pair_slots));
     ok(bufs.alloc(&p.dot_link, n_pair_slots));
@@ -2160,6 +2208,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     p.pass_start = sim->pass_start;
     p.hc_tab = sim->hc_tab;
     p.rec_wide = sim->rec_wide;
+    p.rec_thin = sim->rec_thin;
     p.thr_wide = sim->thr_wide;
     if (d.hc && (rc = upload(sim, sim->hc_tab, hc_tab))) return bail(rc);
     p.jump = sim->jump;
@@ -2209,7 +2258,8 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     }
     if ((rc = upload(sim, sim->thr, thr)) || (rc = upload(sim, sim->mpar, mpar)) ||
         (rc = upload(sim, sim->rec, rec)) || (rc = upload(sim, sim->pass_start, pass_start)) ||
-        (d.wide && ((rc = upload(sim, sim->rec_wide, rec_wide)) || (rc = upload(sim, sim->thr_wide, thr_wide)))) ||
+        (!rec_wide.empty() && (rc = upload(sim, sim->rec_wide, rec_wide))) || (d.wide && (rc = upload(sim, sim->thr_wide, thr_wide))) ||
+        (d.thin_chunks && (rc = upload(sim, sim->rec_thin, rec_thin))) ||
         (rc = upload(sim, sim->jump, jump)) || (rc = upload(sim, sim->nbr_site, nbr_site)) ||
         (rc = upload(sim, sim->jsite, jsite)) || (rc = upload(sim, sim->nbr_wide, nbr_wide)) || (rc = upload(sim, sim->jorg_p, jorg_p)) ||
         (rc = upload(sim, sim->nz_bonds, nz_bonds)) || (rc = upload(sim, sim->dbeta, dbeta)))
@@ -2362,6 +2412,7 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
             q.fresh = consume_fresh(sim->fresh, d, pending.do_accum, pending.accum_overlap);
             PA_HIP(sim, launch_rng_relay(d, sim->p, overlap_owed, q, pending.do_accum, pending.accum_overlap, pending.do_pt,
                                          sim->stream, gibbs));
+            if (pending.do_pt && d.n_temps >= 2 && !(record || pt_this)) PA_HIP(sim, launch_adopt_relay_sums(d, sim->p, sim->stream));
             if (pending.do_pt && d.n_temps >= 2) toggle_system_tables(sim);
         } else if (fused && overlap_owed) {
             PA_HIP(sim, launch_rng_overlap(d, sim->p, sim->stream, gibbs));

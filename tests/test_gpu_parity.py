@@ -827,9 +827,10 @@ def test_set_system_ids_then_sample_matches_an_oracle_that_reached_the_same_stat
 
 
 def test_cached_sums_follow_the_systems_after_a_relayed_event(oracle):
-    """pt_interval > 1 with the run ending inside the warm-up: the sweep after a relayed tempering event would not
+    """pt_interval > 1 with the run ending inside the warm-up: the sweep after a relayed tempering event does not
     compute energies by the protocol, and the cached sums would stay in the slot order from before the swap (advisor
-    finding, round 2).  The getters must return every system's own sums."""
+    finding, round 2).  The getters must return what the reference's caches hold: every system's own sums as of the
+    last sweep that computed them (the one the event ran on) -- not another system's, and not recomputed ones."""
     shape, temps = (6, 6, 6), np.linspace(0.9, 2.5, 6).astype(np.float32)
     couplings = bimodal(shape, 3, 1, 5)
     gpu, cpu = make_pair(oracle, shape, couplings, temps, 2, 3)
@@ -837,14 +838,21 @@ def test_cached_sums_follow_the_systems_after_a_relayed_event(oracle):
     gpu.sample(23, "metropolis", **kw)   # events at sweeps 0, 3, ..., 21; sweep 22 follows the last one
     cpu.sample(23, "metropolis", **kw)
     np.testing.assert_array_equal(gpu.get_system_ids(0), cpu.get_system_ids(0))
-    spins = gpu.get_spins(0)
-    np.testing.assert_array_equal(spins, cpu.get_spins(0))
+    np.testing.assert_array_equal(gpu.get_spins(0), cpu.get_spins(0))
+    np.testing.assert_array_equal(gpu.get_energies(0), cpu.get_energies(0))
+    # ... which are the sums of the state sweep 21 left, system by system (the event moves temperatures, not spins)
+    _, before = make_pair(oracle, shape, couplings, temps, 2, 3)
+    before.sample(22, "metropolis", **kw)
     lib = oracle.load()
     lat = oracle.Lattice(list(shape))
     n_sys = 12
     energies = np.zeros(n_sys, dtype=np.float32)
     mags = np.zeros(n_sys, dtype=np.int64)
     J = np.ascontiguousarray(couplings.reshape(-1))
+    spins = before.get_spins(0)
     lib.orc_compute_energies(lat.handle, spins.ctypes.data, J.ctypes.data, n_sys, energies.ctypes.data, mags.ctypes.data, None)
     np.testing.assert_array_equal(gpu.get_magnetization_sums(0), mags)
     np.testing.assert_array_equal(gpu.get_energies(0), energies)
+    _, earlier = make_pair(oracle, shape, couplings, temps, 2, 3)
+    earlier.sample(21, "metropolis", **kw)  # (sweeps 0..20: without the event of sweep 21)
+    assert not np.array_equal(gpu.get_system_ids(0), earlier.get_system_ids(0))  # that event did exchange systems

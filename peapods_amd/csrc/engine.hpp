@@ -152,6 +152,7 @@ struct DevPtrs {
     uint32_t *swap_epoch;    // [n_real] bumped by every event that accepted a swap
     uint32_t *applied_epoch; // [n_real][W] epoch whose swaps are already in S
     uint32_t *big_counts;     // [n_real][n_sys][4] u32 scratch counters of the large-lattice kernels
+    uint32_t *big_ticket;     // [n_real] workgroups of k_energy_overlap_big done with the realisation (the last one finalises)
     const uint16_t *nbr_site; // [N][12] neighbours by site: f0, b0, f1, b1, ... f5, b5 (self when unused)
     const uint32_t *jsite;    // [n_real][N] by site: neg[0..11] | nz[12..23] for bonds f0,b0,...,f5,b5
     const uint4 *fwd_big;     // [N] large lattices: forward neighbours f0, f1, f2 of every site (self when unused), by site
@@ -261,7 +262,8 @@ bool rng_relay_ladder_supported(const SimDims &d);
 hipError_t launch_adopt_relay_sums(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 hipError_t launch_measure_overlap(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_accum, bool accum_overlap,
                                   bool do_pt, hipStream_t stream);
-hipError_t launch_sweep_pipe(const SimDims &d, const DevPtrs &p, bool gibbs, uint32_t epoch, hipStream_t stream);
+hipError_t launch_sweep_pipe(const SimDims &d, const DevPtrs &p, bool gibbs, uint32_t epoch, hipStream_t stream,
+                             bool apply_swaps = false); // apply_swaps: honoured by the LDS-resident kernel (SimDims::pipe_lds) only
 hipError_t launch_energy_overlap_big(const SimDims &d, const DevPtrs &p, hipStream_t stream); // (d.big, d.nn <= 3)
 hipError_t launch_apply_swaps(const SimDims &d, const DevPtrs &p, hipStream_t stream);
 hipError_t launch_houdayer(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool with_energy = false);

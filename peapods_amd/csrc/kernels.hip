@@ -2930,7 +2930,7 @@ __device__ __forceinline__ bool exchange_valid(const uint4 r, uint32_t base, uin
 }
 
 template <bool GIBBS>
-__global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs p, uint32_t epoch, uint32_t n_tw_pad) {
+__global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs p, uint32_t epoch, uint32_t n_tw_pad, int apply_swaps) {
     typedef __attribute__((address_space(1))) const void GlobalPtr;
     typedef __attribute__((address_space(3))) void LdsPtr;
     constexpr uint32_t D = kSlabDepth, R = kSlabStage;
@@ -2966,10 +2966,36 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
     uint32_t *segs = ctl + 16;                       // [n_levels][2] (first padded position, sites) of this slab
     uint32_t *halo_start = segs + 2 * d.n_levels;    // [n_levels + 2] first staged entry of every level (copy of the table)
     uint32_t *ring_hi = halo_start + d.n_levels + 2; // [D][256] third acceptance plane (heat bath)
-    for (uint32_t i = tid; i < own; i += kSlabThreads) lds[i] = Sold[a + i];
+    // apply_swaps: a tempering event has run since the last sweep and its bit-column exchanges are still deferred
+    // (swap_masks, written for every realisation by every event): they are applied to every word as it is loaded --
+    // the input buffer is not written in this launch -- instead of by two launches in front of this one
+    uint32_t mp[2] = {0, 0}, mc[2] = {0, 0}, mn[2] = {0, 0};
+    if (apply_swaps) {
+        const uint32_t *masks = p.swap_masks + static_cast<size_t>(real) * 2 * d.W;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            mp[r] = w > 0 ? masks[r * d.W + w - 1] : 0u;
+            mc[r] = masks[r * d.W + w];
+            mn[r] = w + 1 < d.W ? masks[r * d.W + w + 1] : 0u;
+        }
+        if (k == 0 && tid == 0) p.applied_epoch[tw] = p.swap_epoch[real]; // (nothing in this launch reads it)
+    }
+    const bool any_swap = (mc[0] | mc[1] | (mp[0] >> 31) | (mp[1] >> 31)) != 0;
+    const bool window = (((mp[0] | mp[1] | mc[0] | mc[1]) >> 31) != 0); // a pair straddles words
+    auto load_word = [&](uint32_t site) -> uint32_t {
+        const uint32_t v = Sold[site];
+        if (!any_swap) return v;
+        uint32_t prev = 0, next = 0;
+        if (window) {
+            if (w > 0) prev = Sold[static_cast<ptrdiff_t>(site) - static_cast<ptrdiff_t>(d.N)];
+            if (w + 1 < d.W) next = Sold[static_cast<size_t>(site) + d.N];
+        }
+        return apply_swaps_window(prev, v, next, mp, mc, mn);
+    };
+    for (uint32_t i = tid; i < own; i += kSlabThreads) lds[i] = load_word(a + i);
     for (uint32_t i = tid; i < P; i += kSlabThreads) { // (only the planes read as OLD values are ever used)
-        lds[own + i] = Sold[lo0 + i];
-        lds[own + P + i] = Sold[hi0 + i];
+        lds[own + i] = load_word(lo0 + i);
+        lds[own + P + i] = load_word(hi0 + i);
     }
     for (uint32_t l = tid; l < d.n_levels; l += kSlabThreads) { // the per-level table reads become LDS reads
         const uint2 sg = p.slab_seg[l * K + k];
@@ -3197,6 +3223,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
             owed = false;
         }
     };
+    uint32_t redo_other = reads_others ? ctl[8 + first % R] : 0u; // the flag of the level the OTHER set sweeps next
     if (p.slab_stamps && tid == 0) {
         p.slab_stamps[static_cast<size_t>(blockIdx.x) * (d.n_levels + 4)] = first;
         p.slab_stamps[static_cast<size_t>(blockIdx.x) * (d.n_levels + 4) + 1] = last;
@@ -3205,7 +3232,9 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
         slab_barrier(); // X(level): last level's spins are visible; the pieces of level + 1 have landed
         const bool mine = (((level - first) & 1u) != 0u) == set_b;
         const uint32_t sslot = level % R;
-        const uint32_t redo = mine ? cur.redo : (reads_others ? ctl[8 + sslot] : 0u);
+        // (registers only: the set that does not sweep this level asked for its flag while it swept the last one -- an
+        // LDS round trip at this point would stand in front of its pick-up of the next level's inputs)
+        const uint32_t redo = mine ? cur.redo : redo_other;
         if (p.slab_stamps && tid == 0) // (diagnostic runs only; bit 63: the level re-read its exchange records)
             p.slab_stamps[static_cast<size_t>(blockIdx.x) * (d.n_levels + 4) + 2 + level] =
                 wall_clock64() | (static_cast<unsigned long long>(redo != 0) << 63);
@@ -3237,6 +3266,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
         }
         if (mine) {
             // ---- this level's sites: reads -> accept -> write, nothing else before the next barrier
+            if (reads_others) redo_other = ctl[8 + (level + 1) % R]; // (set by the fetcher before X(level); used after X(level + 1))
             if (t < cur.count) {
                 uint32_t nb[6] = {lds_load(cur.nb[0]), lds_load(cur.nb[1]), lds_load(cur.nb[2]),
                                   lds_load(cur.nb[3]), lds_load(cur.nb[4]), lds_load(cur.nb[5])};
@@ -3364,9 +3394,36 @@ __global__ __launch_bounds__(256) void k_overlap_big(SimDims d, DevPtrs p, uint3
 
 // Both in one launch (they read the same state and write different counters): the energies of the state a sweep left
 // and its overlap measurement, when nothing comes between them in the protocol.
+// The workgroup that finishes last for its realisation also turns the counts into Esum / Msum and the dots (what
+// k_big_finalize does as a launch of its own elsewhere): every workgroup waits for its counter atomics to be
+// acknowledged (they are performed at the device's coherence point), then draws a ticket.
 __global__ __launch_bounds__(256) void k_energy_overlap_big(SimDims d, DevPtrs p, uint32_t n_chunks, uint32_t n_energy) {
+    __shared__ uint32_t am_last;
+    const uint32_t bid = blockIdx.x < n_energy ? blockIdx.x : blockIdx.x - n_energy;
+    const uint32_t real = bid / (n_chunks * d.W);
     if (blockIdx.x < n_energy) energy_big_block(d, p, blockIdx.x, n_chunks);
     else overlap_big_block(d, p, blockIdx.x - n_energy, n_chunks);
+    drain_global_stores(); // (the atomics without return count as stores)
+    __syncthreads();
+    if (threadIdx.x == 0) am_last = atomicAdd(&p.big_ticket[real], 1u) == 2u * n_chunks * d.W - 1u ? 1u : 0u;
+    __syncthreads();
+    if (!am_last) return;
+    for (uint32_t k = threadIdx.x; k < d.n_sys; k += blockDim.x) {
+        const size_t idx = static_cast<size_t>(real) * d.n_sys + k;
+        uint32_t *cnt = p.big_counts + idx * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = atomicExch(&cnt[j], 0u); // (read where the additions were performed, and cleared)
+        p.Esum[idx] = p.nz_bonds[real] - 2 * static_cast<int32_t>(v[0]);
+        p.Msum[idx] = static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(v[1]);
+        const uint32_t rep = k / d.n_temps, t = k % d.n_temps;
+        if ((rep & 1u) == 0 && rep + 1 < d.n_replicas) {
+            const size_t o = (static_cast<size_t>(real) * d.n_pairs + (rep >> 1)) * d.n_temps + t;
+            p.dot_spin[o] = static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(v[2]);
+            p.dot_link[o] = static_cast<int32_t>(d.N * d.nn) - 2 * static_cast<int32_t>(v[3]);
+        }
+    }
+    if (threadIdx.x == 0) p.big_ticket[real] = 0;
 }
 
 // counts -> Esum / Msum (mode 0), dot_spin / dot_link (mode 1) or both (mode 2); one thread per slot
@@ -3685,14 +3742,15 @@ size_t sweep_slab_lds_bytes(const SimDims &d) {
 }
 
 hipError_t launch_sweep_pipe(const SimDims &d, const DevPtrs &p, bool gibbs, uint32_t epoch,
-                             hipStream_t stream) {
+                             hipStream_t stream, bool apply_swaps) {
     const uint32_t n_tw_pad = (d.n_real * d.W + 7u) & ~7u;
+    // (apply_swaps: only the LDS-resident kernel exchanges the deferred bit columns itself; enqueue_sweep knows)
     if (d.pipe_lds && gibbs)
         hipLaunchKernelGGL(k_sweep_slab<true>, dim3(n_tw_pad * d.pipe_K), dim3(kSlabThreads), sweep_slab_lds_bytes(d),
-                           stream, d, p, epoch, n_tw_pad);
+                           stream, d, p, epoch, n_tw_pad, apply_swaps ? 1 : 0);
     else if (d.pipe_lds)
         hipLaunchKernelGGL(k_sweep_slab<false>, dim3(n_tw_pad * d.pipe_K), dim3(kSlabThreads), sweep_slab_lds_bytes(d),
-                           stream, d, p, epoch, n_tw_pad);
+                           stream, d, p, epoch, n_tw_pad, apply_swaps ? 1 : 0);
     else
         hipLaunchKernelGGL(k_sweep_pipe, dim3(n_tw_pad * d.pipe_K), dim3(256), 0, stream, d, p,
                            gibbs ? 1 : 0, epoch, n_tw_pad);
@@ -3724,7 +3782,6 @@ hipError_t launch_apply_swaps(const SimDims &d, const DevPtrs &p, hipStream_t st
 hipError_t launch_energy_overlap_big(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
     const uint32_t n_chunks = (d.N + 4095) / 4096, n_each = d.n_real * d.W * n_chunks;
     hipLaunchKernelGGL(k_energy_overlap_big, dim3(2 * n_each), dim3(256), 0, stream, d, p, n_chunks, n_each);
-    hipLaunchKernelGGL(k_big_finalize, dim3((d.n_real * d.n_sys + 255) / 256), dim3(256), 0, stream, d, p, 2);
     return hipGetLastError();
 }
 

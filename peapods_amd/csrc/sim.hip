@@ -413,6 +413,7 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     if (d.pipe_lds) q.xchg += static_cast<size_t>(d.W) * d.pipe_K * 2 * d.plane * r0;
 
     q.big_counts += static_cast<size_t>(4) * d.n_sys * r0;
+    q.big_ticket += r0;
     q.Esum += static_cast<size_t>(d.n_sys) * r0;
     q.Msum += static_cast<size_t>(d.n_sys) * r0;
     q.Esum_relay += static_cast<size_t>(d.n_sys) * r0;
@@ -503,12 +504,14 @@ void toggle_spin_buffers(pa_sim *sim) {
 // are materialised first; the LDS kernel applies them itself while loading.
 hipError_t enqueue_sweep(pa_sim *sim, const SimDims &d, const DevPtrs &p, bool with_energy,
                          bool gibbs, hipStream_t stream, bool overlap_too = false) {
-    if ((d.big || d.general) && sim->swaps_pending) {
+    // (the LDS-resident slab kernel exchanges the deferred bit columns while it loads: two launches less per sweep)
+    const bool at_load = d.pipe_K && d.pipe_lds && !std::getenv("PEAPODS_NO_SWAPS_AT_LOAD");
+    if ((d.big || d.general) && sim->swaps_pending && !at_load) {
         hipError_t e = launch_apply_swaps(d, p, stream);
         if (e != hipSuccess) return e;
     }
     if (d.pipe_K) { // pipelined large-lattice sweep S -> S_next, then the energies of the new state
-        hipError_t e = launch_sweep_pipe(d, p, gibbs, sim->pipe_epoch++, stream);
+        hipError_t e = launch_sweep_pipe(d, p, gibbs, sim->pipe_epoch++, stream, at_load && sim->swaps_pending);
         if (e != hipSuccess || !with_energy) return e;
         DevPtrs q = p;
         q.S = p.S_next;
@@ -2198,6 +2201,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     ok(bufs.alloc(&p.dfs_stack, d.N > 65535 ? 1 : static_cast<size_t>(d.n_real) * std::max(d.n_temps * d.n_pairs, d.n_sys) * d.N));
     if (!d.big && d.n_pairs) ok(bufs.alloc(&p.hd_scratch, 2 * tile_words * d.n_real));
     ok(bufs.alloc(&p.big_counts, static_cast<size_t>(d.n_real) * d.n_sys * 4));
+    ok(bufs.alloc(&p.big_ticket, static_cast<size_t>(d.n_real)));
     if (e != hipSuccess) {
         sim->error = std::string("hipMalloc: ") + hipGetErrorString(e);
         return bail(PA_ERR_DEVICE);
@@ -2264,7 +2268,8 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         (rc = upload(sim, sim->jsite, jsite)) || (rc = upload(sim, sim->nbr_wide, nbr_wide)) || (rc = upload(sim, sim->jorg_p, jorg_p)) ||
         (rc = upload(sim, sim->nz_bonds, nz_bonds)) || (rc = upload(sim, sim->dbeta, dbeta)))
         return bail(rc);
-    if (hipMemsetAsync(p.big_counts, 0, sizeof(uint32_t) * d.n_real * d.n_sys * 4, sim->stream) != hipSuccess) {
+    if (hipMemsetAsync(p.big_counts, 0, sizeof(uint32_t) * d.n_real * d.n_sys * 4, sim->stream) != hipSuccess ||
+        hipMemsetAsync(p.big_ticket, 0, sizeof(uint32_t) * d.n_real, sim->stream) != hipSuccess) {
         sim->error = "hipMemsetAsync failed";
         return bail(PA_ERR_DEVICE);
     }

@@ -3238,7 +3238,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_sweep_slab(SimDims d, DevPtrs 
         if (p.slab_stamps && tid == 0) // (diagnostic runs only; bit 63: the level re-read its exchange records)
             p.slab_stamps[static_cast<size_t>(blockIdx.x) * (d.n_levels + 4) + 2 + level] =
                 wall_clock64() | (static_cast<unsigned long long>(redo != 0) << 63);
-        if (__builtin_amdgcn_readfirstlane(redo)) {
+        if (__builtin_expect(__builtin_amdgcn_readfirstlane(redo) != 0, 0)) {
             // ---- the producer was not far enough ahead when this level's records were fetched: read them again
             const uint32_t e0 = halo_start[level], n_h = halo_start[level + 1] - e0;
             if (tid < n_h) { // (threads of set A)

@@ -47,6 +47,36 @@ def test_full_lattice_slice_matches_oracle(oracle):
         np.testing.assert_array_equal(pt_a[key], pt_b[key])
 
 
+@pytest.mark.parametrize("geometry", ["bcc", "fcc"])
+@pytest.mark.parametrize("dilute", [False, True], ids=["dense", "diluted"])
+def test_bench_lattice_with_eight_and_twelve_neighbours_matches_oracle(oracle, geometry, dilute):
+    """The bench ensemble's shape on the reference's bcc / fcc geometries (spin_models.py:5-10): the integer route of 4-6
+    forward directions -- at 16^3 the fcc lattice has 256 dependency levels of 16 sites (swept by one wave, a site's
+    bonds over a quad of lanes), the bcc lattice 16 levels of 256 -- with every bond non-zero and with a fifth removed."""
+    from peapods_amd import IsingSimulation
+    from peapods_amd.spin_models import GEOMETRIES, generate_couplings, seed_material
+
+    offsets = GEOMETRIES[geometry]
+    seq, dyn = seed_material(42)
+    couplings = np.stack(generate_couplings("bimodal", SHAPE, len(offsets), 3, seq))
+    if dilute:
+        couplings[np.random.default_rng(3).random(couplings.shape) < 0.2] = 0.0
+    temps = np.linspace(0.8, 1.4, N_TEMPS).astype(np.float32)
+    gpu = IsingSimulation(list(SHAPE), couplings, temps, N_REP, offsets, dyn)
+    cpu = oracle.OracleSimulation(list(SHAPE), couplings, temps, N_REP, offsets, dyn)
+    for schedule in ("single_random_edge", "full_ladder"):
+        kw = dict(pt_interval=1, pt_schedule=schedule, warmup_ratio=0.25)
+        a = gpu.sample(8, "metropolis", **kw)
+        b = cpu.sample(8, "metropolis", n_threads=3, **kw)
+        for key in ("mags", "mags2", "mags4", "energies", "energies2", "overlap", "overlap2", "overlap4", "link_overlap",
+                    "link_overlap2", "link_overlap4", "ql_at_q_sum", "per_sample_overlap_histogram"):
+            np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+        for r in range(3):
+            np.testing.assert_array_equal(gpu.get_spins(r), cpu.get_spins(r))
+            np.testing.assert_array_equal(gpu.get_system_ids(r), cpu.get_system_ids(r))
+            np.testing.assert_array_equal(gpu.get_energies(r), cpu.get_energies(r))
+
+
 def test_full_ensemble_properties(oracle):
     n_sweeps = 40
     full, couplings, temps, dyn = ensemble(128)
@@ -122,6 +152,7 @@ def test_full_ensemble_properties(oracle):
 
 @pytest.mark.parametrize("shape,kind,n_temps,n_rep,n_dis,n_sweeps", [
     ((24, 24, 24), "bimodal", 3, 2, 2, 6),   # smallest lattice on the large-lattice path
+    ((24, 24, 24), "bimodal", 5, 8, 1, 4),   # 40 slots in two words: the ladder of replica 6 (slots 30..34) straddles them
     ((128, 128), "ferro", 5, 2, 1, 4),        # 2D, 255 dependency levels
     ((64, 64, 64), "ferro", 32, 2, 1, 3),     # BASELINE configs[1]: 64^3 ferromagnet, 32 T x 2 replicas
 ])
@@ -157,6 +188,15 @@ def test_large_lattice_path_matches_oracle(oracle, shape, kind, n_temps, n_rep, 
     np.testing.assert_array_equal(a["energies"], b["energies"])
     np.testing.assert_array_equal(a["per_disorder"]["parallel_tempering"]["edge_acceptances"],
                                   b["per_disorder"]["parallel_tempering"]["edge_acceptances"])
+    for r in range(n_dis):
+        np.testing.assert_array_equal(gpu.get_spins(r), cpu.get_spins(r))
+        np.testing.assert_array_equal(gpu.get_system_ids(r), cpu.get_system_ids(r))
+    # ... and with one random edge per ladder, long enough for every ladder to exchange systems (the deferred bit-column
+    # swaps -- also the pair that straddles two words -- are applied by the slabs while they load)
+    kw1 = dict(pt_interval=1, pt_schedule="single_random_edge", warmup_ratio=0.0)
+    a = gpu.sample(12, "metropolis", **kw1)
+    b = cpu.sample(12, "metropolis", n_threads=8, **kw1)
+    np.testing.assert_array_equal(a["energies"], b["energies"])
     for r in range(n_dis):
         np.testing.assert_array_equal(gpu.get_spins(r), cpu.get_spins(r))
         np.testing.assert_array_equal(gpu.get_system_ids(r), cpu.get_system_ids(r))

@@ -2542,7 +2542,7 @@ __global__ __launch_bounds__(1024) void k_houdayer_grow(SimDims d, DevPtrs p, in
     extern __shared__ uint32_t lds[];
     uint32_t *A = lds;             // [N] active mask of the word
     uint32_t *F = lds + d.N;       // [N] cluster membership
-    uint32_t *changed = F + d.N;   // [1]
+    uint32_t *changed = F + d.N;   // [3] (+ 1 spare)
     uint32_t *sw = changed + 4;    // [N + 1] the word after the move (with_energy)
     uint32_t *scratch = sw + d.N + 4; // [5][48]
     const uint32_t real = blockIdx.x / d.W, w = blockIdx.x % d.W;
@@ -2574,42 +2574,57 @@ __global__ __launch_bounds__(1024) void k_houdayer_grow(SimDims d, DevPtrs p, in
     constexpr int kCached = 4;
     const bool cached = d.N <= kCached * nthreads;
     uint4 mine[kCached];
+    // (in SITE order, from the neighbour table: consecutive lanes then read consecutive words of F -- in schedule order,
+    // along the hyperplanes of the sweep, half of the kernel's LDS cycles were bank conflicts; the growth has no order)
 #pragma unroll
     for (int k = 0; k < kCached; ++k) {
-        const uint32_t pos = tid + k * nthreads;
-        mine[k] = (cached && pos < d.N) ? rec[pos] : make_uint4(0, 0, 0, 0);
+        const uint32_t site = tid + k * nthreads;
+        mine[k] = make_uint4(0, 0, 0, 0);
+        if (cached && site < d.N) {
+            const NbrRow row(p.nbr_site, site);
+            mine[k] = make_uint4((site * 4) | (row.at(0) * 4 << 16), (row.at(1) * 4) | (row.at(2) * 4 << 16),
+                                 (row.at(3) * 4) | (row.at(4) * 4 << 16), row.at(5) * 4);
+        }
     }
-    auto grow_site = [&](const uint4 raw, bool &grew) {
+    uint32_t act[kCached]; // (the active masks of a thread's sites do not change: registers)
+#pragma unroll
+    for (int k = 0; k < kCached; ++k) act[k] = (cached && tid + k * nthreads < d.N) ? A[tid + k * nthreads] : 0u;
+    auto grow_site = [&](const uint4 raw, uint32_t a, bool &grew) {
         const SiteRec r(raw);
         const uint32_t f = lds_word(F, r.site);
         uint32_t g = f;
 #pragma unroll
         for (int k = 0; k < 6; ++k) g |= lds_word(F, r.nb[k]);
-        g &= lds_word(A, r.site);
+        g &= a;
         g |= f;
         if (g != f) {
             F[r.site >> 2] = g;
             grew = true;
         }
     };
+    // (one barrier per convergence check, three flags in turn: the flag of check i + 1 is cleared before the barrier of
+    // check i -- whoever clears it has passed the barrier of check i - 1, behind which every thread had read it last,
+    // as the flag of check i - 2)
+    if (tid < 3) changed[tid] = 0;
+    __syncthreads();
     for (uint32_t iter = 0; iter <= d.N; ++iter) {
         bool grew = false;
         for (int pass = 0; pass < 4; ++pass) {
             if (cached) {
 #pragma unroll
                 for (int k = 0; k < kCached; ++k)
-                    if (tid + k * nthreads < d.N) grow_site(mine[k], grew);
+                    if (tid + k * nthreads < d.N) grow_site(mine[k], act[k], grew);
             } else {
-                for (uint32_t pos = tid; pos < d.N; pos += nthreads) grow_site(rec[pos], grew);
+                for (uint32_t pos = tid; pos < d.N; pos += nthreads) {
+                    const uint4 raw = rec[pos];
+                    grow_site(raw, lds_word(A, SiteRec(raw).site), grew);
+                }
             }
         }
-        if (grew) changed[0] = 1;
+        if (grew) changed[iter % 3u] = 1;
+        if (tid == 0) changed[(iter + 1u) % 3u] = 0;
         __syncthreads();
-        const bool again = changed[0] != 0;
-        __syncthreads();
-        if (!again) break;
-        if (tid == 0) changed[0] = 0;
-        __syncthreads();
+        if (changed[iter % 3u] == 0) break;
     }
     // ---- flip both replicas of every pair on its cluster
     if (!with_energy) {

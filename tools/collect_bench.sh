@@ -18,4 +18,6 @@ python tools/fixed_cost.py > "$out/fixed_cost.json" 2>&1
 python tools/determinism_soak.py full_ladder > "$out/determinism_soak.txt" 2>&1
 python tools/time_variants.py > "$out/variants.txt" 2>&1
 python tools/call_cost.py > "$out/call_cost.json" 2>&1
+python tools/time_gaussian.py metropolis 300 > "$out/gaussian.txt" 2>&1
+PEAPODS_BENCH_FORCE_COMM=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > "$out/bench_20steps_one_rank_rccl.json" 2>>"$out/bench.err"
 echo done

@@ -415,6 +415,10 @@ def worker(args, rank, world, local_rank):
         del parts, gathered
 
     profiled = "overlap_cluster_update_interval" not in sample_kw
+    # (the gathers above left the chip idle for tens of milliseconds: the same settling as before the timed calls, so that
+    # the per-launch times are those of the clocks the timed region ran at)
+    if args.settle_ms > 0 and args.settle_calls > 0:
+        sim.run(config(max(1, int(args.settle_ms * 1e-3 / max(elapsed / args.steps, 1e-6)))))
     kernels_ms = sim.profile_kernels(sim.make_config(args.profile_sweeps, "metropolis", warmup_ratio=0.0, pt_interval=1,
                                                      pt_schedule=args.pt_schedule), args.profile_sweeps)
     if rank == 0:

@@ -152,7 +152,10 @@ uint64_t pa_sim_sweeps_completed(const pa_sim *sim);
  * while running `n_sweeps` sweeps of `cfg`'s protocol (state advances like sample()).
  * ms_out[3] = average milliseconds per launch of: k_rng (random stream -> acceptance levels; on the
  * fused path this launch also measures the previous sweep's overlap), k_sweep (level-ordered sweep +
- * energies), k_measure (statistics + tempering; plus the overlap kernel when it is not fused). */
+ * energies), k_measure (statistics + tempering; plus the overlap kernel when it is not fused).
+ * The first half of the sweeps is timed launch by launch (which stretches every launch: each starts on an idle
+ * queue), the second half as sample() enqueues it, between two events; the figures are the first half's shares of
+ * the second half's time per sweep. */
 int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_sweeps,
                            double ms_out[3]);
 

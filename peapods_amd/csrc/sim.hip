@@ -2391,8 +2391,13 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
     const bool want_overlap = d.n_pairs > 0 && cfg->measure_overlap;
     sim->n_recorded = 0;
     sim->overlap_collected = want_overlap;
-    hipEvent_t ev[4];
+    // The first half of the sweeps is timed launch by launch (an event pair around each, the host waiting after every
+    // sweep), which tells how a sweep's time divides among its launches but stretches all of them: every launch then
+    // starts on an idle queue.  The second half runs as sample() enqueues it, between two events; the per-launch figures
+    // are the first half's shares of the second half's time per sweep.
+    hipEvent_t ev[6];
     for (auto &e : ev) PA_HIP(sim, hipEventCreate(&e));
+    const uint64_t n_instrumented = n_sweeps >= 8 ? n_sweeps / 2 : n_sweeps;
     double total[3] = {0, 0, 0};
     uint64_t count[3] = {0, 0, 0};
     // same launch sequence as run_sweeps on one stream; with the fused path the overlap of the previous sweep --
@@ -2409,7 +2414,9 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
     for (uint64_t sweep_id = 0; sweep_id < n_sweeps; ++sweep_id) {
         const bool record = sweep_id >= cfg->warmup_sweeps;
         const bool pt_this = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0;
-        PA_HIP(sim, hipEventRecord(ev[0], sim->stream));
+        const bool instrumented = sweep_id < n_instrumented;
+        if (instrumented) PA_HIP(sim, hipEventRecord(ev[0], sim->stream));
+        if (sweep_id == n_instrumented) PA_HIP(sim, hipEventRecord(ev[4], sim->stream));
         const bool relayed = relay && pending.any;
         if (relayed) {
             PtParams q = pending.pt;
@@ -2426,12 +2433,12 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
         }
         if (fused && overlap_owed) toggle_dots(sim->p);
         pending.any = false;
-        PA_HIP(sim, hipEventRecord(ev[1], sim->stream));
+        if (instrumented) PA_HIP(sim, hipEventRecord(ev[1], sim->stream));
         PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
         PA_HIP(sim, enqueue_sweep(sim, d, sim->p, record || pt_this, gibbs, sim->stream));
         sim->swaps_pending = false;
         toggle_spin_buffers(sim);
-        PA_HIP(sim, hipEventRecord(ev[2], sim->stream));
+        if (instrumented) PA_HIP(sim, hipEventRecord(ev[2], sim->stream));
         const bool wants_measure = record || pt_this || (fused && overlap_owed);
         bool measured = false;
         if (wants_measure && relay) {
@@ -2454,6 +2461,7 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
         if (pt_this && cfg->pt_schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
         if (fused) overlap_owed = record;
         if (record) sim->n_recorded += 1;
+        if (!instrumented) continue;
         PA_HIP(sim, hipEventRecord(ev[3], sim->stream));
         PA_HIP(sim, hipEventSynchronize(ev[3]));
         for (int k = 0; k < 3; ++k) {
@@ -2463,6 +2471,14 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
             total[k] += ms;
             count[k] += 1;
         }
+    }
+    double plain_ms_per_sweep = 0.0;
+    if (n_instrumented < n_sweeps) {
+        float ms = 0.f;
+        PA_HIP(sim, hipEventRecord(ev[5], sim->stream));
+        PA_HIP(sim, hipEventSynchronize(ev[5]));
+        PA_HIP(sim, hipEventElapsedTime(&ms, ev[4], ev[5]));
+        plain_ms_per_sweep = ms / static_cast<double>(n_sweeps - n_instrumented);
     }
     if (pending.any) {
         PA_HIP(sim, measure_launch(sim->fresh, d, sim->p, pending.pt, pending.do_accum, pending.accum_overlap, pending.do_pt,
@@ -2476,6 +2492,12 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
     for (int k = 0; k < 3; ++k) ms_out[k] = count[k] ? total[k] / static_cast<double>(count[k]) : 0.0;
+    if (plain_ms_per_sweep > 0.0 && n_instrumented > 0) {
+        // (per instrumented sweep: every launch's share, a measurement launch counting with the sweeps it ran in)
+        const double stretched = (total[0] + total[1] + total[2]) / static_cast<double>(n_instrumented);
+        if (stretched > 0.0)
+            for (int k = 0; k < 3; ++k) ms_out[k] *= plain_ms_per_sweep / stretched;
+    }
     int rc_flush = flush_swaps(sim);
     if (rc_flush) return rc_flush;
     PA_HIP(sim, hipStreamSynchronize(sim->stream));

@@ -103,6 +103,8 @@ struct DevPtrs {
     const uint32_t *hc_tab;  // [n_real][N] schedule order: site | wrap flags << 14 | neg bits << 20 (SimDims::hc)
     const uint4 *rec_wide;   // [n_real][2 (N + 1)] SimDims::wide, schedule order (+ dummy): thirteen 16-bit LDS byte
                              //   offsets (site, f0, b0, ..., f5, b5), h = ceil(m / 2), then neg[0..11] | nz[12..23]
+    int32_t *Esum_pre, *Msum_pre;     // [n_real][n_sys] the sums a sweep left, copied by the Houdayer seed launch for the measurement
+                                      //   blocks that ride in the growth launch (which replaces Esum / Msum)
     int32_t *Esum_relay, *Msum_relay; // [n_real][n_sys] sums exchanged by a relayed tempering event, until k_adopt_relay_sums
     uint32_t *relay_swapped;          // [n_real] 1: that event accepted a swap in this realisation
     const uint4 *rec_thin;   // [n_real][thin_chunks][64] SimDims::thin_chunks: lane 4 q + j of a chunk = part j of its q-th site:
@@ -269,6 +271,8 @@ hipError_t launch_apply_swaps(const SimDims &d, const DevPtrs &p, hipStream_t st
 hipError_t launch_houdayer(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool with_energy = false);
 hipError_t launch_houdayer_seeds(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool with_overlap);
 hipError_t launch_houdayer_grow(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool with_energy);
+hipError_t launch_houdayer_grow_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_accum, hipStream_t stream,
+                                        bool with_energy);
 bool houdayer_computes_energy(const SimDims &d); // with_energy is honoured: no energy-only sweep launch needed after the move
 size_t houdayer_lds_bytes(const SimDims &d);
 hipError_t launch_jorg(const SimDims &d, const DevPtrs &p, hipStream_t stream);

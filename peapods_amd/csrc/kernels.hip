@@ -2442,6 +2442,12 @@ __device__ __forceinline__ void houdayer_block(const SimDims &d, const DevPtrs &
     copy_to_lds(tile, Sg, static_cast<uint32_t>(tile_words), tid, nthreads);
     for (size_t i = tid; i < tile_words; i += nthreads) F[i] = 0;
     for (uint32_t k = tid; k < d.n_sys; k += nthreads) partner[k] = k; // unpaired: never active
+    // The sums the sweep left, kept for the measurement that rides in the growth launch (k_houdayer_grow_measure): the
+    // growth workgroups of that launch replace Esum / Msum with the sums after the move.
+    for (uint32_t k = tid; k < d.n_sys; k += nthreads) {
+        p.Esum_pre[static_cast<size_t>(real) * d.n_sys + k] = p.Esum[static_cast<size_t>(real) * d.n_sys + k];
+        p.Msum_pre[static_cast<size_t>(real) * d.n_sys + k] = p.Msum[static_cast<size_t>(real) * d.n_sys + k];
+    }
     __syncthreads();
 
     // ---- pairing: lane (t, 0) shuffles the replicas at temperature t (overlap.rs:44-49).
@@ -2557,14 +2563,13 @@ __global__ __launch_bounds__(1024) void k_houdayer_overlap(SimDims d, DevPtrs p,
 // magnetisations of its word's 32 slots after the move (mod.rs:749-756 recomputes them before the tempering event) --
 // the flipped word is in the LDS anyway, so this replaces an energy-only launch of the sweep kernel.  A word without a
 // seed changes nothing and keeps the sums the sweep left.
-__global__ __launch_bounds__(1024) void k_houdayer_grow(SimDims d, DevPtrs p, int with_energy) {
-    extern __shared__ uint32_t lds[];
+__device__ __forceinline__ void houdayer_grow_block(const SimDims &d, const DevPtrs &p, int with_energy, uint32_t bid, uint32_t *lds) {
     uint32_t *A = lds;             // [N] active mask of the word
     uint32_t *F = lds + d.N;       // [N] cluster membership
     uint32_t *changed = F + d.N;   // [3] (+ 1 spare)
     uint32_t *sw = changed + 4;    // [N + 1] the word after the move (with_energy)
     uint32_t *scratch = sw + d.N + 4; // [5][48]
-    const uint32_t real = blockIdx.x / d.W, w = blockIdx.x % d.W;
+    const uint32_t real = bid / d.W, w = bid % d.W;
     const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
     const size_t tile_words = static_cast<size_t>(d.N) * d.W;
     const uint32_t *Ag = p.hd_scratch + static_cast<size_t>(real) * 2 * tile_words + static_cast<size_t>(w) * d.N;
@@ -2665,6 +2670,28 @@ __global__ __launch_bounds__(1024) void k_houdayer_grow(SimDims d, DevPtrs p, in
     case 1: hc_energy<1>(d, p, real, w, tab, lds_addr_of(sw), scratch, p.Esum, p.Msum); break;
     case 2: hc_energy<2>(d, p, real, w, tab, lds_addr_of(sw), scratch, p.Esum, p.Msum); break;
     default: hc_energy<3>(d, p, real, w, tab, lds_addr_of(sw), scratch, p.Esum, p.Msum); break;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_houdayer_grow(SimDims d, DevPtrs p, int with_energy) {
+    extern __shared__ uint32_t lds[];
+    houdayer_grow_block(d, p, with_energy, blockIdx.x, lds);
+}
+
+// The growth launch with the sweep's measurement blocks riding in it (statistics of the swept state and of the
+// overlap the seed launch measured; no tempering event).  They read the sums the sweep left from Esum_pre / Msum_pre,
+// where the seed launch copied them: the growth workgroups of this very launch replace Esum / Msum.  One launch less
+// on a chain of five per step.
+__global__ __launch_bounds__(1024) void k_houdayer_grow_measure(SimDims d, DevPtrs p, int with_energy, uint32_t n_grow, PtParams pt,
+                                                                int do_accum) {
+    extern __shared__ uint32_t lds[];
+    if (blockIdx.x < n_grow) {
+        houdayer_grow_block(d, p, with_energy, blockIdx.x, lds);
+    } else {
+        DevPtrs q = p;
+        q.Esum = p.Esum_pre;
+        q.Msum = p.Msum_pre;
+        measure_block<false>(d, q, pt, do_accum, 1, 0, nullptr, blockIdx.x - n_grow, lds);
     }
 }
 
@@ -3542,6 +3569,7 @@ hipError_t configure_kernels(const SimDims &) {
                            reinterpret_cast<const void *>(k_houdayer),
                            reinterpret_cast<const void *>(k_houdayer_overlap),
                            reinterpret_cast<const void *>(k_houdayer_grow),
+                           reinterpret_cast<const void *>(k_houdayer_grow_measure),
                            reinterpret_cast<const void *>(k_jorg),
                            reinterpret_cast<const void *>(k_measure<false>),
                            reinterpret_cast<const void *>(k_measure<true>)}) {
@@ -3852,6 +3880,14 @@ hipError_t launch_houdayer_grow(const SimDims &d, const DevPtrs &p, hipStream_t 
     const bool e = with_energy && d.hc && d.dense_nn == d.nn;
     const size_t lds = (2 * static_cast<size_t>(d.N) + 4 + (e ? d.N + 4 + 5 * 48 : 0)) * 4;
     hipLaunchKernelGGL(k_houdayer_grow, dim3(d.n_real * d.W), dim3(1024), lds, stream, d, p, e ? 1 : 0);
+    return hipGetLastError();
+}
+hipError_t launch_houdayer_grow_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_accum, hipStream_t stream,
+                                        bool with_energy) {
+    const bool e = with_energy && d.hc && d.dense_nn == d.nn;
+    const size_t lds = std::max((2 * static_cast<size_t>(d.N) + 4 + (e ? d.N + 4 + 5 * 48 : 0)) * 4, measure_lds_bytes(d));
+    hipLaunchKernelGGL(k_houdayer_grow_measure, dim3(d.n_real * d.W + d.n_real), dim3(1024), lds, stream, d, p, e ? 1 : 0,
+                       d.n_real * d.W, pt, do_accum ? 1 : 0);
     return hipGetLastError();
 }
 hipError_t launch_houdayer(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool with_energy) {

@@ -416,6 +416,8 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     q.big_ticket += r0;
     q.Esum += static_cast<size_t>(d.n_sys) * r0;
     q.Msum += static_cast<size_t>(d.n_sys) * r0;
+    q.Esum_pre += static_cast<size_t>(d.n_sys) * r0;
+    q.Msum_pre += static_cast<size_t>(d.n_sys) * r0;
     q.Esum_relay += static_cast<size_t>(d.n_sys) * r0;
     q.Msum_relay += static_cast<size_t>(d.n_sys) * r0;
     q.relay_swapped += r0;
@@ -1280,8 +1282,11 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                     if (overlap_in_houdayer) {
                         PA_HIP(sim, launch_houdayer_seeds(g.d, g.p, g.stream, true));
                         toggle_dots(g.p);
-                        PA_HIP(sim, measure_launch(g.fresh, g.d, g.p, pt, record, true, false, g.stream));
-                        PA_HIP(sim, launch_houdayer_grow(g.d, g.p, g.stream, energy_done));
+                        // (the measurement of the swept state rides in the growth launch, reading the sums the seed
+                        // launch put aside)
+                        PtParams q = pt;
+                        q.fresh = consume_fresh(g.fresh, g.d, record, true);
+                        PA_HIP(sim, launch_houdayer_grow_measure(g.d, g.p, q, record, g.stream, energy_done));
                     } else {
                         PA_HIP(sim, launch_houdayer(g.d, g.p, g.stream, energy_done));
                     }
@@ -2164,6 +2169,8 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     ok(bufs.alloc(&sim->jump, jump.size()));
     ok(bufs.alloc(&p.Esum, static_cast<size_t>(d.n_real) * d.n_sys));
     ok(bufs.alloc(&p.Msum, static_cast<size_t>(d.n_real) * d.n_sys));
+    ok(bufs.alloc(&p.Esum_pre, static_cast<size_t>(d.n_real) * d.n_sys));
+    ok(bufs.alloc(&p.Msum_pre, static_cast<size_t>(d.n_real) * d.n_sys));
     ok(bufs.alloc(&p.Esum_relay, static_cast<size_t>(d.n_real) * d.n_sys));
     ok(bufs.alloc(&p.Msum_relay, static_cast<size_t>(d.n_real) * d.n_sys));
     ok(bufs.alloc(&p.relay_swapped, static_cast<size_t>(d.n_real)));

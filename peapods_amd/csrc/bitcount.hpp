@@ -117,6 +117,16 @@ __device__ __forceinline__ void planes8(const uint32_t w[8], uint32_t (&p)[4]) {
     p[3] = e0 & e1;
 }
 
+// ... of 4 words: three planes
+__device__ __forceinline__ void planes4(const uint32_t w[4], uint32_t (&p)[3]) {
+    uint32_t s, c;
+    full_add(w[0], w[1], w[2], s, c);
+    p[0] = s ^ w[3];
+    const uint32_t d = s & w[3];
+    p[1] = c ^ d;
+    p[2] = c & d;
+}
+
 // bit-sliced sum of the four lanes of a quad: NP planes in, NP + 2 out, alike in the four lanes
 template <int NP>
 __device__ __forceinline__ void quad_add_planes(const uint32_t (&p)[NP], uint32_t (&o)[NP + 2]) {

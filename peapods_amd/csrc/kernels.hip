@@ -1808,6 +1808,124 @@ __device__ __forceinline__ void overlap_block(const SimDims &d, const DevPtrs &p
     }
 }
 
+// The same measurement by all 1024 threads of a workgroup, for lattices of at most 4096 sites (at most four per thread):
+// where the overlap is not hidden behind a random-stream launch (it rides with the Houdayer seed workgroups, which wait
+// for nothing else) its 256-thread form is the longer part of that launch.  Counts in the quad form of bitcount.hpp:
+// a row of 16 lanes sums lanes of equal class (bytes of at most 4 x 16 = 64), the 64 rows file their sums in `part`
+// and 96 threads add them up.  LDS: [N + 1] + 64 x 24 + 96 words.
+__device__ __forceinline__ void overlap_block_1024(const SimDims &d, const DevPtrs &p, uint32_t bid, uint32_t *lds) {
+    const uint32_t n1 = d.N + 1;
+    uint32_t *Y = lds;
+    uint32_t *part = lds + n1;        // [64][24]
+    uint32_t *total = part + 64 * 24; // [96]
+    uint32_t real, w;
+    tile_of_block(d, bid, real, w);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t q = d.n_temps >> 5, r = d.n_temps & 31u;
+    const uint32_t wa = w + q, wb = w + q + 1;
+    const uint32_t *Sg = p.S + static_cast<size_t>(real) * d.W * d.N;
+    const uint32_t *A = Sg + static_cast<size_t>(w) * d.N;
+    const uint32_t *B0 = wa < d.W ? Sg + static_cast<size_t>(wa) * d.N : nullptr;
+    const uint32_t *B1 = (r && wb < d.W) ? Sg + static_cast<size_t>(wb) * d.N : nullptr;
+    {
+        uint32_t va[4], v0[4], v1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = k * 1024 + tid;
+            va[k] = i < d.N ? A[i] : 0u;
+            v0[k] = (B0 && i < d.N) ? B0[i] : 0u;
+            v1[k] = (B1 && i < d.N) ? B1[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = k * 1024 + tid;
+            if (i < d.N) Y[i] = va[k] ^ (r ? ((v0[k] >> r) | (v1[k] << (32 - r))) : v0[k]);
+        }
+        if (tid == 0) Y[d.N] = 0;
+    }
+    __syncthreads();
+    uint32_t qa[4], qb[4], qc[4];
+    if (d.hc) {
+        const uint32_t *tab_g = p.hc_tab + static_cast<size_t>(real) * d.N;
+        const uint32_t y_addr = lds_addr_of(Y);
+        uint32_t ee[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t pos = k * 1024 + tid;
+            ee[k] = tab_g[pos < d.N ? pos : 0u];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool live_site = k * 1024 + tid < d.N;
+            const HcSite h = hc_decode<3>(d, ee[k], y_addr);
+            const uint32_t y = lds_load(h.site);
+            uint32_t z[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (int dir = 0; dir < 3; ++dir)
+                if (dir < static_cast<int>(d.nn)) z[dir] = y ^ lds_load(h.nb[2 * dir]);
+            qa[k] = live_site ? y : 0u;
+            qb[k] = live_site ? (z[0] ^ z[1] ^ z[2]) : 0u;
+            qc[k] = live_site ? maj3(z[0], z[1], z[2]) : 0u;
+        }
+    } else {
+        const uint4 *rec = p.rec + static_cast<size_t>(real) * n1;
+        uint4 rr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t pos = k * 1024 + tid;
+            rr[k] = rec[pos < d.N ? pos : d.N];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool live_site = k * 1024 + tid < d.N;
+            const SiteRec sr(rr[k]);
+            const uint32_t y = lds_word(Y, sr.site);
+            uint32_t z[3];
+#pragma unroll
+            for (int dir = 0; dir < 3; ++dir)
+                z[dir] = dir < static_cast<int>(d.nn) ? (y ^ lds_word(Y, sr.nb[2 * dir])) : 0u;
+            qa[k] = live_site ? y : 0u;
+            qb[k] = live_site ? (z[0] ^ z[1] ^ z[2]) : 0u;
+            qc[k] = live_site ? maj3(z[0], z[1], z[2]) : 0u;
+        }
+    }
+    {
+        const uint32_t *in[3] = {qa, qb, qc};
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            uint32_t pl3[3], pl5[5], c2[2];
+            planes4(in[s], pl3);
+            quad_add_planes<3>(pl3, pl5);
+            spread_pair<5>(pl5, tid & 3u, c2);
+#pragma unroll
+            for (uint32_t jj = 0; jj < 2; ++jj) {
+                uint32_t v = c2[jj];
+                v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x128, 0xF, 0xF, false));
+                v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x124, 0xF, 0xF, false));
+                if ((tid & 12u) == 12u) part[(tid >> 4) * 24 + s * 8 + 2 * (tid & 3u) + jj] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 96) { // thread = (set, slot); slot = j + 8 * byte of the sliced counters
+        const uint32_t set = tid >> 5, slot = tid & 31u, j = slot & 7u, shift = (slot >> 3) * 8;
+        uint32_t sum = 0;
+#pragma unroll 8
+        for (uint32_t g = 0; g < 64; ++g) sum += (part[g * 24 + set * 8 + j] >> shift) & 0xFFu;
+        total[tid] = sum;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const uint32_t k = w * 32 + tid;
+        const uint32_t rep = k / d.n_temps, t = k % d.n_temps;
+        if (k < d.n_sys && (rep & 1u) == 0 && rep + 1 < d.n_replicas) {
+            const size_t o = (static_cast<size_t>(real) * d.n_pairs + (rep >> 1)) * d.n_temps + t;
+            p.dot_spin[o] = static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(total[tid]);
+            p.dot_link[o] = static_cast<int32_t>(d.N * d.nn) - 2 * static_cast<int32_t>(total[32 + tid] + 2 * total[64 + tid]);
+        }
+    }
+}
+
 // Lattices with four to six forward directions (bcc, fcc): the same pair-difference word, neighbours
 // from the wide table, and the up to six bond terms of a site counted as two groups of three.
 __global__ __launch_bounds__(256) void k_overlap_wide(SimDims d, DevPtrs p) {
@@ -2552,6 +2670,8 @@ __global__ __launch_bounds__(1024) void k_houdayer_overlap(SimDims d, DevPtrs p,
     extern __shared__ uint32_t lds[];
     if (blockIdx.x < n_houdayer) {
         houdayer_block(d, p, blockIdx.x, lds);
+    } else if (d.N <= 4096) {
+        overlap_block_1024(d, p, blockIdx.x - n_houdayer, lds);
     } else {
         if (threadIdx.x >= 256) return; // (a barrier waits for the surviving waves only)
         overlap_block(d, p, blockIdx.x - n_houdayer, lds);
@@ -3524,7 +3644,7 @@ size_t sweep_lds_bytes(const SimDims &d, bool gibbs) {
 size_t measure_lds_bytes(const SimDims &d) { return measure_lds_words(d) * 4; }
 size_t sweep_hc_lds_bytes(const SimDims &d, bool gibbs) { return sweep_hc_lds_words(d, gibbs) * 4; }
 static size_t overlap_lds_bytes(const SimDims &d) {
-    return ((static_cast<size_t>(d.N) + 1) + 17 * 48) * 4; // (block_bit_totals_quad<3>: [17][48])
+    return ((static_cast<size_t>(d.N) + 1) + 64 * 24 + 96) * 4; // (block_bit_totals_quad<3>: [17][48]; overlap_block_1024: [64][24] + [96])
 }
 
 hipError_t configure_kernels(const SimDims &) {

@@ -2033,6 +2033,11 @@ __global__ __launch_bounds__(256) void k_overlap(SimDims d, DevPtrs p) {
     extern __shared__ uint32_t lds_dyn[];
     overlap_block(d, p, blockIdx.x, lds_dyn);
 }
+// (lattices of at most 4096 sites, where the launch stands alone on a chain: four sites per thread, not sixteen)
+__global__ __launch_bounds__(1024) void k_overlap_1024(SimDims d, DevPtrs p) {
+    extern __shared__ uint32_t lds_dyn[];
+    overlap_block_1024(d, p, blockIdx.x, lds_dyn);
+}
 
 // One launch, two kinds of workgroups: the first n_overlap blocks measure the overlap of the
 // state the previous sweep left (latency-bound, few waves), the others draw the random stream
@@ -3663,6 +3668,7 @@ hipError_t configure_kernels(const SimDims &) {
                            reinterpret_cast<const void *>(k_sweep_hc<3>),
                            reinterpret_cast<const void *>(k_sweep_hc<3, true>),
                            reinterpret_cast<const void *>(k_overlap),
+                           reinterpret_cast<const void *>(k_overlap_1024),
                            reinterpret_cast<const void *>(k_overlap_wide),
                            reinterpret_cast<const void *>(k_sweep_wide),
                            reinterpret_cast<const void *>(k_rng_relay<false, false>),
@@ -3981,7 +3987,10 @@ hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream
                            ((static_cast<size_t>(d.N) + 1) + 5 * 80) * 4, stream, d, p);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_overlap, dim3(d.n_real * d.W), dim3(256), overlap_lds_bytes(d), stream, d, p);
+    if (d.N <= 4096 && !std::getenv("PEAPODS_OVERLAP_256"))
+        hipLaunchKernelGGL(k_overlap_1024, dim3(d.n_real * d.W), dim3(1024), overlap_lds_bytes(d), stream, d, p);
+    else
+        hipLaunchKernelGGL(k_overlap, dim3(d.n_real * d.W), dim3(256), overlap_lds_bytes(d), stream, d, p);
     return hipGetLastError();
 }
 

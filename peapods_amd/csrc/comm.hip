@@ -260,8 +260,13 @@ int pa_comm_barrier(pa_comm *c) {
 int pa_comm_gatherv(pa_comm *c, const void *send_host, uint64_t send_bytes, void *recv_host, uint64_t recv_capacity,
                     int32_t root, uint64_t *bytes_per_rank_out) {
     if (root >= c->n_ranks) return comm_fail(c, "gather root out of range");
+    // every rank learns every rank's size AND receive capacity, so the decision to go on is the same everywhere: a
+    // receiver whose buffer is too small fails the call on all ranks before anyone posts a send
+    const uint64_t mine[2] = {send_bytes, recv_capacity};
+    std::vector<uint64_t> all(2 * static_cast<size_t>(c->n_ranks), 0);
+    if (int rc = pa_comm_allgather(c, mine, all.data(), sizeof(mine))) return rc;
     std::vector<uint64_t> sizes(c->n_ranks, 0);
-    if (int rc = pa_comm_allgather(c, &send_bytes, sizes.data(), sizeof(uint64_t))) return rc;
+    for (int r = 0; r < c->n_ranks; ++r) sizes[r] = all[2 * r];
     if (bytes_per_rank_out) std::memcpy(bytes_per_rank_out, sizes.data(), sizes.size() * sizeof(uint64_t));
     uint64_t total = 0;
     std::vector<uint64_t> offset(c->n_ranks, 0);
@@ -270,7 +275,9 @@ int pa_comm_gatherv(pa_comm *c, const void *send_host, uint64_t send_bytes, void
         total += sizes[r];
     }
     const bool receives = root < 0 || root == c->rank;
-    if (receives && total > recv_capacity) return comm_fail(c, "receive buffer smaller than the gathered bytes");
+    for (int r = 0; r < c->n_ranks; ++r)
+        if ((root < 0 || root == r) && total > all[2 * r + 1])
+            return comm_fail(c, "receive buffer of rank " + std::to_string(r) + " smaller than the gathered bytes");
     if (total == 0) return PA_OK;
     PA_COMM_HIP(c, hipSetDevice(c->device));
     if (int rc = reserve(c, std::max<uint64_t>(send_bytes, 1), receives ? total : 1)) return rc;

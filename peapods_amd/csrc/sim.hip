@@ -836,7 +836,10 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     const bool fk = cfg->cluster_interval > 0;
     // (FK single-cluster form: one wave per system with the lattice tables in the LDS, else one lane per system with
     // the whole tile there)
-    if (fk && cfg->cluster_mode == PA_CLUSTER_WOLFF && !cfg->collect_cluster_stats && cfg->cluster_action != PA_ACTION_OBSERVE &&
+    // (a call that reports sizes takes the union-find form; with warm-up sweeps the calls before the first recorded one
+    // are searches all the same, mod.rs:437-484)
+    const bool fk_sizes_always = cfg->collect_cluster_stats && cfg->warmup_sweeps == 0;
+    if (fk && cfg->cluster_mode == PA_CLUSTER_WOLFF && !fk_sizes_always && cfg->cluster_action != PA_ACTION_OBSERVE &&
         fk_wolff_lds_bytes(d) > 160 * 1024 && !(wolff_wave_lds_bytes(d) <= 160 * 1024 && d.N <= 65535))
         return fail(sim, PA_ERR_UNSUPPORTED, "lattice too large for the FK cluster kernel");
     // Joerg single-cluster moves run one wave per pair when the lattice tables fit the LDS (k_wolff_wave)
@@ -847,7 +850,9 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     jorg_wave = jorg_wave && wave_ok;
     // the single-cluster Houdayer search keeps the realisation's tile in the LDS; an ensemble whose tile does not fit
     // takes the move's union-find form, which reaches the same clusters from the same draws (overlap.rs:179-339)
-    const bool houdayer_tile_fits = houdayer_lds_bytes(d) <= 160 * 1024;
+    // (... and so does a large-lattice handle, whatever its slot count: the search kernels read the small-lattice site
+    // records and a scratch tile that such a handle does not have)
+    const bool houdayer_tile_fits = houdayer_lds_bytes(d) <= 160 * 1024 && !d.big;
     const bool has_houdayer_uf = cfg->overlap_cluster_interval > 0 && !houdayer_tile_fits;
     if ((oc_sw || fk || oc_cmr || jorg_wave || has_houdayer_uf) && (rc = ensure_cluster_sw(sim))) return rc;
     if (needs_exp && (rc = ensure_device_exp(sim))) return rc;
@@ -889,7 +894,10 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     sim->overlap_collected = want_overlap;
     // every capability check comes before the first launch: a configuration this build declines is
     // rejected with the state untouched and no group stream forked
-    if (has_oc && !oc_sw && !wave_ok && !collect_overlap) {
+    // (calls that report sizes or observe take the union-find form -- every call when observing, the recorded ones when
+    // collecting statistics: with warm-up sweeps the searches run first, overlap.rs:179-183)
+    const bool oc_uf_always = observe_overlap || (collect_overlap && cfg->warmup_sweeps == 0);
+    if (has_oc && !oc_sw && !wave_ok && !oc_uf_always) {
         // (depth-first Joerg / CMR searches without the one-wave-per-pair kernel: their one-lane-per-pair fallbacks
         // hold the realisation's tile and a bitmap per pair in the LDS)
         for (int k = 0; k < cfg->n_overlap_cluster_modes && k < 4; ++k) {
@@ -1596,6 +1604,15 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         d.inv_temps = recip(d.n_temps);
         d.inv_replicas = recip(d.n_replicas);
         d.inv_W = recip(d.W);
+        // div_small is exact while dividend x divisor < 2^32: tile words (< n_real W + 8) by W, slots (< 32 W) by
+        // n_temps, ladder tasks (<= 256) by n_replicas.  An ensemble beyond that is declined, never mis-indexed.
+        const uint64_t n_tw = static_cast<uint64_t>(d.n_real) * d.W + 8;
+        if (n_tw * d.W >= (1ull << 32) || static_cast<uint64_t>(d.SP) * d.n_temps >= (1ull << 32) ||
+            512ull * d.n_replicas >= (1ull << 32)) {
+            sim->error = "ensemble too large for the 32-bit index arithmetic of the random-stream kernels "
+                         "(n_realizations x ceil(n_systems / 32)^2 must stay below 2^32)";
+            return bail(PA_ERR_UNSUPPORTED);
+        }
         d.rng_waves = 4;
         if (const char *env = std::getenv("PEAPODS_RNG_WAVES")) {
             const long v = std::strtol(env, nullptr, 10);

@@ -419,9 +419,21 @@ def sample(sim, comm, n_sweeps, sweep_mode, root=None, **kwargs):
     `root` only (None elsewhere: the histogram payload is 2.4 MB per realisation at 16^3 x 24 temperatures)."""
     from . import _core
 
-    cfg = sim.make_config(n_sweeps, sweep_mode, **kwargs)
-    sim.run(cfg)
-    parts, meta = sim.collect_parts(cfg, kwargs.get("pt_interval") is not None)
+    # A rank that fails before the first collective (invalid arguments, PA_ERR_UNSUPPORTED, a device error, Ctrl-C) must
+    # not leave the others waiting in it: every rank reports ok / failed first, and all of them raise when one failed.
+    failure, parts, meta = None, None, None
+    try:
+        cfg = sim.make_config(n_sweeps, sweep_mode, **kwargs)
+        sim.run(cfg)
+        parts, meta = sim.collect_parts(cfg, kwargs.get("pt_interval") is not None)
+    except BaseException as exc:  # (re-raised below, after the exchange)
+        failure = exc
+    status = comm.gather_rows(np.array([[0 if failure is None else 1]], dtype=np.uint64))
+    if failure is not None:
+        raise failure
+    if status.any():
+        failed = [int(r) for r in np.nonzero(status[:, 0])[0]]
+        raise RuntimeError(f"sample() failed on rank(s) {failed}; nothing was gathered")
     gathered = gather_parts(parts, comm, root)
     if gathered is None:
         return None

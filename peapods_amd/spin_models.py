@@ -94,6 +94,8 @@ class Ising:
         if isinstance(couplings, np.ndarray):
             coup = couplings.astype(np.float32)
             if comm is not None:
+                if n_disorder == 1 and coup.ndim == len(self.lattice_shape) + 1:
+                    coup = coup[None]  # (the un-batched shape, accepted without comm too)
                 if coup.ndim != len(self.lattice_shape) + 2 or coup.shape[0] != n_disorder:
                     raise ValueError("with comm, explicit couplings must have shape (n_disorder, *lattice, z')")
                 coup = coup[first:stop]

@@ -410,3 +410,74 @@ def test_cluster_moves_on_the_reference_benchmark_lattice(oracle, kwargs):
     np.testing.assert_array_equal(gpu.get_system_ids(0), cpu.get_system_ids(0))
     for s in (0, 15, 16, 31):
         np.testing.assert_array_equal(gpu.get_rng_state(0, s), cpu.get_rng_state(0, s))
+
+
+@pytest.mark.parametrize("kwargs", [
+    dict(overlap_cluster_update_interval=1, overlap_cluster_build_mode="houdayer"),                      # single-cluster search
+    dict(overlap_cluster_update_interval=1, overlap_cluster_build_mode="houdayer", overlap_cluster_mode="sw"),
+])
+def test_houdayer_on_a_large_lattice_handle_with_one_tile_word(oracle, kwargs):
+    """23^3 = 12167 sites, 8 temperatures x 2 replicas = one tile word: the handle is on the large-lattice path
+    (SimDims::big) although its W-word tile would fit the LDS.  The single-cluster Houdayer search reads the
+    small-lattice site records and a scratch tile such a handle does not have (round-3 advisor finding: a null
+    scratch buffer), so it must take the move's union-find form -- same clusters from the same draws
+    (overlap.rs:179-339)."""
+    from peapods_amd import IsingSimulation
+
+    shape = (23, 23, 23)
+    rng = np.random.default_rng(21)
+    couplings = (2 * rng.integers(0, 2, size=shape + (3,)) - 1).astype(np.float32)
+    temps = np.linspace(0.8, 1.6, 8).astype(np.float32)
+    gpu = IsingSimulation(list(shape), couplings, temps, 2, None, 23)
+    cpu = oracle.OracleSimulation(list(shape), couplings, temps, 2, None, 23)
+    kw = dict(pt_interval=1, warmup_ratio=0.25, **kwargs)
+    a = gpu.sample(6, "metropolis", **kw)
+    b = cpu.sample(6, "metropolis", n_threads=8, **kw)
+    for key in ("mags", "mags2", "energies", "energies2", "overlap", "overlap2", "overlap4", "link_overlap", "ql_at_q_sum"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    np.testing.assert_array_equal(gpu.get_spins(0), cpu.get_spins(0))
+    np.testing.assert_array_equal(gpu.get_system_ids(0), cpu.get_system_ids(0))
+    for s in (0, 7, 8, 15):
+        np.testing.assert_array_equal(gpu.get_rng_state(0, s), cpu.get_rng_state(0, s))
+
+
+@pytest.mark.parametrize("kwargs", [
+    dict(overlap_cluster_update_interval=1, overlap_cluster_build_mode="jorg", collect_cluster_stats=True),
+    dict(overlap_cluster_update_interval=1, overlap_cluster_build_mode="cmr", collect_cluster_stats=True),
+    dict(cluster_update_interval=1, cluster_mode="wolff", collect_cluster_stats=True),
+])
+def test_statistics_with_warmup_on_a_large_lattice_are_checked_before_the_first_launch(oracle, kwargs):
+    """collect_cluster_stats sends the RECORDED cluster calls to the union-find form; the warm-up calls before them are
+    searches (overlap.rs:179-183, mod.rs:437-484).  On a lattice where a search kernel does not fit the LDS the
+    configuration is therefore declined up front -- state untouched -- unless there are no warm-up sweeps; where it
+    fits, the run matches the oracle (round-3 advisor finding: a PA_ERR_DEVICE in the middle of the run)."""
+    from peapods_amd import IsingSimulation
+
+    shape = (240, 240)  # 57600 sites
+    rng = np.random.default_rng(3)
+    couplings = (2 * rng.integers(0, 2, size=shape + (2,)) - 1).astype(np.float32)
+    temps = np.linspace(1.4, 2.8, 4).astype(np.float32)
+    gpu = IsingSimulation(list(shape), couplings, temps, 2, None, 31)
+    cpu = oracle.OracleSimulation(list(shape), couplings, temps, 2, None, 31)
+    before = gpu.get_spins(0).copy()
+    try:
+        a = gpu.sample(4, "metropolis", pt_interval=1, warmup_ratio=0.5, **kwargs)
+    except NotImplementedError:
+        np.testing.assert_array_equal(gpu.get_spins(0), before)  # declined before anything ran
+        a = None
+    if a is not None:
+        b = cpu.sample(4, "metropolis", n_threads=8, pt_interval=1, warmup_ratio=0.5, **kwargs)
+        np.testing.assert_array_equal(a["energies"], b["energies"])
+        np.testing.assert_array_equal(gpu.get_spins(0), cpu.get_spins(0))
+        cpu = oracle.OracleSimulation(list(shape), couplings, temps, 2, None, 31)
+        gpu.reset()
+    # without warm-up every call reports sizes: the union-find form throughout, whatever the lattice
+    a = gpu.sample(3, "metropolis", pt_interval=1, warmup_ratio=0.0, **kwargs)
+    b = cpu.sample(3, "metropolis", n_threads=8, pt_interval=1, warmup_ratio=0.0, **kwargs)
+    for key in ("energies", "energies2", "overlap2", "link_overlap"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    for key in ("fk_csd", "overlap_csd", "top_cluster_sizes"):
+        if key in b:
+            np.testing.assert_array_equal(np.asarray(a[key]), np.asarray(b[key]), err_msg=key)
+    np.testing.assert_array_equal(gpu.get_spins(0), cpu.get_spins(0))
+    np.testing.assert_array_equal(gpu.get_system_ids(0), cpu.get_system_ids(0))

@@ -280,3 +280,45 @@ def test_fft_autocorrelation_matches_the_ring_sums():
     for backend in (0, 1):
         lib.pa_autocorrelation_tau(nat.ptr(const), 8, 1, 4, nat.ptr(out), backend)
         assert out[0] == 0.5
+
+
+def test_a_rank_that_fails_before_the_gather_fails_every_rank():
+    """distributed.sample exchanges an ok / failed word before the first result collective, so a rank whose run raises
+    (unsupported configuration, device error, Ctrl-C) does not leave the others blocked in gather_parts."""
+    import threading
+
+    from peapods_amd import distributed as dist
+
+    class Stub:  # the three calls distributed.sample makes on a handle
+        _lib = None
+
+        def __init__(self, fails):
+            self.fails = fails
+
+        def make_config(self, *a, **k):
+            return object()
+
+        def run(self, cfg):
+            if self.fails:
+                raise NotImplementedError("declined on this rank")
+
+        def collect_parts(self, cfg, with_pt):
+            return {"blocks": np.zeros((1, 4))}, {}
+
+    group = dist.LoopbackGroup(3)
+    errors = [None] * 3
+
+    def rank_main(rank):
+        try:
+            dist.sample(Stub(rank == 1), group.endpoint(rank), 4, "metropolis")
+        except BaseException as exc:
+            errors[rank] = exc
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(30)
+    assert not any(t.is_alive() for t in threads)
+    assert isinstance(errors[1], NotImplementedError)
+    assert all(isinstance(errors[r], RuntimeError) and "rank(s) [1]" in str(errors[r]) for r in (0, 2))

@@ -486,6 +486,7 @@ def worker(args, rank, world, local_rank):
             "full_result_gather_ms": full_gather_ms,
             "full_result_gather_bytes": full_gather_bytes,
             "library": nat.lib().pa_version().decode(),
+            "developer_switches": nat.lib().pa_active_switches().decode(),  # "" unless PEAPODS_DEVELOPER=1 + switches
             "checksum_energy_mean": float(mean[3 * work["n_temps"]:4 * work["n_temps"]].sum()),
         }
         if args.config == "c2" and world == 1 and not args.no_other_configs:

@@ -328,6 +328,12 @@ void pa_autocorrelation_tau(const float *series, uint64_t n_samples, uint64_t n_
 /* Number of visible HIP devices (0 when there is none / the runtime is unusable). */
 int pa_device_count(void);
 const char *pa_version(void);
+/* Developer switches honoured so far by this process, space separated ("NAME=value ..."), or "".  Kernel-selection
+ * and tuning variables (PEAPODS_NO_RELAY, PEAPODS_STREAMS, PEAPODS_RNG_BLOCK, ...) are ignored unless
+ * PEAPODS_DEVELOPER=1 is set with them: a stray variable cannot change which kernels a user runs.  (The reference has
+ * the same kind of switches in its own benchmark only: spin-sim/examples/bench.rs:19-21.)  The pointer stays valid
+ * until the next call. */
+const char *pa_active_switches(void);
 
 #ifdef __cplusplus
 }

@@ -128,6 +128,7 @@ SIGNATURES = {
     "pa_abi_layout": (_u64, [_vp, _u64]),
     "pa_device_count": (C.c_int, []),
     "pa_version": (C.c_char_p, []),
+    "pa_active_switches": (C.c_char_p, []),
 }
 
 _lib = None

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libpeapods_amd.so")
-SOURCES = ["host_util.cpp", "kernels.hip", "kernels_general.hip", "kernels_cluster.hip", "sim.hip", "comm.hip", "bandwidth.hip"]
+SOURCES = ["host_util.cpp", "kernels.hip", "kernels_general.hip", "kernels_cluster.hip", "kernels_reg.hip", "sim.hip", "comm.hip", "bandwidth.hip"]
 HEADERS = ["engine.hpp", "host_util.hpp", "device_util.hpp", "bitcount.hpp", os.path.join("..", "..", "include", "peapods_amd.h")]
 FLAGS = [
     "--offload-arch=gfx950",

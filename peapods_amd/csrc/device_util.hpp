@@ -151,6 +151,46 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Deferred tempering swaps (masks: kernels.hip, 'Deferred tempering swaps').
+// One round on a window of three consecutive words; returns the new middle word.  (prev, next)
+// are the old neighbouring words; only their bits next to the middle word matter.
+__device__ __forceinline__ uint32_t swap_round_mid(uint32_t prev, uint32_t v, uint32_t next,
+                                                   uint32_t m_prev, uint32_t m_cur) {
+    const uint32_t t = (v ^ ((v >> 1) | (next << 31))) & m_cur;      // pairs whose lower bit is in v
+    const uint32_t t_prev31 = ((prev >> 31) ^ (v & 1u)) & (m_prev >> 31); // pair (31 of prev, 0 of v)
+    return v ^ t ^ ((t << 1) | t_prev31);
+}
+
+// Both rounds for the middle word of a window (prev, v, next); masks are [round][word-1..word+1].
+__device__ __forceinline__ uint32_t apply_swaps_window(uint32_t prev, uint32_t v, uint32_t next,
+                                                       const uint32_t mp[2], const uint32_t mc[2],
+                                                       const uint32_t mn[2]) {
+    // round 0 on all three words (the outer two only need to be right next to the middle word,
+    // which they are: their far neighbours cannot reach bit 31 of prev / bit 0 of next in one round
+    // except through pairs that are themselves inside the window)
+    const uint32_t v0 = swap_round_mid(prev, v, next, mp[0], mc[0]);
+    const uint32_t p0 = swap_round_mid(0u, prev, v, 0u, mp[0]);
+    const uint32_t n0 = swap_round_mid(v, next, 0u, mc[0], mn[0] & 0x7FFFFFFFu);
+    return swap_round_mid(p0, v0, n0, mp[1], mc[1]);
+}
+
+
+// Workgroups go to the eight XCDs round-robin (blockIdx % 8) and every XCD has its own L2.  The words of one realisation
+// share its schedule table (and the overlap reads the partner replicas' words), so they get block indices eight apart:
+// the table then enters one L2 once per launch instead of once per word (raw FETCH_SIZE of the sweep pair: 25.2 -> 18.9 MB).
+__device__ __forceinline__ void tile_of_block(const SimDims &d, uint32_t bid, uint32_t &real, uint32_t &w) {
+    const uint32_t group = 8u * d.W, eights = d.n_real / 8u;
+    if (bid < eights * group) {
+        real = (bid / group) * 8u + (bid & 7u);
+        w = (bid % group) >> 3;
+    } else { // the realisations left over when their number is not a multiple of eight
+        const uint32_t rest = bid - eights * group;
+        real = eights * 8u + rest / d.W;
+        w = rest % d.W;
+    }
+}
+
+
 // Schedule record of one site (uint4, 16-bit fields holding LDS byte offsets = 4 * site index):
 //   x = site | f0 << 16,  y = b0 | f1 << 16,  z = b1 | f2 << 16,  w = b2 | jmeta << 16
 // Each realisation has N + 1 records; record N is a dummy whose site and neighbours all point

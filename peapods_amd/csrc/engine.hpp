@@ -21,6 +21,9 @@
 
 namespace pa {
 
+// Developer switches (host_util.cpp): getenv(name) when PEAPODS_DEVELOPER=1 is set too, else null.
+const char *dev_env(const char *name);
+
 struct SimDims {
     uint32_t N;          // sites
     uint32_t W;          // words per site
@@ -70,6 +73,11 @@ struct SimDims {
     // level, swept by one wave with a site's bonds spread over a quad of lanes (k_sweep_wide, rec_thin)
     uint32_t thin_chunks;
     uint32_t thin_dense; // 1: every bond of every site of every realisation is non-zero (no masks, h = nn everywhere)
+    // Register-resident sweep (k_sweep_reg, kernels_reg.hip): 16 x 16 x 16, three directions, every bond non-zero.
+    // One wave holds a tile word's 4096 sites in 64 VGPRs per lane; no LDS, no barrier.
+    uint32_t reg_ok;      // 1: the handle's shape admits it (set once by pa_sim_create; PEAPODS_NO_REG=1 clears it)
+    uint32_t planes_perm; // per launch: the random-stream workgroups file a site's acceptance planes at reg_pos[site]
+                          //   (the order k_sweep_reg reads them in) instead of at the site
 };
 
 // hc_tab entry of a site (schedule order): site | wrap flags << 14 | coupling sign bits << 20
@@ -119,6 +127,9 @@ struct DevPtrs {
     const uint2 *slab_seg;   // [n_levels][pipe_K] (first padded schedule position, sites) of a slab at a level;
                              //   positions are padded so that every segment starts at a multiple of 4
     const uint32_t *pos_of;  // [N] site -> padded schedule position (k_rng files the acceptance planes there)
+    const uint32_t *reg_pos; // [N] site -> (level mod 16, z mod 4, lane) slot of k_sweep_reg (SimDims::planes_perm)
+    const uint32_t *reg_cpl; // [n_real][4][3][64] k_sweep_reg: per lane, coupling sign bits of its 64 sites: word (m, dir),
+                             //   bit 2 j = forward bond, bit 2 j + 1 = backward bond of the site in register (m, j)
     uint32_t *slab_error;    // [1] set when a slab gave up waiting for an exchange record
     unsigned long long *slab_stamps; // diagnostic (pa_debug_slab_stamps), normally null: [workgroups][n_levels + 4] s_memrealtime per level
     const uint4 *recS;       // [n_real][planes_stride] by padded position: 8 x u16 = LDS word of the site and of
@@ -250,6 +261,11 @@ struct PtParams {
 };
 
 // All launchers enqueue on `stream` and return the hipGetLastError() of the launch.
+// k_sweep_reg (kernels_reg.hip): the register-resident Metropolis sweep of 16^3 lattices (SimDims::reg_ok)
+uint32_t reg_slot_of_site(uint32_t site);
+hipError_t launch_sweep_reg(const SimDims &d, const DevPtrs &p, bool with_energy, hipStream_t stream,
+                            unsigned long long *stamps = nullptr); // stamps: diagnostic, [workgroups][8] s_memrealtime
+inline bool reg_sweep_applies(const SimDims &d, bool gibbs) { return d.reg_ok && !gibbs; }
 hipError_t launch_rng(const SimDims &d, const DevPtrs &p, bool gibbs, hipStream_t stream);
 hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,
                         bool gibbs, hipStream_t stream);

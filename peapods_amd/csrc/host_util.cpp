@@ -5,6 +5,10 @@
 #include <cstring>
 #include <thread>
 
+#include <mutex>
+#include <set>
+#include <string>
+
 namespace pa {
 
 // reference: spin-sim/src/simulation/realization.rs:9-15 (same body as src/lib.rs:22-28)
@@ -389,6 +393,32 @@ uint32_t build_levels(const LatticeTables &lat, std::vector<uint32_t> &level) {
 // The library's version string carries the hash of the sources it was built from (peapods_amd/build.py
 // source_hash): bench.py prints counter-derived figures only when profiles/counters.json was collected from the
 // same kernels.
+namespace pa {
+namespace {
+std::mutex g_switch_mutex;
+std::set<std::string> g_switches;   // honoured so far
+std::string g_switch_text;          // what pa_active_switches last returned (the pointer stays valid)
+} // namespace
+
+const char *dev_env(const char *name) {
+    const char *gate = std::getenv("PEAPODS_DEVELOPER"); // (read every time: a test may open the gate for one handle)
+    if (!gate || gate[0] != '1' || gate[1] != '\0') return nullptr;
+    const char *value = std::getenv(name);
+    if (value) {
+        std::lock_guard<std::mutex> lock(g_switch_mutex);
+        g_switches.insert(std::string(name) + "=" + value);
+    }
+    return value;
+}
+} // namespace pa
+
+extern "C" const char *pa_active_switches(void) {
+    std::lock_guard<std::mutex> lock(pa::g_switch_mutex);
+    pa::g_switch_text.clear();
+    for (const auto &s : pa::g_switches) pa::g_switch_text += (pa::g_switch_text.empty() ? "" : " ") + s;
+    return pa::g_switch_text.c_str();
+}
+
 #ifndef PA_SOURCE_HASH
 #define PA_SOURCE_HASH "unknown"
 #endif

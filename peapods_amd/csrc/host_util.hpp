@@ -89,6 +89,12 @@ bool build_gibbs_table(const float *couplings, uint64_t n_couplings, const float
 void autocorrelation_tau(const float *series, size_t n_samples, size_t n_cols, size_t max_lag, double *tau_out,
                          bool fft = false);
 
+// Developer switches.  Kernel selection and tuning knobs (PEAPODS_NO_RELAY, PEAPODS_STREAMS, PEAPODS_RNG_BLOCK, ...) are
+// read through dev_env only, and dev_env answers null unless PEAPODS_DEVELOPER=1 is set as well: a stray variable in a
+// user's environment cannot change which kernels run.  Every switch that was honoured is remembered and reported by
+// pa_active_switches() (include/peapods_amd.h) and in bench.py's line.
+const char *dev_env(const char *name);
+
 // level[i] = 1 + max(level[j]) over neighbours j < i (0 if none).  Returns level count.
 uint32_t build_levels(const LatticeTables &lat, std::vector<uint32_t> &level);
 

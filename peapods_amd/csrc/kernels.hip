@@ -390,7 +390,9 @@ __device__ __forceinline__ void rng_block(const SimDims &d, const DevPtrs &p, ui
     uint2 *planes = p.planes + static_cast<size_t>(tw_ok ? tw : 0) * d.planes_stride;
     const uint32_t *mpar = p.mpar + static_cast<size_t>(real) * d.MW;
     // where a site's acceptance planes go: by site, or (k_sweep_slab) at its padded schedule position
-    auto filed = [&](uint32_t site) -> uint32_t { return d.pipe_lds ? p.pos_of[site] : site; };
+    auto filed = [&](uint32_t site) -> uint32_t {
+        return d.planes_perm ? p.reg_pos[site] : (d.pipe_lds ? p.pos_of[site] : site);
+    };
 
     if (GIBBS) {
         uint32_t ce[7] = {0, 0, 0, 0, 0, 0, 0}, co[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -723,28 +725,6 @@ __device__ __forceinline__ void copy2_to_lds(uint32_t *dst_a, const uint32_t *__
 // is k = 32 w + bit; round 0 pairs are applied before round 1 pairs (full ladder: the two
 // parities; single edge: round 0 only).  A pair may straddle two words (bits 31 | 0).
 // ---------------------------------------------------------------------------
-// One round on a window of three consecutive words; returns the new middle word.  (prev, next)
-// are the old neighbouring words; only their bits next to the middle word matter.
-__device__ __forceinline__ uint32_t swap_round_mid(uint32_t prev, uint32_t v, uint32_t next,
-                                                   uint32_t m_prev, uint32_t m_cur) {
-    const uint32_t t = (v ^ ((v >> 1) | (next << 31))) & m_cur;      // pairs whose lower bit is in v
-    const uint32_t t_prev31 = ((prev >> 31) ^ (v & 1u)) & (m_prev >> 31); // pair (31 of prev, 0 of v)
-    return v ^ t ^ ((t << 1) | t_prev31);
-}
-
-// Both rounds for the middle word of a window (prev, v, next); masks are [round][word-1..word+1].
-__device__ __forceinline__ uint32_t apply_swaps_window(uint32_t prev, uint32_t v, uint32_t next,
-                                                       const uint32_t mp[2], const uint32_t mc[2],
-                                                       const uint32_t mn[2]) {
-    // round 0 on all three words (the outer two only need to be right next to the middle word,
-    // which they are: their far neighbours cannot reach bit 31 of prev / bit 0 of next in one round
-    // except through pairs that are themselves inside the window)
-    const uint32_t v0 = swap_round_mid(prev, v, next, mp[0], mc[0]);
-    const uint32_t p0 = swap_round_mid(0u, prev, v, 0u, mp[0]);
-    const uint32_t n0 = swap_round_mid(v, next, 0u, mc[0], mn[0] & 0x7FFFFFFFu);
-    return swap_round_mid(p0, v0, n0, mp[1], mc[1]);
-}
-
 // Materialise pending swaps in place (any lattice size): one thread per site handles all W words.
 __global__ void k_apply_swaps(SimDims d, DevPtrs p) {
     const uint32_t real = blockIdx.y;
@@ -1357,21 +1337,6 @@ __device__ __forceinline__ void hc_energy(const SimDims &d, const DevPtrs &p, ui
         const int32_t unsat = static_cast<int32_t>(tot[0] + 2 * tot[1]);
         Esum[static_cast<size_t>(real) * d.n_sys + slot] = p.nz_bonds[real] - 2 * unsat;
         Msum[static_cast<size_t>(real) * d.n_sys + slot] = static_cast<int32_t>(d.N) - 2 * static_cast<int32_t>(tot[2]);
-    }
-}
-
-// Workgroups go to the eight XCDs round-robin (blockIdx % 8) and every XCD has its own L2.  The words of one realisation
-// share its schedule table (and the overlap reads the partner replicas' words), so they get block indices eight apart:
-// the table then enters one L2 once per launch instead of once per word (raw FETCH_SIZE of the sweep pair: 25.2 -> 18.9 MB).
-__device__ __forceinline__ void tile_of_block(const SimDims &d, uint32_t bid, uint32_t &real, uint32_t &w) {
-    const uint32_t group = 8u * d.W, eights = d.n_real / 8u;
-    if (bid < eights * group) {
-        real = (bid / group) * 8u + (bid & 7u);
-        w = (bid % group) >> 3;
-    } else { // the realisations left over when their number is not a multiple of eight
-        const uint32_t rest = bid - eights * group;
-        real = eights * 8u + rest / d.W;
-        w = rest % d.W;
     }
 }
 
@@ -3722,6 +3687,11 @@ hipError_t launch_rng(const SimDims &d, const DevPtrs &p, bool gibbs, hipStream_
         return hipGetLastError();
     }
     if (d.general) return launch_rng_f(d, p, gibbs, stream);
+    if (reg_sweep_applies(d, gibbs) && !d.planes_perm) { // the sweep that follows reads the planes in its register order
+        SimDims dr = d;
+        dr.planes_perm = 1;
+        return launch_rng(dr, p, gibbs, stream);
+    }
     const uint32_t n_pairs_tw = (d.n_real * d.W + 1) / 2;
     const uint32_t groups = (n_pairs_tw + 3) / 4;
     if (gibbs)
@@ -3736,6 +3706,11 @@ hipError_t launch_rng(const SimDims &d, const DevPtrs &p, bool gibbs, hipStream_
 // Random stream of the next Metropolis sweep fused with the overlap measurement of the current
 // state (LDS kernels, unit couplings only).
 hipError_t launch_rng_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool gibbs) {
+    if (reg_sweep_applies(d, gibbs) && !d.planes_perm) {
+        SimDims dr = d;
+        dr.planes_perm = 1;
+        return launch_rng_overlap(dr, p, stream, gibbs);
+    }
     const uint32_t n_pairs_tw = (d.n_real * d.W + 1) / 2;
     const uint32_t groups = (n_pairs_tw + 3) / 4;
     const uint32_t n_overlap = d.n_real * d.W;
@@ -3769,6 +3744,11 @@ bool rng_relay_ladder_supported(const SimDims &d) {
 
 hipError_t launch_rng_relay(const SimDims &d, const DevPtrs &p, bool with_overlap, const PtParams &pt, bool do_accum,
                             bool accum_overlap, bool do_pt, hipStream_t stream, bool gibbs) {
+    if (reg_sweep_applies(d, gibbs) && !d.planes_perm) {
+        SimDims dr = d;
+        dr.planes_perm = 1;
+        return launch_rng_relay(dr, p, with_overlap, pt, do_accum, accum_overlap, do_pt, stream, gibbs);
+    }
     const uint32_t n_pairs_tw = (d.n_real * d.W + 1) / 2;
     const uint32_t groups = (n_pairs_tw + d.rng_waves - 1) / d.rng_waves;
     const uint32_t n_overlap = with_overlap ? d.n_real * d.W : 0u;
@@ -3777,7 +3757,7 @@ hipError_t launch_rng_relay(const SimDims &d, const DevPtrs &p, bool with_overla
     // behind the jump table: the replayed decisions (one word per ladder), or the ladders' draws and edge masks
     const size_t replay_words = replay == 2 ? static_cast<size_t>(relay_reals_per_block(d)) * d.n_replicas * (d.n_temps + 1) : 256;
     static const size_t lds_floor = [] { // (experiment knob: a larger reservation limits the workgroups per CU)
-        const char *env = std::getenv("PEAPODS_RNG_LDS");
+        const char *env = dev_env("PEAPODS_RNG_LDS");
         return env ? static_cast<size_t>(std::strtol(env, nullptr, 10)) : 0;
     }();
     const size_t lds = std::max({kRngLds + std::max<size_t>(1024, replay_words * 4), n_overlap ? overlap_lds_bytes(d) : 0,
@@ -3839,6 +3819,7 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
         return hipGetLastError();
     }
     if (d.general) return launch_sweep_f(d, p, with_energy, do_sweep, stream);
+    if (do_sweep && reg_sweep_applies(d, gibbs)) return launch_sweep_reg(d, p, with_energy, stream);
     if (d.big) {
         if (do_sweep)
             hipLaunchKernelGGL(k_sweep_big, dim3(d.n_real * d.W), dim3(1024), 0, stream, d, p,
@@ -3854,13 +3835,13 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
     }
     const dim3 grid(d.n_real * d.W), block(256);
     static const size_t pad = [] {
-        const char *env = std::getenv("PEAPODS_SWEEP_LDS");
+        const char *env = dev_env("PEAPODS_SWEEP_LDS");
         return env ? static_cast<size_t>(std::strtol(env, nullptr, 10)) : 0;
     }();
     const size_t lds = std::max(sweep_lds_bytes(d, gibbs && do_sweep), pad);
     unsigned long long *no_stamps = nullptr;
     const int e = with_energy ? 1 : 0, s = do_sweep ? 1 : 0;
-    static const bool no_hc = std::getenv("PEAPODS_NO_HC") != nullptr;
+    static const bool no_hc = dev_env("PEAPODS_NO_HC") != nullptr;
     if (gibbs && do_sweep) {
         if (d.hc && !no_hc && sweep_hc_lds_bytes(d, true) <= 160 * 1024) { // (83 KB at 16^3: one workgroup per CU)
             const dim3 block_hc(512);
@@ -3955,7 +3936,7 @@ hipError_t launch_sweep_stamped(const SimDims &d, const DevPtrs &p, unsigned lon
     }
     if (d.dense_nn == 3)
         hipLaunchKernelGGL((k_sweep<true, 3>), grid, block, sweep_lds_bytes(d, false), stream, d, p,
-                           1 | (std::getenv("PEAPODS_DBG") ? std::atoi(std::getenv("PEAPODS_DBG")) << 8 : 0), 1, stamps);
+                           1 | (dev_env("PEAPODS_DBG") ? std::atoi(dev_env("PEAPODS_DBG")) << 8 : 0), 1, stamps);
     else
         hipLaunchKernelGGL((k_sweep<true, 0>), grid, block, sweep_lds_bytes(d, false), stream, d, p, 1, 1, stamps);
     return hipGetLastError();
@@ -3987,7 +3968,7 @@ hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream
                            ((static_cast<size_t>(d.N) + 1) + 5 * 80) * 4, stream, d, p);
         return hipGetLastError();
     }
-    if (d.N <= 4096 && !std::getenv("PEAPODS_OVERLAP_256"))
+    if (d.N <= 4096 && !dev_env("PEAPODS_OVERLAP_256"))
         hipLaunchKernelGGL(k_overlap_1024, dim3(d.n_real * d.W), dim3(1024), overlap_lds_bytes(d), stream, d, p);
     else
         hipLaunchKernelGGL(k_overlap, dim3(d.n_real * d.W), dim3(256), overlap_lds_bytes(d), stream, d, p);

@@ -1061,7 +1061,7 @@ __host__ __device__ inline size_t wolff_wave_lds_words(const SimDims &d, uint32_
 }
 __host__ inline uint32_t wolff_wave_tasks(const SimDims &d, int mode) {
     const uint32_t n_tasks = mode == kSwFk ? d.n_sys : d.n_temps * d.n_pairs;
-    if (const char *env = std::getenv("PEAPODS_WAVE_TASKS")) {
+    if (const char *env = dev_env("PEAPODS_WAVE_TASKS")) {
         uint32_t tasks = static_cast<uint32_t>(std::max(1l, std::min(16l, std::strtol(env, nullptr, 10))));
         while (tasks > 1 && wolff_wave_lds_words(d, tasks, mode) * 4 > 160 * 1024) tasks /= 2;
         return tasks;

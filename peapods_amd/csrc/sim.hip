@@ -66,6 +66,7 @@ struct pa_sim {
     uint32_t *thr = nullptr, *mpar = nullptr, *pass_start = nullptr, *jump = nullptr;
     uint4 *rec = nullptr, *rec_wide = nullptr, *rec_thin = nullptr;
     uint32_t *hc_tab = nullptr, *thr_wide = nullptr;
+    uint32_t *reg_pos = nullptr, *reg_cpl = nullptr; // k_sweep_reg tables (SimDims::reg_ok)
     uint16_t *nbr_site = nullptr;
     uint32_t *jsite = nullptr, *nbr_wide = nullptr;
     uint4 *fwd_big = nullptr;
@@ -408,6 +409,7 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     q.mpar += static_cast<size_t>(d.MW) * r0;
     q.rec += (static_cast<size_t>(d.N) + 1) * (d.big ? 2 : 1) * r0;
     if (d.hc) q.hc_tab += static_cast<size_t>(d.N) * r0;
+    if (d.reg_ok) q.reg_cpl += static_cast<size_t>(12 * 64) * r0;
     if (d.pipe_lds) q.recS += static_cast<size_t>(d.planes_stride) * r0;
     if (d.pipe_K) q.progress += static_cast<size_t>(d.W) * d.pipe_K * r0;
     if (d.pipe_lds) q.xchg += static_cast<size_t>(d.W) * d.pipe_K * 2 * d.plane * r0;
@@ -471,7 +473,7 @@ void offset_cluster_stats(DevPtrs &q, const DevPtrs &p, const SimDims &d, uint32
 
 int make_groups(pa_sim *sim) {
     uint32_t n_groups = 2; // two interleaved groups overlap a little (5 %); three or more collapse
-    if (const char *env = std::getenv("PEAPODS_STREAMS")) {
+    if (const char *env = dev_env("PEAPODS_STREAMS")) {
         const long v = std::strtol(env, nullptr, 10);
         if (v >= 1 && v <= 16) n_groups = static_cast<uint32_t>(v);
     }
@@ -507,7 +509,7 @@ void toggle_spin_buffers(pa_sim *sim) {
 hipError_t enqueue_sweep(pa_sim *sim, const SimDims &d, const DevPtrs &p, bool with_energy,
                          bool gibbs, hipStream_t stream, bool overlap_too = false) {
     // (the LDS-resident slab kernel exchanges the deferred bit columns while it loads: two launches less per sweep)
-    const bool at_load = d.pipe_K && d.pipe_lds && !std::getenv("PEAPODS_NO_SWAPS_AT_LOAD");
+    const bool at_load = d.pipe_K && d.pipe_lds && !dev_env("PEAPODS_NO_SWAPS_AT_LOAD");
     if ((d.big || d.general) && sim->swaps_pending && !at_load) {
         hipError_t e = launch_apply_swaps(d, p, stream);
         if (e != hipSuccess) return e;
@@ -926,20 +928,20 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     uint64_t overlap_call_count = 0; // mod.rs:300
     size_t equil_next = 0;
     // (the heat bath rides the same launches when its sweep runs on the implicit-neighbour kernel: three planes in LDS)
-    const bool gibbs_fast = gibbs && d.hc && sweep_hc_lds_bytes(d, true) <= 160 * 1024 && !std::getenv("PEAPODS_NO_HC");
+    const bool gibbs_fast = gibbs && d.hc && sweep_hc_lds_bytes(d, true) <= 160 * 1024 && !dev_env("PEAPODS_NO_HC");
     const bool fused = want_overlap && (!gibbs || gibbs_fast) && !fk && !equil && cfg->overlap_cluster_interval == 0 &&
-                       !d.big && !d.general && !std::getenv("PEAPODS_NO_FUSE");
+                       !d.big && !d.general && !dev_env("PEAPODS_NO_FUSE");
     bool overlap_owed = false; // the last recorded sweep's overlap has not been measured yet
     // the measurement block of the previous sweep when it is relayed into the next sweep's random-stream launch
     struct {
         bool any = false, do_accum = false, accum_overlap = false, do_pt = false;
         PtParams pt{};
     } pending;
-    const bool relay = fused && !std::getenv("PEAPODS_NO_RELAY") &&
+    const bool relay = fused && !dev_env("PEAPODS_NO_RELAY") &&
                        (cfg->pt_schedule == PA_PT_SINGLE_RANDOM_EDGE ? rng_relay_supported(d) : rng_relay_ladder_supported(d));
     // (opt-in: measured slower than two launches)
     const bool relay_nf = !fused && !gibbs && !d.big && !d.general && cfg->pt_schedule == PA_PT_SINGLE_RANDOM_EDGE &&
-                          rng_relay_supported(d) && !std::getenv("PEAPODS_NO_RELAY");
+                          rng_relay_supported(d) && !dev_env("PEAPODS_NO_RELAY");
     // Cooperative cancel (src/lib.rs:304-308, mod.rs:406-408): the host runs at most two batches of
     // kBatch sweeps ahead of the device, so a request is honoured within that much queued work; the
     // state then is the one after the last enqueued sweep (a continuation from it is well defined).
@@ -1030,7 +1032,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     // launch), and the dependent-launch hop it shortens in an empty-kernel chain (1.6 against 2.8 us,
     // build_probe/gaps.hip) is not what separates these kernels: most of the ~5 us before a large kernel's first wave
     // is its own wave-launch ramp.
-    const bool graph_enabled = fused && relay && std::getenv("PEAPODS_GRAPH") != nullptr && cfg->pt_interval == 1;
+    const bool graph_enabled = fused && relay && dev_env("PEAPODS_GRAPH") != nullptr && cfg->pt_interval == 1;
     auto pair_key = [&]() -> uint64_t {
         uint64_t h = 1469598103934665603ull;
         auto mix = [&](const void *ptr, size_t n) {
@@ -1595,7 +1597,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         target_block = 256;
     else if (rng_groups * (d.N / 128) < 512)
         target_block = static_cast<uint32_t>(std::min<uint64_t>(128, std::max<uint64_t>(32, rng_groups * d.N / 512)));
-    if (const char *env = std::getenv("PEAPODS_RNG_BLOCK")) {
+    if (const char *env = dev_env("PEAPODS_RNG_BLOCK")) {
         const long v = std::strtol(env, nullptr, 10);
         if (v >= 16 && v <= 65536) target_block = static_cast<uint32_t>(v);
     }
@@ -1614,7 +1616,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
             return bail(PA_ERR_UNSUPPORTED);
         }
         d.rng_waves = 4;
-        if (const char *env = std::getenv("PEAPODS_RNG_WAVES")) {
+        if (const char *env = dev_env("PEAPODS_RNG_WAVES")) {
             const long v = std::strtol(env, nullptr, 10);
             if (v == 4 || v == 8) d.rng_waves = static_cast<uint32_t>(v);
         }
@@ -1641,7 +1643,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     if (d.general && sweep_f_lds_bytes(d) > 160 * 1024) d.big = 1;
     // unit couplings on four to six forward directions: Metropolis sweeps by the integer table (SimDims::wide)
     d.wide = (d.general && d.unit && d.nn > 3 && d.nn <= 6 && !d.big && d.N <= 16383 &&
-              sweep_wide_lds_bytes(d) <= 160 * 1024 && !std::getenv("PEAPODS_NO_WIDE")) ? 1 : 0;
+              sweep_wide_lds_bytes(d) <= 160 * 1024 && !dev_env("PEAPODS_NO_WIDE")) ? 1 : 0;
     std::vector<uint32_t> thr_wide;
     if (d.wide) { // the table's columns in the layout the random-stream kernel reads for the heat bath (thr_gibbs)
         const uint32_t width = 4 * d.nn + 1, off = 2 * d.nn;
@@ -1710,7 +1712,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     // m >= 1 slabs below satisfies level(j) + m <= level(i).
     d.n_levels = n_levels;
     d.slab_lead = 0; // (measured at 64^3: 0..4 levels make no difference, every further level costs 7 us per sweep)
-    if (const char *env = std::getenv("PEAPODS_SLAB_LEAD")) {
+    if (const char *env = dev_env("PEAPODS_SLAB_LEAD")) {
         const long v = std::strtol(env, nullptr, 10);
         if (v >= 0 && v <= 64) d.slab_lead = static_cast<uint32_t>(v);
     }
@@ -1727,7 +1729,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         uint32_t K = 1;
         for (uint32_t c = 1; c <= target; ++c)
             if (lat.shape[0] % c == 0) K = c;
-        if (const char *env = std::getenv("PEAPODS_PIPE_K")) {
+        if (const char *env = dev_env("PEAPODS_PIPE_K")) {
             const long v = std::strtol(env, nullptr, 10);
             if (v >= 1 && v <= 256) K = static_cast<uint32_t>(v);
         }
@@ -1801,7 +1803,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
             }
             return true;
         };
-        if (!std::getenv("PEAPODS_NO_SLAB_LDS") && lat.shape[0] >= 4) {
+        if (!dev_env("PEAPODS_NO_SLAB_LDS") && lat.shape[0] >= 4) {
             uint32_t best = 0;
             for (uint32_t slabs = 2; slabs <= lat.shape[0] / 2 && !best; ++slabs) { // fewest slabs first
                 if (lat.shape[0] % slabs != 0) continue;
@@ -1814,7 +1816,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
                 }
                 if (longest <= 256 && build_halo(slabs)) best = slabs;
             }
-            if (const char *env = std::getenv("PEAPODS_SLAB_K")) {
+            if (const char *env = dev_env("PEAPODS_SLAB_K")) {
                 const long v = std::strtol(env, nullptr, 10);
                 best = (v >= 2 && build_halo(static_cast<uint32_t>(v))) ? static_cast<uint32_t>(v) : 0u;
             }
@@ -1928,10 +1930,10 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     d.thin_chunks = 0;
     d.thin_dense = all_nonzero ? 1 : 0;
     std::vector<uint4> rec_thin;
-    if (d.wide && !std::getenv("PEAPODS_NO_THIN")) {
+    if (d.wide && !dev_env("PEAPODS_NO_THIN")) {
         uint32_t chunks = 0;
         for (uint32_t l = 0; l < n_levels; ++l) chunks += (level_start[l + 1] - level_start[l] + 15) / 16;
-        if (chunks < 3 * d.n_passes || std::getenv("PEAPODS_FORCE_THIN")) {
+        if (chunks < 3 * d.n_passes || dev_env("PEAPODS_FORCE_THIN")) {
             d.thin_chunks = chunks;
             rec_thin.resize(static_cast<size_t>(d.n_real) * chunks * 64);
             for (uint32_t real = 0; real < d.n_real; ++real) {
@@ -1961,7 +1963,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     d.hc = 0;
     std::vector<uint32_t> hc_tab;
     if (!d.big && !d.general && d.nn >= 1 && d.nn <= 3 && d.N < (1u << kHcSiteBits) &&
-        !std::getenv("PEAPODS_NO_HC")) {
+        !dev_env("PEAPODS_NO_HC")) {
         bool ok = true;
         int64_t d0[6] = {0, 0, 0, 0, 0, 0}, d1[6] = {0, 0, 0, 0, 0, 0};
         for (uint32_t k = 0; k < 2 * d.nn && ok; ++k) {
@@ -2006,6 +2008,32 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
                         site | (flags << kHcFlagShift) | ((js & 63u) << kHcNegShift) | (((js >> 12) & 63u) << kHcNzShift);
                 }
         }
+    }
+
+    // ---- register-resident sweep (k_sweep_reg, kernels_reg.hip): 16 x 16 x 16 with three directions and every bond
+    // non-zero.  Tables: where the random-stream kernel files a site's acceptance planes (reg_pos), and per lane the
+    // coupling signs of its 64 sites (reg_cpl).
+    d.reg_ok = 0;
+    d.planes_perm = 0;
+    std::vector<uint32_t> reg_pos, reg_cpl;
+    if (d.hc && d.nn == 3 && d.dense_nn == 3 && desc->n_dims == 3 && !desc->neighbor_offsets && desc->shape[0] == 16 &&
+        desc->shape[1] == 16 && desc->shape[2] == 16 && dev_env("PEAPODS_REG")) {
+        // (opt-in, PEAPODS_DEVELOPER=1 PEAPODS_REG=1: exact, but measured SLOWER than k_sweep_hc -- 48.8 against 24.2 us per
+        // launch on the bench ensemble, a step 86 against 58 us: one wave issues an instruction every ~5 cycles however
+        // independent they are, so a word's ~10 K instructions take 30 us on one wave, while k_sweep_hc spreads its 14.5 K
+        // over eight.  profiles/NOTES.md, round 4.)
+        d.reg_ok = 1;
+        reg_pos.resize(d.N);
+        for (uint32_t site = 0; site < d.N; ++site) reg_pos[site] = reg_slot_of_site(site);
+        reg_cpl.assign(static_cast<size_t>(d.n_real) * 12 * 64, 0u);
+        for (uint32_t real = 0; real < d.n_real; ++real)
+            for (uint32_t site = 0; site < d.N; ++site) {
+                const uint32_t x = site >> 8, y = (site >> 4) & 15u, z = site & 15u;
+                const uint32_t lane = (z >> 2) * 16 + y, m = z & 3u, j = (x + y + z) & 15u;
+                const uint32_t js = jsite[static_cast<size_t>(real) * d.N + site]; // neg bits of f0,b0,f1,b1,f2,b2
+                for (uint32_t dir = 0; dir < 3; ++dir)
+                    reg_cpl[(static_cast<size_t>(real) * 12 + m * 3 + dir) * 64 + lane] |= ((js >> (2 * dir)) & 3u) << (2 * j);
+            }
     }
 
     // ---- k_sweep_slab streams its inputs in schedule order: per (level, slab) segment, padded to
@@ -2183,6 +2211,10 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     ok(bufs.alloc(&sim->rec, rec.size()));
     ok(bufs.alloc(&sim->pass_start, pass_start.size()));
     if (d.hc) ok(bufs.alloc(&sim->hc_tab, hc_tab.size()));
+    if (d.reg_ok) {
+        ok(bufs.alloc(&sim->reg_pos, reg_pos.size()));
+        ok(bufs.alloc(&sim->reg_cpl, reg_cpl.size()));
+    }
     ok(bufs.alloc(&sim->jump, jump.size()));
     ok(bufs.alloc(&p.Esum, static_cast<size_t>(d.n_real) * d.n_sys));
     ok(bufs.alloc(&p.Msum, static_cast<size_t>(d.n_real) * d.n_sys));
@@ -2239,6 +2271,9 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     p.rec_thin = sim->rec_thin;
     p.thr_wide = sim->thr_wide;
     if (d.hc && (rc = upload(sim, sim->hc_tab, hc_tab))) return bail(rc);
+    p.reg_pos = sim->reg_pos;
+    p.reg_cpl = sim->reg_cpl;
+    if (d.reg_ok && ((rc = upload(sim, sim->reg_pos, reg_pos)) || (rc = upload(sim, sim->reg_cpl, reg_cpl)))) return bail(rc);
     p.jump = sim->jump;
     p.nz_bonds = sim->nz_bonds;
     p.dbeta = sim->dbeta;
@@ -2353,7 +2388,7 @@ void pa_sim_request_interrupt(pa_sim *sim) { sim->interrupt.store(true); }
 // 60.4 us per step).  PEAPODS_SYNC_SPIN_US sets the polling time, 0 turns it off.
 static hipError_t wait_for_stream(hipStream_t stream) {
     static const long spin_us = [] {
-        const char *env = std::getenv("PEAPODS_SYNC_SPIN_US");
+        const char *env = dev_env("PEAPODS_SYNC_SPIN_US");
         return env ? std::strtol(env, nullptr, 10) : 2000L;
     }();
     if (spin_us > 0) {
@@ -2427,9 +2462,9 @@ int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_
     uint64_t count[3] = {0, 0, 0};
     // same launch sequence as run_sweeps on one stream; with the fused path the overlap of the previous sweep --
     // and, relayed, its measurement block -- ride in the random-stream launch (reported under k_rng)
-    const bool gibbs_fast = gibbs && d.hc && sweep_hc_lds_bytes(d, true) <= 160 * 1024 && !std::getenv("PEAPODS_NO_HC");
-    const bool fused = want_overlap && (!gibbs || gibbs_fast) && !d.big && !d.general && !std::getenv("PEAPODS_NO_FUSE");
-    const bool relay = fused && !std::getenv("PEAPODS_NO_RELAY") &&
+    const bool gibbs_fast = gibbs && d.hc && sweep_hc_lds_bytes(d, true) <= 160 * 1024 && !dev_env("PEAPODS_NO_HC");
+    const bool fused = want_overlap && (!gibbs || gibbs_fast) && !d.big && !d.general && !dev_env("PEAPODS_NO_FUSE");
+    const bool relay = fused && !dev_env("PEAPODS_NO_RELAY") &&
                        (cfg->pt_schedule == PA_PT_SINGLE_RANDOM_EDGE ? rng_relay_supported(d) : rng_relay_ladder_supported(d));
     struct {
         bool any = false, do_accum = false, accum_overlap = false, do_pt = false;
@@ -2534,7 +2569,9 @@ int pa_debug_sweep_stamps(pa_sim *sim, unsigned long long out[6]) {
     PA_HIP(sim, hipSetDevice(sim->device));
     unsigned long long *dev = nullptr;
     PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&dev), 6 * sizeof(unsigned long long)));
-    PA_HIP(sim, launch_rng(sim->d, sim->p, false, sim->stream));
+    SimDims by_site = sim->d;
+    by_site.reg_ok = 0; // (the stamped kernels read the acceptance planes by site)
+    PA_HIP(sim, launch_rng(by_site, sim->p, false, sim->stream));
     PA_HIP(sim, launch_sweep_stamped(sim->d, sim->p, dev, sim->stream));
     toggle_spin_buffers(sim);
     PA_HIP(sim, hipStreamSynchronize(sim->stream));
@@ -2553,8 +2590,30 @@ int pa_debug_sweep_hc_stamps(pa_sim *sim, unsigned long long *out, uint64_t capa
     unsigned long long *dev = nullptr;
     PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&dev), n_blocks * 8 * sizeof(unsigned long long)));
     PA_HIP(sim, hipMemset(dev, 0, n_blocks * 8 * sizeof(unsigned long long)));
-    PA_HIP(sim, launch_rng(sim->d, sim->p, false, sim->stream));
+    SimDims by_site = sim->d;
+    by_site.reg_ok = 0; // (the stamped kernels read the acceptance planes by site)
+    PA_HIP(sim, launch_rng(by_site, sim->p, false, sim->stream));
     PA_HIP(sim, launch_sweep_stamped(sim->d, sim->p, dev, sim->stream));
+    sim->swaps_pending = false;
+    toggle_spin_buffers(sim);
+    PA_HIP(sim, hipStreamSynchronize(sim->stream));
+    PA_HIP(sim, hipMemcpy(out, dev, n_blocks * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    (void)hipFree(dev);
+    return static_cast<int>(n_blocks);
+}
+
+// Diagnostic only: s_memrealtime stamps of every wave of one k_sweep_reg launch, out[n_blocks][8] (start, spins loaded,
+// planes landed, levels 0-15 / 16-31 / 32-47 done, stored, energy done); 0 when the handle does not use that kernel.
+int pa_debug_sweep_reg_stamps(pa_sim *sim, unsigned long long *out, uint64_t capacity_blocks) {
+    if (!sim->d.reg_ok) return 0;
+    PA_HIP(sim, hipSetDevice(sim->device));
+    const size_t n_blocks = static_cast<size_t>(sim->d.n_real) * sim->d.W;
+    if (n_blocks > capacity_blocks) return fail(sim, PA_ERR_INVALID, "stamp buffer too small");
+    unsigned long long *dev = nullptr;
+    PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&dev), n_blocks * 8 * sizeof(unsigned long long)));
+    PA_HIP(sim, hipMemset(dev, 0, n_blocks * 8 * sizeof(unsigned long long)));
+    PA_HIP(sim, launch_rng(sim->d, sim->p, false, sim->stream));
+    PA_HIP(sim, launch_sweep_reg(sim->d, sim->p, true, sim->stream, dev));
     sim->swaps_pending = false;
     toggle_spin_buffers(sim);
     PA_HIP(sim, hipStreamSynchronize(sim->stream));

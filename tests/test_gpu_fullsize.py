@@ -237,6 +237,7 @@ def test_fallback_sweeps_of_the_large_path_match_oracle(oracle, monkeypatch, kno
     slab cut is admissible) stay as fallbacks and must stay exact."""
     from peapods_amd import IsingSimulation
 
+    monkeypatch.setenv("PEAPODS_DEVELOPER", "1")  # (kernel-selection switches count only behind this gate)
     monkeypatch.setenv("PEAPODS_NO_SLAB_LDS", "1")
     if knob == "PEAPODS_PIPE_K":
         monkeypatch.setenv("PEAPODS_PIPE_K", "1")  # one slab = no pipeline

@@ -339,6 +339,7 @@ def test_record_path_protocol_matches_oracle(oracle, monkeypatch, lattice, mode)
         shape, offsets, nn = (6, 6), [[1, 0], [0, 1], [1, -1]], 3
     else:
         shape, offsets, nn = (6, 6, 6), None, 3
+        monkeypatch.setenv("PEAPODS_DEVELOPER", "1")
         monkeypatch.setenv("PEAPODS_NO_HC", "1")
     couplings = bimodal(shape, nn, 3, 41)
     gpu, cpu = make_pair(oracle, shape, couplings, np.linspace(0.9, 2.2, 7), 4, 12, offsets)
@@ -856,3 +857,32 @@ def test_cached_sums_follow_the_systems_after_a_relayed_event(oracle):
     _, earlier = make_pair(oracle, shape, couplings, temps, 2, 3)
     earlier.sample(21, "metropolis", **kw)  # (sweeps 0..20: without the event of sweep 21)
     assert not np.array_equal(gpu.get_system_ids(0), earlier.get_system_ids(0))  # that event did exchange systems
+
+
+@pytest.mark.parametrize("schedule", ["single_random_edge", "full_ladder"])
+def test_register_resident_sweep_matches_oracle(oracle, monkeypatch, schedule):
+    """k_sweep_reg (kernels_reg.hip, opt-in): a 16^3 tile word's 4096 sites in the registers of ONE wave -- level mod 16 as
+    the register index, y along a DPP row, z across registers and rows -- with the acceptance planes filed in that order
+    by the random-stream kernel (SimDims::planes_perm).  Same trajectory as k_sweep_hc: 40 slots in two words (a
+    tempering pair straddles them), both schedules, energies and overlaps from the swept registers."""
+    from peapods_amd import IsingSimulation, _native as nat
+
+    monkeypatch.setenv("PEAPODS_DEVELOPER", "1")
+    monkeypatch.setenv("PEAPODS_REG", "1")
+    shape = (16, 16, 16)
+    rng = np.random.default_rng(16)
+    couplings = (2 * rng.integers(0, 2, size=(3,) + shape + (3,)) - 1).astype(np.float32)
+    temps = np.linspace(0.8, 1.6, 10).astype(np.float32)
+    gpu = IsingSimulation(list(shape), couplings, temps, 4, None, 77)
+    assert "PEAPODS_REG=1" in nat.lib().pa_active_switches().decode()
+    cpu = oracle.OracleSimulation(list(shape), couplings, temps, 4, None, 77)
+    kw = dict(pt_interval=1, pt_schedule=schedule, warmup_ratio=0.25)
+    a = gpu.sample(12, "metropolis", **kw)
+    b = cpu.sample(12, "metropolis", n_threads=3, **kw)
+    for key in ("mags", "mags2", "mags4", "energies", "energies2", "overlap", "overlap2", "overlap4", "link_overlap",
+                "link_overlap2", "ql_at_q_sum", "per_sample_overlap_histogram"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    for r in range(3):
+        np.testing.assert_array_equal(gpu.get_spins(r), cpu.get_spins(r))
+        np.testing.assert_array_equal(gpu.get_system_ids(r), cpu.get_system_ids(r))
+        np.testing.assert_array_equal(gpu.get_energies(r), cpu.get_energies(r))

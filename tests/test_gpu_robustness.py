@@ -241,6 +241,7 @@ def test_captured_graph_pairs_replay_the_same_trajectory(oracle, monkeypatch, sc
     across calls too (the second call replays the graphs of the first; the Gibbs call captures its own)."""
     from peapods_amd import IsingSimulation
 
+    monkeypatch.setenv("PEAPODS_DEVELOPER", "1")
     monkeypatch.setenv("PEAPODS_GRAPH", "1")
     shape, n_rep = (8, 8, 8), 4
     temps = np.linspace(0.8, 1.4, 6).astype(np.float32)

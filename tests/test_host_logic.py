@@ -29,6 +29,33 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, name), f"{name} declared in the header but not exported"
     assert declared == set(nat.SIGNATURES), "ctypes binding table out of sync with the header"
     assert nat.lib().pa_version().startswith(b"peapods_amd")
+    # ... and nothing else: the diagnostic entry points are declared in their own header, every other pa_* symbol of the
+    # dynamic table is in the public one
+    import subprocess
+
+    debug = set(re.findall(r"\b(pa_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "peapods_amd_debug.h")).read()))
+    assert debug and all(name.startswith("pa_debug_") for name in debug)
+    table = subprocess.run(["nm", "-D", "--defined-only", nat.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in table.splitlines() if line.split()[-1].startswith("pa_")}
+    assert exported == declared | debug, sorted(exported ^ (declared | debug))
+
+
+def test_developer_switches_are_ignored_without_the_gate():
+    """Kernel-selection variables count only together with PEAPODS_DEVELOPER=1 (engine.hpp dev_env); what was honoured
+    is reported by pa_active_switches.  (A fresh process each: the gate is read once.)"""
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path.insert(0, %r); from peapods_amd import _native as n; l = n.lib(); "
+            "d = n.PaSimDesc(); import ctypes as C; h = C.c_void_p(); e = C.create_string_buffer(64); "
+            "l.pa_sim_create(C.byref(d), C.byref(h), e, 64); print('switches=[' + l.pa_active_switches().decode() + ']')" % ROOT)
+    for gate, expected in ((None, "switches=[]"), ("1", "switches=[")):
+        env = dict(os.environ, PEAPODS_NO_RELAY="1", PEAPODS_STREAMS="1")
+        env.pop("PEAPODS_DEVELOPER", None)
+        if gate:
+            env["PEAPODS_DEVELOPER"] = gate
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+        assert expected in out, out
 
 
 def test_abi_layout_and_generated_bindings():

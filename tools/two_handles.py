@@ -2,6 +2,7 @@
 import os, sys, time, threading
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("PEAPODS_DEVELOPER", "1")
 os.environ.setdefault("PEAPODS_STREAMS", "1")
 import bench
 from peapods_amd import IsingSimulation

@@ -148,7 +148,7 @@ def launch_workers(args):
 # ------------------------------------------------------------------------------------------------
 # worker
 # ------------------------------------------------------------------------------------------------
-def build_ensemble(work, rank, n_per_gpu, world, device):
+def build_ensemble(work, rank, n_per_gpu, world, device, stream_groups=0):
     from peapods_amd import IsingSimulation
     from peapods_amd.spin_models import generate_couplings, seed_material
 
@@ -158,8 +158,21 @@ def build_ensemble(work, rank, n_per_gpu, world, device):
                                             realizations=mine))
     temps = np.linspace(*work["t_range"], work["n_temps"]).astype(np.float32)
     sim = IsingSimulation(list(work["shape"]), couplings, temps, work["n_replicas"], None, dynamics_seed,
-                          device=device, first_realization=mine.start)
+                          device=device, first_realization=mine.start, stream_groups=stream_groups)
     return sim, couplings, temps, dynamics_seed
+
+
+def step_profile(work, sample_kw, n_per_gpu, device, n_sweeps=48, settle=200):
+    """Every launch of one step of the timed protocol, by kernel (pa_sim_profile_step): a second handle of the same
+    ensemble with ONE stream group -- a launch's time beside another group's launches says little about the launch --
+    runs sample()'s own launch sequence with an event in front of every launch.  {kernel: {ms_per_step,
+    launches_per_step}}, and the step time of that one-stream handle."""
+    sim, *_ = build_ensemble(work, 0, n_per_gpu, 1, device, stream_groups=1)
+    cfg = sim.make_config(n_sweeps, "metropolis", warmup_ratio=0.0, **sample_kw)
+    sim.run(sim.make_config(settle, "metropolis", warmup_ratio=0.0, **sample_kw))
+    table, step_ms = sim.profile_step(cfg, n_sweeps)
+    rows = {name: {"ms_per_step": ms, "launches_per_step": launches} for name, (ms, launches) in table.items()}
+    return rows, step_ms
 
 
 def host_cores():
@@ -277,12 +290,40 @@ def valu_limiter(kernels_ms, scale):
             "frac_of_probe_peak": fracs(peak_probe)}
 
 
+def roofline_of(work, attempts, ms_per_step, pair_ms, kernels_per_step, one_stream_step_ms, note):
+    """The roofline block of a config: `step` prices the WHOLE step (ms_per_step of the timed run: every launch, the
+    cluster move of c4 included), `pair` the random stream + sweep launches alone (what rounds 1-3 reported as frac)."""
+    alg = (work["bytes"] + BYTES_OVERLAP) * attempts
+    step_gbs = alg / (ms_per_step * 1e-3) / 1e9 if ms_per_step > 0 else 0.0
+    pair_gbs = alg / (pair_ms * 1e-3) / 1e9 if pair_ms and pair_ms > 0 else None
+    return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_step": alg,
+            "achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
+            "frac_is": "algorithmic bytes of one step / ms_per_step of the timed run (every launch of the step)",
+            "pair": {"achieved": pair_gbs, "frac": pair_gbs / HBM_PEAK_GBS if pair_gbs else None, "ms": pair_ms,
+                     "kernels": "the random-stream launch + the sweep launch of one Metropolis sweep"},
+            "kernels_per_step": kernels_per_step, "one_stream_step_ms": one_stream_step_ms, "note": note}
+
+
+def pair_ms_of(kernels_per_step):
+    """Random stream + sweep of one Metropolis sweep out of a step profile (names as written at the launch sites)."""
+    if not kernels_per_step:
+        return None
+    total = 0.0
+    for name, row in kernels_per_step.items():
+        base = name.split("<")[0]
+        if base in ("k_rng", "k_rng_relay", "k_rng_overlap", "k_rng_f") or base.startswith("k_sweep"):
+            total += row["ms_per_step"]
+    return total or None
+
+
 def other_configs(args, device):
-    """configs[1] (64^3 ferromagnet) and configs[4] (12^3 glass with the Houdayer / Joerg overlap move) on this GPU:
-    value, ms_per_step and the roofline fraction of the sweep pair, from a warm-up call and one timed call each."""
+    """configs[1] (64^3 ferromagnet) and configs[4] (12^3 glass with the Houdayer / Joerg overlap move, single-cluster and
+    union-find forms) on this GPU: value and ms_per_step from a warm-up call and one timed call each, then every launch of
+    a step by kernel from a one-stream handle (step_profile), and the roofline fraction of the step and of the sweep pair."""
     out = {}
-    todo = [("c1", "c1", {}, 300), ("c4_houdayer", "c4", dict(overlap_cluster_build_mode="houdayer", overlap_cluster_mode="wolff"), 300),
-            ("c4_jorg", "c4", dict(overlap_cluster_build_mode="jorg", overlap_cluster_mode="wolff"), 100)]
+    c4 = lambda mode, variant: dict(overlap_cluster_build_mode=mode, overlap_cluster_mode=variant)
+    todo = [("c1", "c1", {}, 300), ("c4_houdayer", "c4", c4("houdayer", "wolff"), 300), ("c4_jorg", "c4", c4("jorg", "wolff"), 100),
+            ("c4_houdayer_sw", "c4", c4("houdayer", "sw"), 200), ("c4_jorg_sw", "c4", c4("jorg", "sw"), 200)]
     for name, key, extra, steps in todo:
         work = WORKLOADS[key]
         try:
@@ -295,20 +336,16 @@ def other_configs(args, device):
             sim.run(sim.make_config(steps, "metropolis", warmup_ratio=0.0, **kw), wait=False)
             sim.synchronize()
             dt = time.perf_counter() - t0
-            kernels = sim.profile_kernels(sim.make_config(32, "metropolis", warmup_ratio=0.0, pt_interval=1,
-                                                          pt_schedule=args.pt_schedule), 32)
-            pair_ms = kernels["k_rng"] + kernels["k_sweep"]
-            alg = (work["bytes"] + BYTES_OVERLAP) * attempts
-            achieved = alg / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
+            del sim
+            try:
+                kernels, one_stream = step_profile(work, kw, work["n_disorder"], device, n_sweeps=32, settle=max(steps // 5, 10))
+            except Exception as exc:
+                kernels, one_stream = None, f"{type(exc).__name__}: {exc}"
             out[name] = {"workload": work["title"].format(n=work["n_disorder"], mode="/".join(extra.values()) or "-"),
                          "value": attempts * steps / dt, "unit": "spin-flip attempts/s", "steps": steps,
                          "ms_per_step": dt / steps * 1e3,
-                         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": achieved / HBM_PEAK_GBS, "kernel_ms": kernels,
-                                      "algorithmic_bytes_per_launch": alg,
-                                      "kernels": "random stream + sweep of one Metropolis sweep (the cluster move of c4 is "
-                                                 "in ms_per_step, not in this pair)"}}
-            del sim
+                         "roofline": roofline_of(work, attempts, dt / steps * 1e3, pair_ms_of(kernels), kernels, one_stream,
+                                                 "kernels_per_step: one stream group; ms_per_step: the default two")}
         except Exception as exc:  # the headline line must not be lost to a side measurement
             out[name] = {"error": f"{type(exc).__name__}: {exc}"}
     return out
@@ -416,13 +453,19 @@ def worker(args, rank, world, local_rank):
             full_gather_bytes = int(sum(a.nbytes for a in gathered.values()))
         del parts, gathered
 
-    profiled = "overlap_cluster_update_interval" not in sample_kw
+    profiled = "overlap_cluster_update_interval" not in sample_kw  # (pa_sim_profile_kernels: the sweep pair; kernels_per_step covers the rest)
     # (the gathers above left the chip idle for tens of milliseconds: the same settling as before the timed calls, so that
     # the per-launch times are those of the clocks the timed region ran at)
     if args.settle_ms > 0 and args.settle_calls > 0:
         sim.run(config(max(1, int(args.settle_ms * 1e-3 / max(elapsed / args.steps, 1e-6)))))
     kernels_ms = sim.profile_kernels(sim.make_config(args.profile_sweeps, "metropolis", warmup_ratio=0.0, pt_interval=1,
                                                      pt_schedule=args.pt_schedule), args.profile_sweeps)
+    kernels_per_step, one_stream_step_ms = None, None
+    if rank == 0 and world == 1:
+        try:  # every launch of the step by kernel -- for c4 this is where the cluster move's launches show
+            kernels_per_step, one_stream_step_ms = step_profile(work, sample_kw, n_per_gpu, local_rank)
+        except Exception as exc:
+            one_stream_step_ms = f"{type(exc).__name__}: {exc}"
     if rank == 0:
         value = attempts_per_step * world * args.steps / elapsed
         sweep_ms = kernels_ms["k_rng"] + kernels_ms["k_sweep"]
@@ -477,6 +520,11 @@ def worker(args, rank, world, local_rank):
                 "traffic_collected_at": counters.get("commit") if counters else None,
                 "traffic_null_reason": None if counters else counters_stale,
                 "algorithmic_bytes_per_launch": alg_bytes,
+                "step": {"achieved": alg_bytes / (elapsed / args.steps) / 1e9, "frac": alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                         "is": "the same algorithmic bytes over ms_per_step of the timed run (every launch of the step, "
+                               "two stream groups side by side)"},
+                "kernels_per_step": kernels_per_step,
+                "one_stream_step_ms": one_stream_step_ms,
                 "kernel_ms": kernels_ms,
                 "kernel_ms_protocol": "sweep pipeline of the timed protocol" if profiled else
                                       "sweep pipeline only (the cluster move is in ms_per_step, not here)",

@@ -84,6 +84,10 @@ typedef struct {
      * index (src/lib.rs:30-32), so a disorder ensemble sharded over several handles / GPUs gives
      * the same per-realisation results as one handle holding all of them. */
     uint64_t first_realization;
+    /* Stream groups the realisations are split into (each group's launches go to a stream of its own, so that one
+     * group's random stream overlaps another's sweep); 0 = the default (2).  1 = every launch covers the whole
+     * ensemble on one stream: what pa_sim_profile_step needs.  The trajectory does not depend on it. */
+    uint32_t stream_groups;
 } pa_sim_desc;
 
 /* Keyword arguments of IsingSimulation.sample that are on the path
@@ -156,6 +160,15 @@ uint64_t pa_sim_sweeps_completed(const pa_sim *sim);
  * The first half of the sweeps is timed launch by launch (which stretches every launch: each starts on an idle
  * queue), the second half as sample() enqueues it, between two events; the figures are the first half's shares of
  * the second half's time per sweep. */
+/* Device time of EVERY launch of one step of `cfg`'s protocol, cluster moves included, by kernel (the name is the kernel
+ * expression of the launch site, e.g. "k_rng_relay<P, R, G>").  sample()'s own launch sequence runs for `n_sweeps`
+ * sweeps with an event in front of every launch, then again without events; each kernel's share of the traced run is
+ * applied to the untraced step time *step_ms_out.  names_out: the kernel names, one per line; ms_per_step_out[k] and
+ * launches_per_step_out[k] belong to line k.  The handle must have one stream group (pa_sim_desc.stream_groups = 1).
+ * State advances by 2 n_sweeps sweeps; the results of the handle are those of the second run. */
+int pa_sim_profile_step(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_sweeps, char *names_out, uint64_t names_capacity,
+                        double *ms_per_step_out, double *launches_per_step_out, uint64_t capacity, uint64_t *n_kernels_out,
+                        double *step_ms_out);
 int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_sweeps,
                            double ms_out[3]);
 

@@ -61,7 +61,7 @@ def _parse_overlap_modes(text):
 
 class IsingSimulation:
     def __init__(self, lattice_shape, couplings, temperatures, n_replicas=None,
-                 neighbor_offsets=None, seed=None, device=0, first_realization=0):
+                 neighbor_offsets=None, seed=None, device=0, first_realization=0, stream_groups=0):
         self._lib = nat.lib()
         self._handle = None
         shape = [int(x) for x in lattice_shape]
@@ -107,6 +107,7 @@ class IsingSimulation:
         desc.seed = self.constructor_seed
         desc.device = int(device)
         desc.first_realization = int(first_realization)
+        desc.stream_groups = int(stream_groups)  # 0: the default; 1: one stream (what profile_step needs)
         handle = C.c_void_p()
         err = C.create_string_buffer(512)
         code = self._lib.pa_sim_create(C.byref(desc), C.byref(handle), err, len(err))
@@ -263,6 +264,19 @@ class IsingSimulation:
         self._check(self._lib.pa_sim_profile_kernels(self._handle, C.byref(cfg), int(n_sweeps),
                                                      nat.ptr(out)))
         return dict(zip(("k_rng", "k_sweep", "k_measure"), out.tolist()))
+
+    def profile_step(self, cfg, n_sweeps):
+        """({kernel name: (ms per step, launches per step)}, ms per step) of EVERY launch of a step of `cfg`'s protocol,
+        cluster moves included (pa_sim_profile_step; the handle must have been made with stream_groups=1)."""
+        cap = 64
+        names = C.create_string_buffer(8192)
+        ms = np.zeros(cap, dtype=np.float64)
+        launches = np.zeros(cap, dtype=np.float64)
+        n, step = C.c_uint64(), C.c_double()
+        self._check(self._lib.pa_sim_profile_step(self._handle, C.byref(cfg), int(n_sweeps), names, len(names), nat.ptr(ms),
+                                                  nat.ptr(launches), cap, C.byref(n), C.byref(step)))
+        rows = names.value.decode().splitlines()
+        return {rows[k]: (float(ms[k]), float(launches[k])) for k in range(int(n.value))}, float(step.value)
 
     def synchronize(self):
         self._check(self._lib.pa_sim_synchronize(self._handle))

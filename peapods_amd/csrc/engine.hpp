@@ -21,6 +21,17 @@
 
 namespace pa {
 
+// Launch tracer (diagnostic, pa_sim_profile_step): every kernel launch of the library goes through PA_LAUNCH, which files
+// an event in front of the launch while a trace is open on the calling thread -- a no-op otherwise (one thread-local
+// load).  The name is the kernel expression as written at the launch site.
+void trace_mark(const char *name, hipStream_t stream);
+extern thread_local bool g_trace_on;
+#define PA_LAUNCH(kernel, grid, block, lds, stream, ...)                                           \
+    do {                                                                                           \
+        if (::pa::g_trace_on) ::pa::trace_mark(#kernel, stream);                                   \
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                          \
+    } while (0)
+
 // Developer switches (host_util.cpp): getenv(name) when PEAPODS_DEVELOPER=1 is set too, else null.
 const char *dev_env(const char *name);
 

@@ -3683,7 +3683,7 @@ hipError_t launch_rng(const SimDims &d, const DevPtrs &p, bool gibbs, hipStream_
         DevPtrs q = p;
         q.thr_gibbs = p.thr_wide;
         const uint32_t groups = ((d.n_real * d.W + 1) / 2 + 3) / 4;
-        hipLaunchKernelGGL((k_rng<false, true>), dim3(groups * d.B), dim3(256), kRngLds, stream, d, q);
+        PA_LAUNCH((k_rng<false, true>), dim3(groups * d.B), dim3(256), kRngLds, stream, d, q);
         return hipGetLastError();
     }
     if (d.general) return launch_rng_f(d, p, gibbs, stream);
@@ -3695,11 +3695,11 @@ hipError_t launch_rng(const SimDims &d, const DevPtrs &p, bool gibbs, hipStream_
     const uint32_t n_pairs_tw = (d.n_real * d.W + 1) / 2;
     const uint32_t groups = (n_pairs_tw + 3) / 4;
     if (gibbs)
-        hipLaunchKernelGGL((k_rng<false, true>), dim3(groups * d.B), dim3(256), kRngLds, stream, d, p);
+        PA_LAUNCH((k_rng<false, true>), dim3(groups * d.B), dim3(256), kRngLds, stream, d, p);
     else if (d.thr_preshifted)
-        hipLaunchKernelGGL((k_rng<true, false>), dim3(groups * d.B), dim3(256), kRngLds, stream, d, p);
+        PA_LAUNCH((k_rng<true, false>), dim3(groups * d.B), dim3(256), kRngLds, stream, d, p);
     else
-        hipLaunchKernelGGL((k_rng<false, false>), dim3(groups * d.B), dim3(256), kRngLds, stream, d, p);
+        PA_LAUNCH((k_rng<false, false>), dim3(groups * d.B), dim3(256), kRngLds, stream, d, p);
     return hipGetLastError();
 }
 
@@ -3716,11 +3716,11 @@ hipError_t launch_rng_overlap(const SimDims &d, const DevPtrs &p, hipStream_t st
     const uint32_t n_overlap = d.n_real * d.W;
     const size_t lds = std::max(kRngLds, overlap_lds_bytes(d));
     if (gibbs)
-        hipLaunchKernelGGL((k_rng_overlap<false, true>), dim3(n_overlap + groups * d.B), dim3(256), lds, stream, d, p, n_overlap);
+        PA_LAUNCH((k_rng_overlap<false, true>), dim3(n_overlap + groups * d.B), dim3(256), lds, stream, d, p, n_overlap);
     else if (d.thr_preshifted)
-        hipLaunchKernelGGL(k_rng_overlap<true>, dim3(n_overlap + groups * d.B), dim3(256), lds, stream, d, p, n_overlap);
+        PA_LAUNCH(k_rng_overlap<true>, dim3(n_overlap + groups * d.B), dim3(256), lds, stream, d, p, n_overlap);
     else
-        hipLaunchKernelGGL(k_rng_overlap<false>, dim3(n_overlap + groups * d.B), dim3(256), lds, stream, d, p, n_overlap);
+        PA_LAUNCH(k_rng_overlap<false>, dim3(n_overlap + groups * d.B), dim3(256), lds, stream, d, p, n_overlap);
     return hipGetLastError();
 }
 
@@ -3764,7 +3764,7 @@ hipError_t launch_rng_relay(const SimDims &d, const DevPtrs &p, bool with_overla
                                  n_measure ? measure_lds_bytes(d) : 0, lds_floor});
     const dim3 grid(n_overlap + n_measure + groups * d.B), block(64 * d.rng_waves);
     const int a = do_accum ? 1 : 0, o = accum_overlap ? 1 : 0, t = do_pt ? 1 : 0;
-#define PA_RELAY(P, R, G) hipLaunchKernelGGL((k_rng_relay<P, R, G>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t)
+#define PA_RELAY(P, R, G) PA_LAUNCH((k_rng_relay<P, R, G>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t)
     if (gibbs) { // (heat-bath thresholds are compared unshifted, like k_rng<false, true>)
         if (replay == 2) PA_RELAY(false, 2, true);
         else if (replay == 1) PA_RELAY(false, 1, true);
@@ -3793,7 +3793,7 @@ __global__ __launch_bounds__(256) void k_adopt_relay_sums(SimDims d, DevPtrs p) 
     }
 }
 hipError_t launch_adopt_relay_sums(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
-    hipLaunchKernelGGL(k_adopt_relay_sums, dim3(d.n_real), dim3(256), 0, stream, d, p);
+    PA_LAUNCH(k_adopt_relay_sums, dim3(d.n_real), dim3(256), 0, stream, d, p);
     return hipGetLastError();
 }
 
@@ -3806,15 +3806,15 @@ hipError_t launch_measure_overlap(const SimDims &d, const DevPtrs &p, const PtPa
     const size_t lds = std::max(overlap_lds_bytes(d), measure_lds_bytes(d));
     const dim3 grid(n_overlap + n_measure), block(256);
     const int a = do_accum ? 1 : 0, o = accum_overlap ? 1 : 0, t = do_pt ? 1 : 0;
-    if (d.thr_preshifted) hipLaunchKernelGGL((k_rng_relay<true, false>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
-    else hipLaunchKernelGGL((k_rng_relay<false, false>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
+    if (d.thr_preshifted) PA_LAUNCH((k_rng_relay<true, false>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
+    else PA_LAUNCH((k_rng_relay<false, false>), grid, block, lds, stream, d, p, n_overlap, n_measure, pt, a, o, t);
     return hipGetLastError();
 }
 
 hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bool do_sweep,
                         bool gibbs, hipStream_t stream) {
     if (do_sweep && takes_wide_route(d, gibbs)) {
-        hipLaunchKernelGGL(k_sweep_wide, dim3(d.n_real * d.W), dim3(256), sweep_wide_lds_bytes(d), stream, d, p,
+        PA_LAUNCH(k_sweep_wide, dim3(d.n_real * d.W), dim3(256), sweep_wide_lds_bytes(d), stream, d, p,
                            with_energy ? 1 : 0, 1);
         return hipGetLastError();
     }
@@ -3822,13 +3822,13 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
     if (do_sweep && reg_sweep_applies(d, gibbs)) return launch_sweep_reg(d, p, with_energy, stream);
     if (d.big) {
         if (do_sweep)
-            hipLaunchKernelGGL(k_sweep_big, dim3(d.n_real * d.W), dim3(1024), 0, stream, d, p,
+            PA_LAUNCH(k_sweep_big, dim3(d.n_real * d.W), dim3(1024), 0, stream, d, p,
                                gibbs ? 1 : 0);
         if (with_energy) {
             const uint32_t n_chunks = (d.N + 4095) / 4096;
-            hipLaunchKernelGGL(k_energy_big, dim3(d.n_real * d.W * n_chunks), dim3(256), 0, stream, d,
+            PA_LAUNCH(k_energy_big, dim3(d.n_real * d.W * n_chunks), dim3(256), 0, stream, d,
                                p, n_chunks);
-            hipLaunchKernelGGL(k_big_finalize, dim3((d.n_real * d.n_sys + 255) / 256), dim3(256), 0,
+            PA_LAUNCH(k_big_finalize, dim3((d.n_real * d.n_sys + 255) / 256), dim3(256), 0,
                                stream, d, p, 0);
         }
         return hipGetLastError();
@@ -3846,7 +3846,7 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
         if (d.hc && !no_hc && sweep_hc_lds_bytes(d, true) <= 160 * 1024) { // (83 KB at 16^3: one workgroup per CU)
             const dim3 block_hc(512);
             const size_t lds_g = sweep_hc_lds_bytes(d, true);
-#define PA_HC(NN, G, D) hipLaunchKernelGGL((k_sweep_hc<NN, false, G, D>), grid, block_hc, lds_g, stream, d, p, e, s, no_stamps)
+#define PA_HC(NN, G, D) PA_LAUNCH((k_sweep_hc<NN, false, G, D>), grid, block_hc, lds_g, stream, d, p, e, s, no_stamps)
             if (d.dense_nn == d.nn) {
                 switch (d.nn) {
                 case 1: PA_HC(1, true, true); break;
@@ -3863,7 +3863,7 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
 #undef PA_HC
             return hipGetLastError();
         }
-        hipLaunchKernelGGL((k_sweep<false, 0, true>), grid, block, lds, stream, d, p, e, s, no_stamps);
+        PA_LAUNCH((k_sweep<false, 0, true>), grid, block, lds, stream, d, p, e, s, no_stamps);
         return hipGetLastError();
     }
     if (d.hc && !no_hc) { // implicit neighbours, table in the LDS
@@ -3873,7 +3873,7 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
         const size_t alone = (do_sweep && grid.x <= 256) ? 82 * 1024 : 0;
         const size_t lds_hc = std::max({sweep_hc_lds_bytes(d), pad, alone});
         const dim3 block_hc(512); // two sets of four waves take the passes in turn
-#define PA_HC(NN, D) hipLaunchKernelGGL((k_sweep_hc<NN, false, false, D>), grid, block_hc, lds_hc, stream, d, p, e, s, no_stamps)
+#define PA_HC(NN, D) PA_LAUNCH((k_sweep_hc<NN, false, false, D>), grid, block_hc, lds_hc, stream, d, p, e, s, no_stamps)
         if (d.dense_nn == d.nn) {
             switch (d.nn) {
             case 1: PA_HC(1, true); break;
@@ -3891,10 +3891,10 @@ hipError_t launch_sweep(const SimDims &d, const DevPtrs &p, bool with_energy, bo
         return hipGetLastError();
     }
     switch (d.dense_nn) {
-    case 1: hipLaunchKernelGGL((k_sweep<false, 1>), grid, block, lds, stream, d, p, e, s, no_stamps); break;
-    case 2: hipLaunchKernelGGL((k_sweep<false, 2>), grid, block, lds, stream, d, p, e, s, no_stamps); break;
-    case 3: hipLaunchKernelGGL((k_sweep<false, 3>), grid, block, lds, stream, d, p, e, s, no_stamps); break;
-    default: hipLaunchKernelGGL((k_sweep<false, 0>), grid, block, lds, stream, d, p, e, s, no_stamps); break;
+    case 1: PA_LAUNCH((k_sweep<false, 1>), grid, block, lds, stream, d, p, e, s, no_stamps); break;
+    case 2: PA_LAUNCH((k_sweep<false, 2>), grid, block, lds, stream, d, p, e, s, no_stamps); break;
+    case 3: PA_LAUNCH((k_sweep<false, 3>), grid, block, lds, stream, d, p, e, s, no_stamps); break;
+    default: PA_LAUNCH((k_sweep<false, 0>), grid, block, lds, stream, d, p, e, s, no_stamps); break;
     }
     return hipGetLastError();
 }
@@ -3915,13 +3915,13 @@ hipError_t launch_sweep_pipe(const SimDims &d, const DevPtrs &p, bool gibbs, uin
     const uint32_t n_tw_pad = (d.n_real * d.W + 7u) & ~7u;
     // (apply_swaps: only the LDS-resident kernel exchanges the deferred bit columns itself; enqueue_sweep knows)
     if (d.pipe_lds && gibbs)
-        hipLaunchKernelGGL(k_sweep_slab<true>, dim3(n_tw_pad * d.pipe_K), dim3(kSlabThreads), sweep_slab_lds_bytes(d),
+        PA_LAUNCH(k_sweep_slab<true>, dim3(n_tw_pad * d.pipe_K), dim3(kSlabThreads), sweep_slab_lds_bytes(d),
                            stream, d, p, epoch, n_tw_pad, apply_swaps ? 1 : 0);
     else if (d.pipe_lds)
-        hipLaunchKernelGGL(k_sweep_slab<false>, dim3(n_tw_pad * d.pipe_K), dim3(kSlabThreads), sweep_slab_lds_bytes(d),
+        PA_LAUNCH(k_sweep_slab<false>, dim3(n_tw_pad * d.pipe_K), dim3(kSlabThreads), sweep_slab_lds_bytes(d),
                            stream, d, p, epoch, n_tw_pad, apply_swaps ? 1 : 0);
     else
-        hipLaunchKernelGGL(k_sweep_pipe, dim3(n_tw_pad * d.pipe_K), dim3(256), 0, stream, d, p,
+        PA_LAUNCH(k_sweep_pipe, dim3(n_tw_pad * d.pipe_K), dim3(256), 0, stream, d, p,
                            gibbs ? 1 : 0, epoch, n_tw_pad);
     return hipGetLastError();
 }
@@ -3931,47 +3931,47 @@ hipError_t launch_sweep_stamped(const SimDims &d, const DevPtrs &p, unsigned lon
                                 hipStream_t stream) {
     const dim3 grid(d.n_real * d.W), block(256);
     if (d.hc && d.dense_nn == 3) { // every workgroup stamps: stamps[grid][8]
-        hipLaunchKernelGGL((k_sweep_hc<3, true>), grid, dim3(512), sweep_hc_lds_bytes(d), stream, d, p, 1, 1, stamps);
+        PA_LAUNCH((k_sweep_hc<3, true>), grid, dim3(512), sweep_hc_lds_bytes(d), stream, d, p, 1, 1, stamps);
         return hipGetLastError();
     }
     if (d.dense_nn == 3)
-        hipLaunchKernelGGL((k_sweep<true, 3>), grid, block, sweep_lds_bytes(d, false), stream, d, p,
+        PA_LAUNCH((k_sweep<true, 3>), grid, block, sweep_lds_bytes(d, false), stream, d, p,
                            1 | (dev_env("PEAPODS_DBG") ? std::atoi(dev_env("PEAPODS_DBG")) << 8 : 0), 1, stamps);
     else
-        hipLaunchKernelGGL((k_sweep<true, 0>), grid, block, sweep_lds_bytes(d, false), stream, d, p, 1, 1, stamps);
+        PA_LAUNCH((k_sweep<true, 0>), grid, block, sweep_lds_bytes(d, false), stream, d, p, 1, 1, stamps);
     return hipGetLastError();
 }
 
 hipError_t launch_apply_swaps(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
-    hipLaunchKernelGGL(k_apply_swaps, dim3((d.N + 255) / 256, d.n_real), dim3(256), 0, stream, d, p);
-    hipLaunchKernelGGL(k_mark_applied, dim3((d.n_real * d.W + 255) / 256), dim3(256), 0, stream, d, p);
+    PA_LAUNCH(k_apply_swaps, dim3((d.N + 255) / 256, d.n_real), dim3(256), 0, stream, d, p);
+    PA_LAUNCH(k_mark_applied, dim3((d.n_real * d.W + 255) / 256), dim3(256), 0, stream, d, p);
     return hipGetLastError();
 }
 
 hipError_t launch_energy_overlap_big(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
     const uint32_t n_chunks = (d.N + 4095) / 4096, n_each = d.n_real * d.W * n_chunks;
-    hipLaunchKernelGGL(k_energy_overlap_big, dim3(2 * n_each), dim3(256), 0, stream, d, p, n_chunks, n_each);
+    PA_LAUNCH(k_energy_overlap_big, dim3(2 * n_each), dim3(256), 0, stream, d, p, n_chunks, n_each);
     return hipGetLastError();
 }
 
 hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
     if (d.big) {
         const uint32_t n_chunks = (d.N + 4095) / 4096;
-        hipLaunchKernelGGL(k_overlap_big, dim3(d.n_real * d.W * n_chunks), dim3(256), 0, stream, d, p,
+        PA_LAUNCH(k_overlap_big, dim3(d.n_real * d.W * n_chunks), dim3(256), 0, stream, d, p,
                            n_chunks);
-        hipLaunchKernelGGL(k_big_finalize, dim3((d.n_real * d.n_sys + 255) / 256), dim3(256), 0,
+        PA_LAUNCH(k_big_finalize, dim3((d.n_real * d.n_sys + 255) / 256), dim3(256), 0,
                            stream, d, p, 1);
         return hipGetLastError();
     }
     if (d.nn > 3) {
-        hipLaunchKernelGGL(k_overlap_wide, dim3(d.n_real * d.W), dim3(256),
+        PA_LAUNCH(k_overlap_wide, dim3(d.n_real * d.W), dim3(256),
                            ((static_cast<size_t>(d.N) + 1) + 5 * 80) * 4, stream, d, p);
         return hipGetLastError();
     }
     if (d.N <= 4096 && !dev_env("PEAPODS_OVERLAP_256"))
-        hipLaunchKernelGGL(k_overlap_1024, dim3(d.n_real * d.W), dim3(1024), overlap_lds_bytes(d), stream, d, p);
+        PA_LAUNCH(k_overlap_1024, dim3(d.n_real * d.W), dim3(1024), overlap_lds_bytes(d), stream, d, p);
     else
-        hipLaunchKernelGGL(k_overlap, dim3(d.n_real * d.W), dim3(256), overlap_lds_bytes(d), stream, d, p);
+        PA_LAUNCH(k_overlap, dim3(d.n_real * d.W), dim3(256), overlap_lds_bytes(d), stream, d, p);
     return hipGetLastError();
 }
 
@@ -3980,45 +3980,45 @@ hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream
 hipError_t launch_houdayer_seeds(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool with_overlap) {
     if (with_overlap) {
         const size_t lds = std::max(houdayer_lds_words(d) * 4, overlap_lds_bytes(d));
-        hipLaunchKernelGGL(k_houdayer_overlap, dim3(d.n_real + d.n_real * d.W), dim3(1024), lds, stream, d, p, d.n_real);
+        PA_LAUNCH(k_houdayer_overlap, dim3(d.n_real + d.n_real * d.W), dim3(1024), lds, stream, d, p, d.n_real);
     } else {
-        hipLaunchKernelGGL(k_houdayer, dim3(d.n_real), dim3(1024), houdayer_lds_words(d) * 4, stream, d, p);
+        PA_LAUNCH(k_houdayer, dim3(d.n_real), dim3(1024), houdayer_lds_words(d) * 4, stream, d, p);
     }
     return hipGetLastError();
 }
 hipError_t launch_houdayer_grow(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool with_energy) {
     const bool e = with_energy && d.hc && d.dense_nn == d.nn;
     const size_t lds = (2 * static_cast<size_t>(d.N) + 4 + (e ? d.N + 4 + 5 * 48 : 0)) * 4;
-    hipLaunchKernelGGL(k_houdayer_grow, dim3(d.n_real * d.W), dim3(1024), lds, stream, d, p, e ? 1 : 0);
+    PA_LAUNCH(k_houdayer_grow, dim3(d.n_real * d.W), dim3(1024), lds, stream, d, p, e ? 1 : 0);
     return hipGetLastError();
 }
 hipError_t launch_houdayer_grow_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_accum, hipStream_t stream,
                                         bool with_energy) {
     const bool e = with_energy && d.hc && d.dense_nn == d.nn;
     const size_t lds = std::max((2 * static_cast<size_t>(d.N) + 4 + (e ? d.N + 4 + 5 * 48 : 0)) * 4, measure_lds_bytes(d));
-    hipLaunchKernelGGL(k_houdayer_grow_measure, dim3(d.n_real * d.W + d.n_real), dim3(1024), lds, stream, d, p, e ? 1 : 0,
+    PA_LAUNCH(k_houdayer_grow_measure, dim3(d.n_real * d.W + d.n_real), dim3(1024), lds, stream, d, p, e ? 1 : 0,
                        d.n_real * d.W, pt, do_accum ? 1 : 0);
     return hipGetLastError();
 }
 hipError_t launch_houdayer(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool with_energy) {
-    hipLaunchKernelGGL(k_houdayer, dim3(d.n_real), dim3(1024), houdayer_lds_words(d) * 4, stream, d, p);
+    PA_LAUNCH(k_houdayer, dim3(d.n_real), dim3(1024), houdayer_lds_words(d) * 4, stream, d, p);
     const bool e = with_energy && d.hc && d.dense_nn == d.nn;
     const size_t lds = (2 * static_cast<size_t>(d.N) + 4 + (e ? d.N + 4 + 5 * 48 : 0)) * 4;
-    hipLaunchKernelGGL(k_houdayer_grow, dim3(d.n_real * d.W), dim3(1024), lds, stream, d, p, e ? 1 : 0);
+    PA_LAUNCH(k_houdayer_grow, dim3(d.n_real * d.W), dim3(1024), lds, stream, d, p, e ? 1 : 0);
     return hipGetLastError();
 }
 bool houdayer_computes_energy(const SimDims &d) { return d.hc && d.dense_nn == d.nn; }
 size_t houdayer_lds_bytes(const SimDims &d) { return houdayer_lds_words(d) * 4; }
 
 hipError_t launch_jorg(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
-    hipLaunchKernelGGL(k_jorg, dim3(d.n_real), dim3(1024), jorg_lds_words(d) * 4, stream, d, p);
+    PA_LAUNCH(k_jorg, dim3(d.n_real), dim3(1024), jorg_lds_words(d) * 4, stream, d, p);
     return hipGetLastError();
 }
 size_t jorg_lds_bytes(const SimDims &d) { return jorg_lds_words(d) * 4; }
 
 hipError_t launch_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_overlap,
                           bool do_accum, bool accum_overlap, bool do_pt, hipStream_t stream) {
-    hipLaunchKernelGGL(k_measure<false>, dim3(d.n_real), dim3(1024), measure_lds_bytes(d), stream, d,
+    PA_LAUNCH(k_measure<false>, dim3(d.n_real), dim3(1024), measure_lds_bytes(d), stream, d,
                        p, pt, do_overlap ? 1 : 0, do_accum ? 1 : 0, accum_overlap ? 1 : 0,
                        do_pt ? 1 : 0, static_cast<unsigned long long *>(nullptr));
     return hipGetLastError();
@@ -4026,7 +4026,7 @@ hipError_t launch_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt
 
 hipError_t launch_measure_stamped(const SimDims &d, const DevPtrs &p, const PtParams &pt,
                                   unsigned long long *stamps, hipStream_t stream) {
-    hipLaunchKernelGGL(k_measure<true>, dim3(d.n_real), dim3(1024), measure_lds_bytes(d), stream, d,
+    PA_LAUNCH(k_measure<true>, dim3(d.n_real), dim3(1024), measure_lds_bytes(d), stream, d,
                        p, pt, 1, 1, 1, 1, stamps);
     return hipGetLastError();
 }

@@ -1521,8 +1521,8 @@ __global__ __launch_bounds__(1024) void k_cmr_wolff(SimDims d, DevPtrs p) {
 size_t cmr_wolff_lds_bytes(const SimDims &d) { return cmr_wolff_lds_words(d) * 4; }
 
 hipError_t launch_cmr_wolff(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
-    hipLaunchKernelGGL(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
-    hipLaunchKernelGGL(k_cmr_wolff, dim3(d.n_real), dim3(1024), cmr_wolff_lds_bytes(d), stream, d, p);
+    PA_LAUNCH(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
+    PA_LAUNCH(k_cmr_wolff, dim3(d.n_real), dim3(1024), cmr_wolff_lds_bytes(d), stream, d, p);
     return hipGetLastError();
 }
 
@@ -1534,7 +1534,7 @@ __global__ void k_exp_selftest(float *out) {
 }
 
 hipError_t launch_exp_selftest(float *out, hipStream_t stream) {
-    hipLaunchKernelGGL(k_exp_selftest, dim3((1u << 24) / 256), dim3(256), 0, stream, out);
+    PA_LAUNCH(k_exp_selftest, dim3((1u << 24) / 256), dim3(256), 0, stream, out);
     return hipGetLastError();
 }
 
@@ -1580,23 +1580,23 @@ template <int MODE>
 static void launch_sw_build(int level, dim3 grid, hipStream_t stream, const SimDims &d, const DevPtrs &p, uint32_t group,
                             int single, const ClusterAux &aux) {
     if (cluster_sw_lds_bytes(d) > 160 * 1024) { // the per-site arrays in device memory (p.sw_scratch: ensure_cluster_sw)
-        hipLaunchKernelGGL((k_cluster_sw<MODE, 2, true>), grid, dim3(kSwThreads), cluster_sw_lds_words(d, true) * 4, stream, d, p,
+        PA_LAUNCH((k_cluster_sw<MODE, 2, true>), grid, dim3(kSwThreads), cluster_sw_lds_words(d, true) * 4, stream, d, p,
                            group, single, aux);
         return;
     }
     const size_t lds = cluster_sw_lds_bytes(d);
     if (level == 0)
-        hipLaunchKernelGGL((k_cluster_sw<MODE, 0>), grid, dim3(kSwThreads), lds, stream, d, p, group, single, aux);
+        PA_LAUNCH((k_cluster_sw<MODE, 0>), grid, dim3(kSwThreads), lds, stream, d, p, group, single, aux);
     else if (level == 1)
-        hipLaunchKernelGGL((k_cluster_sw<MODE, 1>), grid, dim3(kSwThreads), lds, stream, d, p, group, single, aux);
+        PA_LAUNCH((k_cluster_sw<MODE, 1>), grid, dim3(kSwThreads), lds, stream, d, p, group, single, aux);
     else
-        hipLaunchKernelGGL((k_cluster_sw<MODE, 2>), grid, dim3(kSwThreads), lds, stream, d, p, group, single, aux);
+        PA_LAUNCH((k_cluster_sw<MODE, 2>), grid, dim3(kSwThreads), lds, stream, d, p, group, single, aux);
 }
 
 hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, uint32_t group, bool wolff,
                              const ClusterAux &aux_in, hipStream_t stream) {
-    hipLaunchKernelGGL(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
-    hipLaunchKernelGGL(k_slot_bitmaps, dim3(d.n_real * d.W * ((d.N + 255) / 256)), dim3(256), 0, stream, d, p);
+    PA_LAUNCH(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
+    PA_LAUNCH(k_slot_bitmaps, dim3(d.n_real * d.W * ((d.N + 255) / 256)), dim3(256), 0, stream, d, p);
     ClusterAux aux = aux_in;
     { // the generators' draws: bonds (stochastic moves) + one per cluster (twice for CMR) + the seed
         const uint32_t draws = (oc_mode == 1 ? 0u : d.N * d.nn) + (oc_mode == 3 ? 2u : 1u) * d.N + 64u;
@@ -1604,9 +1604,9 @@ hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, ui
         const uint32_t *first = oc_mode == 2 ? p.jorg_thr : (oc_mode == 3 ? p.cmr_thr : nullptr);
         const dim3 sgrid(aux.stream_units * ((d.n_real * d.n_temps * d.n_pairs + 255u) / 256u));
         if (d.unit)
-            hipLaunchKernelGGL(k_pair_stream<false>, sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, first, 0);
+            PA_LAUNCH(k_pair_stream<false>, sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, first, 0);
         else
-            hipLaunchKernelGGL(k_pair_stream<true>, sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, first, 0);
+            PA_LAUNCH(k_pair_stream<true>, sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, first, 0);
     }
     const dim3 grid(d.n_real * d.n_temps * (d.n_replicas / group));
     // PA_OC_HOUDAYER = 1 has its single-cluster form in every build
@@ -1625,29 +1625,29 @@ size_t wolff_wave_lds_bytes(const SimDims &d) { return wolff_wave_lds_bytes(d, k
 
 // Joerg single-cluster move, one wave per pair (after the pairing shuffle)
 hipError_t launch_jorg_wave(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
-    hipLaunchKernelGGL(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
+    PA_LAUNCH(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
     const uint32_t n_tasks = d.n_temps * d.n_pairs, per_block = wolff_wave_tasks(d, kSwJorg);
-    hipLaunchKernelGGL(k_wolff_wave<kSwJorg>, dim3(d.n_real * ((n_tasks + per_block - 1) / per_block)), dim3(64 * per_block),
+    PA_LAUNCH(k_wolff_wave<kSwJorg>, dim3(d.n_real * ((n_tasks + per_block - 1) / per_block)), dim3(64 * per_block),
                        wolff_wave_lds_bytes(d, kSwJorg), stream, d, p);
     return hipGetLastError();
 }
 
 hipError_t launch_cmr_wave(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
-    hipLaunchKernelGGL(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
+    PA_LAUNCH(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
     const uint32_t n_tasks = d.n_temps * d.n_pairs, per_block = wolff_wave_tasks(d, kSwCmr);
-    hipLaunchKernelGGL(k_wolff_wave<kSwCmr>, dim3(d.n_real * ((n_tasks + per_block - 1) / per_block)), dim3(64 * per_block),
+    PA_LAUNCH(k_wolff_wave<kSwCmr>, dim3(d.n_real * ((n_tasks + per_block - 1) / per_block)), dim3(64 * per_block),
                        wolff_wave_lds_bytes(d, kSwCmr), stream, d, p);
     return hipGetLastError();
 }
 
 hipError_t launch_top4_accumulate(const SimDims &d, const DevPtrs &p, const ClusterAux &aux, hipStream_t stream) {
-    hipLaunchKernelGGL(k_top4_accumulate, dim3(d.n_real), dim3(128), 0, stream, d, p, aux);
+    PA_LAUNCH(k_top4_accumulate, dim3(d.n_real), dim3(128), 0, stream, d, p, aux);
     return hipGetLastError();
 }
 
 hipError_t launch_uf_replay(const SimDims &d, const DevPtrs &p, bool cmr, hipStream_t stream) {
     const size_t lds = static_cast<size_t>(d.N) * 5 + 16;
-    hipLaunchKernelGGL(k_uf_replay, dim3(d.n_temps), dim3(64), lds, stream, d, p, cmr ? 1 : 0);
+    PA_LAUNCH(k_uf_replay, dim3(d.n_temps), dim3(64), lds, stream, d, p, cmr ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -1660,21 +1660,21 @@ hipError_t launch_fk(const SimDims &d, const DevPtrs &p, bool wolff, const Clust
     if (wolff && aux.flags == 0) { // depth-first single-cluster form: one wave per system if the tables fit the LDS
         const uint32_t per_block = wolff_wave_tasks(d, kSwFk);
         if (wolff_wave_lds_bytes(d, kSwFk) <= 160 * 1024 && d.N <= 65535)
-            hipLaunchKernelGGL(k_wolff_wave<kSwFk>, dim3(d.n_real * ((d.n_sys + per_block - 1) / per_block)),
+            PA_LAUNCH(k_wolff_wave<kSwFk>, dim3(d.n_real * ((d.n_sys + per_block - 1) / per_block)),
                                dim3(64 * per_block), wolff_wave_lds_bytes(d, kSwFk), stream, d, p);
         else
-            hipLaunchKernelGGL(k_fk_wolff, dim3(d.n_real), dim3(1024), fk_wolff_lds_bytes(d), stream, d, p);
+            PA_LAUNCH(k_fk_wolff, dim3(d.n_real), dim3(1024), fk_wolff_lds_bytes(d), stream, d, p);
         return hipGetLastError();
     }
     // union-find forms (they read the per-slot bitmaps and the systems' pre-drawn streams)
-    hipLaunchKernelGGL(k_slot_bitmaps, dim3(d.n_real * d.W * ((d.N + 255) / 256)), dim3(256), 0, stream, d, p);
+    PA_LAUNCH(k_slot_bitmaps, dim3(d.n_real * d.W * ((d.N + 255) / 256)), dim3(256), 0, stream, d, p);
     {
         aux.stream_units = std::min(cluster_stream_units(d), (d.N * d.nn + d.N + 64u + 63u) / 64u + 1u);
         const dim3 sgrid(aux.stream_units * ((d.n_real * d.n_sys + 255u) / 256u));
         if (d.unit)
-            hipLaunchKernelGGL(k_pair_stream<false>, sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, p.fk_thr, 1);
+            PA_LAUNCH(k_pair_stream<false>, sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, p.fk_thr, 1);
         else
-            hipLaunchKernelGGL(k_pair_stream<true>, sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, p.fk_thr, 1);
+            PA_LAUNCH(k_pair_stream<true>, sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, p.fk_thr, 1);
     }
     launch_sw_build<kSwFk>(cluster_sw_level(aux.flags, wolff), dim3(d.n_real * d.n_sys), stream, d, p, 1u, wolff ? 1 : 0, aux);
     return hipGetLastError();

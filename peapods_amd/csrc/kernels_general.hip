@@ -635,7 +635,7 @@ hipError_t configure_general_kernels() {
 }
 
 hipError_t launch_log_selftest(float *out_ln, float *out_logit, hipStream_t stream) {
-    hipLaunchKernelGGL(k_log_selftest, dim3((1u << 24) / 256), dim3(256), 0, stream, out_ln, out_logit);
+    PA_LAUNCH(k_log_selftest, dim3((1u << 24) / 256), dim3(256), 0, stream, out_ln, out_logit);
     return hipGetLastError();
 }
 
@@ -644,9 +644,9 @@ hipError_t launch_rng_f(const SimDims &d, const DevPtrs &p, bool gibbs, hipStrea
     const uint32_t groups = (n_pairs_tw + 3) / 4;
     const size_t lds = 64 * 16 * 8 * 4 + 16 * sizeof(double2);
     if (gibbs)
-        hipLaunchKernelGGL(k_rng_f<true>, dim3(groups * d.B), dim3(256), lds, stream, d, p);
+        PA_LAUNCH(k_rng_f<true>, dim3(groups * d.B), dim3(256), lds, stream, d, p);
     else
-        hipLaunchKernelGGL(k_rng_f<false>, dim3(groups * d.B), dim3(256), lds, stream, d, p);
+        PA_LAUNCH(k_rng_f<false>, dim3(groups * d.B), dim3(256), lds, stream, d, p);
     return hipGetLastError();
 }
 
@@ -655,17 +655,17 @@ static void launch_sweep_f_nn(const SimDims &d, const DevPtrs &p, bool with_ener
     if (do_sweep) {
         const dim3 grid(d.n_real * d.W), block(kSweepFThreads);
         if (d.big)
-            hipLaunchKernelGGL((k_sweep_f<true, NN>), grid, block, 0, stream, d, p, 0);
+            PA_LAUNCH((k_sweep_f<true, NN>), grid, block, 0, stream, d, p, 0);
         else
-            hipLaunchKernelGGL((k_sweep_f<false, NN>), grid, block, sweep_f_lds_bytes(d), stream, d, p, with_energy ? 1 : 0);
+            PA_LAUNCH((k_sweep_f<false, NN>), grid, block, sweep_f_lds_bytes(d), stream, d, p, with_energy ? 1 : 0);
     }
     if (with_energy) {
         if (!do_sweep || d.big) // (the on-chip sweep has written the bond words itself)
-            hipLaunchKernelGGL(k_bonds_f<NN>, dim3((d.N + 255) / 256, d.n_real * d.W), dim3(256), 0, stream, d, p);
+            PA_LAUNCH(k_bonds_f<NN>, dim3((d.N + 255) / 256, d.n_real * d.W), dim3(256), 0, stream, d, p);
         if (d.unit && static_cast<uint64_t>(d.N) * NN < (1u << 24)) // every partial sum is an exact f32 integer
-            hipLaunchKernelGGL(k_energy_unit_f<NN>, dim3(d.n_real * d.W), dim3(256), 0, stream, d, p);
+            PA_LAUNCH(k_energy_unit_f<NN>, dim3(d.n_real * d.W), dim3(256), 0, stream, d, p);
         else
-            hipLaunchKernelGGL(k_energy_f<NN>, dim3(d.n_real * ((d.W + 1) / 2)), dim3(kEnergyThreads),
+            PA_LAUNCH(k_energy_f<NN>, dim3(d.n_real * ((d.W + 1) / 2)), dim3(kEnergyThreads),
                                sizeof(EnergyLds<NN>), stream, d, p);
     }
 }

@@ -328,9 +328,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
 
 hipError_t launch_sweep_reg(const SimDims &d, const DevPtrs &p, bool with_energy, hipStream_t stream, unsigned long long *stamps) {
     if (stamps)
-        hipLaunchKernelGGL(k_sweep_reg<true>, dim3(d.n_real * d.W), dim3(64), 32 * 1024, stream, d, p, with_energy ? 1 : 0, stamps);
+        PA_LAUNCH(k_sweep_reg<true>, dim3(d.n_real * d.W), dim3(64), 32 * 1024, stream, d, p, with_energy ? 1 : 0, stamps);
     else
-        hipLaunchKernelGGL(k_sweep_reg<false>, dim3(d.n_real * d.W), dim3(64), 32 * 1024, stream, d, p, with_energy ? 1 : 0, stamps);
+        PA_LAUNCH(k_sweep_reg<false>, dim3(d.n_real * d.W), dim3(64), 32 * 1024, stream, d, p, with_energy ? 1 : 0, stamps);
     return hipGetLastError();
 }
 

@@ -26,6 +26,28 @@
 
 using namespace pa;
 
+// ---- launch tracer (engine.hpp PA_LAUNCH): open on the thread that runs pa_sim_profile_step ----
+namespace pa {
+thread_local bool g_trace_on = false;
+}
+namespace {
+struct TraceMark {
+    const char *name;
+    hipStream_t stream;
+    hipEvent_t event;
+};
+thread_local std::vector<TraceMark> g_trace_marks;
+thread_local hipError_t g_trace_error = hipSuccess;
+} // namespace
+void pa::trace_mark(const char *name, hipStream_t stream) {
+    hipEvent_t e = nullptr;
+    hipError_t rc = hipEventCreate(&e);
+    if (rc == hipSuccess) rc = hipEventRecord(e, stream);
+    if (rc != hipSuccess && g_trace_error == hipSuccess) g_trace_error = rc;
+    g_trace_marks.push_back({name, stream, e});
+}
+
+
 namespace {
 
 struct DeviceBuffers {
@@ -124,6 +146,7 @@ struct pa_sim {
         uint32_t fresh = 3; // see pa_sim::fresh
     };
     std::vector<Group> groups;
+    uint32_t stream_groups_wanted = 0; // pa_sim_desc.stream_groups (0: the default)
     // Two consecutive steady-state sweeps of the plain protocol captured as one hipGraph per stream group (run_sweeps):
     // the four dependent launches of a pair then cost the graph's 1.6 us per hop instead of the stream's 2.8 us
     // (build_probe/gaps.hip).  `graph_key` hashes every kernel argument of the pair; a mismatch recaptures.
@@ -473,7 +496,8 @@ void offset_cluster_stats(DevPtrs &q, const DevPtrs &p, const SimDims &d, uint32
 
 int make_groups(pa_sim *sim) {
     uint32_t n_groups = 2; // two interleaved groups overlap a little (5 %); three or more collapse
-    if (const char *env = dev_env("PEAPODS_STREAMS")) {
+    if (sim->stream_groups_wanted >= 1 && sim->stream_groups_wanted <= 16) n_groups = sim->stream_groups_wanted;
+    else if (const char *env = dev_env("PEAPODS_STREAMS")) {
         const long v = std::strtol(env, nullptr, 10);
         if (v >= 1 && v <= 16) n_groups = static_cast<uint32_t>(v);
     }
@@ -1572,6 +1596,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     sim->n_real = desc->n_realizations;
     sim->constructor_seed = desc->seed;
     sim->first_realization = desc->first_realization;
+    sim->stream_groups_wanted = desc->stream_groups;
     sim->temps.assign(desc->temperatures, desc->temperatures + desc->n_temps);
 
     SimDims &d = sim->d;
@@ -2435,6 +2460,112 @@ int pa_sim_sample(pa_sim *sim, const pa_sample_config *cfg) {
     return pa_sim_synchronize(sim);
 }
 
+// Device time of EVERY launch of a step of `cfg`'s protocol -- cluster moves included --, by kernel: the launch sequence
+// is the one sample() enqueues (run_sweeps itself runs; the handle must have ONE stream group), an event in front of every launch
+// (PA_LAUNCH) gives each launch's share of a step, and the same number of steps run again without events gives the
+// step time the shares are applied to (events between launches stretch a step by a few per cent).
+int pa_sim_profile_step(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_sweeps, char *names_out, uint64_t names_capacity,
+                        double *ms_per_step_out, double *launches_per_step_out, uint64_t capacity, uint64_t *n_kernels_out,
+                        double *step_ms_out) {
+    int code;
+    const std::string text = validate_text(cfg, sim->n_replicas, &code);
+    if (code != PA_OK) return fail(sim, code, text);
+    if (n_sweeps == 0 || cfg->n_sweeps == 0) return fail(sim, PA_ERR_INVALID, "profiling needs at least one sweep");
+    PA_HIP(sim, hipSetDevice(sim->device));
+    if (int rc = pa_sim_synchronize(sim)) return rc;
+    pa_sample_config run = *cfg;
+    run.n_sweeps = n_sweeps;
+    run.warmup_sweeps = std::min<uint64_t>(cfg->warmup_sweeps, n_sweeps);
+    if (sim->groups.size() != 1)
+        return fail(sim, PA_ERR_INVALID, "per-launch profiling needs a handle with one stream group (pa_sim_desc.stream_groups = 1): "
+                                         "a launch's time beside another group's launches says little about the launch");
+    sim->interrupt.store(false);
+    g_trace_marks.clear();
+    g_trace_error = hipSuccess;
+    pa::g_trace_on = true;
+    int rc = run_sweeps(sim, &run);
+    pa::g_trace_on = false;
+    std::vector<TraceMark> marks;
+    marks.swap(g_trace_marks);
+    // the end of every stream's last launch: an event enqueued behind it, before anything waits
+    std::vector<TraceMark> ends;
+    for (const auto &m : marks) {
+        bool seen = false;
+        for (const auto &e : ends) seen = seen || e.stream == m.stream;
+        if (seen) continue;
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) == hipSuccess && hipEventRecord(e, m.stream) == hipSuccess) ends.push_back({"", m.stream, e});
+        else if (g_trace_error == hipSuccess) g_trace_error = hipErrorUnknown;
+    }
+    auto release = [&] {
+        for (auto &m : marks)
+            if (m.event) (void)hipEventDestroy(m.event);
+        for (auto &m : ends)
+            if (m.event) (void)hipEventDestroy(m.event);
+    };
+    if (rc == PA_OK) rc = pa_sim_synchronize(sim);
+    if (rc != PA_OK || g_trace_error != hipSuccess) {
+        release();
+        return rc != PA_OK ? rc : fail(sim, PA_ERR_DEVICE, std::string("launch tracer: ") + hipGetErrorString(g_trace_error));
+    }
+    struct Acc { double ms = 0.0; uint64_t launches = 0; };
+    std::vector<std::pair<std::string, Acc>> table;
+    auto slot_of = [&](const char *raw) -> Acc & {
+        std::string name(raw);
+        while (!name.empty() && (name.front() == '(' || name.front() == ' ')) name.erase(name.begin());
+        while (!name.empty() && (name.back() == ')' || name.back() == ' ')) name.pop_back();
+        for (auto &row : table)
+            if (row.first == name) return row.second;
+        table.push_back({name, Acc{}});
+        return table.back().second;
+    };
+    double traced_ms = 0.0;
+    for (size_t i = 0; i < marks.size(); ++i) {
+        hipEvent_t until = nullptr;
+        for (size_t k = i + 1; k < marks.size() && !until; ++k)
+            if (marks[k].stream == marks[i].stream) until = marks[k].event;
+        for (size_t k = 0; k < ends.size() && !until; ++k)
+            if (ends[k].stream == marks[i].stream) until = ends[k].event;
+        float ms = 0.f;
+        if (!until || hipEventElapsedTime(&ms, marks[i].event, until) != hipSuccess) continue;
+        Acc &a = slot_of(marks[i].name);
+        a.ms += ms;
+        a.launches += 1;
+        traced_ms += ms;
+    }
+    release();
+    // the same steps without events, between two events on the main stream (the run forks from it and joins it)
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    PA_HIP(sim, hipEventCreate(&t0));
+    PA_HIP(sim, hipEventCreate(&t1));
+    PA_HIP(sim, hipEventRecord(t0, sim->stream));
+    rc = run_sweeps(sim, &run);
+    float plain = 0.f;
+    if (rc == PA_OK && hipEventRecord(t1, sim->stream) != hipSuccess) rc = fail(sim, PA_ERR_DEVICE, "hipEventRecord");
+    if (rc == PA_OK) rc = pa_sim_synchronize(sim);
+    if (rc == PA_OK && hipEventElapsedTime(&plain, t0, t1) != hipSuccess) rc = fail(sim, PA_ERR_DEVICE, "hipEventElapsedTime");
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    if (rc != PA_OK) return rc;
+    const double step_plain = plain / static_cast<double>(n_sweeps);
+    const double scale = traced_ms > 0.0 ? (step_plain * static_cast<double>(n_sweeps)) / traced_ms : 1.0;
+    std::string names;
+    uint64_t n = 0;
+    for (const auto &row : table) {
+        if (n >= capacity) break;
+        if (names.size() + row.first.size() + 2 > names_capacity) break;
+        names += row.first;
+        names += '\n';
+        ms_per_step_out[n] = row.second.ms * scale / static_cast<double>(n_sweeps);
+        launches_per_step_out[n] = static_cast<double>(row.second.launches) / static_cast<double>(n_sweeps);
+        ++n;
+    }
+    if (names_capacity) std::snprintf(names_out, names_capacity, "%s", names.c_str());
+    if (n_kernels_out) *n_kernels_out = n;
+    if (step_ms_out) *step_ms_out = step_plain;
+    return PA_OK;
+}
+
 int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_sweeps,
                            double ms_out[3]) {
     int code;
@@ -2734,7 +2865,7 @@ uint64_t pa_abi_layout(uint64_t *out, uint64_t capacity) {
     std::vector<uint64_t> v;
 #define PA_FIELD(type, field) v.push_back(offsetof(type, field))
     v.push_back(sizeof(pa_sim_desc));
-    v.push_back(12);
+    v.push_back(13);
     PA_FIELD(pa_sim_desc, n_dims);
     PA_FIELD(pa_sim_desc, shape);
     PA_FIELD(pa_sim_desc, n_neighbors);
@@ -2747,6 +2878,7 @@ uint64_t pa_abi_layout(uint64_t *out, uint64_t capacity) {
     PA_FIELD(pa_sim_desc, seed);
     PA_FIELD(pa_sim_desc, device);
     PA_FIELD(pa_sim_desc, first_realization);
+    PA_FIELD(pa_sim_desc, stream_groups);
     v.push_back(sizeof(pa_sample_config));
     v.push_back(19);
     PA_FIELD(pa_sample_config, n_sweeps);

@@ -261,3 +261,39 @@ def test_captured_graph_pairs_replay_the_same_trajectory(oracle, monkeypatch, sc
         pt_a, pt_b = a["per_disorder"]["parallel_tempering"], b["per_disorder"]["parallel_tempering"]
         for key in pt_a:
             np.testing.assert_array_equal(pt_a[key], pt_b[key], err_msg=key)
+
+
+def test_step_profile_names_every_launch_of_a_step():
+    """pa_sim_profile_step: sample()'s own launch sequence with an event in front of every launch (PA_LAUNCH), by kernel --
+    cluster moves included, which pa_sim_profile_kernels declines.  The kernels' times add up to the step."""
+    from peapods_amd import IsingSimulation
+
+    shape = (8, 8, 8)
+    rng = np.random.default_rng(2)
+    couplings = (2 * rng.integers(0, 2, size=(4,) + shape + (3,)) - 1).astype(np.float32)
+    temps = np.linspace(0.8, 1.6, 6).astype(np.float32)
+    two = IsingSimulation(list(shape), couplings, temps, 4, None, 3)
+    cfg = two.make_config(8, "metropolis", pt_interval=1, warmup_ratio=0.0)
+    with pytest.raises(ValueError, match="one stream group"):
+        two.profile_step(cfg, 8)
+    one = IsingSimulation(list(shape), couplings, temps, 4, None, 3, stream_groups=1)
+    table, step_ms = one.profile_step(cfg, 16)
+    bases = {name.split("<")[0] for name in table}
+    assert "k_rng_relay" in bases and "k_sweep_hc" in bases, table
+    assert step_ms > 0 and abs(sum(ms for ms, _ in table.values()) - step_ms) < 0.02 * step_ms + 1e-4
+    relay = [v for k, v in table.items() if k.startswith("k_rng_relay")]
+    assert abs(sum(n for _, n in relay) - 1.0) < 0.15  # one random-stream launch per sweep
+    # a step with the Joerg move: its launches are in the table
+    cfg4 = one.make_config(8, "metropolis", pt_interval=1, warmup_ratio=0.0, overlap_cluster_update_interval=1,
+                           overlap_cluster_build_mode="jorg")
+    table4, step4 = one.profile_step(cfg4, 8)
+    assert any(name.startswith("k_wolff_wave") for name in table4), table4
+    assert step4 > step_ms
+    # the trajectory does not depend on the stream groups: both handles continue alike
+    two.sample(40, "metropolis", pt_interval=1)   # (profile_step ran 2 x 16 + 2 x 8 sweeps, in two protocols: replay them)
+    fresh_one = IsingSimulation(list(shape), couplings, temps, 4, None, 3, stream_groups=1)
+    fresh_two = IsingSimulation(list(shape), couplings, temps, 4, None, 3)
+    a = fresh_one.sample(12, "metropolis", pt_interval=1)
+    b = fresh_two.sample(12, "metropolis", pt_interval=1)
+    np.testing.assert_array_equal(a["energies"], b["energies"])
+    np.testing.assert_array_equal(fresh_one.get_spins(3), fresh_two.get_spins(3))

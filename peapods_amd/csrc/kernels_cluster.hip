@@ -1182,6 +1182,30 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
     if (seed != 0xFFFFFFFFu) {
         const float temp = d.unit ? 0.0f : p.temps[t];
         rng.s0 = uniform64(rng.s0); rng.s1 = uniform64(rng.s1); rng.s2 = uniform64(rng.s2); rng.s3 = uniform64(rng.s3);
+        // The search's draws come from the VECTOR unit (every lane steps the same state; lane 0's value is read back):
+        // with six searches per SIMD the scalar unit, which serves a SIMD once in four cycles, is what the launch waits
+        // for (~80 K scalar instructions per search against 27 K vector ones, profiles/r03_pmc_c4_jorg.csv), and a
+        // generator step is ~20 of the ~35 scalar instructions a draw costs.
+        constexpr bool kVectorRng = true;
+        Rng32 vrng;
+        auto to_vector = [&] {
+            uint32_t st[8] = {static_cast<uint32_t>(rng.s0), static_cast<uint32_t>(rng.s0 >> 32), static_cast<uint32_t>(rng.s1),
+                              static_cast<uint32_t>(rng.s1 >> 32), static_cast<uint32_t>(rng.s2), static_cast<uint32_t>(rng.s2 >> 32),
+                              static_cast<uint32_t>(rng.s3), static_cast<uint32_t>(rng.s3 >> 32)};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(st[k])); // (kept in vector registers: no scalar copy to fall back on)
+            vrng.load(st);
+        };
+        auto to_scalar = [&] {
+            uint32_t st[8];
+            vrng.store(st);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) st[k] = __builtin_amdgcn_readfirstlane(st[k]);
+            rng.s0 = (static_cast<uint64_t>(st[1]) << 32) | st[0];
+            rng.s1 = (static_cast<uint64_t>(st[3]) << 32) | st[2];
+            rng.s2 = (static_cast<uint64_t>(st[5]) << 32) | st[4];
+            rng.s3 = (static_cast<uint64_t>(st[7]) << 32) | st[6];
+        };
         uint32_t top = 0;
         uint32_t next = 0; // the entry on top of the stack, kept in a register: most pops never read the LDS
         bool next_known = false;
@@ -1217,7 +1241,8 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
                     const uint32_t q = __ffs(todo) - 1;
                     todo &= todo - 1;
                     const uint32_t target = __builtin_amdgcn_readlane(nb, q);
-                    const uint32_t draw = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(rng.next() >> 40));
+                    const uint32_t draw = kVectorRng ? __builtin_amdgcn_readfirstlane(vrng.next_top() >> 8)
+                                                     : __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(rng.next() >> 40));
                     uint32_t limit = threshold; // draw < ceil(p 2^24)  <=>  gen::<f32>() < p
                     if (!d.unit) { // this bond's own probability; the coupling belongs to the bond's forward end
                         const uint32_t owner = (q & 1u) ? target : site;
@@ -1249,6 +1274,7 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
         top = 1;
         next = seed;
         next_known = true;
+        if (kVectorRng) to_vector();
         search(0);
         uint32_t k = 3; // which system(s) the final cluster flips: both, except for CMR's grey cluster
         if (CMR) {
@@ -1264,6 +1290,7 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
             }
             next_known = false;
             search(1);
+            if (kVectorRng) to_scalar();
             for (;;) { // rand 0.8.5 u8 gen_range(1..=3): u32 draw, zone = u32::MAX - (2^32 - 3) % 3
                 const uint32_t v = static_cast<uint32_t>(rng.next() >> 32);
                 const uint64_t m = static_cast<uint64_t>(v) * 3u;
@@ -1273,6 +1300,7 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
                 }
             }
         }
+        if (kVectorRng && !CMR) to_scalar();
         // ---- flip the cluster (the pair's / system's bit columns; other tasks own other bits of these words)
         for (uint32_t m = lane; m < d.MW; m += 64) {
             const uint32_t grey = member[m], was_blue = CMR ? blue[m] : 0u;

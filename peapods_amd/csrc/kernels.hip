@@ -2785,6 +2785,61 @@ __global__ __launch_bounds__(1024) void k_houdayer_grow_measure(SimDims d, DevPt
     }
 }
 
+// The riders of the overlap moves that keep their launches to themselves (Joerg, CMR, every union-find form).
+// k_overlap_pairing: the overlap of the swept state, and per realisation a block that (a) shuffles the replicas of every
+// temperature (build_tasks, overlap.rs:35-56: what k_pairing does in a launch of its own) and (b) puts the sweep's sums
+// aside in Esum_pre / Msum_pre for the statistics, which then ride in the launch that recomputes the energies AFTER the
+// move (k_energy_measure) -- two launches less on the chain of a step.
+__device__ __forceinline__ void pairing_presave_block(const SimDims &d, const DevPtrs &p, uint32_t real) {
+    for (uint32_t k = threadIdx.x; k < d.n_sys; k += blockDim.x) {
+        p.Esum_pre[static_cast<size_t>(real) * d.n_sys + k] = p.Esum[static_cast<size_t>(real) * d.n_sys + k];
+        p.Msum_pre[static_cast<size_t>(real) * d.n_sys + k] = p.Msum[static_cast<size_t>(real) * d.n_sys + k];
+    }
+    const uint32_t t = threadIdx.x;
+    if (t >= d.n_temps) return;
+    uint64_t *st = p.pair_rng + (static_cast<size_t>(real) * d.n_temps * d.n_pairs + static_cast<size_t>(t) * d.n_pairs) * 4;
+    DevRng rng;
+    rng.s0 = st[0]; rng.s1 = st[1]; rng.s2 = st[2]; rng.s3 = st[3];
+    uint32_t order[32]; // n_replicas <= 32 (checked on the host)
+    for (uint32_t k = 0; k < d.n_replicas; ++k) order[k] = k;
+    for (uint32_t i = d.n_replicas - 1; i >= 1; --i) { // reverse Fisher-Yates (SliceRandom::shuffle)
+        const uint32_t j = dev_gen_range_u32(rng, i + 1);
+        const uint32_t tmp = order[i];
+        order[i] = order[j];
+        order[j] = tmp;
+    }
+    uint32_t *slots = p.pair_slots + (static_cast<size_t>(real) * d.n_temps + t) * d.n_replicas;
+    for (uint32_t k = 0; k < d.n_replicas; ++k) slots[k] = order[k] * d.n_temps + t;
+    st[0] = rng.s0; st[1] = rng.s1; st[2] = rng.s2; st[3] = rng.s3;
+}
+__global__ __launch_bounds__(1024) void k_overlap_pairing(SimDims d, DevPtrs p, uint32_t n_overlap) {
+    extern __shared__ uint32_t lds[];
+    if (blockIdx.x >= n_overlap) {
+        pairing_presave_block(d, p, blockIdx.x - n_overlap);
+    } else if (d.N <= 4096) {
+        overlap_block_1024(d, p, blockIdx.x, lds);
+    } else {
+        if (threadIdx.x >= 256) return; // (a barrier waits for the surviving waves only)
+        overlap_block(d, p, blockIdx.x, lds);
+    }
+}
+// k_energy_measure: energies and magnetisations of the state the move left (mod.rs:749-756) by the sweep kernel's
+// epilogue, and the statistics of the state BEFORE the move (mod.rs:543-595: sums from Esum_pre / Msum_pre, overlaps
+// from the launch above) in the same launch.
+template <int NN, bool DENSE>
+__global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_per_eu(5))) void
+k_energy_measure(SimDims d, DevPtrs p, uint32_t n_energy, PtParams pt, int do_accum, int accum_overlap) {
+    extern __shared__ uint32_t lds[];
+    if (blockIdx.x < n_energy) {
+        sweep_hc_block<NN, false, false, DENSE>(d, p, blockIdx.x, 1, 0, nullptr, lds);
+    } else {
+        DevPtrs q = p;
+        q.Esum = p.Esum_pre;
+        q.Msum = p.Msum_pre;
+        measure_block<false>(d, q, pt, do_accum, accum_overlap, 0, nullptr, blockIdx.x - n_energy, lds);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // k_jorg: Joerg stochastic overlap-cluster move, single-cluster ("wolff") variant --
 // clusters/overlap.rs:348-553 with dfs_cluster (utils.rs:125-149).  Bonds are
@@ -3662,6 +3717,13 @@ hipError_t configure_kernels(const SimDims &) {
                            reinterpret_cast<const void *>(k_houdayer_grow),
                            reinterpret_cast<const void *>(k_houdayer_grow_measure),
                            reinterpret_cast<const void *>(k_jorg),
+                           reinterpret_cast<const void *>(k_overlap_pairing),
+                           reinterpret_cast<const void *>(k_energy_measure<1, true>),
+                           reinterpret_cast<const void *>(k_energy_measure<2, true>),
+                           reinterpret_cast<const void *>(k_energy_measure<3, true>),
+                           reinterpret_cast<const void *>(k_energy_measure<1, false>),
+                           reinterpret_cast<const void *>(k_energy_measure<2, false>),
+                           reinterpret_cast<const void *>(k_energy_measure<3, false>),
                            reinterpret_cast<const void *>(k_measure<false>),
                            reinterpret_cast<const void *>(k_measure<true>)}) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -4009,6 +4071,36 @@ hipError_t launch_houdayer(const SimDims &d, const DevPtrs &p, hipStream_t strea
 }
 bool houdayer_computes_energy(const SimDims &d) { return d.hc && d.dense_nn == d.nn; }
 size_t houdayer_lds_bytes(const SimDims &d) { return houdayer_lds_words(d) * 4; }
+
+bool move_riders_supported(const SimDims &d) { return d.hc && !d.big && !d.general && d.n_pairs > 0 && d.nn <= 3; }
+hipError_t launch_overlap_pairing(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
+    const uint32_t n_overlap = d.n_real * d.W;
+    PA_LAUNCH(k_overlap_pairing, dim3(n_overlap + d.n_real), dim3(1024), overlap_lds_bytes(d), stream, d, p, n_overlap);
+    return hipGetLastError();
+}
+hipError_t launch_energy_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_accum, bool accum_overlap,
+                                 hipStream_t stream) {
+    const uint32_t n_energy = d.n_real * d.W;
+    const dim3 grid(n_energy + d.n_real), block(512);
+    const size_t lds = std::max(sweep_hc_lds_bytes(d), measure_lds_bytes(d));
+    const int a = do_accum ? 1 : 0, o = accum_overlap ? 1 : 0;
+#define PA_EM(NN, D) PA_LAUNCH((k_energy_measure<NN, D>), grid, block, lds, stream, d, p, n_energy, pt, a, o)
+    if (d.dense_nn == d.nn) {
+        switch (d.nn) {
+        case 1: PA_EM(1, true); break;
+        case 2: PA_EM(2, true); break;
+        default: PA_EM(3, true); break;
+        }
+    } else {
+        switch (d.nn) {
+        case 1: PA_EM(1, false); break;
+        case 2: PA_EM(2, false); break;
+        default: PA_EM(3, false); break;
+        }
+    }
+#undef PA_EM
+    return hipGetLastError();
+}
 
 hipError_t launch_jorg(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
     PA_LAUNCH(k_jorg, dim3(d.n_real), dim3(1024), jorg_lds_words(d) * 4, stream, d, p);

@@ -1622,8 +1622,8 @@ static void launch_sw_build(int level, dim3 grid, hipStream_t stream, const SimD
 }
 
 hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, uint32_t group, bool wolff,
-                             const ClusterAux &aux_in, hipStream_t stream) {
-    PA_LAUNCH(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
+                             const ClusterAux &aux_in, hipStream_t stream, bool paired) {
+    if (!paired) PA_LAUNCH(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
     PA_LAUNCH(k_slot_bitmaps, dim3(d.n_real * d.W * ((d.N + 255) / 256)), dim3(256), 0, stream, d, p);
     ClusterAux aux = aux_in;
     { // the generators' draws: bonds (stochastic moves) + one per cluster (twice for CMR) + the seed
@@ -1652,16 +1652,16 @@ size_t wolff_wave_lds_bytes(const SimDims &d, int mode) { return wolff_wave_lds_
 size_t wolff_wave_lds_bytes(const SimDims &d) { return wolff_wave_lds_bytes(d, kSwCmr); } // the largest of the three forms
 
 // Joerg single-cluster move, one wave per pair (after the pairing shuffle)
-hipError_t launch_jorg_wave(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
-    PA_LAUNCH(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
+hipError_t launch_jorg_wave(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool paired) {
+    if (!paired) PA_LAUNCH(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
     const uint32_t n_tasks = d.n_temps * d.n_pairs, per_block = wolff_wave_tasks(d, kSwJorg);
     PA_LAUNCH(k_wolff_wave<kSwJorg>, dim3(d.n_real * ((n_tasks + per_block - 1) / per_block)), dim3(64 * per_block),
                        wolff_wave_lds_bytes(d, kSwJorg), stream, d, p);
     return hipGetLastError();
 }
 
-hipError_t launch_cmr_wave(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
-    PA_LAUNCH(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
+hipError_t launch_cmr_wave(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool paired) {
+    if (!paired) PA_LAUNCH(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
     const uint32_t n_tasks = d.n_temps * d.n_pairs, per_block = wolff_wave_tasks(d, kSwCmr);
     PA_LAUNCH(k_wolff_wave<kSwCmr>, dim3(d.n_real * ((n_tasks + per_block - 1) / per_block)), dim3(64 * per_block),
                        wolff_wave_lds_bytes(d, kSwCmr), stream, d, p);

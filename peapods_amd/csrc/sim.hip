@@ -1228,7 +1228,22 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                 overlap_in_houdayer = (mode & 0xFF) == PA_OC_HOUDAYER && (mode >> 8) <= 2 && !oc_sw && !collect_overlap &&
                                       !observe_overlap && !(snap_now && first) && houdayer_tile_fits;
             }
-            if (((record && want_overlap) || equil) && d.n_pairs && !overlap_in_houdayer && !big_overlap_done)
+            // The moves that keep their launches to themselves (Joerg, CMR, every union-find form): the shuffles of
+            // build_tasks ride in the overlap launch, which also puts the sweep's sums aside, and the statistics of the swept
+            // state ride in the launch that recomputes the energies after the move -- two launches less per step.
+            bool move_riders = false;
+            if (oc_this && record && want_overlap && !equil && pt_this && move_riders_supported(d) && !overlap_in_houdayer &&
+                !collect_overlap && !observe_overlap && snapshot_interval == 0 && !big_overlap_done &&
+                !dev_env("PEAPODS_NO_MOVE_RIDERS")) {
+                const int mode = cfg->overlap_cluster_modes[overlap_call_count % static_cast<uint64_t>(cfg->n_overlap_cluster_modes)];
+                const int kind = mode & 0xFF;
+                const bool uf = oc_sw || (mode >> 8) > 2 || (kind == PA_OC_HOUDAYER && (d.nn > 3 || !houdayer_tile_fits));
+                move_riders = uf || (kind == PA_OC_JORG && jorg_wave) || (kind == PA_OC_CMR && wave_ok);
+            }
+            if (move_riders) {
+                PA_HIP(sim, launch_overlap_pairing(g.d, g.p, g.stream));
+                toggle_dots(g.p);
+            } else if (((record && want_overlap) || equil) && d.n_pairs && !overlap_in_houdayer && !big_overlap_done)
                 PA_HIP(sim, overlap_launch(g.d, g.p, g.stream)); // :527-529
             PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot,
                         equil ? 1u : 0u, equil_ckpt, static_cast<uint32_t>(sweep_id + 1),
@@ -1250,8 +1265,9 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                     }
                 }
             } else {
-                if ((record || equil) && !overlap_in_houdayer)
+                if ((record || equil) && !overlap_in_houdayer && !move_riders)
                     PA_HIP(sim, measure_launch(g.fresh, g.d, g.p, pt, record, record && want_overlap, false, g.stream));
+                const PtParams pt_stats = pt; // (move_riders: the statistics launch comes after the move)
                 pt.equil = 0; // the tempering launch below must not accumulate the diagnostic again
                 const uint64_t mode_idx = overlap_call_count % static_cast<uint64_t>(cfg->n_overlap_cluster_modes);
                 const int oc_mode = cfg->overlap_cluster_modes[mode_idx];
@@ -1283,7 +1299,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                 if (uf_all || (take_snapshot && first_group && dfs_same)) {
                     ClusterAux a2 = aux;
                     if (take_snapshot && first_group) a2.flags |= kAuxSnapshot;
-                    PA_HIP(sim, launch_cluster_sw(g.d, g.p, oc_kind, oc_group, !oc_sw, a2, g.stream));
+                    PA_HIP(sim, launch_cluster_sw(g.d, g.p, oc_kind, oc_group, !oc_sw, a2, g.stream, move_riders));
                 } else if (take_snapshot && first_group) {
                     // the first realisation alone takes the union-find path, the others the search
                     SimDims d0 = g.d, d1 = g.d;
@@ -1304,11 +1320,11 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                             PA_HIP(sim, launch_jorg(d1, p1, g.stream));
                     }
                 } else if (oc_kind == PA_OC_CMR && wave_ok)
-                    PA_HIP(sim, launch_cmr_wave(g.d, g.p, g.stream)); // :845-965, one wave per pair
+                    PA_HIP(sim, launch_cmr_wave(g.d, g.p, g.stream, move_riders)); // :845-965, one wave per pair
                 else if (oc_kind == PA_OC_CMR)
                     PA_HIP(sim, launch_cmr_wolff(g.d, g.p, g.stream));
                 else if (oc_kind == PA_OC_JORG && jorg_wave)
-                    PA_HIP(sim, launch_jorg_wave(g.d, g.p, g.stream)); // one wave per pair, tables in the LDS
+                    PA_HIP(sim, launch_jorg_wave(g.d, g.p, g.stream, move_riders)); // one wave per pair, tables in the LDS
                 else if (oc_kind == PA_OC_JORG)
                     PA_HIP(sim, launch_jorg(g.d, g.p, g.stream)); // :601-602,660-680
                 else {
@@ -1351,7 +1367,12 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                     sim->snapshots.push_back(std::move(snap));
                 }
                 if (pt_this) { // energies are recomputed after a mutating move (:749-756)
-                    if (!observe_overlap && !energy_done) PA_HIP(sim, launch_sweep(g.d, g.p, true, false, false, g.stream));
+                    if (move_riders) {
+                        PtParams q = pt_stats;
+                        q.fresh = consume_fresh(g.fresh, g.d, record, record && want_overlap);
+                        PA_HIP(sim, launch_energy_measure(g.d, g.p, q, record, record && want_overlap, g.stream));
+                    } else if (!observe_overlap && !energy_done)
+                        PA_HIP(sim, launch_sweep(g.d, g.p, true, false, false, g.stream));
                     if (relay_nf) { // the tempering event rides in the next sweep's random-stream launch
                         pending.any = true;
                         pending.pt = pt;

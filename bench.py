@@ -75,6 +75,8 @@ def parse_args():
     ap.add_argument("--settle-ms", type=float, default=30.0,
                     help="untimed calls of --steps steps are made back to back for this long before the timed ones")
     ap.add_argument("--settle-calls", type=int, default=64, help="... and at most this many of them")
+    ap.add_argument("--no-step-profile", action="store_true",
+                    help="skip the per-kernel step profile (a second, one-stream handle): profiler runs want the timed protocol only")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short measurements of BASELINE configs[1] and configs[4] after the headline")
     return ap.parse_args()
@@ -254,7 +256,7 @@ def current_counters():
     return counters, None
 
 
-def valu_limiter(kernels_ms, scale):
+def valu_limiter(kernels_ms, scale, step_ms=None):
     """What actually bounds the two sweep kernels: VALU issue, priced against BOTH peaks.
     (a) the hardware guide's figure (MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles, 4 SIMDs
         per CU, 256 CUs) at the clock the probe observed under this load;
@@ -287,7 +289,12 @@ def valu_limiter(kernels_ms, scale):
             "frac_of_guide_peak": fracs(peak_guide),
             "peak_probe_wave_insts_per_s": peak_probe,
             "peak_probe_source": "profiles/r03_valu_issue.json: rng_step_full at 8 waves/SIMD (tools/probe/valu_issue.hip; disassembly: tools/probe/valu_issue_excerpt.s)",
-            "frac_of_probe_peak": fracs(peak_probe)}
+            "frac_of_probe_peak": fracs(peak_probe),
+            # both kernels of a sweep over the STEP of the timed run (two stream groups side by side): how busy the vector
+            # units are over a whole step, not inside one launch
+            "frac_of_guide_peak_step": (sum(counts.values()) / (step_ms * 1e-3) / peak_guide) if step_ms and counts else None,
+            "frac_of_probe_peak_step": (sum(counts.values()) / (step_ms * 1e-3) / peak_probe) if step_ms and counts and peak_probe else None,
+            "steady_kernels": counters.get("steady_kernels")}
 
 
 def roofline_of(work, attempts, ms_per_step, pair_ms, kernels_per_step, one_stream_step_ms, note):
@@ -461,7 +468,7 @@ def worker(args, rank, world, local_rank):
     kernels_ms = sim.profile_kernels(sim.make_config(args.profile_sweeps, "metropolis", warmup_ratio=0.0, pt_interval=1,
                                                      pt_schedule=args.pt_schedule), args.profile_sweeps)
     kernels_per_step, one_stream_step_ms = None, None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_step_profile:
         try:  # every launch of the step by kernel -- for c4 this is where the cluster move's launches show
             kernels_per_step, one_stream_step_ms = step_profile(work, sample_kw, n_per_gpu, local_rank)
         except Exception as exc:
@@ -528,7 +535,7 @@ def worker(args, rank, world, local_rank):
                 "kernel_ms": kernels_ms,
                 "kernel_ms_protocol": "sweep pipeline of the timed protocol" if profiled else
                                       "sweep pipeline only (the cluster move is in ms_per_step, not here)",
-                "limiter": valu_limiter(kernels_ms, scale) if args.config == "c2" else None,
+                "limiter": valu_limiter(kernels_ms, scale, elapsed / args.steps * 1e3) if args.config == "c2" else None,
             },
             "observable_allgather_ms": gather_ms,
             "full_result_gather_ms": full_gather_ms,

@@ -21,7 +21,7 @@ stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursi
 if stats:
     shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
     print("kernel stats:", stats[0])
-for sub in ("1stream", "c1", "c4_houdayer", "c4_jorg", "c4_cmr"):
+for sub in ("1stream", "c1", "c4_houdayer", "c4_jorg", "c4_cmr", "c4_houdayer_sw", "c4_jorg_sw"):
     found = glob.glob(os.path.join(src, f"stats_{sub}", "**", "*kernel_stats.csv"), recursive=True)
     if found:
         shutil.copy(found[0], os.path.join(dst, f"{tag}_kernel_stats_{sub}.csv"))
@@ -68,30 +68,28 @@ with open(os.path.join(dst, f"{tag}_pmc_per_launch.csv"), "w", newline="") as fh
 print("pmc per launch:", len(rows), "kernels,", counters)
 
 
-def avg(kernel_prefix, counter):
-    tot = n = 0.0
+def steady(prefixes):
+    """The template instance of a kernel family that ran most often: the steady-state kernel of the run (a run also has a
+    couple of prologue launches of other instances -- k_rng_relay<..., 0, ...> before the first tempering event -- whose
+    counts must not be averaged into it)."""
+    best, launches = None, 0
     for kernel in sums:
-        if kernel.startswith(kernel_prefix) and counts[kernel][counter]:
-            tot += sums[kernel][counter]
-            n += counts[kernel][counter]
-    return tot / n if n else None
+        if any(kernel.startswith(prefix) for prefix in prefixes):
+            n = max(counts[kernel].values())
+            if n > launches:
+                best, launches = kernel, n
+    return best
 
 
-SWEEP = ("pa::k_sweep_hc<", "pa::k_sweep<")  # the on-chip sweep of this build, whichever variant ran
+def value(kernel, counter):
+    return sums[kernel][counter] / counts[kernel][counter] if kernel and counts[kernel][counter] else None
 
 
-def avg_any(prefixes, counter):
-    for prefix in prefixes:
-        v = avg(prefix, counter)
-        if v is not None:
-            return v
-    return None
-
-
-RNG = ("pa::k_rng_relay<", "pa::k_rng_overlap")  # the random-stream launch with its riders
-fetch = [avg_any(RNG, "FETCH_SIZE"), avg_any(SWEEP, "FETCH_SIZE")]
-write = [avg_any(RNG, "WRITE_SIZE"), avg_any(SWEEP, "WRITE_SIZE")]
-insts = {"k_rng": avg_any(RNG, "SQ_INSTS_VALU"), "k_sweep": avg_any(SWEEP, "SQ_INSTS_VALU")}
+SWEEP = steady(("pa::k_sweep_hc<", "pa::k_sweep<"))     # the on-chip sweep of this build, whichever variant ran
+RNG = steady(("pa::k_rng_relay<", "pa::k_rng_overlap"))  # the random-stream launch with its riders
+fetch = [value(RNG, "FETCH_SIZE"), value(SWEEP, "FETCH_SIZE")]
+write = [value(RNG, "WRITE_SIZE"), value(SWEEP, "WRITE_SIZE")]
+insts = {"k_rng": value(RNG, "SQ_INSTS_VALU"), "k_sweep": value(SWEEP, "SQ_INSTS_VALU")}
 head_file = os.path.join(dst, "collect_head.txt")
 commit = open(head_file).read().strip() if os.path.exists(head_file) else "unlabelled"
 if all(v is not None for v in fetch + write):
@@ -104,6 +102,10 @@ if all(v is not None for v in fetch + write):
         "source_hash": _build.source_hash(),  # the kernel sources these counts belong to (bench.py compares it with pa_version)
         "workload": "bench.py --config c2, 128 realisations per launch, one stream group (PEAPODS_STREAMS=1)",
         "wave_insts_per_launch": {k: v for k, v in insts.items() if v is not None},
+        "steady_kernels": {"k_rng": RNG, "k_sweep": SWEEP},  # one row each of the per-launch table: no averaging over instances
+        "wave_insts_per_launch_by_kernel": {k: value(k, "SQ_INSTS_VALU") for k in sorted(sums) if value(k, "SQ_INSTS_VALU")},
+        "lds_bank_conflict_ratio_by_kernel": {k: value(k, "SQ_LDS_BANK_CONFLICT") / value(k, "SQ_LDS_IDX_ACTIVE") for k in sorted(sums)
+                                              if value(k, "SQ_LDS_IDX_ACTIVE")},
         "hbm_bytes_per_sweep": (2 * fetch_kb + write_kb) * 1024,
         "kernels": "k_rng_relay + k_sweep_hc: the two launches of one Metropolis sweep of 50 331 648 attempts (the first "
                    "also carries the previous sweep's overlap measurement, statistics and tempering event)",

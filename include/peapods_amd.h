@@ -152,14 +152,6 @@ void pa_sim_request_interrupt(pa_sim *sim);
 /* Sweeps the last sample() ran: n_sweeps, or fewer when it was interrupted (always whole sweeps). */
 uint64_t pa_sim_sweeps_completed(const pa_sim *sim);
 
-/* Per-kernel device time of the sweep pipeline, measured with HIP events on the handle's stream
- * while running `n_sweeps` sweeps of `cfg`'s protocol (state advances like sample()).
- * ms_out[3] = average milliseconds per launch of: k_rng (random stream -> acceptance levels; on the
- * fused path this launch also measures the previous sweep's overlap), k_sweep (level-ordered sweep +
- * energies), k_measure (statistics + tempering; plus the overlap kernel when it is not fused).
- * The first half of the sweeps is timed launch by launch (which stretches every launch: each starts on an idle
- * queue), the second half as sample() enqueues it, between two events; the figures are the first half's shares of
- * the second half's time per sweep. */
 /* Device time of EVERY launch of one step of `cfg`'s protocol, cluster moves included, by kernel (the name is the kernel
  * expression of the launch site, e.g. "k_rng_relay<P, R, G>").  sample()'s own launch sequence runs for `n_sweeps`
  * sweeps with an event in front of every launch, then again without events; each kernel's share of the traced run is
@@ -169,8 +161,6 @@ uint64_t pa_sim_sweeps_completed(const pa_sim *sim);
 int pa_sim_profile_step(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_sweeps, char *names_out, uint64_t names_capacity,
                         double *ms_per_step_out, double *launches_per_step_out, uint64_t capacity, uint64_t *n_kernels_out,
                         double *step_ms_out);
-int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_sweeps,
-                           double ms_out[3]);
 
 /* ---- phase-level entry points (inner boundary; state stays on the device) -- */
 int pa_sim_metropolis_sweep(pa_sim *sim, uint64_t n_sweeps);

@@ -258,13 +258,6 @@ class IsingSimulation:
             raise
         self._check(outcome["code"])
 
-    def profile_kernels(self, cfg, n_sweeps):
-        """Average device milliseconds per launch of (k_rng, k_sweep, k_measure)."""
-        out = np.zeros(3, dtype=np.float64)
-        self._check(self._lib.pa_sim_profile_kernels(self._handle, C.byref(cfg), int(n_sweeps),
-                                                     nat.ptr(out)))
-        return dict(zip(("k_rng", "k_sweep", "k_measure"), out.tolist()))
-
     def profile_step(self, cfg, n_sweeps):
         """({kernel name: (ms per step, launches per step)}, ms per step) of EVERY launch of a step of `cfg`'s protocol,
         cluster moves included (pa_sim_profile_step; the handle must have been made with stream_groups=1)."""

@@ -70,7 +70,6 @@ SIGNATURES = {
     "pa_sim_synchronize": (C.c_int, [_vp]),
     "pa_sim_request_interrupt": (None, [_vp]),
     "pa_sim_sweeps_completed": (_u64, [_vp]),
-    "pa_sim_profile_kernels": (C.c_int, [_vp, C.POINTER(PaSampleConfig), _u64, _vp]),
     "pa_sim_profile_step": (C.c_int, [_vp, C.POINTER(PaSampleConfig), _u64, _vp, _u64, _vp, _vp, _u64, _vp, _vp]),
     "pa_sim_metropolis_sweep": (C.c_int, [_vp, _u64]),
     "pa_sim_gibbs_sweep": (C.c_int, [_vp, _u64]),

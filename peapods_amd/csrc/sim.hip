@@ -155,7 +155,7 @@ struct pa_sim {
     uint64_t graph_key = 0;
     // Running sums are never memset between sample() calls: bit 0 (moments) / bit 1 (overlap moments, P(q)
     // bitmap) says that the next accumulating k_measure launch starts them from zero (PtParams::fresh).  One
-    // copy per stream group (run_sweeps) and one for whole-ensemble launches (pa_sim_profile_kernels).
+    // copy per stream group (run_sweeps) and one for whole-ensemble launches (the standalone phase entries).
     uint32_t fresh = 3;
     hipEvent_t fork = nullptr;
     hipEvent_t batch_events[2] = {nullptr, nullptr}; // run-ahead bound of run_sweeps (cooperative cancel)
@@ -978,6 +978,8 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     // One sweep of the plain protocol on the on-chip kernels: its launches (launch = true) and the host's bookkeeping --
     // buffer roles, the pending measurement block, counters.  With launch = false only the bookkeeping runs: the launches
     // are being replayed from a captured graph (graph_pair).
+    // (the captured-graph path, opt-in: see graph_pair below)
+    const bool graph_enabled = fused && relay && dev_env("PEAPODS_GRAPH") != nullptr && cfg->pt_interval == 1;
     auto fused_sweep = [&](uint64_t sweep_id, bool launch) -> int {
         const bool record = sweep_id >= cfg->warmup_sweeps; // mod.rs:410
         const bool pt_this = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0; // :486-488
@@ -1056,7 +1058,6 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     // launch), and the dependent-launch hop it shortens in an empty-kernel chain (1.6 against 2.8 us,
     // build_probe/gaps.hip) is not what separates these kernels: most of the ~5 us before a large kernel's first wave
     // is its own wave-launch ramp.
-    const bool graph_enabled = fused && relay && dev_env("PEAPODS_GRAPH") != nullptr && cfg->pt_interval == 1;
     auto pair_key = [&]() -> uint64_t {
         uint64_t h = 1469598103934665603ull;
         auto mix = [&](const void *ptr, size_t n) {
@@ -2584,135 +2585,6 @@ int pa_sim_profile_step(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_swe
     if (names_capacity) std::snprintf(names_out, names_capacity, "%s", names.c_str());
     if (n_kernels_out) *n_kernels_out = n;
     if (step_ms_out) *step_ms_out = step_plain;
-    return PA_OK;
-}
-
-int pa_sim_profile_kernels(pa_sim *sim, const pa_sample_config *cfg, uint64_t n_sweeps,
-                           double ms_out[3]) {
-    int code;
-    const std::string text = validate_text(cfg, sim->n_replicas, &code);
-    if (code != PA_OK) return fail(sim, code, text);
-    PA_HIP(sim, hipSetDevice(sim->device));
-    const SimDims &d = sim->d;
-    if (cfg->cluster_interval > 0 || cfg->overlap_cluster_interval > 0)
-        return fail(sim, PA_ERR_UNSUPPORTED, "kernel profiling covers the sweep pipeline without cluster moves");
-    const bool gibbs = cfg->sweep_mode == PA_SWEEP_GIBBS;
-    int rc = gibbs ? ensure_gibbs(sim) : PA_OK;
-    if (rc) return rc;
-    if ((rc = zero_accumulators(sim))) return rc;
-    const bool want_overlap = d.n_pairs > 0 && cfg->measure_overlap;
-    sim->n_recorded = 0;
-    sim->overlap_collected = want_overlap;
-    // The first half of the sweeps is timed launch by launch (an event pair around each, the host waiting after every
-    // sweep), which tells how a sweep's time divides among its launches but stretches all of them: every launch then
-    // starts on an idle queue.  The second half runs as sample() enqueues it, between two events; the per-launch figures
-    // are the first half's shares of the second half's time per sweep.
-    hipEvent_t ev[6];
-    for (auto &e : ev) PA_HIP(sim, hipEventCreate(&e));
-    const uint64_t n_instrumented = n_sweeps >= 8 ? n_sweeps / 2 : n_sweeps;
-    double total[3] = {0, 0, 0};
-    uint64_t count[3] = {0, 0, 0};
-    // same launch sequence as run_sweeps on one stream; with the fused path the overlap of the previous sweep --
-    // and, relayed, its measurement block -- ride in the random-stream launch (reported under k_rng)
-    const bool gibbs_fast = gibbs && d.hc && sweep_hc_lds_bytes(d, true) <= 160 * 1024 && !dev_env("PEAPODS_NO_HC");
-    const bool fused = want_overlap && (!gibbs || gibbs_fast) && !d.big && !d.general && !dev_env("PEAPODS_NO_FUSE");
-    const bool relay = fused && !dev_env("PEAPODS_NO_RELAY") &&
-                       (cfg->pt_schedule == PA_PT_SINGLE_RANDOM_EDGE ? rng_relay_supported(d) : rng_relay_ladder_supported(d));
-    struct {
-        bool any = false, do_accum = false, accum_overlap = false, do_pt = false;
-        PtParams pt{};
-    } pending;
-    bool overlap_owed = false;
-    for (uint64_t sweep_id = 0; sweep_id < n_sweeps; ++sweep_id) {
-        const bool record = sweep_id >= cfg->warmup_sweeps;
-        const bool pt_this = cfg->pt_interval > 0 && sweep_id % cfg->pt_interval == 0;
-        const bool instrumented = sweep_id < n_instrumented;
-        if (instrumented) PA_HIP(sim, hipEventRecord(ev[0], sim->stream));
-        if (sweep_id == n_instrumented) PA_HIP(sim, hipEventRecord(ev[4], sim->stream));
-        const bool relayed = relay && pending.any;
-        if (relayed) {
-            PtParams q = pending.pt;
-            q.relay = 1;
-            q.fresh = consume_fresh(sim->fresh, d, pending.do_accum, pending.accum_overlap);
-            PA_HIP(sim, launch_rng_relay(d, sim->p, overlap_owed, q, pending.do_accum, pending.accum_overlap, pending.do_pt,
-                                         sim->stream, gibbs));
-            if (pending.do_pt && d.n_temps >= 2 && !(record || pt_this)) PA_HIP(sim, launch_adopt_relay_sums(d, sim->p, sim->stream));
-            if (pending.do_pt && d.n_temps >= 2) toggle_system_tables(sim);
-        } else if (fused && overlap_owed) {
-            PA_HIP(sim, launch_rng_overlap(d, sim->p, sim->stream, gibbs));
-        } else {
-            PA_HIP(sim, launch_rng(d, sim->p, gibbs, sim->stream));
-        }
-        if (fused && overlap_owed) toggle_dots(sim->p);
-        pending.any = false;
-        if (instrumented) PA_HIP(sim, hipEventRecord(ev[1], sim->stream));
-        PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
-        PA_HIP(sim, enqueue_sweep(sim, d, sim->p, record || pt_this, gibbs, sim->stream));
-        sim->swaps_pending = false;
-        toggle_spin_buffers(sim);
-        if (instrumented) PA_HIP(sim, hipEventRecord(ev[2], sim->stream));
-        const bool wants_measure = record || pt_this || (fused && overlap_owed);
-        bool measured = false;
-        if (wants_measure && relay) {
-            pending.any = true;
-            pending.pt = pt;
-            pending.do_accum = record;
-            pending.accum_overlap = overlap_owed;
-            pending.do_pt = pt_this;
-        } else if (wants_measure) {
-            measured = true;
-            if (fused) {
-                PA_HIP(sim, measure_launch(sim->fresh, d, sim->p, pt, record, overlap_owed, pt_this, sim->stream));
-            } else {
-                if (record && want_overlap) PA_HIP(sim, overlap_launch(d, sim->p, sim->stream));
-                PA_HIP(sim, measure_launch(sim->fresh, d, sim->p, pt, record, record && want_overlap, pt_this,
-                                           sim->stream));
-            }
-            if (pt_this) sim->swaps_pending = true;
-        }
-        if (pt_this && cfg->pt_schedule == PA_PT_FULL_LADDER) sim->next_parity = 1 - sim->next_parity;
-        if (fused) overlap_owed = record;
-        if (record) sim->n_recorded += 1;
-        if (!instrumented) continue;
-        PA_HIP(sim, hipEventRecord(ev[3], sim->stream));
-        PA_HIP(sim, hipEventSynchronize(ev[3]));
-        for (int k = 0; k < 3; ++k) {
-            if (k == 2 && !measured) continue;
-            float ms = 0.f;
-            PA_HIP(sim, hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
-            total[k] += ms;
-            count[k] += 1;
-        }
-    }
-    double plain_ms_per_sweep = 0.0;
-    if (n_instrumented < n_sweeps) {
-        float ms = 0.f;
-        PA_HIP(sim, hipEventRecord(ev[5], sim->stream));
-        PA_HIP(sim, hipEventSynchronize(ev[5]));
-        PA_HIP(sim, hipEventElapsedTime(&ms, ev[4], ev[5]));
-        plain_ms_per_sweep = ms / static_cast<double>(n_sweeps - n_instrumented);
-    }
-    if (pending.any) {
-        PA_HIP(sim, measure_launch(sim->fresh, d, sim->p, pending.pt, pending.do_accum, pending.accum_overlap, pending.do_pt,
-                                   sim->stream));
-        if (pending.do_pt) sim->swaps_pending = true;
-    }
-    if (overlap_owed) {
-        PtParams pt{cfg->pt_schedule, sim->next_parity, sim->hot_slot, sim->cold_slot};
-        PA_HIP(sim, overlap_launch(d, sim->p, sim->stream));
-        PA_HIP(sim, measure_launch(sim->fresh, d, sim->p, pt, false, true, false, sim->stream));
-    }
-    for (auto &e : ev) (void)hipEventDestroy(e);
-    for (int k = 0; k < 3; ++k) ms_out[k] = count[k] ? total[k] / static_cast<double>(count[k]) : 0.0;
-    if (plain_ms_per_sweep > 0.0 && n_instrumented > 0) {
-        // (per instrumented sweep: every launch's share, a measurement launch counting with the sweeps it ran in)
-        const double stretched = (total[0] + total[1] + total[2]) / static_cast<double>(n_instrumented);
-        if (stretched > 0.0)
-            for (int k = 0; k < 3; ++k) ms_out[k] *= plain_ms_per_sweep / stretched;
-    }
-    int rc_flush = flush_swaps(sim);
-    if (rc_flush) return rc_flush;
-    PA_HIP(sim, hipStreamSynchronize(sim->stream));
     return PA_OK;
 }
 

@@ -184,21 +184,23 @@ def test_rccl_communicator_single_rank(oracle):
 
 
 @pytest.mark.parametrize("schedule", ["single_random_edge", "full_ladder"])
-def test_profile_kernels_advances_the_state_like_sample(oracle, schedule):
-    """pa_sim_profile_kernels times the launches of the same protocol (relayed measurement block included) and
-    must leave the ensemble exactly where sample() would: bench.py calls it on the live handle."""
+def test_profile_step_advances_the_state_like_sample(oracle, schedule):
+    """pa_sim_profile_step runs sample()'s own launch sequence (relayed measurement block included), once with an event in
+    front of every launch and once without: the ensemble ends exactly where two sample() calls would leave it, and the
+    results are those of the second."""
     from peapods_amd import IsingSimulation
 
     shape, n_rep = (8, 8, 8), 4
     temps = np.linspace(0.8, 1.4, 6).astype(np.float32)
     J = bimodal(shape, 3, 17)
-    gpu = IsingSimulation(list(shape), J, temps, n_rep, None, 12)
+    gpu = IsingSimulation(list(shape), J, temps, n_rep, None, 12, stream_groups=1)
     cpu = oracle.OracleSimulation(list(shape), J, temps, n_rep, None, 12)
     kw = dict(pt_interval=1, pt_schedule=schedule, warmup_ratio=0.0)
     gpu.sample(7, "metropolis", **kw)
     cpu.sample(7, "metropolis", **kw)
-    times = gpu.profile_kernels(gpu.make_config(9, "metropolis", **kw), 9)
-    assert times["k_rng"] > 0 and times["k_sweep"] > 0
+    table, step_ms = gpu.profile_step(gpu.make_config(9, "metropolis", **kw), 9)
+    assert step_ms > 0 and any(name.startswith("k_rng") for name in table) and any(name.startswith("k_sweep") for name in table)
+    cpu.sample(9, "metropolis", **kw)
     want = cpu.sample(9, "metropolis", **kw)
     for r in range(3):
         np.testing.assert_array_equal(gpu.get_spins(r), cpu.get_spins(r))

@@ -16,4 +16,5 @@ for label, kw in (("sweep only", dict(warmup_ratio=1.0)), ("sweep + measurement"
         t0 = time.perf_counter(); sim.run(cfg); times.append((time.perf_counter() - t0) / 50 * 1e6)
     flips = 64**3 * 64
     print("64^3 x 64 systems, %s: %s us/sweep, best %.2f Gflips/s" % (label, [round(t) for t in times], flips / min(times) / 1e3))
-print(sim.profile_kernels(sim.make_config(10, "metropolis", warmup_ratio=0.0), 10))
+one = IsingSimulation(list(shape), np.ones(shape + (3,), np.float32), np.linspace(4.111, 4.911, 32).astype(np.float32), 2, None, 42, stream_groups=1)
+print(one.profile_step(one.make_config(10, "metropolis", warmup_ratio=0.0, pt_interval=1), 10))

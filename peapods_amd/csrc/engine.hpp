@@ -317,7 +317,8 @@ size_t sweep_hc_lds_bytes(const SimDims &d, bool gibbs = false);
 size_t sweep_slab_lds_bytes(const SimDims &d);
 size_t sweep_slab_lds_bytes_for(uint32_t own_sites, uint32_t plane_sites, uint32_t n_levels);
 // kernels_cluster.hip
-// (paired: the shuffles of build_tasks have been made by a rider block of the overlap launch, k_overlap_pairing)
+// (paired: the shuffles of build_tasks -- and the per-slot bitmaps -- have been made by rider blocks of the overlap launch,
+// k_overlap_pairing)
 hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, uint32_t group, bool wolff,
                              const ClusterAux &aux, hipStream_t stream, bool paired = false);
 hipError_t launch_top4_accumulate(const SimDims &d, const DevPtrs &p, const ClusterAux &aux, hipStream_t stream);
@@ -327,7 +328,7 @@ hipError_t launch_jorg_wave(const SimDims &d, const DevPtrs &p, hipStream_t stre
 hipError_t launch_cmr_wave(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool paired = false);
 // kernels.hip: riders of the overlap moves (k_overlap_pairing, k_energy_measure)
 bool move_riders_supported(const SimDims &d);
-hipError_t launch_overlap_pairing(const SimDims &d, const DevPtrs &p, hipStream_t stream);
+hipError_t launch_overlap_pairing(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool with_bitmaps);
 hipError_t launch_energy_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_accum, bool accum_overlap,
                                  hipStream_t stream);
 size_t wolff_wave_lds_bytes(const SimDims &d);

@@ -2812,9 +2812,35 @@ __device__ __forceinline__ void pairing_presave_block(const SimDims &d, const De
     for (uint32_t k = 0; k < d.n_replicas; ++k) slots[k] = order[k] * d.n_temps + t;
     st[0] = rng.s0; st[1] = rng.s1; st[2] = rng.s2; st[3] = rng.s3;
 }
+// (c) with_bitmaps (the union-find forms): the per-slot site bitmaps of the swept state (k_slot_bitmaps: slot_bits[real][slot][MW],
+// 64 sites x 32 slots per wave by 32 ballots), four chunks of 256 sites per block
+__device__ __forceinline__ void slot_bitmaps_block(const SimDims &d, const DevPtrs &p, uint32_t bid) {
+    const uint32_t n_chunks = (d.N + 255) / 256, n_quads = (n_chunks + 3) / 4;
+    const uint32_t chunk = (bid % n_quads) * 4 + (threadIdx.x >> 8), w = (bid / n_quads) % d.W, real = bid / (n_quads * d.W);
+    const uint32_t t256 = threadIdx.x & 255u, lane = t256 & 63u, i0 = chunk * 256 + (t256 & ~63u), i = i0 + lane;
+    if (chunk >= n_chunks || i0 >= d.N) return;
+    const uint32_t v = i < d.N ? p.S[(static_cast<size_t>(real) * d.W + w) * d.N + i] : 0u;
+    uint32_t keep_lo = 0, keep_hi = 0; // lane k (< 32) ends up with the two words of slot k
+#pragma unroll
+    for (uint32_t k = 0; k < 32; ++k) {
+        const unsigned long long votes = __ballot((v >> k) & 1u);
+        if (lane == k) {
+            keep_lo = static_cast<uint32_t>(votes);
+            keep_hi = static_cast<uint32_t>(votes >> 32);
+        }
+    }
+    if (lane < 32) {
+        uint32_t *row = p.slot_bits + (static_cast<size_t>(real) * d.SP + w * 32 + lane) * d.MW;
+        const uint32_t word = i0 >> 5;
+        row[word] = keep_lo;
+        if (word + 1 < d.MW) row[word + 1] = keep_hi;
+    }
+}
 __global__ __launch_bounds__(1024) void k_overlap_pairing(SimDims d, DevPtrs p, uint32_t n_overlap) {
     extern __shared__ uint32_t lds[];
-    if (blockIdx.x >= n_overlap) {
+    if (blockIdx.x >= n_overlap + d.n_real) {
+        slot_bitmaps_block(d, p, blockIdx.x - n_overlap - d.n_real);
+    } else if (blockIdx.x >= n_overlap) {
         pairing_presave_block(d, p, blockIdx.x - n_overlap);
     } else if (d.N <= 4096) {
         overlap_block_1024(d, p, blockIdx.x, lds);
@@ -4073,9 +4099,10 @@ bool houdayer_computes_energy(const SimDims &d) { return d.hc && d.dense_nn == d
 size_t houdayer_lds_bytes(const SimDims &d) { return houdayer_lds_words(d) * 4; }
 
 bool move_riders_supported(const SimDims &d) { return d.hc && !d.big && !d.general && d.n_pairs > 0 && d.nn <= 3; }
-hipError_t launch_overlap_pairing(const SimDims &d, const DevPtrs &p, hipStream_t stream) {
+hipError_t launch_overlap_pairing(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool with_bitmaps) {
     const uint32_t n_overlap = d.n_real * d.W;
-    PA_LAUNCH(k_overlap_pairing, dim3(n_overlap + d.n_real), dim3(1024), overlap_lds_bytes(d), stream, d, p, n_overlap);
+    const uint32_t n_bitmaps = with_bitmaps ? d.n_real * d.W * (((d.N + 255) / 256 + 3) / 4) : 0u;
+    PA_LAUNCH(k_overlap_pairing, dim3(n_overlap + d.n_real + n_bitmaps), dim3(1024), overlap_lds_bytes(d), stream, d, p, n_overlap);
     return hipGetLastError();
 }
 hipError_t launch_energy_measure(const SimDims &d, const DevPtrs &p, const PtParams &pt, bool do_accum, bool accum_overlap,

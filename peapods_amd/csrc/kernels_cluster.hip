@@ -1623,8 +1623,10 @@ static void launch_sw_build(int level, dim3 grid, hipStream_t stream, const SimD
 
 hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, uint32_t group, bool wolff,
                              const ClusterAux &aux_in, hipStream_t stream, bool paired) {
-    if (!paired) PA_LAUNCH(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
-    PA_LAUNCH(k_slot_bitmaps, dim3(d.n_real * d.W * ((d.N + 255) / 256)), dim3(256), 0, stream, d, p);
+    if (!paired) {
+        PA_LAUNCH(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
+        PA_LAUNCH(k_slot_bitmaps, dim3(d.n_real * d.W * ((d.N + 255) / 256)), dim3(256), 0, stream, d, p);
+    }
     ClusterAux aux = aux_in;
     { // the generators' draws: bonds (stochastic moves) + one per cluster (twice for CMR) + the seed
         const uint32_t draws = (oc_mode == 1 ? 0u : d.N * d.nn) + (oc_mode == 3 ? 2u : 1u) * d.N + 64u;

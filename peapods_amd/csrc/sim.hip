@@ -1232,7 +1232,7 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
             // The moves that keep their launches to themselves (Joerg, CMR, every union-find form): the shuffles of
             // build_tasks ride in the overlap launch, which also puts the sweep's sums aside, and the statistics of the swept
             // state ride in the launch that recomputes the energies after the move -- two launches less per step.
-            bool move_riders = false;
+            bool move_riders = false, move_is_uf = false;
             if (oc_this && record && want_overlap && !equil && pt_this && move_riders_supported(d) && !overlap_in_houdayer &&
                 !collect_overlap && !observe_overlap && snapshot_interval == 0 && !big_overlap_done &&
                 !dev_env("PEAPODS_NO_MOVE_RIDERS")) {
@@ -1240,9 +1240,10 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                 const int kind = mode & 0xFF;
                 const bool uf = oc_sw || (mode >> 8) > 2 || (kind == PA_OC_HOUDAYER && (d.nn > 3 || !houdayer_tile_fits));
                 move_riders = uf || (kind == PA_OC_JORG && jorg_wave) || (kind == PA_OC_CMR && wave_ok);
+                move_is_uf = uf;
             }
             if (move_riders) {
-                PA_HIP(sim, launch_overlap_pairing(g.d, g.p, g.stream));
+                PA_HIP(sim, launch_overlap_pairing(g.d, g.p, g.stream, move_is_uf));
                 toggle_dots(g.p);
             } else if (((record && want_overlap) || equil) && d.n_pairs && !overlap_in_houdayer && !big_overlap_done)
                 PA_HIP(sim, overlap_launch(g.d, g.p, g.stream)); // :527-529

@@ -1,5 +1,7 @@
 """Diagnostic: phase times of every k_sweep_reg wave of one launch on the bench ensemble (s_memrealtime)."""
 import ctypes as C, os, sys
+os.environ.setdefault("PEAPODS_DEVELOPER", "1")  # the register-resident sweep is opt-in
+os.environ.setdefault("PEAPODS_REG", "1")
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench

@@ -1666,7 +1666,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         d.rng_waves = 4;
         if (const char *env = dev_env("PEAPODS_RNG_WAVES")) {
             const long v = std::strtol(env, nullptr, 10);
-            if (v == 4 || v == 8) d.rng_waves = static_cast<uint32_t>(v);
+            if (v >= 4 && v <= 8) d.rng_waves = static_cast<uint32_t>(v);
         }
     }
     d.B = std::max<uint32_t>(1, (d.N + target_block / 2) / target_block);

@@ -143,6 +143,26 @@ __device__ __forceinline__ void jump_state_lds(uint32_t st[8], const uint32_t *t
 }
 
 
+// The same jump by a whole wave from a table in device memory: lane p looks up the row of nibble p (one 32-byte entry
+// per lane instead of 64 dependent-looking loads in one), the rows are folded by an XOR butterfly, and every lane
+// ends up with the new state.  st must hold the same state in every lane; all 64 lanes must be active.
+__device__ __forceinline__ void jump_state_wave(uint32_t st[8], const uint32_t *tab) {
+    const uint32_t p = threadIdx.x & 63u;
+    uint32_t word = st[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) word = (p >> 3) == static_cast<uint32_t>(k) ? st[k] : word;
+    const uint32_t nib = (word >> ((p & 7u) * 4)) & 15u;
+    const uint4 *e = reinterpret_cast<const uint4 *>(tab + p * 128 + nib * 4);
+    const uint4 a = e[0], b = e[16]; // second half: + 64 dwords
+    uint32_t acc[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] ^= __shfl_xor(acc[j], off);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) st[j] = acc[j];
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which
 // would stall every schedule pass on the global prefetch issued just before it.
 __device__ __forceinline__ void lds_barrier() {

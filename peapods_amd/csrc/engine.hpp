@@ -178,6 +178,8 @@ struct DevPtrs {
     uint32_t *big_counts;     // [n_real][n_sys][4] u32 scratch counters of the large-lattice kernels
     uint32_t *big_ticket;     // [n_real] workgroups of k_energy_overlap_big done with the realisation (the last one finalises)
     const uint16_t *nbr_site; // [N][12] neighbours by site: f0, b0, f1, b1, ... f5, b5 (self when unused)
+    const uint32_t *sw_wrap;  // SimDims::hc: [3][MW] bitmaps over the sites -- the forward neighbour f0 / f1 / f2 lies through the wrap
+    const uint32_t *sw_cpl;   // SimDims::hc: [n_real][6][MW] bitmaps -- forward coupling negative (3 directions), then non-zero (3)
     const uint32_t *jsite;    // [n_real][N] by site: neg[0..11] | nz[12..23] for bonds f0,b0,...,f5,b5
     const uint4 *fwd_big;     // [N] large lattices: forward neighbours f0, f1, f2 of every site (self when unused), by site
     const uint32_t *nbr_wide; // [N][16] in schedule order: site, f0, b0, ..., f5, b5, 0, 0, 0 (general path)

@@ -78,10 +78,24 @@ __global__ void k_pairing(SimDims d, DevPtrs p) {
 // bit 1 draw < 1 - e^(-2/T) (CMR red), bits 2-3 the two top bits of the draw (bit 3 clear <=> coin
 // "< 0.5"; both = rand's u8 gen_range(0..=3)).  Other couplings: the 24-bit draw itself.
 // ---------------------------------------------------------------------------
-template <bool RAW>
-__global__ __launch_bounds__(256) void k_pair_stream(SimDims d, DevPtrs p, uint32_t n_units, const uint32_t *first_thr, int fk) {
+// A workgroup serves kStreamRun consecutive units with ONE table: it enters the stream at unit u and steps through the
+// following ones.  Staging 32 KB for 64 draws per lane made the table loads the kernel (Joerg at 12^3: 110 units x 12
+// chunks = 1320 workgroups, 47 us for 11 M instructions).
+static uint32_t stream_run() {
+    static const uint32_t run = [] {
+        const char *e = dev_env("PEAPODS_STREAM_RUN");
+        const int v = e ? atoi(e) : 0;
+        return v >= 1 && v <= 64 ? static_cast<uint32_t>(v) : 4u;
+    }();
+    return run;
+}
+// SECOND: the second-threshold and bit-30 planes as well (the two-phase CMR move reads all four).
+template <bool RAW, bool SECOND>
+__global__ __launch_bounds__(256) void k_pair_stream(SimDims d, DevPtrs p, uint32_t n_units, const uint32_t *first_thr, int fk, uint32_t kStreamRun) {
     extern __shared__ uint32_t tab[]; // [64][2][16][4] nibble tables of T^(64 u)
-    const uint32_t u = blockIdx.x % n_units, chunk = blockIdx.x / n_units;
+    const uint32_t n_runs = (n_units + kStreamRun - 1) / kStreamRun;
+    const uint32_t u = (blockIdx.x % n_runs) * kStreamRun, chunk = blockIdx.x / n_runs;
+    const uint32_t n_here = min(kStreamRun, n_units - u); // units this workgroup draws
     const uint32_t tid = threadIdx.x;
     const uint32_t per_real = fk ? d.n_sys : d.n_temps * d.n_pairs;
     const uint32_t task = chunk * 256 + tid, n_tasks = d.n_real * per_real;
@@ -111,7 +125,7 @@ __global__ __launch_bounds__(256) void k_pair_stream(SimDims d, DevPtrs p, uint3
     const size_t stride = static_cast<size_t>(cluster_stream_units(d)) * 64; // positions a task's stream has room for
     if (RAW) {
         uint32_t *out = p.stream_raw + static_cast<size_t>(task) * stride + u * 64;
-        for (uint32_t j = 0; j < 64; j += 4) {
+        for (uint32_t j = 0; j < 64 * n_here; j += 4) {
             uint4 v;
             v.x = rng.next_top() >> 8;
             v.y = rng.next_top() >> 8;
@@ -120,22 +134,32 @@ __global__ __launch_bounds__(256) void k_pair_stream(SimDims d, DevPtrs p, uint3
             *reinterpret_cast<uint4 *>(out + j) = v;
         }
     } else {
+        // Four bit planes over the stream positions (bit q & 31 of word q >> 5): draw < first threshold, draw < second,
+        // bits 30 and 31 of the 32-bit draw.  A lane owns whole words, so a plane costs it two instructions per draw
+        // (compare into the carry, add-with-carry shifts it in) or one (funnel shift for a bit of the draw), and the
+        // cluster workgroups copy words instead of classifying a byte per draw.
         const uint32_t first = first_thr ? first_thr[t] : 0u;
         const uint32_t second = p.fk_thr[t];
-        uint8_t *out = p.stream_bits + static_cast<size_t>(task) * stride + u * 64;
-        for (uint32_t j = 0; j < 64; j += 16) {
-            uint32_t w[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                w[q] = 0;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const uint32_t top = rng.next_top(), draw = top >> 8;
-                    const uint32_t code = (draw < first ? 1u : 0u) | (draw < second ? 2u : 0u) | ((top >> 30) << 2);
-                    w[q] |= code << (8 * b);
+        const uint32_t plane_words = static_cast<uint32_t>(stride / 32);
+        uint32_t *out = reinterpret_cast<uint32_t *>(p.stream_bits + static_cast<size_t>(task) * stride) + u * 2;
+        for (uint32_t w = 0; w < 2 * n_here; ++w) {
+            uint32_t lt1 = 0, lt2 = 0, b30 = 0, b31 = 0; // the word's first draw ends up in bit 31: reversed below
+#pragma unroll 8
+            for (int j = 0; j < 32; ++j) {
+                const uint32_t top = rng.next_top(), draw = top >> 8;
+                asm("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(lt1) : "v"(draw), "v"(first) : "vcc");
+                if (SECOND) {
+                    asm("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(lt2) : "v"(draw), "v"(second) : "vcc");
+                    b30 = __builtin_amdgcn_alignbit(b30, top << 1, 31);
                 }
+                b31 = __builtin_amdgcn_alignbit(b31, top, 31);
             }
-            *reinterpret_cast<uint4 *>(out + j) = make_uint4(w[0], w[1], w[2], w[3]);
+            out[w] = __brev(lt1);
+            if (SECOND) {
+                out[plane_words + w] = __brev(lt2);
+                out[2 * plane_words + w] = __brev(b30);
+            }
+            out[3 * plane_words + w] = __brev(b31);
         }
     }
 }
@@ -230,6 +254,7 @@ template <bool GLOBAL> struct SwLds {
     uint32_t *flip_b;  // [MW] accumulated flips of the second system
     uint32_t *bits;    // [n_bit_words] accept / coin bits by draw position
     uint32_t *bits2;   // [n_bit_words] second bit of the CMR grey draw
+    uint32_t *wrapm;   // [3][MW] implicit neighbours: the site's forward neighbour lies through the periodic wrap
     uint32_t *scratch; // [8]
     uint32_t *misc;    // [16] 0 changed, 1 seed / root, 2 draws, 3-4 winding x/y, 5 large, 6 bonds, 8-11 top four
 };
@@ -238,7 +263,7 @@ __host__ __device__ inline size_t cluster_sw_bit_words(const SimDims &d) {
     return (static_cast<size_t>(d.N) * d.nn + 255) / 256 * 8 + 16;
 }
 __host__ __device__ inline size_t cluster_sw_lds_words(const SimDims &d, bool global_labels = false) {
-    return (global_labels ? 0 : 2 * static_cast<size_t>(d.N)) + 26 * static_cast<size_t>(d.MW) + 1 +
+    return (global_labels ? 0 : 2 * static_cast<size_t>(d.N)) + 29 * static_cast<size_t>(d.MW) + 1 +
            2 * cluster_sw_bit_words(d) + 24 + (d.unit ? 0 : static_cast<size_t>(d.N) * d.nn);
 }
 
@@ -254,7 +279,7 @@ enum { kSwHoudayer = 0, kSwJorg = 1, kSwFk = 2, kSwCmr = 3 };
 // FK 312 -> 363 us), and the reporting builds need their registers.
 // GLOBAL: the union-find's per-site arrays in device memory (large lattices; the full build only).
 template <int MODE, int LEVEL, bool GLOBAL = false>
-__global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4 : (LEVEL == 1 ? 3 : 2)) void k_cluster_sw(
+__global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || MODE == kSwJorg) ? 6 : 4) : (LEVEL == 1 ? 3 : 2)) void k_cluster_sw(
     SimDims d, DevPtrs p, uint32_t group, int wolff, ClusterAux aux) {
     constexpr bool EXTRAS = LEVEL > 0; // sizes / top four and the single-cluster forms
     constexpr bool FULL = LEVEL > 1;   // + observation metrics, winding, snapshots
@@ -284,11 +309,16 @@ __global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4
         L.flip_b = q; q += d.MW;
         L.bits = q; q += cluster_sw_bit_words(d);
         L.bits2 = q; q += cluster_sw_bit_words(d);
+        L.wrapm = q; q += 3 * d.MW;
         L.scratch = q; q += 8;
         L.misc = q; q += 16;
         L.thr = q;
     }
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    auto stamp = [&](int k) {
+        if (p.slab_stamps && threadIdx.x == 0) p.slab_stamps[static_cast<size_t>(blockIdx.x) * 16 + k] = wall_clock64();
+    };
+    stamp(0);
     const uint32_t n_groups = FK ? 1u : d.n_replicas / group;
     const uint32_t n_lanes = FK ? d.n_sys : d.n_temps * n_groups;
     const uint32_t real = blockIdx.x / n_lanes, task = blockIdx.x % n_lanes;
@@ -317,6 +347,26 @@ __global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4
         if (lane == 32 && word + 1 < d.MW) bitmap[word + 1] = static_cast<uint32_t>(votes >> 32);
     };
     auto get_bit = [&](const uint32_t *bitmap, uint32_t i) -> uint32_t { return (bitmap[i >> 5] >> (i & 31u)) & 1u; };
+    // Implicit neighbours (SimDims::hc, at most three directions): the forward neighbour of a site lies at the
+    // direction's regular offset or, for the sites flagged in the wrap bitmap, at the wrapped one.  With that the
+    // per-site phases that only combine bits of a site and its neighbours run on whole 32-site words of the bitmaps:
+    // "the neighbour's bit" is the bitmap shifted by the offset, picked per site by the wrap bitmap.
+    const bool implicit = d.hc != 0;
+    auto offset_of = [&](uint32_t dd, bool wrapped) -> int32_t { // in sites (dd may differ between lanes)
+        const int32_t reg = dd == 0 ? d.hc_d0[0] : (dd == 1 ? d.hc_d0[2] : d.hc_d0[4]);
+        const int32_t ext = dd == 0 ? d.hc_dd[0] : (dd == 1 ? d.hc_dd[2] : d.hc_dd[4]);
+        return (reg + (wrapped ? ext : 0)) >> 2;
+    };
+    auto shifted = [&](const uint32_t *bitmap, uint32_t m, int32_t off) -> uint32_t { // word m of: bit i = bitmap bit i + off
+        const int32_t s = static_cast<int32_t>(32 * m) + off, w = s >> 5;
+        const uint32_t lo = (w >= 0 && w < static_cast<int32_t>(d.MW)) ? bitmap[w] : 0u;
+        const uint32_t hi = (w + 1 >= 0 && w + 1 < static_cast<int32_t>(d.MW)) ? bitmap[w + 1] : 0u;
+        return __builtin_amdgcn_alignbit(hi, lo, static_cast<uint32_t>(s) & 31u);
+    };
+    // the direction whose regular forward neighbour is the next site (3: none)
+    const uint32_t run_dd = !implicit ? 3u : (d.hc_d0[0] == 4 ? 0u : (d.nn > 1 && d.hc_d0[2] == 4 ? 1u : (d.nn > 2 && d.hc_d0[4] == 4 ? 2u : 3u)));
+    if (implicit)
+        for (uint32_t m = tid; m < 3 * d.MW; m += kSwThreads) L.wrapm[m] = p.sw_wrap[m];
 
     // ---- A: active sites and the systems' spins, from the per-slot bitmaps (k_slot_bitmaps)
     {
@@ -326,7 +376,7 @@ __global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4
             const uint32_t live = m + 1 == d.MW ? tail : 0xFFFFFFFFu;
             const uint32_t wa = bits[static_cast<size_t>(sa) * d.MW + m], wb = bits[static_cast<size_t>(sb) * d.MW + m];
             uint32_t active = (FK || CMR) ? live : (wa ^ wb);
-            if (MODE == kSwHoudayer && group > 2) { // the group's spins sum to zero (overlap.rs:199-205): group / 2 are -1
+            if (EXTRAS && MODE == kSwHoudayer && group > 2) { // the group's spins sum to zero (overlap.rs:199-205): group / 2 are -1
                 uint32_t c[6] = {0, 0, 0, 0, 0, 0}; // bit-sliced count of the members' -1 spins per site
                 for (uint32_t k = 0; k < group; ++k) {
                     uint32_t carry = bits[static_cast<size_t>(members[k]) * d.MW + m];
@@ -363,6 +413,7 @@ __global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4
     }
     __syncthreads();
 
+    stamp(1);
     // number of set entries before (i, dd) in (site, dim) order, from the per-word prefix wbase
     auto entries_before = [&](uint32_t i, uint32_t dd) -> uint32_t {
         const uint32_t m = i >> 5, k = i & 31u, below = (1u << k) - 1u;
@@ -389,17 +440,19 @@ __global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4
         return carry;
     };
 
-    // the generator at draw 256 * block after its position at entry (stride-256 jump tables)
-    uint32_t base_state[8];
-    if (FK) {
-        load_cursor(p.cursor, real, d.SP, sa, base_state);
-    } else {
+    // the generator's state at entry (read by the one lane that needs it, when it needs it: nothing else in this
+    // workgroup writes it before the end)
+    auto load_base_state = [&](uint32_t base_state[8]) {
+        if (FK) {
+            load_cursor(p.cursor, real, d.SP, sa, base_state);
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            base_state[2 * k] = static_cast<uint32_t>(rng_state[k]);
-            base_state[2 * k + 1] = static_cast<uint32_t>(rng_state[k] >> 32);
+            for (int k = 0; k < 4; ++k) {
+                base_state[2 * k] = static_cast<uint32_t>(rng_state[k]);
+                base_state[2 * k + 1] = static_cast<uint32_t>(rng_state[k] >> 32);
+            }
         }
-    }
+    };
     // Bits of the draws at stream positions [start, start + count), read from the task's pre-drawn stream
     // (k_pair_stream): kind 0 / 1 = below the move's first / second threshold, 2 = coin (draw < 1/2), 3 = the two top
     // bits of the draw (rand's u8 gen_range(0..=3), overlap.rs:827); with thr_by_rank (couplings that are not
@@ -408,32 +461,63 @@ __global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4
     const size_t stream_stride = static_cast<size_t>(cluster_stream_units(d)) * 64;
     const size_t stream_task = FK ? static_cast<size_t>(real) * d.n_sys + task
                                   : (static_cast<size_t>(real) * d.n_temps + t) * d.n_pairs + g;
-    auto draw_bits = [&](uint32_t start, uint32_t count, uint32_t kind, const uint32_t *thr_by_rank) {
+    // Prefetch: the plane words a later draw_bits(start, ...) will want, one per thread from the word of position
+    // 256 * (start / 256) on, requested while other work hides the trip to memory (the count is not known yet, the
+    // start is).  pre[0] = the plane of kinds 0 / 1 / 2, or bit 30 for kind 3; pre[1] = bit 31 for kind 3.
+    struct PlaneWords { uint32_t w0, v[2]; };
+    const uint32_t plane_words = static_cast<uint32_t>(stream_stride / 32);
+    auto prefetch_bits = [&](uint32_t start, uint32_t kind) -> PlaneWords {
+        PlaneWords pre{0xFFFFFFFFu, {0u, 0u}};
+        if (!d.unit) return pre;
+        pre.w0 = (start / 256) * 8;
+        const uint32_t w = pre.w0 + tid;
+        if (w < 2 * aux.stream_units) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(p.stream_bits + stream_task * stream_stride) + w;
+            pre.v[0] = src[(kind == 2 ? 3u : (kind == 3 ? 2u : kind)) * plane_words];
+            if (kind == 3) pre.v[1] = src[3 * plane_words];
+        }
+        return pre;
+    };
+    auto draw_bits = [&](uint32_t start, uint32_t count, uint32_t kind, const uint32_t *thr_by_rank, const PlaneWords &pre) {
         if (count == 0) return;
         const uint32_t base_q = (start / 256) * 256, end = start + count;
         if (end > aux.stream_units * 64u) { // only after > 64 rejections of a seed draw (p < 2^-50 each): refuse, never guess
             if (tid == 0) atomicOr(p.stream_error, 1u);
             return;
         }
-        const uint8_t *codes = p.stream_bits + stream_task * stream_stride;
+        if (d.unit) { // the planes k_pair_stream left: a word copy (positions before `start` in the first word are never read)
+            const uint32_t *planes = reinterpret_cast<const uint32_t *>(p.stream_bits + stream_task * stream_stride);
+            const uint32_t w0 = base_q / 32, n_words = (end - base_q + 31) / 32;
+            if (pre.w0 == w0 && n_words <= kSwThreads) { // the words are here already
+                if (tid < n_words) {
+                    L.bits[tid] = kind == 2 ? ~pre.v[0] : pre.v[0];
+                    if (kind == 3) L.bits2[tid] = pre.v[1];
+                }
+                return;
+            }
+            for (uint32_t w = tid; w < n_words; w += kSwThreads) {
+                const uint32_t *src = planes + w0 + w;
+                if (kind == 3) {
+                    L.bits[w] = src[2 * plane_words];
+                    L.bits2[w] = src[3 * plane_words];
+                } else {
+                    L.bits[w] = kind == 2 ? ~src[3 * plane_words] : src[kind * plane_words];
+                }
+            }
+            return;
+        }
         const uint32_t *raw = p.stream_raw + stream_task * stream_stride;
         for (uint32_t q0 = base_q; q0 < end; q0 += kSwThreads) {
             const uint32_t q = q0 + tid;
             const bool live = q >= start && q < end;
             bool b0 = false, b1 = false;
             if (live) {
-                if (!d.unit) {
-                    const uint32_t draw = raw[q];
-                    if (kind == 3) {
-                        b0 = (draw >> 22) & 1u;
-                        b1 = (draw >> 23) & 1u;
-                    } else {
-                        b0 = draw < (kind == 2 ? (1u << 23) : thr_by_rank[q - start]);
-                    }
+                const uint32_t draw = raw[q];
+                if (kind == 3) {
+                    b0 = (draw >> 22) & 1u;
+                    b1 = (draw >> 23) & 1u;
                 } else {
-                    const uint32_t code = codes[q];
-                    b0 = kind == 3 ? (code >> 2) & 1u : (kind == 2 ? !((code >> 3) & 1u) : (code >> kind) & 1u);
-                    b1 = (code >> 3) & 1u;
+                    b0 = draw < (kind == 2 ? (1u << 23) : thr_by_rank[q - start]);
                 }
             }
             const unsigned long long v0 = __ballot(b0), v1 = __ballot(b1);
@@ -463,8 +547,7 @@ __global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4
     // the task's generator `at` draws after its position at entry (one lane)
     auto rng_at = [&](uint32_t at) -> DevRng {
         uint32_t js[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) js[k] = base_state[k];
+        load_base_state(js);
         if (at / 64) jump_state_lds(js, p.jump_unit + static_cast<size_t>(at / 64) * (64 * 16 * 8));
         Rng32 r32;
         r32.load(js);
@@ -661,11 +744,18 @@ __global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4
     };
     // one flip step: decide(i, fa, fb) per site; both systems' bitmaps and the accumulated flips follow
     auto flip_step = [&](auto decide) {
-        for (uint32_t r = 0; r < n_rounds; ++r) {
-            const uint32_t i = r * kSwThreads + tid;
-            bool fa = false, fb = false;
-            if (i < d.N) decide(i, fa, fb);
-            const unsigned long long va = __ballot(fa), vb = __ballot(fb);
+        for (uint32_t r0 = 0; r0 < n_rounds; r0 += 4) { // (reads of four rounds, then their ballots)
+          bool fa4[4] = {false, false, false, false}, fb4[4] = {false, false, false, false};
+#pragma unroll
+          for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t i = (r0 + q) * kSwThreads + tid;
+            if (r0 + q < n_rounds && i < d.N) decide(i, fa4[q], fb4[q]);
+          }
+#pragma unroll
+          for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t r = r0 + q;
+            if (r >= n_rounds) break;
+            const unsigned long long va = __ballot(fa4[q]), vb = __ballot(fb4[q]);
             const uint32_t word = (r * kSwThreads + (tid & ~63u)) >> 5;
             if (lane == 0 && word < d.MW) {
                 L.flip_a[word] ^= static_cast<uint32_t>(va);
@@ -679,6 +769,7 @@ __global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4
                 L.spa[word + 1] ^= static_cast<uint32_t>(va >> 32);
                 L.spb[word + 1] ^= static_cast<uint32_t>(vb >> 32);
             }
+          }
         }
     };
     uint32_t pos = 0; // draws of the generator consumed so far
@@ -702,10 +793,37 @@ __global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4
     const uint32_t cmr_seed = (EXTRAS && CMR && wolff) ? L.misc[1] : 0u;
     __syncthreads();
     for (uint32_t phase = 0; phase < N_PHASES; ++phase) {
+        const uint32_t bond_kind = (CMR && phase == 1) ? 1u : 0u, cluster_kind = (CMR && phase == 1) ? 3u : 2u;
+        // the draws of a stochastic move's bonds start at `pos`; a deterministic move goes straight to the cluster draws
+        const PlaneWords pre_bonds = prefetch_bits(pos, bond_kind);
+        PlaneWords pre_clusters = prefetch_bits(pos, cluster_kind);
         // ---- B: eligible forward bonds.  Houdayer: both ends active (overlap.rs:228-231).
         // Joerg: both ends active and s_a(i) s_a(j) J > 0 (:417-429).  FK: s_i s_j J > 0
         // (fk.rs:113-120).  CMR: blue = satisfied in both systems (:588-596), red = satisfied in
         // exactly one (:779-792).
+        if (implicit) { // one thread per (direction, word of 32 sites)
+            const uint32_t *cpl = p.sw_cpl + static_cast<size_t>(real) * 6 * d.MW;
+            for (uint32_t cell = tid; cell < d.nn * d.MW; cell += kSwThreads) {
+                const uint32_t dd = cell / d.MW, m = cell - dd * d.MW;
+                const int32_t reg = offset_of(dd, false), wrp = offset_of(dd, true);
+                const uint32_t wm = L.wrapm[cell];
+                auto at_neighbour = [&](const uint32_t *bitmap) -> uint32_t {
+                    return (shifted(bitmap, m, reg) & ~wm) | (shifted(bitmap, m, wrp) & wm);
+                };
+                uint32_t e = L.act[m] & at_neighbour(L.act);
+                if (STOCHASTIC) {
+                    const uint32_t neg = cpl[cell], nz = cpl[3 * d.MW + cell];
+                    const uint32_t a_sat = ~(L.spa[m] ^ at_neighbour(L.spa) ^ neg);
+                    if (CMR) {
+                        const uint32_t b_sat = ~(L.spb[m] ^ at_neighbour(L.spb) ^ neg);
+                        e &= nz & (phase == 0 ? (a_sat & b_sat) : (a_sat ^ b_sat));
+                    } else {
+                        e &= nz & a_sat;
+                    }
+                }
+                L.bond[cell] = e;
+            }
+        } else
         for (uint32_t r0 = 0; r0 < n_rounds; r0 += 4) { // neighbour / coupling loads of 4 rounds in flight
             uint32_t jm[4], nbj[4][6];
 #pragma unroll
@@ -721,34 +839,41 @@ __global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4
                         if (dd < d.nn) nbj[q][dd] = p.nbr_site[i * 12 + 2 * dd];
                 }
             }
+            // reads first, for all four rounds, then the ballots: the bitmaps they write share the LDS with the ones read
+            uint32_t eligible[4] = {0, 0, 0, 0};
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) {
                 const uint32_t r = r0 + q, i = r * kSwThreads + tid;
                 if (r >= n_rounds) break;
-                bool e[6] = {false, false, false, false, false, false};
-                if (i < d.N && get_bit(L.act, i)) {
+                const uint32_t ic = i < d.N ? i : 0u;
+                const uint32_t live = i < d.N ? get_bit(L.act, ic) : 0u;
+                const uint32_t sa_i = STOCHASTIC ? get_bit(L.spa, ic) : 0u, sb_i = CMR ? get_bit(L.spb, ic) : 0u;
 #pragma unroll
-                    for (uint32_t dd = 0; dd < 6; ++dd) {
-                        if (dd >= d.nn) continue;
-                        const uint32_t j = nbj[q][dd];
-                        bool ok = get_bit(L.act, j) != 0;
-                        if (STOCHASTIC && ok) {
-                            const bool nz = (jm[q] >> (12 + 2 * dd)) & 1u;
-                            const uint32_t neg = (jm[q] >> (2 * dd)) & 1u;
-                            const bool a_sat = (get_bit(L.spa, i) ^ get_bit(L.spa, j) ^ neg) == 0;
-                            if (CMR) {
-                                const bool b_sat = (get_bit(L.spb, i) ^ get_bit(L.spb, j) ^ neg) == 0;
-                                ok = nz && (phase == 0 ? (a_sat && b_sat) : (a_sat != b_sat));
-                            } else {
-                                ok = nz && a_sat;
-                            }
+                for (uint32_t dd = 0; dd < 6; ++dd) {
+                    if (dd >= d.nn) continue;
+                    const uint32_t j = nbj[q][dd];
+                    uint32_t ok = live & get_bit(L.act, j);
+                    if (STOCHASTIC) {
+                        const uint32_t nz = (jm[q] >> (12 + 2 * dd)) & 1u, neg = (jm[q] >> (2 * dd)) & 1u;
+                        const uint32_t a_sat = (sa_i ^ get_bit(L.spa, j) ^ neg) ^ 1u;
+                        if (CMR) {
+                            const uint32_t b_sat = (sb_i ^ get_bit(L.spb, j) ^ neg) ^ 1u;
+                            ok &= nz & (phase == 0 ? (a_sat & b_sat) : (a_sat ^ b_sat));
+                        } else {
+                            ok &= nz & a_sat;
                         }
-                        e[dd] = ok;
                     }
+                    eligible[q] |= ok << dd;
                 }
-                for (uint32_t dd = 0; dd < d.nn; ++dd) put_ballot(L.bond + dd * d.MW, r, e[dd]);
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                const uint32_t r = r0 + q;
+                if (r >= n_rounds) break;
+                for (uint32_t dd = 0; dd < d.nn; ++dd) put_ballot(L.bond + dd * d.MW, r, (eligible[q] >> dd) & 1u);
             }
         }
+        stamp(2);
         __syncthreads();
         // ---- C, D, E (stochastic bonds): the bond at rank k of the eligible ones, in (site, dim)
         // order, sees draw pos + k of the generator
@@ -771,64 +896,208 @@ __global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4
                         }
                 __syncthreads();
             }
-            draw_bits(pos, n_eligible, (CMR && phase == 1) ? 1u : 0u, d.unit ? nullptr : L.thr);
+            draw_bits(pos, n_eligible, bond_kind, d.unit ? nullptr : L.thr, pre_bonds);
+            // the cluster draws follow the bond draws: their words travel while the components are built
+            pre_clusters = prefetch_bits(pos + n_eligible, cluster_kind);
             __syncthreads();
             const uint32_t rel = pos - (pos / 256) * 256;
             uint32_t *accepted = (CMR && phase == 0) ? L.blue : L.acc;
-            for (uint32_t r = 0; r < n_rounds; ++r) {
-                const uint32_t i = r * kSwThreads + tid;
-                bool e[6] = {false, false, false, false, false, false};
-                if (i < d.N)
-                    for (uint32_t dd = 0; dd < d.nn; ++dd)
-                        if (get_bit(L.bond + dd * d.MW, i)) {
-                            const uint32_t q = rel + entries_before(i, dd);
-                            e[dd] = (L.bits[q >> 5] >> (q & 31u)) & 1u;
-                        }
-                for (uint32_t dd = 0; dd < d.nn; ++dd) put_ballot(accepted + dd * d.MW, r, e[dd]);
+            for (uint32_t r0 = 0; r0 < n_rounds; r0 += 4) { // (reads of four rounds, then their ballots)
+                uint32_t taken[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (uint32_t qq = 0; qq < 4; ++qq) {
+                    const uint32_t i = (r0 + qq) * kSwThreads + tid;
+                    if (r0 + qq >= n_rounds) break;
+                    if (i < d.N) { // the site's bonds take consecutive draws from the rank of its first one
+                        const uint32_t m = i >> 5, k = i & 31u, below = (1u << k) - 1u;
+                        uint32_t q = rel + L.wbase[m], mine = 0;
+#pragma unroll
+                        for (uint32_t x = 0; x < 6; ++x)
+                            if (x < d.nn) {
+                                const uint32_t wv = L.bond[x * d.MW + m];
+                                q += __popc(wv & below);
+                                mine |= ((wv >> k) & 1u) << x;
+                            }
+                        const uint32_t lo = L.bits[q >> 5], hi = L.bits[(q >> 5) + 1];
+                        uint32_t window = __builtin_amdgcn_alignbit(hi, lo, q & 31u); // draws q, q + 1, ...
+#pragma unroll
+                        for (uint32_t x = 0; x < 6; ++x)
+                            if (x < d.nn) {
+                                const uint32_t has = (mine >> x) & 1u;
+                                taken[qq] |= (has & window) << x;
+                                window >>= has;
+                            }
+                    }
+                }
+#pragma unroll
+                for (uint32_t qq = 0; qq < 4; ++qq) {
+                    if (r0 + qq >= n_rounds) break;
+                    for (uint32_t dd = 0; dd < d.nn; ++dd) put_ballot(accepted + dd * d.MW, r0 + qq, (taken[qq] >> dd) & 1u);
+                }
             }
             __syncthreads();
             pos += n_eligible;
         }
 
+        stamp(3);
         // ---- F: connected components.  Roots are hooked under the smaller root, so a component's
         // final root is its smallest site -- the order in which the reference meets the clusters.
-        for (uint32_t i = tid; i < d.N; i += kSwThreads) L.label[i] = i;
-        __syncthreads();
         // bonds of this phase: the eligible ones of a deterministic move, else the accepted ones
         // (CMR keeps the blue bonds: grey clusters are blue + red)
         const uint32_t *links = !STOCHASTIC ? L.bond : ((CMR && phase == 0) ? L.blue : L.acc);
         auto bonded = [&](uint32_t dd, uint32_t i) -> bool {
             return get_bit(links + dd * d.MW, i) || (CMR && phase == 1 && get_bit(L.blue + dd * d.MW, i));
         };
+        if (tid == 0) L.misc[12] = L.misc[13] = 0; // packed bonds, overflow
+        if (run_dd < 3) {
+            // Bonds to the next site need no union: a site starts under the first site of its run of such bonds (at most
+            // 32 sites back: a longer run is a chain of parents, which the finds below follow like any other).
+            auto run_word = [&](uint32_t m) -> uint32_t { // bit k: site 32 m + k is bonded to site 32 m + k + 1
+                uint32_t wv = links[run_dd * d.MW + m];
+                if (CMR && phase == 1) wv |= L.blue[run_dd * d.MW + m];
+                return wv & ~L.wrapm[run_dd * d.MW + m];
+            };
+            for (uint32_t i = tid; i < d.N; i += kSwThreads) {
+                const uint32_t m = i >> 5, k = i & 31u;
+                const uint32_t prev = m ? run_word(m - 1) : 0u;
+                const uint32_t before = k ? __builtin_amdgcn_alignbit(run_word(m), prev, k) : prev; // bit 31: bond (i - 1, i)
+                L.label[i] = i - static_cast<uint32_t>(__clz(static_cast<int>(~before)));
+            }
+        } else {
+            for (uint32_t i = tid; i < d.N; i += kSwThreads) L.label[i] = i;
+        }
+        stamp(12);
+        __syncthreads();
         // Lock-free union: every bond is visited once; the larger root is hooked under the smaller
         // one with a compare-and-swap, retried from the new roots when another lane got there first
         // (labels only ever decrease, so every chain ends and the loop terminates).
-        for (uint32_t i = tid; i < d.N; i += kSwThreads)
-            for (uint32_t dd = 0; dd < d.nn; ++dd)
-                if (bonded(dd, i)) {
-                    uint32_t ra = find_root(i), rb = find_root(p.nbr_site[i * 12 + 2 * dd]);
-                    while (ra != rb) {
-                        if (ra < rb) {
-                            const uint32_t tmp = ra;
-                            ra = rb;
-                            rb = tmp;
-                        }
-                        const uint32_t old = atomicCAS(&L.label[ra], ra, rb); // ra > rb
-                        if (old == ra) break;
-                        ra = find_root(old);
-                        rb = find_root(rb);
+        auto unite = [&](uint32_t a, uint32_t b) {
+            uint32_t ra = find_root(a), rb = find_root(b);
+            while (ra != rb) {
+                if (ra < rb) {
+                    const uint32_t tmp = ra;
+                    ra = rb;
+                    rb = tmp;
+                }
+                const uint32_t old = atomicCAS(&L.label[ra], ra, rb); // ra > rb
+                if (old == ra) break;
+                ra = find_root(old);
+                rb = find_root(rb);
+            }
+        };
+        // The bonds that need a union are few and scattered over the (site, direction) grid -- a union per grid cell runs
+        // its divergent loops for a handful of lanes, 3 x rounds times over.  So the cells with a bond are first packed
+        // into a list (site | neighbour << 16, in the `aux` words, which are free until the flatten below), one wave-level
+        // counter bump per round, and the unions then run over the list with every lane busy.  A list that would not fit
+        // (capacity N; a dense graph has up to N nn bonds) sets the overflow flag and the unions run over the grid.
+        // (on implicit lattices straight from the bond words: one thread per (direction, word), offsets by a scan)
+        auto union_word = [&](uint32_t cell) -> uint32_t { // the bonds of a (direction, word) cell that need a union
+            uint32_t wv = links[cell];
+            if (CMR && phase == 1) wv |= L.blue[cell];
+            return (run_dd < 3 && cell / d.MW == run_dd) ? wv & L.wrapm[cell] : wv;
+        };
+        auto site_bonds = [&](uint32_t i, uint32_t nb[6]) -> uint32_t { // bit dd: bond (i, nb[dd]) needs a union
+            uint32_t todo = 0;
+            if (i >= d.N) return 0u;
+            if (implicit) {
+#pragma unroll
+                for (uint32_t dd = 0; dd < 3; ++dd)
+                    if (dd < d.nn && ((union_word(dd * d.MW + (i >> 5)) >> (i & 31u)) & 1u)) {
+                        todo |= 1u << dd;
+                        nb[dd] = static_cast<uint32_t>(static_cast<int32_t>(i) + offset_of(dd, get_bit(L.wrapm + dd * d.MW, i) != 0));
+                    }
+            } else {
+#pragma unroll
+                for (uint32_t dd = 0; dd < 6; ++dd)
+                    if (dd < d.nn && bonded(dd, i)) {
+                        todo |= 1u << dd;
+                        nb[dd] = p.nbr_site[i * 12 + 2 * dd];
+                    }
+            }
+            return todo;
+        };
+        if (implicit) {
+            uint32_t carry = 0;
+            for (uint32_t c0 = 0; c0 < d.nn * d.MW; c0 += kSwThreads) {
+                const uint32_t cell = c0 + tid;
+                uint32_t wv = cell < d.nn * d.MW ? union_word(cell) : 0u, part = 0;
+                uint32_t at = carry + block_exclusive_scan(static_cast<uint32_t>(__popc(wv)), L.scratch, &part);
+                carry += part;
+                if (wv && at + __popc(wv) <= d.N) {
+                    const uint32_t dd = cell / d.MW, m = cell - dd * d.MW, wm = L.wrapm[cell];
+                    const int32_t reg = offset_of(dd, false), wrp = offset_of(dd, true);
+                    while (wv) {
+                        const uint32_t k = static_cast<uint32_t>(__ffs(static_cast<int>(wv))) - 1u, i = 32 * m + k;
+                        wv &= wv - 1u;
+                        L.aux[at++] = i | (static_cast<uint32_t>(static_cast<int32_t>(i) + (((wm >> k) & 1u) ? wrp : reg)) << 16);
                     }
                 }
+            }
+            if (tid == 0) {
+                L.misc[12] = carry;
+                L.misc[13] = carry > d.N ? 1u : 0u;
+            }
+        } else
+        for (uint32_t r = 0; r < n_rounds; ++r) {
+            const uint32_t i = r * kSwThreads + tid;
+            uint32_t nb[6] = {0, 0, 0, 0, 0, 0};
+            const uint32_t todo = site_bonds(i, nb);
+            unsigned long long votes[6];
+            uint32_t total = 0;
+#pragma unroll
+            for (uint32_t dd = 0; dd < 6; ++dd) {
+                votes[dd] = dd < d.nn ? __ballot((todo >> dd) & 1u) : 0ull;
+                total += static_cast<uint32_t>(__popcll(votes[dd]));
+            }
+            if (total == 0) continue; // (wave-uniform)
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&L.misc[12], total);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base + total > d.N) {
+                if (lane == 0) L.misc[13] = 1;
+                continue;
+            }
+#pragma unroll
+            for (uint32_t dd = 0; dd < 6; ++dd) {
+                if (dd >= d.nn) continue;
+                const uint32_t before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(votes[dd] >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(votes[dd]), 0u));
+                if ((todo >> dd) & 1u) L.aux[base + before] = i | (nb[dd] << 16);
+                base += static_cast<uint32_t>(__popcll(votes[dd]));
+            }
+        }
+        stamp(13);
+        __syncthreads();
+        stamp(14);
+        if (tid == 0 && p.slab_stamps) p.slab_stamps[static_cast<size_t>(blockIdx.x) * 16 + 15] = L.misc[12] | (static_cast<unsigned long long>(L.misc[13]) << 32);
+        if (L.misc[13] == 0) {
+            const uint32_t n_list = L.misc[12];
+            for (uint32_t e = tid; e < n_list; e += kSwThreads) {
+                const uint32_t pair = L.aux[e];
+                unite(pair & 0xFFFFu, pair >> 16);
+            }
+        } else {
+            for (uint32_t r = 0; r < n_rounds; ++r) {
+                const uint32_t i = r * kSwThreads + tid;
+                uint32_t nb[6] = {0, 0, 0, 0, 0, 0};
+                const uint32_t todo = site_bonds(i, nb);
+#pragma unroll
+                for (uint32_t dd = 0; dd < 6; ++dd)
+                    if ((todo >> dd) & 1u) unite(i, nb[dd]);
+            }
+        }
+        stamp(4);
         __syncthreads();
         for (uint32_t i = tid; i < d.N; i += kSwThreads) L.aux[i] = find_root(i); // flatten (reads only)
         __syncthreads();
         for (uint32_t i = tid; i < d.N; i += kSwThreads) L.label[i] = L.aux[i];
         __syncthreads();
 
+        stamp(5);
         // ---- what the call reports (mod.rs:442-455,604-626): sizes of this phase's clusters -- for
         // CMR the blue ones (overlap.rs:725-742) -- and the accepted bonds of a snapshot
         const uint32_t *links2 = (CMR && phase == 1) ? L.blue : nullptr;
-        const bool seed_first = wolff && (MODE == kSwHoudayer || (EXTRAS && JORG)); // reports only once a seed is found
+        const bool seed_first = EXTRAS && wolff && (MODE == kSwHoudayer || JORG); // reports only once a seed is found
         const bool reports = EXTRAS && (aux.flags & (kAuxSizes | kAuxMetrics)) != 0 && phase == 0;
         if (reports && !seed_first) report(links, links2);
         if (snap_here) {
@@ -856,7 +1125,7 @@ __global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4
             if (root == 0xFFFFFFFFu) return; // no seed: nothing flips and nothing is reported
             for (uint32_t i = tid; i < d.N; i += kSwThreads)
                 if (L.label[i] == root) {
-                    if (MODE == kSwHoudayer && group > 2) {
+                    if (EXTRAS && MODE == kSwHoudayer && group > 2) {
                         for (uint32_t k = 0; k < group; ++k)
                             atomicXor(&Stile[static_cast<size_t>(members[k] >> 5) * d.N + i], 1u << (members[k] & 31u));
                     } else {
@@ -908,6 +1177,7 @@ __global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4
             __syncthreads();
             continue;
         }
+        stamp(6);
         // ---- G: clusters that draw -- more than one site for the overlap moves (overlap.rs:312-318,
         // :757-762, :822-828), every cluster for FK (fk.rs:182-192) -- ranked by their smallest site
         for (uint32_t i = tid; i < d.N; i += kSwThreads) L.aux[i] = 0;
@@ -920,13 +1190,15 @@ __global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4
             put_ballot(L.roots, r, i < d.N && L.label[i] == i && (FK || L.aux[i] != 0));
         }
         __syncthreads();
+        stamp(7);
         const uint32_t n_clusters = scan_words([&](uint32_t m) { return static_cast<uint32_t>(__popc(L.roots[m])); });
         // ---- H: the cluster draws continue the stream after the bond draws: a coin
         // gen::<f32>() < 0.5, or for the grey clusters of CMR gen_range(0..=3) = the top two bits
         const bool grey = CMR && phase == 1;
-        draw_bits(pos, n_clusters, grey ? 3u : 2u, nullptr);
+        draw_bits(pos, n_clusters, cluster_kind, nullptr, pre_clusters);
         __syncthreads();
         const uint32_t rel = pos - (pos / 256) * 256;
+        stamp(8);
         // ---- I: flips (both systems for a coin; bit 0 / bit 1 of k for the two systems of a grey cluster)
         flip_step([&](uint32_t i, bool &fa, bool &fb) {
             const uint32_t root = L.label[i];
@@ -944,26 +1216,28 @@ __global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4
         pos += n_clusters;
         __syncthreads();
     }
+    stamp(9);
     // ---- the generator ends `pos` draws after where it started
-    if (tid == 0 && !rng_stored) {
+    if (tid < 64 && !rng_stored) { // (the first wave: its lanes share the jump, lane 0 walks the rest and stores)
         uint32_t js[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) js[k] = base_state[k];
-        if (pos / 64) jump_state_lds(js, p.jump_unit + static_cast<size_t>(pos / 64) * (64 * 16 * 8));
-        Rng32 rng;
-        rng.load(js);
-        for (uint32_t k = 0; k < (pos & 63u); ++k) (void)rng.next_top();
-        uint32_t st[8];
-        rng.store(st);
-        if (FK) {
-            store_cursor(p.cursor, real, d.SP, sa, st);
-        } else {
-            for (int q = 0; q < 4; ++q) rng_state[q] = (static_cast<uint64_t>(st[2 * q + 1]) << 32) | st[2 * q];
+        load_base_state(js);
+        if (pos / 64) jump_state_wave(js, p.jump_unit + static_cast<size_t>(pos / 64) * (64 * 16 * 8));
+        if (tid == 0) {
+            Rng32 rng;
+            rng.load(js);
+            for (uint32_t k = 0; k < (pos & 63u); ++k) (void)rng.next_top();
+            uint32_t st[8];
+            rng.store(st);
+            if (FK) {
+                store_cursor(p.cursor, real, d.SP, sa, st);
+            } else {
+                for (int q = 0; q < 4; ++q) rng_state[q] = (static_cast<uint64_t>(st[2 * q + 1]) << 32) | st[2 * q];
+            }
         }
     }
     // ---- apply the accumulated flips to the bit columns of the systems
     for (uint32_t i = tid; i < d.N; i += kSwThreads) {
-        if (MODE == kSwHoudayer && group > 2) { // every replica of the group flips with the cluster
+        if (EXTRAS && MODE == kSwHoudayer && group > 2) { // every replica of the group flips with the cluster
             if (get_bit(L.flip_a, i))
                 for (uint32_t k = 0; k < group; ++k)
                     atomicXor(&Stile[static_cast<size_t>(members[k] >> 5) * d.N + i], 1u << (members[k] & 31u));
@@ -972,6 +1246,7 @@ __global__ __launch_bounds__(kSwThreads, (LEVEL <= 1 && MODE == kSwHoudayer) ? 4
         if (get_bit(L.flip_a, i)) atomicXor(&Sa[i], 1u << ba);
         if (!FK && get_bit(L.flip_b, i)) atomicXor(&Sb[i], 1u << bb);
     }
+    stamp(11);
 }
 
 // k_top4_accumulate: top4_accum[mode][t][k] += top4 / N over the pairs of a call, in pair order
@@ -1632,15 +1907,18 @@ hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, ui
         const uint32_t draws = (oc_mode == 1 ? 0u : d.N * d.nn) + (oc_mode == 3 ? 2u : 1u) * d.N + 64u;
         aux.stream_units = std::min(cluster_stream_units(d), (draws + 63u) / 64u + 1u);
         const uint32_t *first = oc_mode == 2 ? p.jorg_thr : (oc_mode == 3 ? p.cmr_thr : nullptr);
-        const dim3 sgrid(aux.stream_units * ((d.n_real * d.n_temps * d.n_pairs + 255u) / 256u));
-        if (d.unit)
-            PA_LAUNCH(k_pair_stream<false>, sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, first, 0);
+        const uint32_t kStreamRun = stream_run();
+        const dim3 sgrid(((aux.stream_units + kStreamRun - 1) / kStreamRun) * ((d.n_real * d.n_temps * d.n_pairs + 255u) / 256u));
+        if (!d.unit)
+            PA_LAUNCH((k_pair_stream<true, false>), sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, first, 0, kStreamRun);
+        else if (oc_mode == 3) // CMR: both thresholds and the two-bit draws of the grey clusters
+            PA_LAUNCH((k_pair_stream<false, true>), sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, first, 0, kStreamRun);
         else
-            PA_LAUNCH(k_pair_stream<true>, sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, first, 0);
+            PA_LAUNCH((k_pair_stream<false, false>), sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, first, 0, kStreamRun);
     }
     const dim3 grid(d.n_real * d.n_temps * (d.n_replicas / group));
     // PA_OC_HOUDAYER = 1 has its single-cluster form in every build
-    const int level = cluster_sw_level(aux.flags, wolff && oc_mode != 1);
+    const int level = cluster_sw_level(aux.flags, wolff || group > 2);
     if (oc_mode == 2) // PA_OC_JORG
         launch_sw_build<kSwJorg>(level, grid, stream, d, p, 2u, wolff ? 1 : 0, aux);
     else if (oc_mode == 3) // PA_OC_CMR
@@ -1700,11 +1978,12 @@ hipError_t launch_fk(const SimDims &d, const DevPtrs &p, bool wolff, const Clust
     PA_LAUNCH(k_slot_bitmaps, dim3(d.n_real * d.W * ((d.N + 255) / 256)), dim3(256), 0, stream, d, p);
     {
         aux.stream_units = std::min(cluster_stream_units(d), (d.N * d.nn + d.N + 64u + 63u) / 64u + 1u);
-        const dim3 sgrid(aux.stream_units * ((d.n_real * d.n_sys + 255u) / 256u));
+        const uint32_t kStreamRun = stream_run();
+        const dim3 sgrid(((aux.stream_units + kStreamRun - 1) / kStreamRun) * ((d.n_real * d.n_sys + 255u) / 256u));
         if (d.unit)
-            PA_LAUNCH(k_pair_stream<false>, sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, p.fk_thr, 1);
+            PA_LAUNCH((k_pair_stream<false, false>), sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, p.fk_thr, 1, kStreamRun);
         else
-            PA_LAUNCH(k_pair_stream<true>, sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, p.fk_thr, 1);
+            PA_LAUNCH((k_pair_stream<true, false>), sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, p.fk_thr, 1, kStreamRun);
     }
     launch_sw_build<kSwFk>(cluster_sw_level(aux.flags, wolff), dim3(d.n_real * d.n_sys), stream, d, p, 1u, wolff ? 1 : 0, aux);
     return hipGetLastError();

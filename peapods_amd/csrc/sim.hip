@@ -91,6 +91,7 @@ struct pa_sim {
     uint32_t *reg_pos = nullptr, *reg_cpl = nullptr; // k_sweep_reg tables (SimDims::reg_ok)
     uint16_t *nbr_site = nullptr;
     uint32_t *jsite = nullptr, *nbr_wide = nullptr;
+    uint32_t *sw_wrap = nullptr, *sw_cpl = nullptr; // bitmaps of the word-parallel cluster phases (SimDims::hc)
     uint4 *fwd_big = nullptr;
     float *jorg_p = nullptr;
     uint32_t *thr_gibbs = nullptr; // built by the first Gibbs sample (ensure_gibbs)
@@ -466,6 +467,7 @@ DevPtrs offset_ptrs(const DevPtrs &p, const SimDims &d, uint32_t r0) {
     q.swap_masks += static_cast<size_t>(2) * d.W * r0;
     q.pair_rng += static_cast<size_t>(4) * d.n_temps * d.n_pairs * r0;
     q.jsite += static_cast<size_t>(d.N) * r0;
+    if (q.sw_cpl) q.sw_cpl += static_cast<size_t>(6) * d.MW * r0;
     if (q.eq_sum) {
         q.eq_sum += static_cast<size_t>(2) * d.n_temps * r0;
         q.eq_ckpt += static_cast<size_t>(64) * 2 * d.n_temps * r0;
@@ -1301,7 +1303,23 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                 if (uf_all || (take_snapshot && first_group && dfs_same)) {
                     ClusterAux a2 = aux;
                     if (take_snapshot && first_group) a2.flags |= kAuxSnapshot;
-                    PA_HIP(sim, launch_cluster_sw(g.d, g.p, oc_kind, oc_group, !oc_sw, a2, g.stream, move_riders));
+                    DevPtrs qq = g.p;
+                    static unsigned long long *stamp_buf = nullptr;
+                    static int stamp_calls = 0;
+                    const char *stamp_path = dev_env("PEAPODS_SW_STAMPS");
+                    const size_t stamp_words = static_cast<size_t>(g.d.n_real) * d.n_temps * d.n_pairs * 16;
+                    if (stamp_path) {
+                        if (!stamp_buf) { (void)hipMalloc(reinterpret_cast<void **>(&stamp_buf), stamp_words * 8); }
+                        qq.slab_stamps = stamp_buf;
+                    }
+                    PA_HIP(sim, launch_cluster_sw(g.d, qq, oc_kind, oc_group, !oc_sw, a2, g.stream, move_riders));
+                    if (stamp_path && ++stamp_calls == 100) {
+                        (void)hipStreamSynchronize(g.stream);
+                        std::vector<unsigned long long> host(stamp_words);
+                        (void)hipMemcpy(host.data(), stamp_buf, stamp_words * 8, hipMemcpyDeviceToHost);
+                        FILE *fh = fopen(stamp_path, "wb");
+                        if (fh) { fwrite(host.data(), 8, stamp_words, fh); fclose(fh); }
+                    }
                 } else if (take_snapshot && first_group) {
                     // the first realisation alone takes the union-find path, the others the search
                     SimDims d0 = g.d, d1 = g.d;
@@ -2292,6 +2310,24 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     ok(bufs.alloc(&p.swap_masks, static_cast<size_t>(d.n_real) * 2 * d.W));
     ok(bufs.alloc(&p.pair_rng, static_cast<size_t>(d.n_real) * d.n_temps * d.n_pairs * 4));
     ok(bufs.alloc(&sim->nbr_site, nbr_site.size()));
+    // the same per-site facts as bitmaps over the sites, for the cluster kernels' word-parallel phases
+    std::vector<uint32_t> sw_wrap, sw_cpl;
+    if (d.hc) {
+        sw_wrap.assign(static_cast<size_t>(3) * d.MW, 0u);
+        sw_cpl.assign(static_cast<size_t>(d.n_real) * 6 * d.MW, 0u);
+        for (uint32_t real = 0; real < d.n_real; ++real)
+            for (uint32_t i = 0; i < d.N; ++i) {
+                const uint32_t js = jsite[static_cast<size_t>(real) * d.N + i];
+                for (uint32_t dd = 0; dd < 3; ++dd) {
+                    if (real == 0 && static_cast<int64_t>(lat.fwd[i * d.nn + (dd < d.nn ? dd : 0)]) - static_cast<int64_t>(i) != d.hc_d0[2 * dd] / 4 && dd < d.nn)
+                        sw_wrap[dd * d.MW + (i >> 5)] |= 1u << (i & 31u);
+                    if ((js >> (2 * dd)) & 1u) sw_cpl[(static_cast<size_t>(real) * 6 + dd) * d.MW + (i >> 5)] |= 1u << (i & 31u);
+                    if ((js >> (12 + 2 * dd)) & 1u) sw_cpl[(static_cast<size_t>(real) * 6 + 3 + dd) * d.MW + (i >> 5)] |= 1u << (i & 31u);
+                }
+            }
+        ok(bufs.alloc(&sim->sw_wrap, sw_wrap.size()));
+        ok(bufs.alloc(&sim->sw_cpl, sw_cpl.size()));
+    }
     ok(bufs.alloc(&sim->jsite, jsite.size()));
     std::vector<uint4> fwd_big;
     if (d.big) { // forward neighbours by site for the energy / overlap kernels of the large path
@@ -2327,6 +2363,8 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
     p.dbeta = sim->dbeta;
     p.nbr_site = sim->nbr_site;
     p.jsite = sim->jsite;
+    p.sw_wrap = sim->sw_wrap;
+    p.sw_cpl = sim->sw_cpl;
     p.fwd_big = sim->fwd_big;
     if (d.big && (rc = upload(sim, sim->fwd_big, fwd_big))) return bail(rc);
     p.nbr_wide = sim->nbr_wide;
@@ -2372,6 +2410,7 @@ int pa_sim_create(const pa_sim_desc *desc, pa_sim **out, char *err, size_t err_l
         (!rec_wide.empty() && (rc = upload(sim, sim->rec_wide, rec_wide))) || (d.wide && (rc = upload(sim, sim->thr_wide, thr_wide))) ||
         (d.thin_chunks && (rc = upload(sim, sim->rec_thin, rec_thin))) ||
         (rc = upload(sim, sim->jump, jump)) || (rc = upload(sim, sim->nbr_site, nbr_site)) ||
+        (d.hc && ((rc = upload(sim, sim->sw_wrap, sw_wrap)) || (rc = upload(sim, sim->sw_cpl, sw_cpl)))) ||
         (rc = upload(sim, sim->jsite, jsite)) || (rc = upload(sim, sim->nbr_wide, nbr_wide)) || (rc = upload(sim, sim->jorg_p, jorg_p)) ||
         (rc = upload(sim, sim->nz_bonds, nz_bonds)) || (rc = upload(sim, sim->dbeta, dbeta)))
         return bail(rc);

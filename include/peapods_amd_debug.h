@@ -23,6 +23,11 @@ int pa_debug_sweep_reg_stamps(pa_sim *sim, unsigned long long *out, uint64_t cap
 /* s_memrealtime at every level of every workgroup of one k_sweep_slab launch after `settle` ordinary sweeps:
  * out[workgroups][n_levels + 4] = {first level, last level, stamp per level ...}; returns the number of workgroups */
 int pa_debug_slab_stamps(pa_sim *sim, unsigned long long *out, uint64_t capacity_words, uint32_t settle);
+/* phase stamps of the union-find cluster kernel (k_cluster_sw), every workgroup = one pair / system of one move.
+ * enable != 0: the handle's sampling calls stamp from now on (use a handle with one stream group); enable == 0: copy the
+ * rows of the last launch, out[workgroups][16] (s_memrealtime, 100 MHz; the slots are listed in tools/stamps_cluster.py),
+ * and stop.  Returns the number of workgroups. */
+int pa_debug_cluster_stamps(pa_sim *sim, int enable, unsigned long long *out, uint64_t capacity_blocks);
 /* shader-clock stamps of the phases of one measurement launch (k_measure) */
 int pa_debug_measure_stamps(pa_sim *sim, unsigned long long out[7]);
 

@@ -315,6 +315,9 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
         L.thr = q;
     }
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    // diagnostic (pa_debug_cluster_stamps; the pointer is null otherwise): s_memrealtime of the first lane at the phase
+    // boundaries -- 0 entry, 1 bitmaps, 2 eligible bonds, 3 bond draws, 12 labelled by runs, 4 united,
+    // 5 flattened, 6 reported, 7 drawing roots, 8 cluster draws, 9 flips decided, 11 end
     auto stamp = [&](int k) {
         if (p.slab_stamps && threadIdx.x == 0) p.slab_stamps[static_cast<size_t>(blockIdx.x) * 16 + k] = wall_clock64();
     };
@@ -996,47 +999,50 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
             if (CMR && phase == 1) wv |= L.blue[cell];
             return (run_dd < 3 && cell / d.MW == run_dd) ? wv & L.wrapm[cell] : wv;
         };
-        auto site_bonds = [&](uint32_t i, uint32_t nb[6]) -> uint32_t { // bit dd: bond (i, nb[dd]) needs a union
+        auto site_bonds = [&](uint32_t i, uint32_t nb[6]) -> uint32_t { // (table lattices) bit dd: bond (i, nb[dd]) needs a union
             uint32_t todo = 0;
             if (i >= d.N) return 0u;
-            if (implicit) {
 #pragma unroll
-                for (uint32_t dd = 0; dd < 3; ++dd)
-                    if (dd < d.nn && ((union_word(dd * d.MW + (i >> 5)) >> (i & 31u)) & 1u)) {
-                        todo |= 1u << dd;
-                        nb[dd] = static_cast<uint32_t>(static_cast<int32_t>(i) + offset_of(dd, get_bit(L.wrapm + dd * d.MW, i) != 0));
-                    }
-            } else {
-#pragma unroll
-                for (uint32_t dd = 0; dd < 6; ++dd)
-                    if (dd < d.nn && bonded(dd, i)) {
-                        todo |= 1u << dd;
-                        nb[dd] = p.nbr_site[i * 12 + 2 * dd];
-                    }
-            }
+            for (uint32_t dd = 0; dd < 6; ++dd)
+                if (dd < d.nn && bonded(dd, i)) {
+                    todo |= 1u << dd;
+                    nb[dd] = p.nbr_site[i * 12 + 2 * dd];
+                }
             return todo;
         };
         if (implicit) {
-            uint32_t carry = 0;
-            for (uint32_t c0 = 0; c0 < d.nn * d.MW; c0 += kSwThreads) {
-                const uint32_t cell = c0 + tid;
-                uint32_t wv = cell < d.nn * d.MW ? union_word(cell) : 0u, part = 0;
-                uint32_t at = carry + block_exclusive_scan(static_cast<uint32_t>(__popc(wv)), L.scratch, &part);
-                carry += part;
-                if (wv && at + __popc(wv) <= d.N) {
-                    const uint32_t dd = cell / d.MW, m = cell - dd * d.MW, wm = L.wrapm[cell];
-                    const int32_t reg = offset_of(dd, false), wrp = offset_of(dd, true);
-                    while (wv) {
-                        const uint32_t k = static_cast<uint32_t>(__ffs(static_cast<int>(wv))) - 1u, i = 32 * m + k;
-                        wv &= wv - 1u;
-                        L.aux[at++] = i | (static_cast<uint32_t>(static_cast<int32_t>(i) + (((wm >> k) & 1u) ? wrp : reg)) << 16);
+            // pack the cells [c_lo, c_hi) and unite over the list; false (nothing united) when the list would not fit
+            auto union_pass = [&](uint32_t c_lo, uint32_t c_hi) -> bool {
+                uint32_t carry = 0; // (every thread sees the same totals)
+                for (uint32_t c0 = c_lo; c0 < c_hi; c0 += kSwThreads) {
+                    const uint32_t cell = c0 + tid;
+                    uint32_t wv = cell < c_hi ? union_word(cell) : 0u, part = 0;
+                    uint32_t at = carry + block_exclusive_scan(static_cast<uint32_t>(__popc(wv)), L.scratch, &part);
+                    carry += part;
+                    if (wv && at + __popc(wv) <= d.N) {
+                        const uint32_t dd = cell / d.MW, m = cell - dd * d.MW, wm = L.wrapm[cell];
+                        const int32_t reg = offset_of(dd, false), wrp = offset_of(dd, true);
+                        while (wv) {
+                            const uint32_t k = static_cast<uint32_t>(__ffs(static_cast<int>(wv))) - 1u, i = 32 * m + k;
+                            wv &= wv - 1u;
+                            L.aux[at++] = i | (static_cast<uint32_t>(static_cast<int32_t>(i) + (((wm >> k) & 1u) ? wrp : reg)) << 16);
+                        }
                     }
                 }
-            }
-            if (tid == 0) {
-                L.misc[12] = carry;
-                L.misc[13] = carry > d.N ? 1u : 0u;
-            }
+                __syncthreads();
+                if (carry > d.N) return false;
+                for (uint32_t e = tid; e < carry; e += kSwThreads) {
+                    const uint32_t pair = L.aux[e];
+                    unite(pair & 0xFFFFu, pair >> 16);
+                }
+                return true;
+            };
+            // all directions at once when their bonds fit the list, else one direction at a time (at most N bonds each)
+            if (!union_pass(0, d.nn * d.MW))
+                for (uint32_t dd = 0; dd < d.nn; ++dd) {
+                    union_pass(dd * d.MW, (dd + 1) * d.MW);
+                    __syncthreads();
+                }
         } else
         for (uint32_t r = 0; r < n_rounds; ++r) {
             const uint32_t i = r * kSwThreads + tid;
@@ -1066,11 +1072,9 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
                 base += static_cast<uint32_t>(__popcll(votes[dd]));
             }
         }
-        stamp(13);
         __syncthreads();
-        stamp(14);
-        if (tid == 0 && p.slab_stamps) p.slab_stamps[static_cast<size_t>(blockIdx.x) * 16 + 15] = L.misc[12] | (static_cast<unsigned long long>(L.misc[13]) << 32);
-        if (L.misc[13] == 0) {
+        if (implicit) {
+        } else if (L.misc[13] == 0) {
             const uint32_t n_list = L.misc[12];
             for (uint32_t e = tid; e < n_list; e += kSwThreads) {
                 const uint32_t pair = L.aux[e];

@@ -92,6 +92,7 @@ struct pa_sim {
     uint16_t *nbr_site = nullptr;
     uint32_t *jsite = nullptr, *nbr_wide = nullptr;
     uint32_t *sw_wrap = nullptr, *sw_cpl = nullptr; // bitmaps of the word-parallel cluster phases (SimDims::hc)
+    unsigned long long *cluster_stamps = nullptr; // pa_debug_cluster_stamps: [tasks][16] phase stamps of the last k_cluster_sw launch
     uint4 *fwd_big = nullptr;
     float *jorg_p = nullptr;
     uint32_t *thr_gibbs = nullptr; // built by the first Gibbs sample (ensure_gibbs)
@@ -1304,22 +1305,8 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                     ClusterAux a2 = aux;
                     if (take_snapshot && first_group) a2.flags |= kAuxSnapshot;
                     DevPtrs qq = g.p;
-                    static unsigned long long *stamp_buf = nullptr;
-                    static int stamp_calls = 0;
-                    const char *stamp_path = dev_env("PEAPODS_SW_STAMPS");
-                    const size_t stamp_words = static_cast<size_t>(g.d.n_real) * d.n_temps * d.n_pairs * 16;
-                    if (stamp_path) {
-                        if (!stamp_buf) { (void)hipMalloc(reinterpret_cast<void **>(&stamp_buf), stamp_words * 8); }
-                        qq.slab_stamps = stamp_buf;
-                    }
+                    qq.slab_stamps = sim->cluster_stamps; // diagnostic (pa_debug_cluster_stamps), normally null
                     PA_HIP(sim, launch_cluster_sw(g.d, qq, oc_kind, oc_group, !oc_sw, a2, g.stream, move_riders));
-                    if (stamp_path && ++stamp_calls == 100) {
-                        (void)hipStreamSynchronize(g.stream);
-                        std::vector<unsigned long long> host(stamp_words);
-                        (void)hipMemcpy(host.data(), stamp_buf, stamp_words * 8, hipMemcpyDeviceToHost);
-                        FILE *fh = fopen(stamp_path, "wb");
-                        if (fh) { fwrite(host.data(), 8, stamp_words, fh); fclose(fh); }
-                    }
                 } else if (take_snapshot && first_group) {
                     // the first realisation alone takes the union-find path, the others the search
                     SimDims d0 = g.d, d1 = g.d;
@@ -2454,6 +2441,7 @@ void pa_sim_destroy(pa_sim *sim) {
                             static_cast<void *>(sim->p.snap_ids), static_cast<void *>(sim->p.snap_blue),
                             static_cast<void *>(sim->p.snap_spins), static_cast<void *>(sim->p.snap_sids)})
             if (extra) (void)hipFree(extra);
+        if (sim->cluster_stamps) (void)hipFree(sim->cluster_stamps);
         for (void *area : sim->uncached_areas) (void)hipFree(area);
         sim->buffers.release();
         (void)hipStreamDestroy(sim->stream);
@@ -2709,6 +2697,30 @@ int pa_debug_slab_stamps(pa_sim *sim, unsigned long long *out, uint64_t capacity
     PA_HIP(sim, hipStreamSynchronize(sim->stream));
     PA_HIP(sim, hipMemcpy(out, dev, words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     (void)hipFree(dev);
+    return static_cast<int>(n_blocks);
+}
+
+// Diagnostic only.  enable != 0: every union-find cluster launch of the handle's sampling calls from now on leaves
+// s_memrealtime (100 MHz) stamps of its phases, [workgroup][16] (kernels_cluster.hip: stamp(k)); meant for a handle with one
+// stream group (two groups would write the same rows).  enable == 0: copy the rows of the last launch to out, stop stamping;
+// returns the number of workgroups.
+int pa_debug_cluster_stamps(pa_sim *sim, int enable, unsigned long long *out, uint64_t capacity_blocks) {
+    const SimDims &d = sim->d;
+    PA_HIP(sim, hipSetDevice(sim->device));
+    const size_t n_blocks = static_cast<size_t>(d.n_real) * std::max(d.n_temps * std::max(d.n_pairs, 1u), d.n_sys);
+    if (enable) {
+        if (!sim->cluster_stamps) {
+            PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&sim->cluster_stamps), n_blocks * 16 * sizeof(unsigned long long)));
+            PA_HIP(sim, hipMemset(sim->cluster_stamps, 0, n_blocks * 16 * sizeof(unsigned long long)));
+        }
+        return static_cast<int>(n_blocks);
+    }
+    if (!sim->cluster_stamps) return 0;
+    if (capacity_blocks < n_blocks) return fail(sim, PA_ERR_INVALID, "stamp buffer too small");
+    PA_HIP(sim, hipDeviceSynchronize());
+    PA_HIP(sim, hipMemcpy(out, sim->cluster_stamps, n_blocks * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    (void)hipFree(sim->cluster_stamps);
+    sim->cluster_stamps = nullptr;
     return static_cast<int>(n_blocks);
 }
 

@@ -360,11 +360,14 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
         const int32_t ext = dd == 0 ? d.hc_dd[0] : (dd == 1 ? d.hc_dd[2] : d.hc_dd[4]);
         return (reg + (wrapped ? ext : 0)) >> 2;
     };
-    auto shifted = [&](const uint32_t *bitmap, uint32_t m, int32_t off) -> uint32_t { // word m of: bit i = bitmap bit i + off
+    auto shifted_words = [&](auto word_at, uint32_t m, int32_t off) -> uint32_t { // word m of: bit i = bit i + off of the bitmap
         const int32_t s = static_cast<int32_t>(32 * m) + off, w = s >> 5;
-        const uint32_t lo = (w >= 0 && w < static_cast<int32_t>(d.MW)) ? bitmap[w] : 0u;
-        const uint32_t hi = (w + 1 >= 0 && w + 1 < static_cast<int32_t>(d.MW)) ? bitmap[w + 1] : 0u;
+        const uint32_t lo = (w >= 0 && w < static_cast<int32_t>(d.MW)) ? word_at(static_cast<uint32_t>(w)) : 0u;
+        const uint32_t hi = (w + 1 >= 0 && w + 1 < static_cast<int32_t>(d.MW)) ? word_at(static_cast<uint32_t>(w + 1)) : 0u;
         return __builtin_amdgcn_alignbit(hi, lo, static_cast<uint32_t>(s) & 31u);
+    };
+    auto shifted = [&](const uint32_t *bitmap, uint32_t m, int32_t off) -> uint32_t {
+        return shifted_words([&](uint32_t w) { return bitmap[w]; }, m, off);
     };
     // the direction whose regular forward neighbour is the next site (3: none)
     const uint32_t run_dd = !implicit ? 3u : (d.hc_d0[0] == 4 ? 0u : (d.nn > 1 && d.hc_d0[2] == 4 ? 1u : (d.nn > 2 && d.hc_d0[4] == 4 ? 2u : 3u)));
@@ -966,6 +969,8 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
                 const uint32_t before = k ? __builtin_amdgcn_alignbit(run_word(m), prev, k) : prev; // bit 31: bond (i - 1, i)
                 L.label[i] = i - static_cast<uint32_t>(__clz(static_cast<int>(~before)));
             }
+            // the run bonds as a bitmap of their own (in `roots`, free until the clusters draw): union_word below
+            for (uint32_t m = tid; m < d.MW; m += kSwThreads) L.roots[m] = run_word(m);
         } else {
             for (uint32_t i = tid; i < d.N; i += kSwThreads) L.label[i] = i;
         }
@@ -994,10 +999,23 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
         // counter bump per round, and the unions then run over the list with every lane busy.  A list that would not fit
         // (capacity N; a dense graph has up to N nn bonds) sets the overflow flag and the unions run over the grid.
         // (on implicit lattices straight from the bond words: one thread per (direction, word), offsets by a scan)
-        auto union_word = [&](uint32_t cell) -> uint32_t { // the bonds of a (direction, word) cell that need a union
-            uint32_t wv = links[cell];
-            if (CMR && phase == 1) wv |= L.blue[cell];
-            return (run_dd < 3 && cell / d.MW == run_dd) ? wv & L.wrapm[cell] : wv;
+        // The bonds of a (direction, word) cell that need a union.  In the run direction only the bonds through the wrap
+        // are left.  In the others a bond at site i adds nothing when the previous site has the same bond and run bonds
+        // join the two sites on both sides (a square of bonds: any three connect its corners) -- of a stretch of such
+        // bonds between two runs only the first stays, which in a compact cluster is most of them gone.
+        auto union_word = [&](uint32_t cell) -> uint32_t {
+            auto bonds_of = [&](uint32_t c) -> uint32_t { return links[c] | ((CMR && phase == 1) ? L.blue[c] : 0u); };
+            const uint32_t wv = bonds_of(cell);
+            if (run_dd >= 3) return wv;
+            const uint32_t dd = cell / d.MW, m = cell - dd * d.MW;
+            if (dd == run_dd) return wv & L.wrapm[cell];
+            const int32_t reg = offset_of(dd, false), wrp = offset_of(dd, true);
+            auto squares = [&](uint32_t c, uint32_t mm) -> uint32_t { // bit j: bond at j, run bonds (j, j + 1) here and across
+                const uint32_t wm = L.wrapm[c];
+                return bonds_of(c) & L.roots[mm] & ((shifted(L.roots, mm, reg) & ~wm) | (shifted(L.roots, mm, wrp) & wm));
+            };
+            const uint32_t carry_in = m ? squares(cell - 1, m - 1) >> 31 : 0u;
+            return wv & ~((squares(cell, m) << 1) | carry_in);
         };
         auto site_bonds = [&](uint32_t i, uint32_t nb[6]) -> uint32_t { // (table lattices) bit dd: bond (i, nb[dd]) needs a union
             uint32_t todo = 0;
@@ -1092,9 +1110,29 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
         }
         stamp(4);
         __syncthreads();
-        for (uint32_t i = tid; i < d.N; i += kSwThreads) L.aux[i] = find_root(i); // flatten (reads only)
-        __syncthreads();
-        for (uint32_t i = tid; i < d.N; i += kSwThreads) L.label[i] = L.aux[i];
+        if (implicit) {
+            // flatten in place: with finds that only read, a label is written by its own thread alone, and whoever reads
+            // it on the way meets the old parent or the root.  The roots go to a bitmap (`roots`; the run bonds are done).
+            for (uint32_t r = 0; r < n_rounds; ++r) {
+                const uint32_t i = r * kSwThreads + tid;
+                bool is_root = false;
+                if (i < d.N) {
+                    uint32_t x = i;
+                    for (;;) {
+                        const uint32_t up = L.label[x];
+                        if (up == x) break;
+                        x = up;
+                    }
+                    L.label[i] = x;
+                    is_root = x == i;
+                }
+                put_ballot(L.roots, r, is_root);
+            }
+        } else {
+            for (uint32_t i = tid; i < d.N; i += kSwThreads) L.aux[i] = find_root(i); // flatten (reads only)
+            __syncthreads();
+            for (uint32_t i = tid; i < d.N; i += kSwThreads) L.label[i] = L.aux[i];
+        }
         __syncthreads();
 
         stamp(5);
@@ -1184,18 +1222,45 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
         stamp(6);
         // ---- G: clusters that draw -- more than one site for the overlap moves (overlap.rs:312-318,
         // :757-762, :822-828), every cluster for FK (fk.rs:182-192) -- ranked by their smallest site
-        for (uint32_t i = tid; i < d.N; i += kSwThreads) L.aux[i] = 0;
-        __syncthreads();
-        for (uint32_t i = tid; i < d.N; i += kSwThreads)
-            if (L.label[i] != i) L.aux[L.label[i]] = 1;
-        __syncthreads();
-        for (uint32_t r = 0; r < n_rounds; ++r) {
-            const uint32_t i = r * kSwThreads + tid;
-            put_ballot(L.roots, r, i < d.N && L.label[i] == i && (FK || L.aux[i] != 0));
+        uint32_t n_clusters;
+        if (implicit) {
+            // a root's cluster has more than one site exactly when a bond touches the root: its own forward bonds, or the
+            // forward bonds of its backward neighbours (the bond words shifted the other way) -- whole words again
+            auto touched = [&](uint32_t m) -> uint32_t {
+                auto bonds_of = [&](uint32_t c) -> uint32_t { return links[c] | ((CMR && phase == 1) ? L.blue[c] : 0u); };
+                uint32_t any = 0;
+#pragma unroll
+                for (uint32_t dd = 0; dd < 3; ++dd)
+                    if (dd < d.nn) {
+                        auto plain = [&](uint32_t w) { return bonds_of(dd * d.MW + w) & ~L.wrapm[dd * d.MW + w]; };
+                        auto wrapped = [&](uint32_t w) { return bonds_of(dd * d.MW + w) & L.wrapm[dd * d.MW + w]; };
+                        // (an extent of one makes a site its own neighbour: such a bond joins nothing)
+                        const int32_t reg = offset_of(dd, false), wrp = offset_of(dd, true);
+                        if (reg != 0) any |= plain(m) | shifted_words(plain, m, -reg);
+                        if (wrp != 0) any |= wrapped(m) | shifted_words(wrapped, m, -wrp);
+                    }
+                return any;
+            };
+            stamp(7);
+            n_clusters = scan_words([&](uint32_t m) {
+                const uint32_t drawing = FK ? L.roots[m] : (L.roots[m] & touched(m));
+                L.roots[m] = drawing;
+                return static_cast<uint32_t>(__popc(drawing));
+            });
+        } else {
+            for (uint32_t i = tid; i < d.N; i += kSwThreads) L.aux[i] = 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < d.N; i += kSwThreads)
+                if (L.label[i] != i) L.aux[L.label[i]] = 1;
+            __syncthreads();
+            for (uint32_t r = 0; r < n_rounds; ++r) {
+                const uint32_t i = r * kSwThreads + tid;
+                put_ballot(L.roots, r, i < d.N && L.label[i] == i && (FK || L.aux[i] != 0));
+            }
+            __syncthreads();
+            stamp(7);
+            n_clusters = scan_words([&](uint32_t m) { return static_cast<uint32_t>(__popc(L.roots[m])); });
         }
-        __syncthreads();
-        stamp(7);
-        const uint32_t n_clusters = scan_words([&](uint32_t m) { return static_cast<uint32_t>(__popc(L.roots[m])); });
         // ---- H: the cluster draws continue the stream after the bond draws: a coin
         // gen::<f32>() < 0.5, or for the grey clusters of CMR gen_range(0..=3) = the top two bits
         const bool grey = CMR && phase == 1;
@@ -1204,6 +1269,32 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
         const uint32_t rel = pos - (pos / 256) * 256;
         stamp(8);
         // ---- I: flips (both systems for a coin; bit 0 / bit 1 of k for the two systems of a grey cluster)
+        if (implicit) {
+            // the draws of a word's roots are consecutive bits of the stream: deposit them at the roots' positions, once
+            // per word, and a site's flip is one bit of that map at its label (`acc`: the bonds are done with)
+            for (uint32_t m = tid; m < d.MW; m += kSwThreads) {
+                uint32_t at = L.roots[m], coin_a = 0, coin_b = 0;
+                const uint32_t q = rel + L.wbase[m];
+                uint32_t draws_a = __builtin_amdgcn_alignbit(L.bits[(q >> 5) + 1], L.bits[q >> 5], q & 31u);
+                uint32_t draws_b = grey ? __builtin_amdgcn_alignbit(L.bits2[(q >> 5) + 1], L.bits2[q >> 5], q & 31u) : 0u;
+                while (at) {
+                    const uint32_t k = static_cast<uint32_t>(__ffs(static_cast<int>(at))) - 1u;
+                    at &= at - 1u;
+                    coin_a |= (draws_a & 1u) << k;
+                    coin_b |= (draws_b & 1u) << k;
+                    draws_a >>= 1;
+                    draws_b >>= 1;
+                }
+                L.acc[m] = coin_a;
+                L.acc[d.MW + m] = grey ? coin_b : coin_a;
+            }
+            __syncthreads();
+            flip_step([&](uint32_t i, bool &fa, bool &fb) {
+                const uint32_t root = L.label[i];
+                fa = get_bit(L.acc, root) != 0;
+                fb = get_bit(L.acc + d.MW, root) != 0;
+            });
+        } else
         flip_step([&](uint32_t i, bool &fa, bool &fb) {
             const uint32_t root = L.label[i];
             if (FK || L.aux[root]) {

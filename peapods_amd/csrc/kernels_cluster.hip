@@ -779,6 +779,7 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
         }
     };
     uint32_t pos = 0; // draws of the generator consumed so far
+    bool flips_applied = false; // the flips went to the bit columns as they were decided
     bool rng_stored = false; // a single-cluster form has already written the generator back
     if (EXTRAS && CMR && wolff) { // the single-cluster form of the union-find path draws its seed first (overlap.rs:691-695)
         if (tid == 0) {
@@ -908,6 +909,23 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
             __syncthreads();
             const uint32_t rel = pos - (pos / 256) * 256;
             uint32_t *accepted = (CMR && phase == 0) ? L.blue : L.acc;
+            if (implicit) { // one thread per (direction, word): its eligible bonds one by one, each at its rank in the word
+                for (uint32_t cell = tid; cell < d.nn * d.MW; cell += kSwThreads) {
+                    const uint32_t dd = cell / d.MW, m = cell - dd * d.MW;
+                    const uint32_t e0 = L.bond[m], e1 = d.nn > 1 ? L.bond[d.MW + m] : 0u, e2 = d.nn > 2 ? L.bond[2 * d.MW + m] : 0u;
+                    const uint32_t first = dd > 0 ? e0 : 0u, second = dd > 1 ? e1 : 0u; // the site's bonds drawn before this one
+                    const uint32_t q0 = rel + L.wbase[m];
+                    uint32_t todo = dd == 0 ? e0 : (dd == 1 ? e1 : e2), taken = 0;
+                    while (todo) {
+                        const uint32_t k = static_cast<uint32_t>(__ffs(static_cast<int>(todo))) - 1u, below = (1u << k) - 1u;
+                        todo &= todo - 1u;
+                        const uint32_t q = q0 + __popc(e0 & below) + __popc(e1 & below) + __popc(e2 & below) + ((first >> k) & 1u) +
+                                           ((second >> k) & 1u);
+                        taken |= ((L.bits[q >> 5] >> (q & 31u)) & 1u) << k;
+                    }
+                    accepted[cell] = taken;
+                }
+            } else
             for (uint32_t r0 = 0; r0 < n_rounds; r0 += 4) { // (reads of four rounds, then their ballots)
                 uint32_t taken[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -1289,6 +1307,17 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
                 L.acc[d.MW + m] = grey ? coin_b : coin_a;
             }
             __syncthreads();
+            if (N_PHASES == 1 && !(EXTRAS && MODE == kSwHoudayer && group > 2)) {
+                // nothing reads the systems' bitmaps after a single-phase move: the flips go straight to the bit columns
+                for (uint32_t i = tid; i < d.N; i += kSwThreads) {
+                    const uint32_t root = L.label[i];
+                    if (get_bit(L.acc, root)) {
+                        atomicXor(&Sa[i], 1u << ba);
+                        if (!FK) atomicXor(&Sb[i], 1u << bb);
+                    }
+                }
+                flips_applied = true;
+            } else
             flip_step([&](uint32_t i, bool &fa, bool &fb) {
                 const uint32_t root = L.label[i];
                 fa = get_bit(L.acc, root) != 0;
@@ -1317,12 +1346,12 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
         uint32_t js[8];
         load_base_state(js);
         if (pos / 64) jump_state_wave(js, p.jump_unit + static_cast<size_t>(pos / 64) * (64 * 16 * 8));
+        // (the tables of T^1 .. T^63 follow those of the units)
+        if (pos & 63u) jump_state_wave(js, p.jump_unit + static_cast<size_t>(cluster_stream_units(d) + (pos & 63u)) * (64 * 16 * 8));
         if (tid == 0) {
-            Rng32 rng;
-            rng.load(js);
-            for (uint32_t k = 0; k < (pos & 63u); ++k) (void)rng.next_top();
             uint32_t st[8];
-            rng.store(st);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) st[k] = js[k];
             if (FK) {
                 store_cursor(p.cursor, real, d.SP, sa, st);
             } else {
@@ -1331,6 +1360,7 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
         }
     }
     // ---- apply the accumulated flips to the bit columns of the systems
+    if (!flips_applied)
     for (uint32_t i = tid; i < d.N; i += kSwThreads) {
         if (EXTRAS && MODE == kSwHoudayer && group > 2) { // every replica of the group flips with the cluster
             if (get_bit(L.flip_a, i))

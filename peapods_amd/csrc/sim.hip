@@ -617,13 +617,20 @@ int ensure_cluster_sw(pa_sim *sim) {
         sim->p.sw_scratch = static_cast<uint32_t *>(area);
     }
     const uint32_t n_units = cluster_stream_units(d);
-    std::vector<uint32_t> jump_unit(static_cast<size_t>(n_units) * 64 * 16 * 8);
+    // ... followed by the tables of T^0 .. T^63: a generator that ends k draws into a unit takes the unit's jump, then T^k
+    std::vector<uint32_t> jump_unit(static_cast<size_t>(n_units + 64) * 64 * 16 * 8);
     {
         JumpMatrix step = JumpMatrix::steps(64);
         JumpMatrix acc = JumpMatrix::identity();
         for (uint32_t b = 0; b < n_units; ++b) {
             acc.nibble_table(&jump_unit[static_cast<size_t>(b) * 64 * 16 * 8]);
             if (b + 1 < n_units) acc = step.compose(acc);
+        }
+        step = JumpMatrix::steps(1);
+        acc = JumpMatrix::identity();
+        for (uint32_t k = 0; k < 64; ++k) {
+            acc.nibble_table(&jump_unit[static_cast<size_t>(n_units + k) * 64 * 16 * 8]);
+            if (k + 1 < 64) acc = step.compose(acc);
         }
     }
     // gen::<f32>() < p on the 2^24 grid as an integer threshold; p by the host's expf for a

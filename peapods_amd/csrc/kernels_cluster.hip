@@ -272,11 +272,10 @@ enum { kSwHoudayer = 0, kSwJorg = 1, kSwFk = 2, kSwCmr = 3 };
 // group: replicas per task (2 except for the experimental "houdN" moves: N replicas whose spins
 // sum to zero on the active sites, all of them flipped).  wolff: single-cluster variant of a
 // deterministic-bond move (find_seed, utils.rs:107-119, then flip the seed's component).
-// LEVEL = 0 is the lean build of the plain moves (no reporting; single-cluster form only for the
-// deterministic Houdayer bonds): the reporting code costs ~100 VGPRs and a third of the occupancy.
-// The lean Houdayer build (no bond draws) is capped at 128 VGPRs: four workgroups per CU instead of three, 461 ->
-// 400 us per call on 6144 pairs.  The moves that draw bonds lose more to the spills than they gain (Joerg 792 -> 853 us,
-// FK 312 -> 363 us), and the reporting builds need their registers.
+// LEVEL = 0 is the lean build of the plain moves (no reporting, no single-cluster forms, pairs only): the reporting and
+// seed-drawing code costs ~100 VGPRs and a third of the occupancy.  The lean Houdayer and Joerg builds fit 80 VGPRs -- six
+// workgroups per CU, which is what the 6144 pairs of BASELINE configs[4] divide into (four rounds of 1536) -- and the
+// kernel is bound by its instruction count at that occupancy: see the word-parallel phases below.
 // GLOBAL: the union-find's per-site arrays in device memory (large lattices; the full build only).
 template <int MODE, int LEVEL, bool GLOBAL = false>
 __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || MODE == kSwJorg) ? 6 : 4) : (LEVEL == 1 ? 3 : 2)) void k_cluster_sw(
@@ -548,6 +547,13 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
             if (upup == up) return up;
             L.label[x] = upup;
             x = upup;
+        }
+    };
+    auto root_of = [&](uint32_t x) -> uint32_t { // the same, reading only (once the unions are over)
+        for (;;) {
+            const uint32_t up = L.label[x];
+            if (up == x) return x;
+            x = up;
         }
     };
     // the task's generator `at` draws after its position at entry (one lane)
@@ -997,8 +1003,20 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
         // Lock-free union: every bond is visited once; the larger root is hooked under the smaller
         // one with a compare-and-swap, retried from the new roots when another lane got there first
         // (labels only ever decrease, so every chain ends and the loop terminates).
-        auto unite = [&](uint32_t a, uint32_t b) {
-            uint32_t ra = find_root(a), rb = find_root(b);
+        // (the two finds of a union walk their chains side by side: two reads in flight per step instead of one)
+        auto find_roots = [&](uint32_t &x, uint32_t &y) {
+            for (;;) {
+                const uint32_t ux = L.label[x], uy = L.label[y];
+                if (ux == x && uy == y) return;
+                const uint32_t uux = L.label[ux], uuy = L.label[uy];
+                if (uux != ux) L.label[x] = uux; // path halving; x is not a root here (a root's label is itself)
+                if (uuy != uy) L.label[y] = uuy;
+                x = uux;
+                y = uuy;
+            }
+        };
+        auto unite = [&](uint32_t ra, uint32_t rb) {
+            find_roots(ra, rb);
             while (ra != rb) {
                 if (ra < rb) {
                     const uint32_t tmp = ra;
@@ -1007,8 +1025,8 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
                 }
                 const uint32_t old = atomicCAS(&L.label[ra], ra, rb); // ra > rb
                 if (old == ra) break;
-                ra = find_root(old);
-                rb = find_root(rb);
+                ra = old;
+                find_roots(ra, rb);
             }
         };
         // The bonds that need a union are few and scattered over the (site, direction) grid -- a union per grid cell runs
@@ -1135,12 +1153,7 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
                 const uint32_t i = r * kSwThreads + tid;
                 bool is_root = false;
                 if (i < d.N) {
-                    uint32_t x = i;
-                    for (;;) {
-                        const uint32_t up = L.label[x];
-                        if (up == x) break;
-                        x = up;
-                    }
+                    const uint32_t x = root_of(i);
                     L.label[i] = x;
                     is_root = x == i;
                 }

@@ -16,6 +16,8 @@ for m in houdayer jorg; do   # the union-find forms
     python bench.py --config c4 --oc-mode $m --oc-variant sw --steps 200 --warmup 20 --no-cpu-baseline > "$out/bench_c4_${m}_sw.json" 2>>"$out/bench.err"
 done
 python tools/stamps_reg.py > "$out/stamps_reg.txt" 2>&1
+python tools/stamps_cluster.py jorg sw > "$out/stamps_cluster_jorg_sw.txt" 2>&1
+python tools/stamps_cluster.py houdayer sw > "$out/stamps_cluster_houdayer_sw.txt" 2>&1
 python tools/stamps_hc.py > "$out/stamps_hc.txt" 2>&1
 python tools/stamps_slab.py > "$out/stamps_slab.txt" 2>&1
 python tools/fixed_cost.py > "$out/fixed_cost.json" 2>&1

@@ -527,6 +527,40 @@ def test_sw_variant_of_the_overlap_moves_matches_oracle(oracle, mode, shape, n_t
     assert_state_equal(gpu, cpu, check_energy=False)
 
 
+@pytest.mark.parametrize("shape,n_temps,n_rep", [((16, 16, 16), 3, 2), ((7, 9, 11), 3, 4), ((3, 5, 40), 3, 2),
+                                                 ((70,), 3, 2), ((33, 3), 4, 2), ((1, 6, 2), 3, 2)])
+def test_word_parallel_cluster_phases_on_awkward_extents(oracle, shape, n_temps, n_rep):
+    """The union-find kernel works on 32-site words of its bitmaps wherever the lattice is hypercubic (k_cluster_sw:
+    neighbour = shifted bitmap, unions from packed bond words, coins deposited per word).  Extents that are not
+    multiples of 32 put rows across word boundaries; 16^3 has more (direction, word) cells than threads; a row of 40
+    has runs longer than a word; extents of 1 and 2 make self-bonds and double bonds.  All three moves, same state and
+    results as the reference's site-by-site loops (overlap.rs:228-318,417-520,555-971)."""
+    couplings = bimodal(shape, len(shape), 2, 77)
+    temps = np.linspace(0.6, 2.2, n_temps)
+    gpu, cpu = make_pair(oracle, shape, couplings, temps, n_rep, 23)
+    for mode in ("houdayer", "jorg", "cmr"):
+        kwargs = dict(pt_interval=1, overlap_cluster_update_interval=1, overlap_cluster_build_mode=mode,
+                      overlap_cluster_mode="sw", warmup_ratio=0.0)
+        a = gpu.sample(5, "metropolis", **kwargs)
+        b = cpu.sample(5, "metropolis", **kwargs)
+        assert_results_equal(a, b)
+        assert_state_equal(gpu, cpu, check_energy=False)
+
+
+@pytest.mark.parametrize("shape,temp", [((8, 8, 8), 1.2), ((12, 12, 12), 2.5), ((16, 16, 16), 4.4), ((30, 30), 1.5)])
+def test_swendsen_wang_with_more_bonds_than_the_union_list_holds(oracle, shape, temp):
+    """A cold ferromagnet accepts nearly every bond: more bonds than the N entries of the packed union list, so the
+    kernel falls back to one pass per direction (k_cluster_sw, union_pass).  fk.rs:113-192."""
+    couplings = np.ones(tuple(shape) + (len(shape),), np.float32)
+    temps = np.array([temp, temp * 1.5])
+    gpu, cpu = make_pair(oracle, shape, couplings, temps, 1, 5)
+    kwargs = dict(cluster_update_interval=1, cluster_mode="sw", pt_interval=1, warmup_ratio=0.0)
+    a = gpu.sample(6, "metropolis", **kwargs)
+    b = cpu.sample(6, "metropolis", **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+
+
 @pytest.mark.parametrize("inner", ["sw", "wolff"])
 @pytest.mark.parametrize("mode", ["cmr", "houdayer+cmr+jorg"])
 @pytest.mark.parametrize("shape,n_temps,n_rep,n_dis", [((4, 4), 3, 2, 1), ((6, 6, 6), 5, 4, 2),

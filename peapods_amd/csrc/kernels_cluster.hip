@@ -483,31 +483,53 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
         }
         return pre;
     };
+    // One word of a plane made on the spot, by the lane that needs it: the jump to the word's unit through the tables in
+    // device memory, then its 32 draws -- what k_pair_stream would have stored there (the same planes, the same bit order).
+    // Slow (a lane's serial jump), and rare: the launcher sizes the stream for what moves take, not for what they could.
+    auto late_plane_words = [&](uint32_t word, uint32_t kind, uint32_t &v0, uint32_t &v1) {
+        uint32_t js[8];
+        load_base_state(js);
+        if (word / 2) jump_state_lds(js, p.jump_unit + static_cast<size_t>(word / 2) * (64 * 16 * 8));
+        Rng32 rng;
+        rng.load(js);
+        if (word & 1u)
+            for (int j = 0; j < 32; ++j) (void)rng.next_top();
+        const uint32_t first = JORG ? p.jorg_thr[t] : (CMR ? p.cmr_thr[t] : (FK ? p.fk_thr[t] : 0u)), second = p.fk_thr[t];
+        v0 = v1 = 0;
+        for (uint32_t j = 0; j < 32; ++j) {
+            const uint32_t top = rng.next_top(), draw = top >> 8;
+            const uint32_t b = kind == 0 ? (draw < first ? 1u : 0u) : (kind == 1 ? (draw < second ? 1u : 0u) : (kind == 2 ? top >> 31 : (top >> 30) & 1u));
+            v0 |= b << j;
+            if (kind == 3) v1 |= (top >> 31) << j;
+        }
+    };
     auto draw_bits = [&](uint32_t start, uint32_t count, uint32_t kind, const uint32_t *thr_by_rank, const PlaneWords &pre) {
         if (count == 0) return;
         const uint32_t base_q = (start / 256) * 256, end = start + count;
-        if (end > aux.stream_units * 64u) { // only after > 64 rejections of a seed draw (p < 2^-50 each): refuse, never guess
+        // the tables reach cluster_stream_units units; past them only after > 64 rejections of a seed draw (p < 2^-50
+        // each): refuse, never guess.  (Streams of other couplings are always made in full.)
+        if (end > (d.unit ? cluster_stream_units(d) : aux.stream_units) * 64u) {
             if (tid == 0) atomicOr(p.stream_error, 1u);
             return;
         }
         if (d.unit) { // the planes k_pair_stream left: a word copy (positions before `start` in the first word are never read)
             const uint32_t *planes = reinterpret_cast<const uint32_t *>(p.stream_bits + stream_task * stream_stride);
             const uint32_t w0 = base_q / 32, n_words = (end - base_q + 31) / 32;
-            if (pre.w0 == w0 && n_words <= kSwThreads) { // the words are here already
-                if (tid < n_words) {
-                    L.bits[tid] = kind == 2 ? ~pre.v[0] : pre.v[0];
-                    if (kind == 3) L.bits2[tid] = pre.v[1];
-                }
-                return;
-            }
             for (uint32_t w = tid; w < n_words; w += kSwThreads) {
-                const uint32_t *src = planes + w0 + w;
-                if (kind == 3) {
-                    L.bits[w] = src[2 * plane_words];
-                    L.bits2[w] = src[3 * plane_words];
+                const uint32_t at = w0 + w;
+                uint32_t v0, v1 = 0;
+                if (at >= 2 * aux.stream_units) {
+                    late_plane_words(at, kind, v0, v1); // k_pair_stream stopped short of this word (it makes what a move usually takes)
+                } else if (pre.w0 == w0 && w == tid) { // the word is here already
+                    v0 = pre.v[0];
+                    v1 = pre.v[1];
                 } else {
-                    L.bits[w] = kind == 2 ? ~src[3 * plane_words] : src[kind * plane_words];
+                    const uint32_t *src = planes + at;
+                    v0 = src[(kind == 2 ? 3u : (kind == 3 ? 2u : kind)) * plane_words];
+                    if (kind == 3) v1 = src[3 * plane_words];
                 }
+                L.bits[w] = kind == 2 ? ~v0 : v0;
+                if (kind == 3) L.bits2[w] = v1;
             }
             return;
         }
@@ -2044,8 +2066,18 @@ hipError_t launch_cluster_sw(const SimDims &d, const DevPtrs &p, int oc_mode, ui
     { // the generators' draws: bonds (stochastic moves) + one per cluster (twice for CMR) + the seed
         const uint32_t draws = (oc_mode == 1 ? 0u : d.N * d.nn) + (oc_mode == 3 ? 2u : 1u) * d.N + 64u;
         aux.stream_units = std::min(cluster_stream_units(d), (draws + 63u) / 64u + 1u);
+        if (d.unit) {
+            // The Houdayer move draws a coin per multi-site cluster: far fewer than the one per site it could take, so the
+            // stream is made for N / 8 of them, and a pair that runs past it makes the words it lacks itself (k_cluster_sw,
+            // late_plane_words): exact either way.  The moves that draw bonds keep their full streams: two replicas on
+            // opposite sides of the global flip differ almost everywhere, and such a pair does draw most of its bonds
+            // (Joerg at 12^3 with 45 of 110 units: the stream 38 -> 26 us, the cluster kernel 101 -> 108).
+            uint32_t usual = oc_mode == 1 ? d.N / 8 + 64u : draws;
+            if (const char *e = dev_env("PEAPODS_STREAM_UNITS")) usual = static_cast<uint32_t>(std::max(1, atoi(e))) * 64u - 64u;
+            aux.stream_units = std::min(aux.stream_units, (usual + 63u) / 64u + 1u);
+        }
         const uint32_t *first = oc_mode == 2 ? p.jorg_thr : (oc_mode == 3 ? p.cmr_thr : nullptr);
-        const uint32_t kStreamRun = stream_run();
+        const uint32_t kStreamRun = aux.stream_units <= 16 ? 1u : stream_run(); // (a short stream: every unit its own workgroup)
         const dim3 sgrid(((aux.stream_units + kStreamRun - 1) / kStreamRun) * ((d.n_real * d.n_temps * d.n_pairs + 255u) / 256u));
         if (!d.unit)
             PA_LAUNCH((k_pair_stream<true, false>), sgrid, dim3(256), 32 * 1024, stream, d, p, aux.stream_units, first, 0, kStreamRun);

@@ -286,6 +286,10 @@ hipError_t launch_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream
 hipError_t launch_rng_overlap(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool gibbs = false);
 // The random stream of a sweep with the previous sweep's overlap measurement (with_overlap) and / or its deferred
 // measurement block (statistics + tempering event, pt.relay = 1) riding in the same launch.
+// experiment (PEAPODS_FLAGGED): stream + sweep of one Metropolis sweep in one launch, sweep workgroups released by counters
+bool flagged_sweep_applies(const SimDims &d);
+hipError_t launch_stream_sweep_flagged(const SimDims &d, const DevPtrs &p, uint32_t *flags, uint32_t epoch, uint32_t *timed_out,
+                                       hipStream_t stream);
 hipError_t launch_rng_relay(const SimDims &d, const DevPtrs &p, bool with_overlap, const PtParams &pt, bool do_accum,
                             bool accum_overlap, bool do_pt, hipStream_t stream, bool gibbs = false);
 bool rng_relay_supported(const SimDims &d);

@@ -1640,6 +1640,44 @@ k_sweep_hc(SimDims d, DevPtrs p, int with_energy, int do_sweep,
     sweep_hc_block<NN, STAMPS, GIBBS, DENSE>(d, p, blockIdx.x, with_energy, do_sweep, stamps, lds);
 }
 
+// EXPERIMENT (developer switch PEAPODS_FLAGGED, sweep-only entry points): the random stream and the sweep of ONE Metropolis
+// sweep in one launch, the sweep workgroup of a tile word released by a counter as soon as the stream workgroups of its
+// words have stored their planes -- the dependency-flag form the round-2 all-in-one kernel (k_rs) did not try.  Stream
+// workgroups come first in block order (= dispatch order: every one of them is resident or done before a sweep workgroup
+// takes a slot, so the waiting cannot starve them) and have eight waves, so that one launch geometry (512 threads, the
+// sweep's LDS) holds as many stream waves per CU as the plain launch does.  Release: every stream lane fences its stores
+// (agent scope: the planes cross XCDs), one lane bumps flags[group]; acquire: one lane polls, the workgroup fences.
+// Measured slower than the two launches (profiles/NOTES.md, round 4) -- kept for the record, not on any product path.
+template <int NN, bool DENSE>
+__global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_per_eu(4))) void
+k_stream_sweep_flagged(SimDims d, DevPtrs p, uint32_t n_stream, uint32_t *flags, uint32_t target, uint32_t *timed_out) {
+    extern __shared__ uint32_t lds_dyn[];
+    if (blockIdx.x < n_stream) {
+        rng_block<true, false>(d, p, blockIdx.x, lds_dyn);
+        drain_global_stores(); // every wave's stores have left the CU ...
+        __syncthreads();
+        if (threadIdx.x == 0) { // ... and ONE lane publishes them (the release writes back the L2: once per workgroup, not per wave)
+            __threadfence();
+            __hip_atomic_fetch_add(&flags[blockIdx.x / d.B], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    const uint32_t bid = blockIdx.x - n_stream; // tile word; a stream workgroup of eight waves serves sixteen of them
+    if (threadIdx.x == 0) {
+        uint32_t spins = 0;
+        while (__hip_atomic_load(&flags[bid / 16u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > (1u << 22)) { // (~1 s: a lost release must not hang the device)
+                atomicOr(timed_out, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __threadfence(); // acquire, once per workgroup
+    }
+    __syncthreads();
+    sweep_hc_block<NN, false, false, DENSE>(d, p, bid, 0, 1, nullptr, lds_dyn);
+}
+
 // ---------------------------------------------------------------------------
 // k_overlap: workgroup = (tile, word), 256 threads.  Replica 2p and 2p+1 at
 // temperature t sit n_temps bit positions apart, so Y = V ^ (V >> n_temps) lines
@@ -3750,6 +3788,7 @@ hipError_t configure_kernels(const SimDims &) {
                            reinterpret_cast<const void *>(k_houdayer_grow),
                            reinterpret_cast<const void *>(k_houdayer_grow_measure),
                            reinterpret_cast<const void *>(k_jorg),
+                           reinterpret_cast<const void *>(k_stream_sweep_flagged<3, true>),
                            reinterpret_cast<const void *>(k_overlap_pairing),
                            reinterpret_cast<const void *>(k_energy_measure<1, true>),
                            reinterpret_cast<const void *>(k_energy_measure<2, true>),
@@ -3874,6 +3913,20 @@ hipError_t launch_rng_relay(const SimDims &d, const DevPtrs &p, bool with_overla
         else PA_RELAY(false, 0, false);
     }
 #undef PA_RELAY
+    return hipGetLastError();
+}
+
+// (experiment, see k_stream_sweep_flagged) flags: one counter per stream workgroup of eight waves, never reset -- launch
+// number `epoch` (from 1) waits for epoch * B
+bool flagged_sweep_applies(const SimDims &d) {
+    return d.hc && !d.general && !d.wide && d.thr_preshifted && d.dense_nn == d.nn && d.nn == 3 && sweep_hc_lds_bytes(d) >= kRngLds + 1024;
+}
+hipError_t launch_stream_sweep_flagged(const SimDims &d, const DevPtrs &p, uint32_t *flags, uint32_t epoch, uint32_t *timed_out,
+                                       hipStream_t stream) {
+    const uint32_t n_pairs_tw = (d.n_real * d.W + 1) / 2, groups = (n_pairs_tw + 7) / 8;
+    const uint32_t n_stream = groups * d.B;
+    PA_LAUNCH((k_stream_sweep_flagged<3, true>), dim3(n_stream + d.n_real * d.W), dim3(512), sweep_hc_lds_bytes(d), stream, d, p,
+              n_stream, flags, epoch * d.B, timed_out);
     return hipGetLastError();
 }
 

@@ -92,6 +92,7 @@ struct pa_sim {
     uint16_t *nbr_site = nullptr;
     uint32_t *jsite = nullptr, *nbr_wide = nullptr;
     uint32_t *sw_wrap = nullptr, *sw_cpl = nullptr; // bitmaps of the word-parallel cluster phases (SimDims::hc)
+    uint32_t *flag_words = nullptr, flag_groups = 0, flag_epoch = 0; // experiment PEAPODS_FLAGGED (sweep_only)
     unsigned long long *cluster_stamps = nullptr; // pa_debug_cluster_stamps: [tasks][16] phase stamps of the last k_cluster_sw launch
     uint4 *fwd_big = nullptr;
     float *jorg_p = nullptr;
@@ -2449,6 +2450,7 @@ void pa_sim_destroy(pa_sim *sim) {
                             static_cast<void *>(sim->p.snap_spins), static_cast<void *>(sim->p.snap_sids)})
             if (extra) (void)hipFree(extra);
         if (sim->cluster_stamps) (void)hipFree(sim->cluster_stamps);
+        if (sim->flag_words) (void)hipFree(sim->flag_words);
         for (void *area : sim->uncached_areas) (void)hipFree(area);
         sim->buffers.release();
         (void)hipStreamDestroy(sim->stream);
@@ -2754,13 +2756,32 @@ static int sweep_only(pa_sim *sim, uint64_t n_sweeps, bool gibbs) {
     PA_HIP(sim, hipSetDevice(sim->device));
     if (gibbs)
         if (int rc = ensure_gibbs(sim)) return rc;
+    // (experiment behind the developer gate: one flagged launch per sweep, see k_stream_sweep_flagged)
+    const bool flagged = !gibbs && dev_env("PEAPODS_FLAGGED") && flagged_sweep_applies(sim->d) && !sim->swaps_pending;
+    if (flagged && !sim->flag_words) {
+        const uint32_t groups = ((sim->d.n_real * sim->d.W + 1) / 2 + 7) / 8;
+        PA_HIP(sim, hipMalloc(reinterpret_cast<void **>(&sim->flag_words), (groups + 1) * sizeof(uint32_t)));
+        PA_HIP(sim, hipMemset(sim->flag_words, 0, (groups + 1) * sizeof(uint32_t)));
+        sim->flag_groups = groups;
+    }
     for (uint64_t k = 0; k < n_sweeps; ++k) {
-        PA_HIP(sim, launch_rng(sim->d, sim->p, gibbs, sim->stream));
-        PA_HIP(sim, enqueue_sweep(sim, sim->d, sim->p, false, gibbs, sim->stream));
+        if (flagged) {
+            PA_HIP(sim, launch_stream_sweep_flagged(sim->d, sim->p, sim->flag_words, ++sim->flag_epoch,
+                                                    sim->flag_words + sim->flag_groups, sim->stream));
+        } else {
+            PA_HIP(sim, launch_rng(sim->d, sim->p, gibbs, sim->stream));
+            PA_HIP(sim, enqueue_sweep(sim, sim->d, sim->p, false, gibbs, sim->stream));
+        }
         sim->swaps_pending = false;
         toggle_spin_buffers(sim);
     }
-    return pa_sim_synchronize(sim);
+    if (int rc = pa_sim_synchronize(sim)) return rc;
+    if (flagged) {
+        uint32_t timed_out = 0;
+        PA_HIP(sim, hipMemcpy(&timed_out, sim->flag_words + sim->flag_groups, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (timed_out) return fail(sim, PA_ERR_DEVICE, "flagged sweep: a release counter never arrived");
+    }
+    return PA_OK;
 }
 
 int pa_sim_metropolis_sweep(pa_sim *sim, uint64_t n_sweeps) { return sweep_only(sim, n_sweeps, false); }

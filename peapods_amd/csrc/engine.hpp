@@ -193,7 +193,8 @@ struct DevPtrs {
     uint32_t *sw_scratch;    // [tasks][2][N] large lattices: the union-find's per-site arrays of every k_cluster_sw
                              //   workgroup (uncached device memory; tasks = n_real * max(n_temps * n_pairs, n_sys))
     const uint32_t *jump_unit; // [cluster_stream_units + 64][64][2][16][4] nibble tables of T^(64 u), then of T^0 .. T^63
-    uint8_t *stream_bits;    // [n_real][n_sys][cluster_stream_units * 64] classified draws of the cluster generators (unit couplings)
+    uint8_t *stream_bits;    // [n_real][n_sys][cluster_stream_units * 64 bytes] the cluster generators' draws, classified (unit
+                             //   couplings): per task four bit planes of 2 words per unit (k_pair_stream), in half of the room
     uint32_t *stream_raw;    // same shape: the 24-bit draws themselves (other couplings)
     uint32_t *stream_error;  // [1] set if a task ever needed draws beyond its stream (checked by pa_sim_synchronize)
     const uint32_t *jorg_thr;// [n_temps] ceil((1 - exp(-4/T)) 2^24): draw < thr <=> gen::<f32>() < p

@@ -73,14 +73,15 @@ __global__ void k_pairing(SimDims d, DevPtrs p) {
 // position 64 u needs the same matrix T^(64 u) for every task.  So: one workgroup per (u, 256
 // tasks) stages that 32 KB table in the LDS once, each lane jumps its task's state and steps 64
 // times.  (Inside the cluster kernel the same jumps were gathers from L2-resident tables, two per
-// 64 draws and lane: 60 % of the Joerg move's time.)  Unit couplings: one byte per position --
-// bit 0 draw < first threshold of the move (FK 1 - e^(-2/T), Joerg 1 - e^(-4/T), CMR blue 1 - r^2),
-// bit 1 draw < 1 - e^(-2/T) (CMR red), bits 2-3 the two top bits of the draw (bit 3 clear <=> coin
-// "< 0.5"; both = rand's u8 gen_range(0..=3)).  Other couplings: the 24-bit draw itself.
+// 64 draws and lane: 60 % of the Joerg move's time.)  Unit couplings: four bit planes over the
+// stream positions, [plane][2 words per unit] per task -- plane 0: draw < first threshold of the move
+// (FK 1 - e^(-2/T), Joerg 1 - e^(-4/T), CMR blue 1 - r^2), plane 1: draw < 1 - e^(-2/T) (CMR red),
+// planes 2 / 3: bits 30 / 31 of the 32-bit draw (bit 31 clear <=> coin "< 0.5"; both = rand's u8
+// gen_range(0..=3)); planes 1 and 2 only for CMR.  Other couplings: the 24-bit draw itself.
 // ---------------------------------------------------------------------------
 // A workgroup serves kStreamRun consecutive units with ONE table: it enters the stream at unit u and steps through the
-// following ones.  Staging 32 KB for 64 draws per lane made the table loads the kernel (Joerg at 12^3: 110 units x 12
-// chunks = 1320 workgroups, 47 us for 11 M instructions).
+// following ones (1 / 2 / 4 / 8 / 16 / 32 units per workgroup: 49 / 46 / 44 / 54 / 55 / 97 us for Joerg at 12^3 x 6144
+// pairs -- at four the table loads and the lone-wave stepping balance; a short stream takes one unit per workgroup).
 static uint32_t stream_run() {
     static const uint32_t run = [] {
         const char *e = dev_env("PEAPODS_STREAM_RUN");

@@ -299,3 +299,35 @@ def test_step_profile_names_every_launch_of_a_step():
     b = fresh_two.sample(12, "metropolis", pt_interval=1)
     np.testing.assert_array_equal(a["energies"], b["energies"])
     np.testing.assert_array_equal(fresh_one.get_spins(3), fresh_two.get_spins(3))
+
+
+def test_cluster_phase_stamps_cover_every_pair_and_do_not_disturb_the_run():
+    """pa_debug_cluster_stamps (include/peapods_amd_debug.h): every workgroup of the union-find cluster kernel stamps its
+    phase boundaries; the stamps of a workgroup rise, and a run that stamps leaves the state of one that does not."""
+    import ctypes as C
+
+    from peapods_amd import IsingSimulation
+    from peapods_amd import _native as nat
+
+    shape = (6, 6, 6)
+    rng = np.random.default_rng(5)
+    couplings = (2 * rng.integers(0, 2, size=(3,) + shape + (3,)) - 1).astype(np.float32)
+    temps = np.linspace(0.8, 1.8, 5).astype(np.float32)
+    kw = dict(pt_interval=1, overlap_cluster_update_interval=1, overlap_cluster_build_mode="jorg", overlap_cluster_mode="sw")
+    stamped = IsingSimulation(list(shape), couplings, temps, 4, None, 9, stream_groups=1)
+    plain = IsingSimulation(list(shape), couplings, temps, 4, None, 9, stream_groups=1)
+    lib = nat.lib()
+    lib.pa_debug_cluster_stamps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
+    n_blocks = lib.pa_debug_cluster_stamps(stamped._handle, 1, None, 0)
+    assert n_blocks == 3 * 5 * 4  # >= realisations x temperatures x pairs; the buffer also covers one block per system
+    a = stamped.sample(6, "metropolis", **kw)
+    b = plain.sample(6, "metropolis", **kw)
+    out = np.zeros((n_blocks, 16), dtype=np.uint64)
+    assert lib.pa_debug_cluster_stamps(stamped._handle, 0, nat.ptr(out), n_blocks) == n_blocks
+    rows = out[: 3 * 5 * 2].astype(np.int64)  # the pairs of the last launch
+    order = [0, 1, 2, 3, 12, 4, 5, 6, 7, 8, 9, 11]
+    assert (rows[:, order] > 0).all()
+    assert (np.diff(rows[:, order], axis=1) >= 0).all()
+    np.testing.assert_array_equal(a["energies"], b["energies"])
+    np.testing.assert_array_equal(stamped.get_spins(2), plain.get_spins(2))
+    assert lib.pa_debug_cluster_stamps(stamped._handle, 0, nat.ptr(out), n_blocks) == 0  # stopped: nothing to read

@@ -245,9 +245,9 @@ template <bool GLOBAL> struct SwLds {
     uint32_t *act;     // [MW] active sites (the pair's spins differ)
     uint32_t *spa;     // [MW] spin of the pair's first system (1 <=> -1)
     uint32_t *spb;     // [MW] spin of the pair's second system
-    uint32_t *bond;    // [6][MW] eligible, later accepted, forward bonds per direction
-    uint32_t *blue;    // [6][MW] CMR: accepted blue bonds, kept for the grey clusters
-    uint32_t *acc;     // [6][MW] accepted bonds of the current phase
+    uint32_t *bond;    // [nn][MW] eligible, later accepted, forward bonds per direction (at least two rows)
+    uint32_t *blue;    // [nn][MW] CMR: accepted blue bonds, kept for the grey clusters
+    uint32_t *acc;     // [nn][MW] accepted bonds of the current phase; then the coin maps of the flips
     uint32_t *thr;     // [N nn] non-unit couplings: threshold of every eligible bond by its draw rank
     uint32_t *wbase;   // [MW + 1] exclusive prefix (eligible bonds / drawing roots) per 32-site word
     uint32_t *roots;   // [MW] roots that draw
@@ -264,7 +264,8 @@ __host__ __device__ inline size_t cluster_sw_bit_words(const SimDims &d) {
     return (static_cast<size_t>(d.N) * d.nn + 255) / 256 * 8 + 16;
 }
 __host__ __device__ inline size_t cluster_sw_lds_words(const SimDims &d, bool global_labels = false) {
-    return (global_labels ? 0 : 2 * static_cast<size_t>(d.N)) + 29 * static_cast<size_t>(d.MW) + 1 +
+    // (bond / blue / acc hold one row per forward direction, at least two: the coin maps of the flips take two rows of acc)
+    return (global_labels ? 0 : 2 * static_cast<size_t>(d.N)) + (11 + 3 * static_cast<size_t>(d.nn < 2 ? 2 : d.nn)) * d.MW + 1 +
            2 * cluster_sw_bit_words(d) + 24 + (d.unit ? 0 : static_cast<size_t>(d.N) * d.nn);
 }
 
@@ -279,7 +280,7 @@ enum { kSwHoudayer = 0, kSwJorg = 1, kSwFk = 2, kSwCmr = 3 };
 // kernel is bound by its instruction count at that occupancy: see the word-parallel phases below.
 // GLOBAL: the union-find's per-site arrays in device memory (large lattices; the full build only).
 template <int MODE, int LEVEL, bool GLOBAL = false>
-__global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || MODE == kSwJorg) ? 6 : 4) : (LEVEL == 1 ? 3 : 2)) void k_cluster_sw(
+__global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || MODE == kSwJorg) ? 8 : 4) : (LEVEL == 1 ? 3 : 2)) void k_cluster_sw(
     SimDims d, DevPtrs p, uint32_t group, int wolff, ClusterAux aux) {
     constexpr bool EXTRAS = LEVEL > 0; // sizes / top four and the single-cluster forms
     constexpr bool FULL = LEVEL > 1;   // + observation metrics, winding, snapshots
@@ -300,9 +301,10 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
         L.act = q; q += d.MW;
         L.spa = q; q += d.MW;
         L.spb = q; q += d.MW;
-        L.bond = q; q += 6 * d.MW;
-        L.blue = q; q += 6 * d.MW;
-        L.acc = q; q += 6 * d.MW;
+        const uint32_t bond_rows = d.nn < 2 ? 2u : d.nn;
+        L.bond = q; q += bond_rows * d.MW;
+        L.blue = q; q += bond_rows * d.MW;
+        L.acc = q; q += bond_rows * d.MW;
         L.wbase = q; q += d.MW + 1;
         L.roots = q; q += d.MW;
         L.flip_a = q; q += d.MW;

@@ -3865,7 +3865,8 @@ hipError_t launch_rng_overlap(const SimDims &d, const DevPtrs &p, hipStream_t st
 static uint32_t relay_reals_per_block(const SimDims &d) { return (2u * d.rng_waves - 1u) / d.W + 2u; }
 
 bool rng_relay_supported(const SimDims &d) {
-    return !d.general && !d.big && d.n_sys <= 512 && d.n_temps <= 256 && d.n_replicas <= 256 && 2 * d.W <= 256 &&
+    // (large lattices: on the LDS-resident slab path, whose sweep launch exchanges the deferred bit columns as it loads)
+    return !d.general && (!d.big || (d.pipe_K && d.pipe_lds)) && d.n_sys <= 512 && d.n_temps <= 256 && d.n_replicas <= 256 && 2 * d.W <= 256 &&
            relay_reals_per_block(d) * d.n_replicas <= 256 && measure_lds_bytes(d) <= 64 * 1024;
 }
 

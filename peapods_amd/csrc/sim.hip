@@ -975,7 +975,8 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
     const bool relay = fused && !dev_env("PEAPODS_NO_RELAY") &&
                        (cfg->pt_schedule == PA_PT_SINGLE_RANDOM_EDGE ? rng_relay_supported(d) : rng_relay_ladder_supported(d));
     // (opt-in: measured slower than two launches)
-    const bool relay_nf = !fused && !gibbs && !d.big && !d.general && cfg->pt_schedule == PA_PT_SINGLE_RANDOM_EDGE &&
+    const bool slab_at_load = d.pipe_K && d.pipe_lds && !dev_env("PEAPODS_NO_SWAPS_AT_LOAD");
+    const bool relay_nf = !fused && !gibbs && (!d.big || slab_at_load) && !d.general && cfg->pt_schedule == PA_PT_SINGLE_RANDOM_EDGE &&
                           rng_relay_supported(d) && !dev_env("PEAPODS_NO_RELAY");
     // Cooperative cancel (src/lib.rs:304-308, mod.rs:406-408): the host runs at most two batches of
     // kBatch sweeps ahead of the device, so a request is honoured within that much queued work; the
@@ -1204,6 +1205,8 @@ int run_sweeps(pa_sim *sim, const pa_sample_config *cfg) {
                 PA_HIP(sim, launch_adopt_relay_sums(g.d, g.p, g.stream));
             const bool with_e = (record || pt_this || equil) && !fk_this;
             const bool big_fuse = g.d.pipe_K && with_e && !fk_this && !equil && record && want_overlap && d.n_pairs && d.nn <= 3;
+            // (slab path: the relayed event of this sweep's random-stream launch has left bit columns to exchange at load)
+            if (relayed_nf && pending.do_pt && d.n_temps >= 2 && d.big) sim->swaps_pending = true;
             PA_HIP(sim, enqueue_sweep(sim, g.d, g.p, with_e, gibbs, g.stream, big_fuse));
             if (big_fuse) toggle_dots(g.p);
             big_overlap_done = big_fuse; // (one stream group on this path)

@@ -275,9 +275,9 @@ enum { kSwHoudayer = 0, kSwJorg = 1, kSwFk = 2, kSwCmr = 3 };
 // sum to zero on the active sites, all of them flipped).  wolff: single-cluster variant of a
 // deterministic-bond move (find_seed, utils.rs:107-119, then flip the seed's component).
 // LEVEL = 0 is the lean build of the plain moves (no reporting, no single-cluster forms, pairs only): the reporting and
-// seed-drawing code costs ~100 VGPRs and a third of the occupancy.  The lean Houdayer and Joerg builds fit 80 VGPRs -- six
-// workgroups per CU, which is what the 6144 pairs of BASELINE configs[4] divide into (four rounds of 1536) -- and the
-// kernel is bound by its instruction count at that occupancy: see the word-parallel phases below.
+// seed-drawing code costs ~100 VGPRs and most of the occupancy.  The lean Houdayer and Joerg builds fit 64 VGPRs and
+// 19.7 KB of LDS at 12^3 -- eight workgroups per CU, so the 6144 pairs of BASELINE configs[4] are three full rounds of
+// 2048 -- and what a pair's workgroup executes is kept short by the word-parallel phases below.
 // GLOBAL: the union-find's per-site arrays in device memory (large lattices; the full build only).
 template <int MODE, int LEVEL, bool GLOBAL = false>
 __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || MODE == kSwJorg) ? 8 : 4) : (LEVEL == 1 ? 3 : 2)) void k_cluster_sw(

@@ -95,6 +95,8 @@ def load(path=None):
         "orc_rng_gen_f32": (f32, [P(OrcRng)]),
         "orc_rng_gen_range_usize": (u64, [P(OrcRng), u64, u64]),
         "orc_rng_shuffle_usize": (None, [P(OrcRng), vp, C.c_size_t]),
+        "orc_pin_sample_single_u32": (C.c_size_t, [u32, u32, vp, C.c_size_t, P(u32)]),
+        "orc_pin_f32_of_word": (f32, [u32]),
         "orc_lattice_new": (vp, [vp, C.c_int]),
         "orc_lattice_with_offsets": (vp, [vp, C.c_int, vp, C.c_size_t]),
         "orc_lattice_free": (None, [vp]),

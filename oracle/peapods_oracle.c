@@ -3,7 +3,8 @@
  *
  * TEST INFRASTRUCTURE ONLY (see peapods_oracle.h).  PARITY UNPINNED against
  * upstream binaries; pinned by the reference's own known-answer tests and the
- * published xoshiro256** / SplitMix64 vectors (tests/test_oracle_*.py).
+ * published xoshiro256** / SplitMix64 vectors (tests/test_oracle_*.py); the u32 range
+ * sampling and the f32 conversion also by rand 0.8.5's own value-stability vectors.
  *
  * Reference paths are relative to the reference root; "ss/" = spin-sim/src/.
  * Floating-point note: the reference is Rust; f32::ln / f32::exp lower to the
@@ -77,10 +78,8 @@ uint32_t orc_rng_next_u32(orc_rng *rng) { return (uint32_t)(orc_rng_next_u64(rng
 
 /* rand 0.8.5 Standard f32: 24 high bits of one u32, scaled by 2^-24
  * (confirmed by the in-tree comment ss/mcmc/sweep.rs:179-181). */
-float orc_rng_gen_f32(orc_rng *rng) {
-    uint32_t value = orc_rng_next_u32(rng);
-    return (float)(value >> 8) * (1.0f / 16777216.0f);
-}
+static inline float f32_of_word(uint32_t value) { return (float)(value >> 8) * (1.0f / 16777216.0f); }
+float orc_rng_gen_f32(orc_rng *rng) { return f32_of_word(orc_rng_next_u32(rng)); }
 
 /* rand 0.8.5 UniformInt<usize>::sample_single (64-bit): widening multiply with
  * the "conservative zone" rejection.  Call sites: tempering.rs:33, utils.rs:113. */
@@ -98,17 +97,31 @@ uint64_t orc_rng_gen_range_usize(orc_rng *rng, uint64_t low, uint64_t high) {
 
 /* rand 0.8.5 UniformInt<u32>::sample_single, used by gen_index for bounds that
  * fit a u32 (seq/mod.rs gen_index). */
-static uint32_t gen_range_u32(orc_rng *rng, uint32_t low, uint32_t high) {
-    uint32_t range = high - low;
-    int lz = __builtin_clz(range);
-    uint32_t zone = (range << lz) - 1;
-    for (;;) {
-        uint32_t v = orc_rng_next_u32(rng);
-        uint64_t m = (uint64_t)v * (uint64_t)range;
-        uint32_t hi = (uint32_t)(m >> 32), lo = (uint32_t)m;
-        if (lo <= zone) return low + hi;
-    }
+static inline uint32_t u32_zone(uint32_t range) { return (range << __builtin_clz(range)) - 1; }
+/* one attempt on the word v: 1 and *out = the sample if v is accepted */
+static inline int u32_attempt(uint32_t v, uint32_t low, uint32_t range, uint32_t zone, uint32_t *out) {
+    uint64_t m = (uint64_t)v * (uint64_t)range;
+    uint32_t hi = (uint32_t)(m >> 32), lo = (uint32_t)m;
+    if (lo > zone) return 0;
+    *out = low + hi;
+    return 1;
 }
+static uint32_t gen_range_u32(orc_rng *rng, uint32_t low, uint32_t high) {
+    uint32_t range = high - low, zone = u32_zone(range), out;
+    for (;;)
+        if (u32_attempt(orc_rng_next_u32(rng), low, range, zone, &out)) return out;
+}
+
+/* Pinning only (tests/test_oracle_golden.py): the arithmetic of gen_range_u32 and orc_rng_gen_f32 on a word stream the
+ * test supplies, so that rand 0.8.5's own value-stability vectors -- which that crate draws from a Pcg32, not from
+ * xoshiro -- apply to the very code the oracle runs.  Returns the words consumed, 0 if the stream ran out. */
+size_t orc_pin_sample_single_u32(uint32_t low, uint32_t high, const uint32_t *words, size_t n_words, uint32_t *out) {
+    uint32_t range = high - low, zone = u32_zone(range);
+    for (size_t k = 0; k < n_words; ++k)
+        if (u32_attempt(words[k], low, range, zone, out)) return k + 1;
+    return 0;
+}
+float orc_pin_f32_of_word(uint32_t word) { return f32_of_word(word); }
 
 /* rand 0.8.5 UniformInt<u8>::sample_single_inclusive (uniform.rs, uniform_int_impl! with
  * $u_large = u32): zone = u32::MAX - (u32::MAX - range + 1) % range, one u32 per attempt.

@@ -46,6 +46,9 @@ uint32_t orc_rng_next_u32(orc_rng *rng);
 float orc_rng_gen_f32(orc_rng *rng);
 uint64_t orc_rng_gen_range_usize(orc_rng *rng, uint64_t low, uint64_t high);
 void orc_rng_shuffle_usize(orc_rng *rng, uint64_t *values, size_t len);
+/* pinning only: the oracle's u32 range sampling / f32 conversion on a supplied word stream (rand 0.8.5 value-stability vectors) */
+size_t orc_pin_sample_single_u32(uint32_t low, uint32_t high, const uint32_t *words, size_t n_words, uint32_t *out);
+float orc_pin_f32_of_word(uint32_t word);
 
 /* ---- lattice (ss/geometry/lattice.rs:9-109, offsets.rs) ------------------- */
 #define ORC_MAX_DIMS 8

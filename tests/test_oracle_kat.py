@@ -68,6 +68,48 @@ def test_f32_and_u32_share_the_high_bits(oracle):
         assert 0.0 <= f < 1.0
 
 
+class _Pcg32:
+    """rand_pcg 0.3 Lcg64Xsh32 -- the generator rand 0.8.5's own tests draw from (`crate::test::rng(seed)` =
+    `Pcg32::new(seed, 11634580027462260723)`), restated here to feed the oracle's sampling code the words those tests saw."""
+    MUL, MASK = 6364136223846793005, (1 << 64) - 1
+
+    def __init__(self, state, stream=11634580027462260723):
+        self.inc = ((stream << 1) | 1) & self.MASK
+        self.state = (state + self.inc) & self.MASK
+        self._step()
+
+    def _step(self):
+        self.state = (self.state * self.MUL + self.inc) & self.MASK
+
+    def next_u32(self):
+        st = self.state
+        self._step()
+        rot, xsh = st >> 59, (((st >> 18) ^ st) >> 27) & 0xFFFFFFFF
+        return ((xsh >> rot) | (xsh << ((32 - rot) & 31))) & 0xFFFFFFFF
+
+
+def test_range_sampling_reproduces_rand_085_value_stability_vectors(oracle):
+    """rand 0.8.5 pins its own outputs: `distributions/uniform.rs`, test `value_stability` --
+    `sample_single(11u32, 219)` three times on `test::rng(897)` gives [17, 66, 214]; `distributions/float.rs`, test
+    `value_stability` -- `Standard` f32 on `test::rng(0x6f44f5646c2a7334)` gives [0.0035963655, 0.7346052, 0.09778172].
+    The oracle's range sampling (gen_range_u32: the shuffles of build_tasks, overlap.rs:48) and its f32 conversion
+    (orc_rng_gen_f32: every Metropolis draw, sweep.rs:179-181) run on those word streams and must give those values."""
+    lib = oracle.load()
+    rng = _Pcg32(897)
+    words = np.array([rng.next_u32() for _ in range(64)], dtype=np.uint32)
+    got, at = [], 0
+    for _ in range(3):
+        out = C.c_uint32()
+        used = lib.orc_pin_sample_single_u32(11, 219, words[at:].ctypes.data, len(words) - at, C.byref(out))
+        assert used >= 1
+        at += used
+        got.append(out.value)
+    assert got == [17, 66, 214]
+    rng = _Pcg32(0x6F44F5646C2A7334)
+    floats = [lib.orc_pin_f32_of_word(rng.next_u32()) for _ in range(3)]
+    assert [np.float32(f) for f in floats] == [np.float32(0.0035963655), np.float32(0.7346052), np.float32(0.09778172)]
+
+
 def test_gen_range_and_shuffle_are_in_range_and_permute(oracle):
     lib = oracle.load()
     rng = oracle.make_rngs([7])[0]

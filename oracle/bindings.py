@@ -97,6 +97,7 @@ def load(path=None):
         "orc_rng_shuffle_usize": (None, [P(OrcRng), vp, C.c_size_t]),
         "orc_pin_sample_single_u32": (C.c_size_t, [u32, u32, vp, C.c_size_t, P(u32)]),
         "orc_pin_f32_of_word": (f32, [u32]),
+        "orc_pin_sample_single_inclusive_u8": (C.c_size_t, [C.c_uint8, C.c_uint8, vp, C.c_size_t, P(C.c_uint8)]),
         "orc_lattice_new": (vp, [vp, C.c_int]),
         "orc_lattice_with_offsets": (vp, [vp, C.c_int, vp, C.c_size_t]),
         "orc_lattice_free": (None, [vp]),

@@ -126,16 +126,22 @@ float orc_pin_f32_of_word(uint32_t word) { return f32_of_word(word); }
 /* rand 0.8.5 UniformInt<u8>::sample_single_inclusive (uniform.rs, uniform_int_impl! with
  * $u_large = u32): zone = u32::MAX - (u32::MAX - range + 1) % range, one u32 per attempt.
  * Call sites: ss/clusters/overlap.rs:808 (1..=3), :827 (0..=3), :950 (1..=3). */
+static inline uint32_t u8_range_inclusive(uint8_t low, uint8_t high) { return (uint32_t)(uint8_t)(high - low + 1); }
+static inline uint32_t u8_zone(uint32_t range) { return UINT32_MAX - (UINT32_MAX - range + 1) % range; }
 static uint8_t gen_range_u8_inclusive(orc_rng *rng, uint8_t low, uint8_t high) {
-    uint32_t range = (uint32_t)(uint8_t)(high - low + 1);
-    uint32_t ints_to_reject = (UINT32_MAX - range + 1) % range;
-    uint32_t zone = UINT32_MAX - ints_to_reject;
-    for (;;) {
-        uint32_t v = orc_rng_next_u32(rng);
-        uint64_t m = (uint64_t)v * (uint64_t)range;
-        uint32_t hi = (uint32_t)(m >> 32), lo = (uint32_t)m;
-        if (lo <= zone) return (uint8_t)(low + hi);
-    }
+    uint32_t range = u8_range_inclusive(low, high), zone = u8_zone(range), out;
+    for (;;)
+        if (u32_attempt(orc_rng_next_u32(rng), low, range, zone, &out)) return (uint8_t)out;
+}
+/* pinning only, as orc_pin_sample_single_u32: rand's sample_single(low, high) on u8 = the inclusive form with high - 1 */
+size_t orc_pin_sample_single_inclusive_u8(uint8_t low, uint8_t high, const uint32_t *words, size_t n_words, uint8_t *out) {
+    uint32_t range = u8_range_inclusive(low, high), zone = u8_zone(range), v;
+    for (size_t k = 0; k < n_words; ++k)
+        if (u32_attempt(words[k], low, range, zone, &v)) {
+            *out = (uint8_t)v;
+            return k + 1;
+        }
+    return 0;
 }
 
 /* rand 0.8.5 SliceRandom::shuffle: for i in (1..len).rev() swap(i, gen_index(i+1)).

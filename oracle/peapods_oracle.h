@@ -49,6 +49,7 @@ void orc_rng_shuffle_usize(orc_rng *rng, uint64_t *values, size_t len);
 /* pinning only: the oracle's u32 range sampling / f32 conversion on a supplied word stream (rand 0.8.5 value-stability vectors) */
 size_t orc_pin_sample_single_u32(uint32_t low, uint32_t high, const uint32_t *words, size_t n_words, uint32_t *out);
 float orc_pin_f32_of_word(uint32_t word);
+size_t orc_pin_sample_single_inclusive_u8(uint8_t low, uint8_t high, const uint32_t *words, size_t n_words, uint8_t *out);
 
 /* ---- lattice (ss/geometry/lattice.rs:9-109, offsets.rs) ------------------- */
 #define ORC_MAX_DIMS 8

@@ -105,6 +105,16 @@ def test_range_sampling_reproduces_rand_085_value_stability_vectors(oracle):
         at += used
         got.append(out.value)
     assert got == [17, 66, 214]
+    # the same test's u8 line (`test_samples(11u8, 219, &[17, 66, 214], ..)`): small integer types take another zone formula
+    # (uniform.rs, uniform_int_impl!) -- the one the oracle's gen_range_u8_inclusive uses for CMR's 1..=3 / 0..=3 draws
+    got, at = [], 0
+    for _ in range(3):
+        out8 = C.c_uint8()
+        used = lib.orc_pin_sample_single_inclusive_u8(11, 218, words[at:].ctypes.data, len(words) - at, C.byref(out8))
+        assert used >= 1
+        at += used
+        got.append(out8.value)
+    assert got == [17, 66, 214]
     rng = _Pcg32(0x6F44F5646C2A7334)
     floats = [lib.orc_pin_f32_of_word(rng.next_u32()) for _ in range(3)]
     assert [np.float32(f) for f in floats] == [np.float32(0.0035963655), np.float32(0.7346052), np.float32(0.09778172)]

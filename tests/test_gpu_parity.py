@@ -547,6 +547,32 @@ def test_word_parallel_cluster_phases_on_awkward_extents(oracle, shape, n_temps,
         assert_state_equal(gpu, cpu, check_energy=False)
 
 
+@pytest.mark.parametrize("shape,offsets", [((40,), [[1], [2]]), ((6, 10), [[1, 0], [0, 1], [0, 2]]),
+                                           ((9, 7), [[0, 1], [2, 0]]), ((5, 6, 7), [[0, 0, 1], [0, 1, 0], [0, 0, 3]])])
+def test_word_parallel_cluster_phases_with_longer_axis_offsets(oracle, shape, offsets):
+    """Offsets of more than one site along an axis still give two offsets per direction (implicit neighbours), but the
+    wrap flag of such a direction changes along a run of next-site bonds: the square rule that drops redundant unions
+    (k_cluster_sw, union_word) and the shifted-bitmap neighbours must hold there too.  Pair moves and Swendsen-Wang."""
+    nn = len(offsets)
+    rng = np.random.default_rng(11)
+    couplings = (2 * rng.integers(0, 2, size=(2,) + tuple(shape) + (nn,)) - 1).astype(np.float32)
+    temps = np.linspace(0.7, 2.1, 3)
+    gpu, cpu = make_pair(oracle, shape, couplings, temps, 4, 29, offsets)
+    for mode in ("houdayer", "jorg", "cmr"):
+        kwargs = dict(pt_interval=1, overlap_cluster_update_interval=1, overlap_cluster_build_mode=mode,
+                      overlap_cluster_mode="sw", warmup_ratio=0.0)
+        a = gpu.sample(5, "metropolis", **kwargs)
+        b = cpu.sample(5, "metropolis", **kwargs)
+        assert_results_equal(a, b)
+        assert_state_equal(gpu, cpu, check_energy=False)
+    gpu, cpu = make_pair(oracle, shape, np.abs(couplings), temps * 2, 1, 3, offsets)
+    kwargs = dict(cluster_update_interval=1, cluster_mode="sw", pt_interval=1, warmup_ratio=0.0)
+    a = gpu.sample(6, "metropolis", **kwargs)
+    b = cpu.sample(6, "metropolis", **kwargs)
+    assert_results_equal(a, b)
+    assert_state_equal(gpu, cpu)
+
+
 @pytest.mark.parametrize("shape,temp", [((8, 8, 8), 1.2), ((12, 12, 12), 2.5), ((16, 16, 16), 4.4), ((30, 30), 1.5)])
 def test_swendsen_wang_with_more_bonds_than_the_union_list_holds(oracle, shape, temp):
     """A cold ferromagnet accepts nearly every bond: more bonds than the N entries of the packed union list, so the

@@ -1527,7 +1527,8 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
     return (static_cast<uint64_t>(hi) << 32) | lo;
 }
 
-template <int MODE>
+// UNIT: every coupling is +-1 or 0 (SimDims::unit) -- the per-bond probabilities (expf) stay out of the search loop's code
+template <int MODE, bool UNIT>
 __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
     const uint32_t kWaveTasks = blockDim.x / 64;
     constexpr bool FK = MODE == kSwFk, CMR = MODE == kSwCmr;
@@ -1618,7 +1619,7 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
         }
     }
     if (seed != 0xFFFFFFFFu) {
-        const float temp = d.unit ? 0.0f : p.temps[t];
+        const float temp = UNIT ? 0.0f : p.temps[t];
         rng.s0 = uniform64(rng.s0); rng.s1 = uniform64(rng.s1); rng.s2 = uniform64(rng.s2); rng.s3 = uniform64(rng.s3);
         // The search's draws come from the VECTOR unit (every lane steps the same state; lane 0's value is read back):
         // with six searches per SIMD the scalar unit, which serves a SIMD once in four cycles, is what the launch waits
@@ -1682,7 +1683,7 @@ __global__ __launch_bounds__(1024) void k_wolff_wave(SimDims d, DevPtrs p) {
                     const uint32_t draw = kVectorRng ? __builtin_amdgcn_readfirstlane(vrng.next_top() >> 8)
                                                      : __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(rng.next() >> 40));
                     uint32_t limit = threshold; // draw < ceil(p 2^24)  <=>  gen::<f32>() < p
-                    if (!d.unit) { // this bond's own probability; the coupling belongs to the bond's forward end
+                    if (!UNIT) { // this bond's own probability; the coupling belongs to the bond's forward end
                         const uint32_t owner = (q & 1u) ? target : site;
                         const float j_abs = fabsf(p.Jf[(static_cast<size_t>(real) * d.N + owner) * d.nn + (q >> 1)]);
                         limit = FK ? fk_threshold(j_abs, temp)
@@ -2025,9 +2026,12 @@ hipError_t configure_cluster_kernels() {
                            reinterpret_cast<const void *>(k_cluster_sw<kSwFk, 2>),
                            reinterpret_cast<const void *>(k_cluster_sw<kSwCmr, 2>),
                            reinterpret_cast<const void *>(k_fk_wolff),
-                           reinterpret_cast<const void *>(k_wolff_wave<kSwJorg>),
-                           reinterpret_cast<const void *>(k_wolff_wave<kSwFk>),
-                           reinterpret_cast<const void *>(k_wolff_wave<kSwCmr>),
+                           reinterpret_cast<const void *>(k_wolff_wave<kSwJorg, true>),
+                           reinterpret_cast<const void *>(k_wolff_wave<kSwFk, true>),
+                           reinterpret_cast<const void *>(k_wolff_wave<kSwCmr, true>),
+                           reinterpret_cast<const void *>(k_wolff_wave<kSwJorg, false>),
+                           reinterpret_cast<const void *>(k_wolff_wave<kSwFk, false>),
+                           reinterpret_cast<const void *>(k_wolff_wave<kSwCmr, false>),
                            reinterpret_cast<const void *>(k_cmr_wolff),
                            reinterpret_cast<const void *>(k_uf_replay)}) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2108,16 +2112,18 @@ size_t wolff_wave_lds_bytes(const SimDims &d) { return wolff_wave_lds_bytes(d, k
 hipError_t launch_jorg_wave(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool paired) {
     if (!paired) PA_LAUNCH(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
     const uint32_t n_tasks = d.n_temps * d.n_pairs, per_block = wolff_wave_tasks(d, kSwJorg);
-    PA_LAUNCH(k_wolff_wave<kSwJorg>, dim3(d.n_real * ((n_tasks + per_block - 1) / per_block)), dim3(64 * per_block),
-                       wolff_wave_lds_bytes(d, kSwJorg), stream, d, p);
+    const dim3 grid(d.n_real * ((n_tasks + per_block - 1) / per_block)), block(64 * per_block);
+    if (d.unit) PA_LAUNCH((k_wolff_wave<kSwJorg, true>), grid, block, wolff_wave_lds_bytes(d, kSwJorg), stream, d, p);
+    else PA_LAUNCH((k_wolff_wave<kSwJorg, false>), grid, block, wolff_wave_lds_bytes(d, kSwJorg), stream, d, p);
     return hipGetLastError();
 }
 
 hipError_t launch_cmr_wave(const SimDims &d, const DevPtrs &p, hipStream_t stream, bool paired) {
     if (!paired) PA_LAUNCH(k_pairing, dim3(d.n_real), dim3(std::max(64u, (d.n_temps + 63u) & ~63u)), 0, stream, d, p);
     const uint32_t n_tasks = d.n_temps * d.n_pairs, per_block = wolff_wave_tasks(d, kSwCmr);
-    PA_LAUNCH(k_wolff_wave<kSwCmr>, dim3(d.n_real * ((n_tasks + per_block - 1) / per_block)), dim3(64 * per_block),
-                       wolff_wave_lds_bytes(d, kSwCmr), stream, d, p);
+    const dim3 grid(d.n_real * ((n_tasks + per_block - 1) / per_block)), block(64 * per_block);
+    if (d.unit) PA_LAUNCH((k_wolff_wave<kSwCmr, true>), grid, block, wolff_wave_lds_bytes(d, kSwCmr), stream, d, p);
+    else PA_LAUNCH((k_wolff_wave<kSwCmr, false>), grid, block, wolff_wave_lds_bytes(d, kSwCmr), stream, d, p);
     return hipGetLastError();
 }
 
@@ -2140,11 +2146,13 @@ hipError_t launch_fk(const SimDims &d, const DevPtrs &p, bool wolff, const Clust
     ClusterAux aux = aux_in;
     if (wolff && aux.flags == 0) { // depth-first single-cluster form: one wave per system if the tables fit the LDS
         const uint32_t per_block = wolff_wave_tasks(d, kSwFk);
-        if (wolff_wave_lds_bytes(d, kSwFk) <= 160 * 1024 && d.N <= 65535)
-            PA_LAUNCH(k_wolff_wave<kSwFk>, dim3(d.n_real * ((d.n_sys + per_block - 1) / per_block)),
-                               dim3(64 * per_block), wolff_wave_lds_bytes(d, kSwFk), stream, d, p);
-        else
+        if (wolff_wave_lds_bytes(d, kSwFk) <= 160 * 1024 && d.N <= 65535) {
+            const dim3 grid(d.n_real * ((d.n_sys + per_block - 1) / per_block)), block(64 * per_block);
+            if (d.unit) PA_LAUNCH((k_wolff_wave<kSwFk, true>), grid, block, wolff_wave_lds_bytes(d, kSwFk), stream, d, p);
+            else PA_LAUNCH((k_wolff_wave<kSwFk, false>), grid, block, wolff_wave_lds_bytes(d, kSwFk), stream, d, p);
+        } else {
             PA_LAUNCH(k_fk_wolff, dim3(d.n_real), dim3(1024), fk_wolff_lds_bytes(d), stream, d, p);
+        }
         return hipGetLastError();
     }
     // union-find forms (they read the per-slot bitmaps and the systems' pre-drawn streams)

@@ -283,6 +283,8 @@ template <int MODE, int LEVEL, bool GLOBAL = false>
 __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || MODE == kSwJorg) ? 8 : 4) : (LEVEL == 1 ? 3 : 2)) void k_cluster_sw(
     SimDims d, DevPtrs p, uint32_t group, int wolff, ClusterAux aux) {
     constexpr bool EXTRAS = LEVEL > 0; // sizes / top four and the single-cluster forms
+    // the lean build is for unit couplings (launch_sw_build): the per-bond thresholds and raw streams of other couplings stay out of it
+    const bool unit = LEVEL == 0 || d.unit != 0;
     constexpr bool FULL = LEVEL > 1;   // + observation metrics, winding, snapshots
     constexpr bool JORG = MODE == kSwJorg, FK = MODE == kSwFk, CMR = MODE == kSwCmr;
     constexpr bool STOCHASTIC = JORG || FK || CMR; // bonds are drawn
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
     const uint32_t plane_words = static_cast<uint32_t>(stream_stride / 32);
     auto prefetch_bits = [&](uint32_t start, uint32_t kind) -> PlaneWords {
         PlaneWords pre{0xFFFFFFFFu, {0u, 0u}};
-        if (!d.unit) return pre;
+        if (!unit) return pre;
         pre.w0 = (start / 256) * 8;
         const uint32_t w = pre.w0 + tid;
         if (w < 2 * aux.stream_units) {
@@ -511,11 +513,11 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
         const uint32_t base_q = (start / 256) * 256, end = start + count;
         // the tables reach cluster_stream_units units; past them only after > 64 rejections of a seed draw (p < 2^-50
         // each): refuse, never guess.  (Streams of other couplings are always made in full.)
-        if (end > (d.unit ? cluster_stream_units(d) : aux.stream_units) * 64u) {
+        if (end > (unit ? cluster_stream_units(d) : aux.stream_units) * 64u) {
             if (tid == 0) atomicOr(p.stream_error, 1u);
             return;
         }
-        if (d.unit) { // the planes k_pair_stream left: a word copy (positions before `start` in the first word are never read)
+        if (unit) { // the planes k_pair_stream left: a word copy (positions before `start` in the first word are never read)
             const uint32_t *planes = reinterpret_cast<const uint32_t *>(p.stream_bits + stream_task * stream_stride);
             const uint32_t w0 = base_q / 32, n_words = (end - base_q + 31) / 32;
             for (uint32_t w = tid; w < n_words; w += kSwThreads) {
@@ -922,7 +924,7 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
                 return c;
             });
             // draw < ceil(p 2^24)  <=>  gen::<f32>() < p (unit couplings: classified by k_pair_stream)
-            if (!d.unit) { // every bond has its own probability: thresholds by draw rank
+            if (!unit) { // every bond has its own probability: thresholds by draw rank
                 const float temp = p.temps[t];
                 for (uint32_t i = tid; i < d.N; i += kSwThreads)
                     for (uint32_t dd = 0; dd < d.nn; ++dd)
@@ -934,7 +936,7 @@ __global__ __launch_bounds__(kSwThreads, LEVEL == 0 ? ((MODE == kSwHoudayer || M
                         }
                 __syncthreads();
             }
-            draw_bits(pos, n_eligible, bond_kind, d.unit ? nullptr : L.thr, pre_bonds);
+            draw_bits(pos, n_eligible, bond_kind, unit ? nullptr : L.thr, pre_bonds);
             // the cluster draws follow the bond draws: their words travel while the components are built
             pre_clusters = prefetch_bits(pos + n_eligible, cluster_kind);
             __syncthreads();
@@ -2055,6 +2057,7 @@ static void launch_sw_build(int level, dim3 grid, hipStream_t stream, const SimD
         return;
     }
     const size_t lds = cluster_sw_lds_bytes(d);
+    if (level == 0 && !d.unit) level = 1; // (the lean build assumes unit couplings)
     if (level == 0)
         PA_LAUNCH((k_cluster_sw<MODE, 0>), grid, dim3(kSwThreads), lds, stream, d, p, group, single, aux);
     else if (level == 1)
